@@ -1,0 +1,154 @@
+#!/usr/bin/env python3 -B
+"""Generate golden vectors from the reference's own hook.py (run in the build container only).
+
+The reference (`/root/reference/data_generation/hook.py`) imports `diffusers` for two type
+names only (hook.py:5-6).  `diffusers` is not installed here, so two empty stand-in *type
+names* are registered in ``sys.modules`` before the import; every line of arithmetic executed
+below is the reference's own code (`_unravel_attn` hook.py:28-56, `compute_global_heat_map`
+hook.py:59-81, `__call__` hook.py:83-122).  Only inputs/outputs (data) are written to
+``tests/golden/*.npz`` -- never reference source or bytecode.
+
+Run:  PYTHONDONTWRITEBYTECODE=1 python3 -B tests/golden/make_golden_hook.py
+"""
+import os
+import sys
+import types
+import math
+
+sys.dont_write_bytecode = True
+import numpy as np
+import torch
+import torch.nn as nn
+
+REF = "/root/reference/data_generation"
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+# -- two type-name stand-ins (no behaviour) -----------------------------------------------
+_d = types.ModuleType("diffusers")
+_d.StableDiffusionPipeline = type("StableDiffusionPipeline", (), {})
+_dm = types.ModuleType("diffusers.models")
+_da = types.ModuleType("diffusers.models.attention_processor")
+_da.Attention = type("Attention", (), {})
+sys.modules["diffusers"] = _d
+sys.modules["diffusers.models"] = _dm
+sys.modules["diffusers.models.attention_processor"] = _da
+sys.path.insert(0, REF)
+import hook as ref_hook  # noqa: E402  (the reference module itself)
+
+
+class DuckAttn:
+    """Duck-typed `attn` exposing exactly what hook.py:92-120 touches; semantics of the
+    helper methods follow diffusers==0.21.2 `Attention` [upstream-knowledge]."""
+
+    def __init__(self, C, ctx_dim, heads, gen, cross):
+        self.heads = heads
+        self.scale = (C // heads) ** -0.5
+        self.norm_cross = None
+        kdim = ctx_dim if cross else C
+        self.to_q = nn.Linear(C, C, bias=False)
+        self.to_k = nn.Linear(kdim, C, bias=False)
+        self.to_v = nn.Linear(kdim, C, bias=False)
+        self.to_out = nn.ModuleList([nn.Linear(C, C, bias=True), nn.Dropout(0.0)])
+        with torch.no_grad():
+            for lin in (self.to_q, self.to_k, self.to_v, self.to_out[0]):
+                lin.weight.copy_(torch.randn(lin.weight.shape, generator=gen) / math.sqrt(lin.in_features))
+            self.to_out[0].bias.copy_(torch.randn(C, generator=gen) * 0.1)
+
+    def prepare_attention_mask(self, mask, n, b):
+        return mask
+
+    def head_to_batch_dim(self, t):
+        b, n, c = t.shape
+        h = self.heads
+        return t.reshape(b, n, h, c // h).permute(0, 2, 1, 3).reshape(b * h, n, c // h)
+
+    def batch_to_head_dim(self, t):
+        bh, n, d = t.shape
+        h = self.heads
+        return t.reshape(bh // h, h, n, d).permute(0, 2, 1, 3).reshape(bh // h, n, d * h)
+
+    def get_attention_scores(self, q, k, mask=None):
+        s = torch.baddbmm(torch.empty(q.shape[0], q.shape[1], k.shape[1], dtype=q.dtype),
+                          q, k.transpose(-1, -2), beta=0, alpha=self.scale)
+        return s.softmax(dim=-1)
+
+
+def main():
+    out = {}
+    # (1) _unravel_attn ---------------------------------------------------------------
+    g = torch.Generator().manual_seed(20260130)
+    for ci, (B, H, hw, T) in enumerate([(2, 8, 64, 77), (2, 4, 256, 20), (4, 2, 1024, 6)]):
+        P = torch.rand(B * H, hw, T, generator=g).softmax(-1)
+        out[f"unravel{ci}_in"] = P.numpy()
+        for is_train in (True, False):
+            hk = ref_hook.UNetCrossAttentionHooker(is_train=is_train, latent_hw=64)
+            m = hk._unravel_attn(P, H)
+            out[f"unravel{ci}_out_train{int(is_train)}"] = m.numpy()
+    # (2) compute_global_heat_map -----------------------------------------------------
+    hk = ref_hook.UNetCrossAttentionHooker(is_train=False, latent_hw=64)
+    maps = []
+    for i, r in enumerate([8, 16, 32, 64, 16, 8]):
+        m = torch.rand(1, 20, r, r, generator=g)
+        if i in (1, 4):  # sharp spikes -> bicubic undershoot -> clamp is exercised
+            m = (m > 0.93).float() * 5.0 + m * 0.01
+        maps.append(m)
+        out[f"global_in{i}"] = m.numpy()
+    hk.cross_attn_maps = [m.clone() for m in maps]
+    gm = hk.compute_global_heat_map()
+    out["global_out"] = gm.numpy()
+    # un-clamped variant proves the clamp matters in this fixture
+    import torch.nn.functional as F
+    unclamped = torch.stack([F.interpolate(m, size=(64, 64), mode="bicubic") for m in maps]).mean(0)
+    out["global_min_unclamped"] = np.array(float(unclamped.min()))
+    assert float(unclamped.min()) < 0 <= float(gm.min())
+    hk2 = ref_hook.UNetCrossAttentionHooker(is_train=False, latent_hw=64)
+    try:
+        hk2.compute_global_heat_map()
+        out["global_empty_raises"] = np.array(0)
+    except RuntimeError as e:
+        out["global_empty_raises"] = np.array(1)
+        out["global_empty_msg"] = np.array(str(e))
+    # train-mode batched global map (B'=2)
+    hk3 = ref_hook.UNetCrossAttentionHooker(is_train=True, latent_hw=32)
+    ms = [torch.rand(2, 5, r, r, generator=g) for r in (8, 16, 32)]
+    for i, m in enumerate(ms):
+        out[f"global_b2_in{i}"] = m.numpy()
+    hk3.cross_attn_maps = [m.clone() for m in ms]
+    out["global_b2_out"] = hk3.compute_global_heat_map().numpy()
+    # (3) __call__ end-to-end (cross + self) ------------------------------------------
+    C, H, T, ctxd = 160, 4, 77, 96
+    for name, N in (("call_hw64", 64), ("call_hw144", 144)):
+        gw = torch.Generator().manual_seed(7 + N)
+        cross = DuckAttn(C, ctxd, H, gw, cross=True)
+        selfa = DuckAttn(C, ctxd, H, gw, cross=False)
+        x = torch.randn(2, N, C, generator=gw)
+        ctx = torch.randn(2, T, ctxd, generator=gw)
+        for key, a in (("cross", cross), ("self", selfa)):
+            out[f"{name}_{key}_wq"] = a.to_q.weight.detach().numpy()
+            out[f"{name}_{key}_wk"] = a.to_k.weight.detach().numpy()
+            out[f"{name}_{key}_wv"] = a.to_v.weight.detach().numpy()
+            out[f"{name}_{key}_wo"] = a.to_out[0].weight.detach().numpy()
+            out[f"{name}_{key}_bo"] = a.to_out[0].bias.detach().numpy()
+        out[f"{name}_x"] = x.numpy()
+        out[f"{name}_ctx"] = ctx.numpy()
+        for is_train in (True, False):
+            hk = ref_hook.UNetCrossAttentionHooker(is_train=is_train, latent_hw=64)
+            with torch.no_grad():
+                yc = hk(cross, x, encoder_hidden_states=ctx)
+                n_after_cross = len(hk.cross_attn_maps)
+                ys = hk(selfa, x)
+                n_after_self = len(hk.cross_attn_maps)
+            out[f"{name}_cross_y_train{int(is_train)}"] = yc.numpy()
+            out[f"{name}_self_y_train{int(is_train)}"] = ys.numpy()
+            out[f"{name}_map_train{int(is_train)}"] = hk.cross_attn_maps[0].numpy()
+            out[f"{name}_nmaps_train{int(is_train)}"] = np.array([n_after_cross, n_after_self])
+    # split to keep each fixture small
+    groups = {"hook_unravel": "unravel", "hook_global": "global", "hook_call": "call"}
+    for fn, pref in groups.items():
+        sub = {k: (v.astype(np.float32) if v.dtype == np.float64 else v) for k, v in out.items() if k.startswith(pref)}
+        np.savez_compressed(os.path.join(OUT, fn + ".npz"), **sub)
+        print(fn, len(sub), "arrays", os.path.getsize(os.path.join(OUT, fn + ".npz")) // 1024, "KiB")
+
+
+if __name__ == "__main__":
+    main()

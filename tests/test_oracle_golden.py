@@ -1,0 +1,62 @@
+"""Pin the oracle's hook.py restatement against golden vectors produced by the reference's own
+hook.py (tests/golden/make_golden_hook.py).  CPU only."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import sd_oracle as O
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+@pytest.mark.parametrize("case,heads", [(0, 8), (1, 4), (2, 2)])
+@pytest.mark.parametrize("is_train", [True, False])
+def test_unravel_attn_matches_reference(golden_dir, case, heads, is_train):
+    z = _load(golden_dir, "hook_unravel.npz")
+    p = torch.from_numpy(z[f"unravel{case}_in"])
+    want = z[f"unravel{case}_out_train{int(is_train)}"]
+    got = O.hooker_unravel_attn(p, heads, is_train).numpy()
+    assert got.shape == want.shape
+    np.testing.assert_allclose(got, want, rtol=0, atol=1e-7)
+
+
+def test_global_heat_map_matches_reference(golden_dir):
+    z = _load(golden_dir, "hook_global.npz")
+    maps = [torch.from_numpy(z[f"global_in{i}"]) for i in range(6)]
+    got = O.hooker_global_heat_map(maps, 64).numpy()
+    np.testing.assert_allclose(got, z["global_out"], rtol=0, atol=1e-6)
+    assert float(z["global_min_unclamped"]) < 0 <= got.min()      # the clamp is exercised
+    maps2 = [torch.from_numpy(z[f"global_b2_in{i}"]) for i in range(3)]
+    got2 = O.hooker_global_heat_map(maps2, 32).numpy()
+    np.testing.assert_allclose(got2, z["global_b2_out"], rtol=0, atol=1e-6)
+
+
+def test_global_heat_map_empty_raises(golden_dir):
+    z = _load(golden_dir, "hook_global.npz")
+    assert int(z["global_empty_raises"]) == 1
+    with pytest.raises(RuntimeError, match=str(z["global_empty_msg"])):
+        O.hooker_global_heat_map([], 64)
+
+
+@pytest.mark.parametrize("name", ["call_hw64", "call_hw144"])
+@pytest.mark.parametrize("is_train", [True, False])
+def test_processor_call_matches_reference(golden_dir, name, is_train):
+    z = _load(golden_dir, "hook_call.npz")
+    x, ctx = torch.from_numpy(z[name + "_x"]), torch.from_numpy(z[name + "_ctx"])
+    rec = O.HookRecorder(is_train=is_train, latent_hw=64)
+    w = {k: torch.from_numpy(z[f"{name}_cross_{k}"]) for k in ("wq", "wk", "wv", "wo", "bo")}
+    y = O.explicit_attention_processor(x, ctx, w["wq"], w["wk"], w["wv"], w["wo"], w["bo"], 4, recorder=rec)
+    np.testing.assert_allclose(y.numpy(), z[f"{name}_cross_y_train{int(is_train)}"], rtol=1e-5, atol=2e-6)
+    assert len(rec.cross_attn_maps) == 1
+    np.testing.assert_allclose(rec.cross_attn_maps[0].numpy(), z[f"{name}_map_train{int(is_train)}"],
+                               rtol=1e-5, atol=1e-7)
+    w = {k: torch.from_numpy(z[f"{name}_self_{k}"]) for k in ("wq", "wk", "wv", "wo", "bo")}
+    ys = O.explicit_attention_processor(x, None, w["wq"], w["wk"], w["wv"], w["wo"], w["bo"], 4, recorder=rec)
+    np.testing.assert_allclose(ys.numpy(), z[f"{name}_self_y_train{int(is_train)}"], rtol=1e-5, atol=2e-6)
+    # self-attention records nothing (hook.py:110)
+    assert len(rec.cross_attn_maps) == 1
+    assert list(z[f"{name}_nmaps_train{int(is_train)}"]) == [1, 1]
