@@ -1,0 +1,276 @@
+// Flash attention for gfx950 with fused cross-attention probability recording (DAAM / hook.py).
+//
+// Replaces: the attention-processor body of reference data_generation/hook.py:104-115
+// (head_to_batch_dim, get_attention_scores = softmax(scale*QK^T), bmm(P,V), batch_to_head_dim)
+// and, fused into the same kernel, the recorder side channel: daam's per-(layer,head) time-summed
+// maps or hook.py:28-56 `_unravel_attn` head-mean maps (row H2).
+// The [B*H, N, 77] probability tensor of hook.py:108 is never materialised in HBM.
+//
+// Formulation (CDNA4, 64-wide waves, v_mfma_f32_32x32x16_bf16):
+//   S^T[key][query] = K . Q^T   (A = K rows from LDS, B = Q fragments held in registers)
+//     -> accumulator has the QUERY on the lane and the keys in registers, so the softmax row
+//        max/sum are in-lane reductions + one cross-half shuffle;
+//   O^T[d][query]  += V^T . P^T (A = V^T via ds_read_b64_tr_b16 from a row-major V tile,
+//                                B = the S^T accumulator registers converted to bf16 in place);
+//   recorded probabilities are stored token-major [T][h*w]: for a fixed register the 32 lanes
+//   of a half-wave hold 32 consecutive pixels -> 128-B coalesced read-modify-write.
+#include "kernels.h"
+
+template <int D> struct AttnCfg {
+  static constexpr int KSTEPS = (D + 15) / 16;           // QK^T k-steps (d padded to 16)
+  static constexpr int DBLK = (D + 31) / 32;             // PV output d-blocks (d padded to 32)
+  static constexpr int KCH = KSTEPS * 2;                 // 16-B chunks per K row incl. zero pad
+  static constexpr int KPITCH = ((KCH | 1)) * 16;        // odd #chunks -> conflict-free b128 row reads
+  static constexpr int VPITCH = ((DBLK | 1)) * 64;       // odd multiple of 64 B -> conflict-free tr reads
+  static constexpr int CH = D / 8;                       // real 16-B chunks per row
+};
+
+template <int D, int KB, int RECORD>
+__global__ __launch_bounds__(256) void attn_kernel(const AttnP p) {
+  using C = AttnCfg<D>;
+  constexpr int KEYS = KB * 32;
+  constexpr int KSTEPS = C::KSTEPS, DBLK = C::DBLK, KPITCH = C::KPITCH, VPITCH = C::VPITCH, CH = C::CH;
+  constexpr int NCHUNK = KEYS * CH;                      // 16-B chunks per K (or V) tile
+  constexpr int LD_IT = (NCHUNK + 255) / 256;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sK = smem;
+  char* sV = smem + KEYS * KPITCH;
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int c = lane & 31, hh = lane >> 5;
+  const int head = blockIdx.y, b = blockIdx.z;
+  const int q0 = blockIdx.x * 128 + wid * 32;
+  const bf16_t* qp = p.q + b * p.sq + head * D;
+  const bf16_t* kp = p.k + b * p.sk + head * D;
+  const bf16_t* vp = p.v + b * p.sv + head * D;
+
+  // zero the K pad chunks once (never overwritten by tile loads)
+  if constexpr (C::KCH > CH) {
+    for (int i = tid; i < KEYS * (C::KCH - CH); i += 256) {
+      const int r = i / (C::KCH - CH), cc = CH + i % (C::KCH - CH);
+      *(u32x4*)(sK + r * KPITCH + cc * 16) = u32x4{0, 0, 0, 0};
+    }
+  }
+  if constexpr (DBLK * 4 > CH) {
+    for (int i = tid; i < KEYS * (DBLK * 4 - CH); i += 256) {
+      const int r = i / (DBLK * 4 - CH), cc = CH + i % (DBLK * 4 - CH);
+      *(u32x4*)(sV + r * VPITCH + cc * 16) = u32x4{0, 0, 0, 0};
+    }
+  }
+
+  // Q fragments: lane (c, hh) holds Q[q0+c][16s + 8hh .. +8]
+  bf16x8 qf[KSTEPS];
+  {
+    const int qrow = q0 + c;
+    const bool qok = qrow < p.Nq;
+#pragma unroll
+    for (int s = 0; s < KSTEPS; ++s) {
+      const int d0 = 16 * s + 8 * hh;
+      u32x4 v = u32x4{0, 0, 0, 0};
+      if (qok && d0 < D) v = *(const u32x4*)(qp + (long long)qrow * p.ldq + d0);
+      qf[s] = __builtin_bit_cast(bf16x8, v);
+    }
+  }
+
+  u32x4 kreg[LD_IT], vreg[LD_IT];
+  auto gload = [&](int tile) {
+#pragma unroll
+    for (int it = 0; it < LD_IT; ++it) {
+      const int idx = tid + it * 256;
+      const int r = idx / CH, cc = idx - r * CH;
+      const int key = tile * KEYS + r;
+      kreg[it] = u32x4{0, 0, 0, 0};
+      vreg[it] = u32x4{0, 0, 0, 0};
+      if (idx < NCHUNK && key < p.Nk) {
+        kreg[it] = *(const u32x4*)(kp + (long long)key * p.ldk + cc * 8);
+        vreg[it] = *(const u32x4*)(vp + (long long)key * p.ldv + cc * 8);
+      }
+    }
+  };
+  auto lstore = [&]() {
+#pragma unroll
+    for (int it = 0; it < LD_IT; ++it) {
+      const int idx = tid + it * 256;
+      const int r = idx / CH, cc = idx - r * CH;
+      if (idx < NCHUNK) {
+        *(u32x4*)(sK + r * KPITCH + cc * 16) = kreg[it];
+        *(u32x4*)(sV + r * VPITCH + cc * 16) = vreg[it];
+      }
+    }
+  };
+
+  f32x16 oacc[DBLK];
+#pragma unroll
+  for (int i = 0; i < DBLK; ++i)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) oacc[i][j] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+  const float sc = p.scale * 1.44269504088896340736f;   // exp(x) = exp2(x*log2e)
+
+  const int ntiles = (p.Nk + KEYS - 1) / KEYS;
+  gload(0);
+  __syncthreads();            // pad zeroing done before first tile store (disjoint chunks, but keep ordering simple)
+  lstore();
+  __syncthreads();
+
+  // V^T fragment addressing for ds_read_b64_tr_b16: lane supplies row (key) q, 4 columns at 4*pp
+  const int gi = lane & 15;
+  const int tr_row = (gi >> 2) + 4 * hh;                 // + 16*s (+8 second half) + 32*kb
+  const int tr_col = ((lane >> 4) & 1) * 16 + (gi & 3) * 4;  // + 32*db   (elements)
+
+  for (int t = 0; t < ntiles; ++t) {
+    if (t + 1 < ntiles) gload(t + 1);
+    // ---- S^T = K . Q^T ----
+    f32x16 sacc[KB];
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+#pragma unroll
+      for (int j = 0; j < 16; ++j) sacc[kb][j] = 0.f;
+#pragma unroll
+      for (int s = 0; s < KSTEPS; ++s) {
+        const bf16x8 a = *(const bf16x8*)(sK + (kb * 32 + c) * KPITCH + (2 * s + hh) * 16);
+        sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[s], sacc[kb], 0, 0, 0);
+      }
+    }
+    // ---- online softmax (query on the lane) ----
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int key = t * KEYS + kb * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+        const float s = (key < p.Nk) ? sacc[kb][i] * sc : -INFINITY;
+        sacc[kb][i] = s;
+        mx = fmaxf(mx, s);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = exp2f(m_run - m_new);
+    float rs = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const float pv = exp2f(sacc[kb][i] - m_new);
+        sacc[kb][i] = pv;
+        rs += pv;
+      }
+    l_run = l_run * alpha + rs;
+    m_run = m_new;
+#pragma unroll
+    for (int db = 0; db < DBLK; ++db)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) oacc[db][j] *= alpha;
+
+    if constexpr (RECORD) {
+      // single-tile case (host guarantees Nk <= KEYS): probabilities are final here
+      if (p.record_mode != 0 && b >= p.rec_b0 && (q0 + c) < p.Nq) {
+        const float lt = l_run + __shfl_xor(l_run, 32);
+        const float inv = 1.0f / lt;
+        const int img = b - p.rec_b0;
+        if (p.record_mode == 1) {
+          float* rp = p.rec + img * p.rec_img_stride + head * p.rec_head_stride + (q0 + c);
+#pragma unroll
+          for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+              const int tok = kb * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+              if (tok < p.rec_T) rp[(long long)tok * p.Nq] += sacc[kb][i] * inv;
+            }
+        } else {
+          float* rp = p.rec + img * p.rec_img_stride + (q0 + c);
+          const float invh = inv / (float)p.H;
+#pragma unroll
+          for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+              const int tok = kb * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+              if (tok < p.rec_T) atomicAdd(rp + (long long)tok * p.Nq, sacc[kb][i] * invh);
+            }
+        }
+      } else {
+        (void)__shfl_xor(l_run, 32);
+      }
+    }
+
+    // ---- O^T += V^T . P^T ----
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        bf16x8 pf;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pf[j] = (__bf16)sacc[kb][8 * s + j];
+        const char* vb = sV + (kb * 32 + 16 * s + tr_row) * VPITCH + tr_col * 2;
+#pragma unroll
+        for (int db = 0; db < DBLK; ++db) {
+          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vb + db * 64));
+          const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vb + 8 * VPITCH + db * 64));
+          s16x8 a8;
+          a8[0] = lo[0]; a8[1] = lo[1]; a8[2] = lo[2]; a8[3] = lo[3];
+          a8[4] = hi[0]; a8[5] = hi[1]; a8[6] = hi[2]; a8[7] = hi[3];
+          oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a8), pf, oacc[db], 0, 0, 0);
+        }
+      }
+    if (t + 1 < ntiles) {
+      __syncthreads();
+      lstore();
+      __syncthreads();
+    }
+  }
+
+  // ---- finalize + store O[query][d] ----
+  const float lt = l_run + __shfl_xor(l_run, 32);
+  const float inv = 1.0f / lt;
+  const int qrow = q0 + c;
+  if (qrow < p.Nq) {
+    bf16_t* op = p.o + b * p.so + (long long)qrow * p.ldo + head * D;
+#pragma unroll
+    for (int db = 0; db < DBLK; ++db)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d0 = db * 32 + 8 * g + 4 * hh;
+        if (d0 < D) {
+          u32x2 pk;
+          pk[0] = pack_bf2(oacc[db][4 * g + 0] * inv, oacc[db][4 * g + 1] * inv);
+          pk[1] = pack_bf2(oacc[db][4 * g + 2] * inv, oacc[db][4 * g + 3] * inv);
+          *(u32x2*)(op + d0) = pk;
+        }
+      }
+  }
+}
+
+template <int D, int KB, int RECORD>
+static int launch_attn_t(const AttnP& p, hipStream_t st) {
+  using C = AttnCfg<D>;
+  constexpr int lds = KB * 32 * (C::KPITCH + C::VPITCH);
+  dim3 grid((p.Nq + 127) / 128, p.H, p.B);
+  auto kfn = attn_kernel<D, KB, RECORD>;
+  hipLaunchKernelGGL(kfn, grid, dim3(256), lds, st, p);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+
+template <int D>
+static int launch_attn_d(const AttnP& p, hipStream_t st) {
+  if (p.record_mode != 0) {
+    if (p.Nk > 96) { agd_set_error("attention: recording needs Nk <= 96 (got %d)", p.Nk); return -1; }
+    return launch_attn_t<D, 3, 1>(p, st);
+  }
+  if (p.Nk <= 96 && p.Nk > 64) return launch_attn_t<D, 3, 0>(p, st);
+  return launch_attn_t<D, 2, 0>(p, st);
+}
+
+int launch_attention(const AttnP& p, hipStream_t st) {
+  if ((p.ldq | p.ldk | p.ldv | p.ldo) & 3) { agd_set_error("attention: row pitches must be multiples of 4 elements"); return -1; }
+  if ((p.ldq | p.ldk | p.ldv) & 7) { agd_set_error("attention: q/k/v pitches must be multiples of 8 elements"); return -1; }
+  switch (p.D) {
+    case 32: return launch_attn_d<32>(p, st);
+    case 40: return launch_attn_d<40>(p, st);
+    case 64: return launch_attn_d<64>(p, st);
+    case 80: return launch_attn_d<80>(p, st);
+    case 128: return launch_attn_d<128>(p, st);
+    case 160: return launch_attn_d<160>(p, st);
+    default: agd_set_error("attention: unsupported head dim %d", p.D); return -1;
+  }
+}

@@ -1,0 +1,45 @@
+// Common device/host helpers for the agenda_amd HIP library (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef unsigned short bf16_t;  // raw bf16 bits
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+#define AGD_DEV __device__ __forceinline__
+
+AGD_DEV float bf2f(bf16_t b) { return __uint_as_float(((unsigned int)b) << 16); }
+AGD_DEV bf16_t f2bf(float f) { return __builtin_bit_cast(unsigned short, (__bf16)f); }
+AGD_DEV unsigned int pack_bf2(float lo, float hi) {
+  return (unsigned int)f2bf(lo) | ((unsigned int)f2bf(hi) << 16);
+}
+AGD_DEV float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+AGD_DEV float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+// global -> LDS direct (LDS-DMA), 16 B per lane; LDS destination = wave-uniform base + lane*16.
+AGD_DEV void glds16(const void* gsrc, void* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+// XCD-aware bijective block remap: consecutive logical ids land on the same XCD (8 XCDs,
+// round-robin dispatch), so tiles that share an operand panel share an L2.  Speed only.
+AGD_DEV int xcd_remap(int bid, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7, x = bid & 7;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+}
+
+#define HIP_CHECK_RET(expr)                                                      \
+  do {                                                                           \
+    hipError_t _e = (expr);                                                      \
+    if (_e != hipSuccess) { agd_set_error("%s:%d %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e)); return -1; } \
+  } while (0)
+
+extern "C" void agd_set_error(const char* fmt, ...);

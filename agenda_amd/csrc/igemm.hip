@@ -1,0 +1,272 @@
+// Implicit-GEMM convolution / linear kernel for gfx950 (CDNA4), bf16 in, fp32 accumulate.
+//
+// Replaces on the reference path (all reached through diffusers from
+// reference data_generation/data_generation.py:59): ResnetBlock2D 3x3 convs, Down/Upsample2D
+// convs, Transformer2DModel proj_in/out 1x1 convs, every nn.Linear (to_q/k/v/out, GEGLU FF),
+// and the VAE decoder convs (SURVEY.md §8a rows U1,U4,U6,U7,V1).
+//
+// Design (MI355X-first, not a cuDNN/cuBLAS translation):
+//  * activations live NHWC bf16, so a conv tap is a contiguous 128-B channel run per pixel and a
+//    transformer token row IS a pixel row -- no NCHW<->NHWC transposes anywhere;
+//  * A (im2col rows) and B (weights [N][K], K = tap-major) tiles go global->LDS by LDS-DMA
+//    (global_load_lds_dwordx4, per-lane source address = free gather; padding pixels read a zero
+//    page), double-buffered, one barrier per 64-deep K step;
+//  * LDS rows are 128 B with the 16-B chunk index XOR (row&7): conflict-free ds_read_b128 for the
+//    16x16x32 MFMA operand fetch; the XOR is applied on the SOURCE address (LDS-DMA writes
+//    lane-linear);
+//  * skip-connection concat, nearest-2x upsample and stride-2 are folded into the gather;
+//  * epilogue goes through LDS as fp32 and is written as whole 16-B row chunks with bias /
+//    time-embedding row add / residual / GEGLU / SiLU fused, one rounding to bf16;
+//  * block->tile map is XCD-aware (tiles sharing an A panel share an L2).
+#include "kernels.h"
+
+template <int BM, int BN, int WM, int WN, int KS>
+__global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(const IgemmP p) {
+  constexpr int NT = WM * WN * 64;
+  constexpr int NW = WM * WN;
+  constexpr int WTM = BM / WM, WTN = BN / WN;
+  constexpr int MI = WTM / 16, NI = WTN / 16;
+  constexpr int A_IT = BM * 8 / NT, B_IT = BN * 8 / NT;
+  constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
+  static_assert(A_IT >= 1 && B_IT >= 1, "tile too small for thread count");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wid / WN, wn = wid % WN;
+  const int tiles_n = (p.N + BN - 1) / BN;
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int tn = bid % tiles_n, tm = bid / tiles_n;
+  const int bz = blockIdx.y;
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  const bf16_t* src0 = p.src0 + bz * p.sA0;
+  const bf16_t* src1 = p.src1 ? p.src1 + bz * p.sA1 : nullptr;
+  const bf16_t* Wp = p.W + bz * p.sW;
+  const bf16_t* zp = p.zero_page;
+
+  // ---- per-thread gather state ---------------------------------------------------------
+  const int lrow = lane >> 3;                       // row within the 8-row DMA group
+  const int lchunk = (lane & 7) ^ lrow;             // logical 16-B chunk this lane fetches (swizzle on source)
+  const int HWo = p.Hout * p.Wout;
+  const int ush = (p.up == 2) ? 1 : 0;
+  const int Hup = p.Hin << ush, Wup = p.Win << ush;
+  int a_b[A_IT], a_y[A_IT], a_x[A_IT];
+  unsigned a_rowok = 0;
+#pragma unroll
+  for (int i = 0; i < A_IT; ++i) {
+    const int m = m0 + (i * NW + wid) * 8 + lrow;
+    const bool ok = m < p.M;
+    const int mm = ok ? m : 0;
+    const int b = mm / HWo, rem = mm - b * HWo;
+    const int oy = rem / p.Wout, ox = rem - oy * p.Wout;
+    a_b[i] = b; a_y[i] = oy * p.stride - p.pad; a_x[i] = ox * p.stride - p.pad;
+    a_rowok |= (ok ? 1u : 0u) << i;
+  }
+  const bf16_t* bptr[B_IT];
+  unsigned b_ok = 0;
+#pragma unroll
+  for (int i = 0; i < B_IT; ++i) {
+    const int n = n0 + (i * NW + wid) * 8 + lrow;
+    const bool ok = n < p.N;
+    bptr[i] = Wp + (long long)(ok ? n : 0) * p.K + lchunk * 8;
+    b_ok |= (ok ? 1u : 0u) << i;
+  }
+  const bf16_t* aptr[A_IT];
+  unsigned a_ok = 0;
+  int seg_left = 0, tap = -1, cursrc = 1;           // first new_segment() -> tap 0, src 0
+
+  auto new_segment = [&]() {
+    if (cursrc == 0 && p.C1 > 0) cursrc = 1; else { cursrc = 0; ++tap; }
+    const int kh = (KS == 3) ? tap / 3 : 0, kw = (KS == 3) ? tap - kh * 3 : 0;
+    const bf16_t* base = cursrc ? src1 : src0;
+    const int Cs = cursrc ? p.C1 : p.C0;
+    seg_left = Cs >> 6;
+    a_ok = 0;
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+      const int iy = a_y[i] + kh, ix = a_x[i] + kw;
+      const bool ok = ((a_rowok >> i) & 1) && (unsigned)iy < (unsigned)Hup && (unsigned)ix < (unsigned)Wup;
+      const long long pix = ((long long)a_b[i] * p.Hin + (iy >> ush)) * p.Win + (ix >> ush);
+      aptr[i] = base + (ok ? pix * Cs : 0) + lchunk * 8;
+      a_ok |= (ok ? 1u : 0u) << i;
+    }
+  };
+
+  auto issue = [&](int stage) {
+    if (seg_left == 0) new_segment();
+    char* sA = smem + stage * STAGE;
+    char* sB = sA + A_BYTES;
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+      const bf16_t* g = ((a_ok >> i) & 1) ? aptr[i] : zp;
+      glds16(g, sA + (i * NW + wid) * 1024);
+      aptr[i] += 64;
+    }
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) {
+      const bf16_t* g = ((b_ok >> i) & 1) ? bptr[i] : zp;
+      glds16(g, sB + (i * NW + wid) * 1024);
+      bptr[i] += 64;
+    }
+    --seg_left;
+  };
+
+  f32x4 acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // fragment read offsets (row&7 == lane&7 because every row base is a multiple of 16)
+  const int frow = lane & 15;
+  int foff[2];
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk) foff[kk] = frow * 128 + ((((kk << 2) + (lane >> 4)) ^ (lane & 7)) << 4);
+
+  const int nk = p.K >> 6;
+  issue(0);
+  for (int ks = 0; ks < nk; ++ks) {
+    const int cur = ks & 1;
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    if (ks + 1 < nk) issue(cur ^ 1);
+    const char* sA = smem + cur * STAGE + wm * WTM * 128;
+    const char* sB = smem + cur * STAGE + A_BYTES + wn * WTN * 128;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      bf16x8 af[MI], bfr[NI];
+#pragma unroll
+      for (int i = 0; i < MI; ++i) af[i] = *(const bf16x8*)(sA + i * 2048 + foff[kk]);
+#pragma unroll
+      for (int j = 0; j < NI; ++j) bfr[j] = *(const bf16x8*)(sB + j * 2048 + foff[kk]);
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    }
+  }
+
+  // ---- epilogue: acc -> LDS fp32 [BM][BN] -> coalesced row chunks -------------------------
+  __syncthreads();
+  float* stg = (float*)smem;
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int ml = wm * WTM + i * 16 + (lane >> 4) * 4 + r;
+        const int nl = wn * WTN + j * 16 + (lane & 15);
+        stg[ml * BN + nl] = acc[i][j][r] * p.alpha;
+      }
+  __syncthreads();
+
+  const int OW = p.geglu ? BN / 2 : BN;            // output columns produced by this tile
+  const int Nout = p.geglu ? p.N / 2 : p.N;
+  const int no0 = p.geglu ? tn * (BN / 2) : n0;
+  const int cpr = OW / 8;
+  const bool vec_ok = ((p.ldo & 7) == 0) && (!p.residual || (p.ldr & 7) == 0);
+  for (int c = tid; c < BM * cpr; c += NT) {
+    const int r = c / cpr, cc = c - r * cpr;
+    const int m = m0 + r;
+    const int no = no0 + cc * 8;
+    if (m >= p.M || no >= Nout) continue;
+    float v[8];
+    const float* sp = stg + r * BN + cc * 8;
+    *(f32x4*)&v[0] = *(const f32x4*)sp;
+    *(f32x4*)&v[4] = *(const f32x4*)(sp + 4);
+    const int nvalid = (Nout - no) < 8 ? (Nout - no) : 8;
+    if (p.geglu) {
+      float g[8];
+      *(f32x4*)&g[0] = *(const f32x4*)(sp + BN / 2);
+      *(f32x4*)&g[4] = *(const f32x4*)(sp + BN / 2 + 4);
+      if (p.bias) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          if (e < nvalid) { v[e] += p.bias[no + e]; g[e] += p.bias[Nout + no + e]; }
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = v[e] * gelu_erf_f(g[e]);
+    } else {
+      if (p.bias_mode == 1) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) if (e < nvalid) v[e] += p.bias[no + e];
+      } else if (p.bias_mode == 2) {
+        const float bm = p.bias[m];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += bm;
+      }
+      if (p.rowadd) {
+        const float* ra = p.rowadd + (long long)(m / HWo) * p.rowadd_ld + no;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) if (e < nvalid) v[e] += ra[e];
+      }
+    }
+    if (p.residual) {
+      const bf16_t* rp = p.residual + bz * p.sR + (long long)m * p.ldr + no;
+      if (vec_ok && nvalid == 8) {
+        const s16x8 rv = *(const s16x8*)rp;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += bf2f((bf16_t)rv[e]);
+      } else {
+        for (int e = 0; e < nvalid; ++e) v[e] += bf2f(rp[e]);
+      }
+    }
+    if (p.act == 1) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = silu_f(v[e]);
+    }
+    if (p.out_f32) {
+      float* op = (float*)p.out + bz * p.sO + (long long)m * p.ldo + no;
+      if (((p.ldo & 3) == 0) && nvalid == 8) {
+        *(f32x4*)op = *(f32x4*)&v[0];
+        *(f32x4*)(op + 4) = *(f32x4*)&v[4];
+      } else {
+        for (int e = 0; e < nvalid; ++e) op[e] = v[e];
+      }
+    } else {
+      bf16_t* op = (bf16_t*)p.out + bz * p.sO + (long long)m * p.ldo + no;
+      if (vec_ok && nvalid == 8) {
+        u32x4 pk;
+        pk[0] = pack_bf2(v[0], v[1]); pk[1] = pack_bf2(v[2], v[3]);
+        pk[2] = pack_bf2(v[4], v[5]); pk[3] = pack_bf2(v[6], v[7]);
+        *(u32x4*)op = pk;
+      } else {
+        for (int e = 0; e < nvalid; ++e) op[e] = f2bf(v[e]);
+      }
+    }
+  }
+}
+
+template <int BM, int BN, int WM, int WN>
+static int launch_cfg(const IgemmP& p, hipStream_t st) {
+  constexpr int NT = WM * WN * 64;
+  constexpr int stage = (BM + BN) * 128;
+  constexpr int lds = (2 * stage > BM * BN * 4) ? 2 * stage : BM * BN * 4;
+  const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+  dim3 grid(tiles, p.batch > 0 ? p.batch : 1);
+  if (p.ksize == 3) {
+    auto kfn = igemm_kernel<BM, BN, WM, WN, 3>;
+    static bool attr3 = false;
+    if (!attr3) { HIP_CHECK_RET(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); attr3 = true; }
+    hipLaunchKernelGGL(kfn, grid, dim3(NT), lds, st, p);
+  } else {
+    auto kfn = igemm_kernel<BM, BN, WM, WN, 1>;
+    static bool attr1 = false;
+    if (!attr1) { HIP_CHECK_RET(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); attr1 = true; }
+    hipLaunchKernelGGL(kfn, grid, dim3(NT), lds, st, p);
+  }
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+
+int launch_igemm(const IgemmP& p, hipStream_t st) {
+  if (p.K & 63 || p.C0 & 63 || p.C1 & 63) { agd_set_error("igemm: K/C0/C1 must be multiples of 64 (K=%d C0=%d C1=%d)", p.K, p.C0, p.C1); return -1; }
+  if (p.K != p.ksize * p.ksize * (p.C0 + p.C1)) { agd_set_error("igemm: K=%d != ks^2*(C0+C1)=%d", p.K, p.ksize * p.ksize * (p.C0 + p.C1)); return -1; }
+  if (p.ksize != 1 && p.ksize != 3) { agd_set_error("igemm: ksize %d", p.ksize); return -1; }
+  if (p.geglu && (p.N % 128)) { agd_set_error("igemm: geglu needs N %% 128 == 0"); return -1; }
+  const long long t128 = (long long)((p.M + 127) / 128) * ((p.N + 127) / 128) * (p.batch > 0 ? p.batch : 1);
+  if (t128 >= 192 || p.geglu) return launch_cfg<128, 128, 2, 2>(p, st);
+  return launch_cfg<64, 64, 2, 2>(p, st);
+}

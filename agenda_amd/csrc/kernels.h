@@ -1,0 +1,81 @@
+// Internal launcher interface between the C-ABI/runtime (model.hip) and the HIP kernels.
+#pragma once
+#include "common.h"
+
+// ---------------------------------------------------------------------------------------
+// Implicit GEMM:  out[M][N] = epilogue( alpha * sum_k A[m][k] * W[n][k] )
+//   A is gathered on the fly from one or two NHWC bf16 sources (channel concat), with optional
+//   nearest-2x upsample of the input and stride/pad (3x3 or 1x1 taps).  k = tap*(C0+C1) + c.
+//   Linear layers are the KS=1, stride=1 case with Hin*Win = tokens.
+// ---------------------------------------------------------------------------------------
+struct IgemmP {
+  const bf16_t* src0; const bf16_t* src1;
+  int C0, C1;
+  int Hin, Win, Hout, Wout;
+  int ksize, stride, pad, up;       // ksize 1|3 ; up 1|2
+  const bf16_t* W;                  // [N][ksize*ksize*(C0+C1)]
+  const float* bias; int bias_mode; // 0 none, 1 per-n, 2 per-m
+  const float* rowadd; int rowadd_ld;  // [image][N] added per output row's image (m / (Hout*Wout))
+  const bf16_t* residual; int ldr;  // [M][Nout]
+  void* out; int out_f32; int ldo;  // Nout = geglu ? N/2 : N
+  int M, N, K;
+  float alpha;
+  int geglu;                        // 1: tile columns are [val half | gate half] -> val*gelu(gate)
+  int act;                          // 0 none, 1 silu on the output
+  int batch;                        // grid.y
+  long long sA0, sA1, sW, sO, sR;   // per-batch element strides
+  const bf16_t* zero_page;          // >= 256 B of zeros
+};
+int launch_igemm(const IgemmP& p, hipStream_t st);
+
+// ---------------------------------------------------------------------------------------
+// Attention (flash, swapped-QK^T formulation).  Q [B][Nq][ldq] (+head*D), K/V [B][Nk][ldk].
+// record_mode: 0 none; 1 DAAM: acc[img][head][t][pix] += P for batch rows >= rec_b0;
+//              2 HOOK: hookmap[img][t][pix] += P / heads (atomic) for batch rows >= rec_b0.
+// ---------------------------------------------------------------------------------------
+struct AttnP {
+  const bf16_t* q; const bf16_t* k; const bf16_t* v; bf16_t* o;
+  int ldq, ldk, ldv, ldo;           // row pitches in elements
+  long long sq, sk, sv, so;         // per-batch strides in elements
+  int B, H, D, Nq, Nk;
+  float scale;
+  int record_mode; int rec_b0;      // first batch row that records (B/2 for CFG inference, 0 for train)
+  float* rec; long long rec_img_stride; long long rec_head_stride;  // DAAM: [img][head][T][Nq]
+  int rec_T;                        // number of token rows to record (<= Nk)
+};
+int launch_attention(const AttnP& p, hipStream_t st);
+
+// ---------------------------------------------------------------------------------------
+// Norms
+// ---------------------------------------------------------------------------------------
+struct GroupNormP {
+  const bf16_t* x0; const bf16_t* x1; int C0, C1;   // optional channel-concat input
+  bf16_t* y;                                         // [B][HW][C0+C1]
+  const float* gamma; const float* beta;
+  int B, HW, groups; float eps; int silu;
+  float* ws;                                         // workspace: B*C*2 (sums) + B*C*2 (scale/shift)
+};
+int launch_groupnorm(const GroupNormP& p, hipStream_t st);
+int launch_layernorm(const bf16_t* x, bf16_t* y, const float* g, const float* b, int rows, int C, float eps, hipStream_t st);
+
+// ---------------------------------------------------------------------------------------
+// Misc elementwise / layout kernels
+// ---------------------------------------------------------------------------------------
+int launch_convert_weight(const float* w, bf16_t* out, int N, int Cin, int taps, int Cpad, int geglu_bn, hipStream_t st);
+int launch_f32_to_bf16(const float* x, bf16_t* y, long long n, hipStream_t st);
+int launch_bf16_to_f32(const bf16_t* x, float* y, long long n, hipStream_t st);
+int launch_prep_latents(const float* lat_nchw, bf16_t* out_nhwc, int B, int C, int HW, int Cpad, int dup, float scale, hipStream_t st);
+int launch_timestep_embed(float t, float* out, int dim, hipStream_t st);
+int launch_small_linear(const float* x, const bf16_t* W, const float* bias, float* out, int M, int N, int K, int silu_in,
+                        int silu_out, hipStream_t st);
+int launch_cfg_ddim(const float* eps_nhwc, int ldc, float* lat_nchw, int B, int C, int HW, float guidance,
+                    float a_t, float a_p, int vpred, hipStream_t st);
+int launch_image_u8(const float* x_nhwc, int ldc, unsigned char* out, long long npix, int C, hipStream_t st);
+int launch_nchw_from_nhwc_f32(const float* x, int ldc, float* out, int B, int C, int HW, hipStream_t st);
+int launch_softmax_rows(const float* s, bf16_t* p, int rows, int cols, hipStream_t st);
+
+// Heat maps
+struct HeatLayer { const float* acc; int side; int heads; long long img_stride; long long head_stride; };
+int launch_daam_global(const HeatLayer* layers, int n_layers, int total_maps, int T, int S, int img, float* out, hipStream_t st);
+int launch_hook_accum(const float* map, int B, int T, int side, int S, float* sum, hipStream_t st);
+int launch_scale(float* x, long long n, float s, hipStream_t st);

@@ -1,0 +1,282 @@
+// Layout / elementwise / heat-map kernels (HBM-bound byte movers) for the AGenDA path on gfx950.
+#include "kernels.h"
+
+// ---------------------------------------------------------------------------------------
+// Weight re-layout: torch [N][Cin][taps] fp32 -> [N][tap][Cpad] bf16 (K = tap-major, channel
+// minor, zero-padded to Cpad).  geglu_bn>0: permute rows so every geglu_bn-wide tile holds
+// [val half | gate half] (ff.net.0.proj: first N/2 rows are values, last N/2 are gates).
+// ---------------------------------------------------------------------------------------
+__global__ void convert_weight_kernel(const float* __restrict__ w, bf16_t* __restrict__ out, int N, int Cin, int taps,
+                                      int Cpad, int geglu_bn) {
+  const long long total = (long long)N * taps * Cpad;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % Cpad);
+    const int tap = (int)((i / Cpad) % taps);
+    const int n = (int)(i / ((long long)Cpad * taps));
+    int src_n = n;
+    if (geglu_bn > 0) {
+      const int half = geglu_bn / 2, j = n / geglu_bn, wi = n % geglu_bn;
+      src_n = (wi < half) ? j * half + wi : N / 2 + j * half + (wi - half);
+    }
+    float v = 0.f;
+    if (c < Cin) v = w[((long long)src_n * Cin + c) * taps + tap];
+    out[i] = f2bf(v);
+  }
+}
+int launch_convert_weight(const float* w, bf16_t* out, int N, int Cin, int taps, int Cpad, int geglu_bn, hipStream_t st) {
+  const long long total = (long long)N * taps * Cpad;
+  const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  hipLaunchKernelGGL(convert_weight_kernel, dim3(grid), dim3(256), 0, st, w, out, N, Cin, taps, Cpad, geglu_bn);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+
+__global__ void f32_to_bf16_kernel(const float* __restrict__ x, bf16_t* __restrict__ y, long long n) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) y[i] = f2bf(x[i]);
+}
+__global__ void bf16_to_f32_kernel(const bf16_t* __restrict__ x, float* __restrict__ y, long long n) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) y[i] = bf2f(x[i]);
+}
+static inline int grid_for(long long n) { long long g = (n + 255) / 256; return (int)(g < 1 ? 1 : (g > 8192 ? 8192 : g)); }
+int launch_f32_to_bf16(const float* x, bf16_t* y, long long n, hipStream_t st) {
+  hipLaunchKernelGGL(f32_to_bf16_kernel, dim3(grid_for(n)), dim3(256), 0, st, x, y, n);
+  HIP_CHECK_RET(hipGetLastError()); return 0;
+}
+int launch_bf16_to_f32(const bf16_t* x, float* y, long long n, hipStream_t st) {
+  hipLaunchKernelGGL(bf16_to_f32_kernel, dim3(grid_for(n)), dim3(256), 0, st, x, y, n);
+  HIP_CHECK_RET(hipGetLastError()); return 0;
+}
+
+// latents NCHW fp32 [B][C][HW] -> NHWC bf16 [dup*B][HW][Cpad] (zero channel pad), * scale
+__global__ void prep_latents_kernel(const float* __restrict__ lat, bf16_t* __restrict__ out, int B, int C, int HW, int Cpad,
+                                    int dup, float scale) {
+  const long long total = (long long)dup * B * HW * Cpad;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % Cpad);
+    const long long px = i / Cpad;
+    const int p = (int)(px % HW);
+    const int b = (int)((px / HW) % B);
+    out[i] = f2bf(c < C ? lat[((long long)b * C + c) * HW + p] * scale : 0.f);
+  }
+}
+int launch_prep_latents(const float* lat, bf16_t* out, int B, int C, int HW, int Cpad, int dup, float scale, hipStream_t st) {
+  hipLaunchKernelGGL(prep_latents_kernel, dim3(grid_for((long long)dup * B * HW * Cpad)), dim3(256), 0, st, lat, out, B, C, HW, Cpad, dup, scale);
+  HIP_CHECK_RET(hipGetLastError()); return 0;
+}
+
+// diffusers Timesteps(dim, flip_sin_to_cos=True, downscale_freq_shift=0): [cos | sin], fp32
+__global__ void timestep_embed_kernel(float t, float* __restrict__ out, int dim) {
+  const int half = dim / 2;
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= half) return;
+  const float freq = expf(-logf(10000.0f) * (float)k / (float)half);
+  const float a = t * freq;
+  out[k] = cosf(a);
+  out[half + k] = sinf(a);
+}
+int launch_timestep_embed(float t, float* out, int dim, hipStream_t st) {
+  hipLaunchKernelGGL(timestep_embed_kernel, dim3((dim / 2 + 255) / 256), dim3(256), 0, st, t, out, dim);
+  HIP_CHECK_RET(hipGetLastError()); return 0;
+}
+
+// Small-M linear (time embedding MLP, per-resnet time_emb_proj): out[m][n] = act(W[n].act_in(x[m]) + b[n])
+// one wave per output column n, M <= 8, W streamed once with 16-B loads.
+__global__ __launch_bounds__(256) void small_linear_kernel(const float* __restrict__ x, const bf16_t* __restrict__ W,
+                                                           const float* __restrict__ bias, float* __restrict__ out,
+                                                           int M, int N, int K, int silu_in, int silu_out) {
+  const int lane = threadIdx.x & 63;
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= N) return;
+  float acc[8];
+#pragma unroll
+  for (int m = 0; m < 8; ++m) acc[m] = 0.f;
+  for (int k0 = lane * 8; k0 < K; k0 += 512) {
+    const s16x8 wv = *(const s16x8*)(W + (long long)n * K + k0);
+    float wf[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) wf[e] = bf2f((bf16_t)wv[e]);
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+      if (m < M) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float xv = x[(long long)m * K + k0 + e];
+          if (silu_in) xv = silu_f(xv);
+          acc[m] += wf[e] * xv;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int m = 0; m < 8; ++m) {
+    float a = acc[m];
+    for (int o = 32; o >= 1; o >>= 1) a += __shfl_xor(a, o);
+    if (lane == 0 && m < M) {
+      a += bias ? bias[n] : 0.f;
+      out[(long long)m * N + n] = silu_out ? silu_f(a) : a;
+    }
+  }
+}
+int launch_small_linear(const float* x, const bf16_t* W, const float* bias, float* out, int M, int N, int K, int silu_in,
+                        int silu_out, hipStream_t st) {
+  if (M > 8 || (K & 7)) { agd_set_error("small_linear: M=%d K=%d unsupported", M, K); return -1; }
+  hipLaunchKernelGGL(small_linear_kernel, dim3((N + 3) / 4), dim3(256), 0, st, x, W, bias, out, M, N, K, silu_in, silu_out);
+  HIP_CHECK_RET(hipGetLastError()); return 0;
+}
+
+// CFG combine + DDIM step (eta=0), in place on fp32 NCHW latents.
+// eps NHWC fp32 [2B][HW][ldc]: rows [0,B) unconditional, [B,2B) conditional.
+__global__ void cfg_ddim_kernel(const float* __restrict__ eps, int ldc, float* __restrict__ lat, int B, int C, int HW,
+                                float guidance, float sa_t, float s1a_t, float sa_p, float s1a_p, int vpred) {
+  const long long total = (long long)B * C * HW;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int p = (int)(i % HW);
+    const int c = (int)((i / HW) % C);
+    const int b = (int)(i / ((long long)HW * C));
+    const float eu = eps[((long long)b * HW + p) * ldc + c];
+    const float ec = eps[((long long)(b + B) * HW + p) * ldc + c];
+    const float mo = eu + guidance * (ec - eu);
+    const float x = lat[i];
+    float x0, e;
+    if (!vpred) { x0 = (x - s1a_t * mo) / sa_t; e = mo; }
+    else { x0 = sa_t * x - s1a_t * mo; e = sa_t * mo + s1a_t * x; }
+    lat[i] = sa_p * x0 + s1a_p * e;
+  }
+}
+int launch_cfg_ddim(const float* eps, int ldc, float* lat, int B, int C, int HW, float guidance, float a_t, float a_p,
+                    int vpred, hipStream_t st) {
+  hipLaunchKernelGGL(cfg_ddim_kernel, dim3(grid_for((long long)B * C * HW)), dim3(256), 0, st, eps, ldc, lat, B, C, HW, guidance,
+                     sqrtf(a_t), sqrtf(1.f - a_t), sqrtf(a_p), sqrtf(1.f - a_p), vpred);
+  HIP_CHECK_RET(hipGetLastError()); return 0;
+}
+
+// diffusers post-process: (x/2+0.5).clamp(0,1) -> round-half-even(255 x) -> uint8, NHWC
+__global__ void image_u8_kernel(const float* __restrict__ x, int ldc, unsigned char* __restrict__ out, long long npix, int C) {
+  const long long total = npix * C;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long px = i / C; const int c = (int)(i % C);
+    float v = x[px * ldc + c] * 0.5f + 0.5f;
+    v = fminf(fmaxf(v, 0.f), 1.f);
+    out[i] = (unsigned char)rintf(v * 255.0f);
+  }
+}
+int launch_image_u8(const float* x, int ldc, unsigned char* out, long long npix, int C, hipStream_t st) {
+  hipLaunchKernelGGL(image_u8_kernel, dim3(grid_for(npix * C)), dim3(256), 0, st, x, ldc, out, npix, C);
+  HIP_CHECK_RET(hipGetLastError()); return 0;
+}
+
+__global__ void nchw_from_nhwc_kernel(const float* __restrict__ x, int ldc, float* __restrict__ out, int B, int C, int HW) {
+  const long long total = (long long)B * C * HW;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int p = (int)(i % HW); const int c = (int)((i / HW) % C); const int b = (int)(i / ((long long)HW * C));
+    out[i] = x[((long long)b * HW + p) * ldc + c];
+  }
+}
+int launch_nchw_from_nhwc_f32(const float* x, int ldc, float* out, int B, int C, int HW, hipStream_t st) {
+  hipLaunchKernelGGL(nchw_from_nhwc_kernel, dim3(grid_for((long long)B * C * HW)), dim3(256), 0, st, x, ldc, out, B, C, HW);
+  HIP_CHECK_RET(hipGetLastError()); return 0;
+}
+
+// Row softmax fp32 -> bf16 (VAE mid-block single-head attention, N x N scores)
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ s, bf16_t* __restrict__ p, int cols) {
+  __shared__ float red[8];
+  const long long row = blockIdx.x;
+  const float* sr = s + row * cols;
+  float mx = -INFINITY;
+  for (int i = threadIdx.x; i < cols; i += 256) mx = fmaxf(mx, sr[i]);
+  for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  float sum = 0.f;
+  for (int i = threadIdx.x; i < cols; i += 256) sum += __expf(sr[i] - mx);
+  for (int o = 32; o >= 1; o >>= 1) sum += __shfl_xor(sum, o);
+  if ((threadIdx.x & 63) == 0) red[4 + (threadIdx.x >> 6)] = sum;
+  __syncthreads();
+  sum = red[4] + red[5] + red[6] + red[7];
+  const float inv = 1.f / sum;
+  for (int i = threadIdx.x; i < cols; i += 256) p[row * cols + i] = f2bf(__expf(sr[i] - mx) * inv);
+}
+int launch_softmax_rows(const float* s, bf16_t* p, int rows, int cols, hipStream_t st) {
+  hipLaunchKernelGGL(softmax_rows_kernel, dim3(rows), dim3(256), 0, st, s, p, cols);
+  HIP_CHECK_RET(hipGetLastError()); return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// Heat-map aggregation.  PyTorch upsample_bicubic2d semantics (align_corners=False, A=-0.75):
+// src = scale*(dst+0.5)-0.5, taps clamped to the border.
+// ---------------------------------------------------------------------------------------
+AGD_DEV float cc1(float x) { const float A = -0.75f; return ((A + 2.f) * x - (A + 3.f)) * x * x + 1.f; }
+AGD_DEV float cc2(float x) { const float A = -0.75f; return ((A * x - 5.f * A) * x + 8.f * A) * x - 4.f * A; }
+AGD_DEV void cubic_coeffs(float t, float* c) { c[0] = cc2(t + 1.f); c[1] = cc1(t); c[2] = cc1(1.f - t); c[3] = cc2(2.f - t); }
+
+AGD_DEV float bicubic_at(const float* __restrict__ m, int side, int S, int oy, int ox) {
+  if (side == S) return m[oy * side + ox];
+  const float scale = (float)side / (float)S;
+  const float ry = scale * (oy + 0.5f) - 0.5f, rx = scale * (ox + 0.5f) - 0.5f;
+  const float fy = floorf(ry), fx = floorf(rx);
+  const int iy = (int)fy, ix = (int)fx;
+  float cy[4], cx[4];
+  cubic_coeffs(ry - fy, cy);
+  cubic_coeffs(rx - fx, cx);
+  float acc = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int yy = min(max(iy - 1 + i, 0), side - 1);
+    float r = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int xx = min(max(ix - 1 + j, 0), side - 1);
+      r += m[yy * side + xx] * cx[j];
+    }
+    acc += r * cy[i];
+  }
+  return acc;
+}
+
+struct HeatLayers { HeatLayer l[24]; int n; };
+
+// daam compute_global_heat_map: mean over every (layer, head) accumulator of clamp(bicubic(acc), 0)
+__global__ void daam_global_kernel(HeatLayers L, int total_maps, int T, int S, int img, float* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= T * S * S) return;
+  const int ox = i % S, oy = (i / S) % S, t = i / (S * S);
+  float sum = 0.f;
+  for (int li = 0; li < L.n; ++li) {
+    const HeatLayer& hl = L.l[li];
+    for (int h = 0; h < hl.heads; ++h) {
+      const float* m = hl.acc + img * hl.img_stride + h * hl.head_stride + (long long)t * hl.side * hl.side;
+      sum += fmaxf(bicubic_at(m, hl.side, S, oy, ox), 0.f);
+    }
+  }
+  out[i] = sum / (float)total_maps;
+}
+int launch_daam_global(const HeatLayer* layers, int n_layers, int total_maps, int T, int S, int img, float* out, hipStream_t st) {
+  if (n_layers > 24) { agd_set_error("daam_global: too many layers"); return -1; }
+  HeatLayers L; L.n = n_layers;
+  for (int i = 0; i < n_layers; ++i) L.l[i] = layers[i];
+  hipLaunchKernelGGL(daam_global_kernel, dim3((T * S * S + 255) / 256), dim3(256), 0, st, L, total_maps, T, S, img, out);
+  HIP_CHECK_RET(hipGetLastError()); return 0;
+}
+
+// hook.py compute_global_heat_map, streamed: sum[b][t] += clamp(bicubic(map[b][t]), 0) per recorded call
+__global__ void hook_accum_kernel(const float* __restrict__ map, int BT, int side, int S, float* __restrict__ sum) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)BT * S * S) return;
+  const int ox = (int)(i % S), oy = (int)((i / S) % S);
+  const long long bt = i / ((long long)S * S);
+  sum[i] += fmaxf(bicubic_at(map + bt * side * side, side, S, oy, ox), 0.f);
+}
+int launch_hook_accum(const float* map, int B, int T, int side, int S, float* sum, hipStream_t st) {
+  const long long n = (long long)B * T * S * S;
+  hipLaunchKernelGGL(hook_accum_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, map, B * T, side, S, sum);
+  HIP_CHECK_RET(hipGetLastError()); return 0;
+}
+
+__global__ void scale_kernel(float* x, long long n, float s) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) x[i] *= s;
+}
+int launch_scale(float* x, long long n, float s, hipStream_t st) {
+  hipLaunchKernelGGL(scale_kernel, dim3(grid_for(n)), dim3(256), 0, st, x, n, s);
+  HIP_CHECK_RET(hipGetLastError()); return 0;
+}

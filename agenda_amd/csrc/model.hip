@@ -1,0 +1,892 @@
+// Host runtime + C-ABI of libagenda_hip.so (see include/agenda_hip.h for the contract).
+// Owns: bf16 re-laid weights, an activation arena, cross-attention K/V caches, heat-map
+// accumulators; walks the SD UNet / VAE-decoder graphs as stream-ordered HIP kernel launches.
+#include "../../include/agenda_hip.h"
+#include "kernels.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+// ---------------------------------------------------------------------------------------
+// errors
+// ---------------------------------------------------------------------------------------
+static thread_local char g_err[2048] = "";
+extern "C" void agd_set_error(const char* fmt, ...) {
+  va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof(g_err), fmt, ap); va_end(ap);
+}
+extern "C" long long agd_groupnorm_ws_floats(int B, int C, int HW, int groups);
+#define CK(expr) do { if ((expr) != 0) return -1; } while (0)
+#define FAIL(...) do { agd_set_error(__VA_ARGS__); return -1; } while (0)
+
+struct WMat { bf16_t* w = nullptr; int N = 0, Cin = 0, Cpad = 0, taps = 0; };
+struct Act { bf16_t* p = nullptr; int B = 0, H = 0, W = 0, C = 0; long long n() const { return (long long)B * H * W * C; } };
+
+struct Arena {
+  char* base = nullptr; size_t cap = 0, off = 0, peak = 0;
+  void* alloc(size_t bytes) {
+    size_t a = (off + 255) & ~(size_t)255;
+    if (a + bytes > cap) { agd_set_error("activation arena exhausted: need %zu + %zu > %zu bytes (raise workspace_bytes)", a, bytes, cap); return nullptr; }
+    off = a + bytes; if (off > peak) peak = off;
+    return base + a;
+  }
+  size_t mark() const { return off; }
+  void release(size_t m) { off = m; }
+};
+
+enum { PC_CONV3 = 0, PC_GEMM, PC_ATTN_SELF, PC_ATTN_CROSS, PC_GN, PC_LN, PC_ELEM, PC_HEAT, PC_VAE_ATTN, PC_OTHER };
+static const char* kClassNames[AGD_N_CLASSES] = {"igemm_conv3x3", "igemm_linear_1x1", "attn_self_flash", "attn_cross_daam",
+                                                 "groupnorm", "layernorm", "elementwise", "heatmap", "vae_attn_softmax", "other"};
+
+struct XLayer {
+  std::string name; int C = 0, heads = 0, level = 0; bool mid = false;
+  WMat wkv; bf16_t* kv = nullptr; float* acc = nullptr; int acc_side = 0;
+};
+
+struct ProfEv { int cls; double flops; hipEvent_t a, b; };
+
+struct agd_ctx {
+  int device = 0; agd_config cfg{}; std::string err;
+  std::unordered_map<std::string, WMat> W;
+  std::unordered_map<std::string, float*> V;
+  std::unordered_map<std::string, int> Vn;
+  std::vector<void*> owned;
+  Arena arena; bf16_t* zero_page = nullptr;
+  float* stage = nullptr; size_t stage_bytes = 0;
+  bool finalized = false;
+  // time embedding
+  WMat tproj_all; float* tproj_bias = nullptr; float* tproj_out = nullptr; int tproj_total = 0;
+  std::unordered_map<std::string, int> tproj_off;
+  float* temb_buf = nullptr;   // [dim | 4dim | 4dim] fp32 scratch
+  float* t_dev = nullptr;
+  // cross attention
+  std::vector<XLayer> xl; std::unordered_map<std::string, int> xl_idx;
+  bf16_t* ctx_bf16 = nullptr; int ctx_B2 = 0, ctx_T = 0;
+  // recorder
+  int rec_mode = 0, rec_is_train = 0, rec_T = 0, rec_B = 0, rec_L = 0;
+  float* hook_sum = nullptr; float* hook_scratch = nullptr; int hook_count = 0, hook_Bp = 0;
+  // denoise scratch
+  bf16_t* lat_bf16 = nullptr; float* eps_nhwc = nullptr; size_t lat_cap = 0;
+  // profiling
+  bool prof_on = false; std::vector<ProfEv> prof; std::vector<hipEvent_t> ev_pool; size_t ev_used = 0;
+  long long launches[AGD_N_CLASSES] = {0};
+};
+
+static int fail_ctx(agd_ctx* c) { if (c) c->err = g_err; return -1; }
+#define API_CK(c, expr) do { if ((expr) != 0) return fail_ctx(c); } while (0)
+
+struct ProfScope {
+  agd_ctx* c; hipStream_t st; bool on; size_t idx;
+  ProfScope(agd_ctx* c_, hipStream_t st_, int cls, double flops) : c(c_), st(st_), on(c_ && c_->prof_on), idx(0) {
+    if (c) c->launches[cls]++;
+    if (!on) return;
+    auto get = [&]() { if (c->ev_used == c->ev_pool.size()) { hipEvent_t e; hipEventCreate(&e); c->ev_pool.push_back(e); } return c->ev_pool[c->ev_used++]; };
+    ProfEv pe; pe.cls = cls; pe.flops = flops; pe.a = get(); pe.b = get();
+    hipEventRecord(pe.a, st);
+    idx = c->prof.size(); c->prof.push_back(pe);
+  }
+  ~ProfScope() { if (on) hipEventRecord(c->prof[idx].b, st); }
+};
+
+template <typename T> static T* dmalloc(agd_ctx* c, size_t n) {
+  void* p = nullptr;
+  if (hipMalloc(&p, n * sizeof(T) ? n * sizeof(T) : 256) != hipSuccess) { agd_set_error("hipMalloc(%zu) failed", n * sizeof(T)); return nullptr; }
+  if (c) c->owned.push_back(p);
+  return (T*)p;
+}
+
+static Act alloc_act(agd_ctx* c, int B, int H, int W, int C) {
+  Act a; a.B = B; a.H = H; a.W = W; a.C = C;
+  a.p = (bf16_t*)c->arena.alloc((size_t)a.n() * 2);
+  return a;
+}
+
+// ---------------------------------------------------------------------------------------
+// op wrappers
+// ---------------------------------------------------------------------------------------
+struct GemmOpt {
+  const float* bias = nullptr; const float* rowadd = nullptr; int rowadd_ld = 0;
+  const bf16_t* residual = nullptr; int ldr = 0; int geglu = 0; int act = 0; int out_f32 = 0; int ldo = 0;
+  int stride = 1, up = 1; float alpha = 1.f;
+};
+
+static int run_conv(agd_ctx* c, hipStream_t st, const bf16_t* s0, int C0, const bf16_t* s1, int C1, int B, int Hin, int Win,
+                    const WMat& w, int ksize, void* out, const GemmOpt& o, const bf16_t* zero_page) {
+  IgemmP p{};
+  p.src0 = s0; p.src1 = s1; p.C0 = C0; p.C1 = C1; p.Hin = Hin; p.Win = Win;
+  p.ksize = ksize; p.stride = o.stride; p.pad = ksize == 3 ? 1 : 0; p.up = o.up;
+  p.Hout = (Hin * o.up + 2 * p.pad - ksize) / o.stride + 1;
+  p.Wout = (Win * o.up + 2 * p.pad - ksize) / o.stride + 1;
+  p.W = w.w; p.bias = o.bias; p.bias_mode = o.bias ? 1 : 0; p.rowadd = o.rowadd; p.rowadd_ld = o.rowadd_ld;
+  p.residual = o.residual; p.N = w.N; p.K = w.taps * w.Cpad; p.M = B * p.Hout * p.Wout;
+  const int nout = o.geglu ? w.N / 2 : w.N;
+  p.ldr = o.ldr ? o.ldr : nout; p.out = out; p.out_f32 = o.out_f32; p.ldo = o.ldo ? o.ldo : nout;
+  p.alpha = o.alpha; p.geglu = o.geglu; p.act = o.act; p.batch = 1; p.zero_page = zero_page;
+  if (w.taps != ksize * ksize || w.Cpad != C0 + C1) FAIL("conv: weight [N=%d taps=%d Cpad=%d] does not match input C=%d+%d ksize=%d", w.N, w.taps, w.Cpad, C0, C1, ksize);
+  ProfScope ps(c, st, ksize == 3 ? PC_CONV3 : PC_GEMM, 2.0 * p.M * (double)p.N * p.K);
+  return launch_igemm(p, st);
+}
+
+static int run_gn(agd_ctx* c, hipStream_t st, const bf16_t* x0, int C0, const bf16_t* x1, int C1, int B, int HW,
+                  const float* gamma, const float* beta, int groups, float eps, int silu, bf16_t* y) {
+  GroupNormP g{}; g.x0 = x0; g.x1 = x1; g.C0 = C0; g.C1 = C1; g.y = y; g.gamma = gamma; g.beta = beta;
+  g.B = B; g.HW = HW; g.groups = groups; g.eps = eps; g.silu = silu;
+  const long long wsf = agd_groupnorm_ws_floats(B, C0 + C1, HW, groups);
+  const size_t mk = c->arena.mark();
+  g.ws = (float*)c->arena.alloc((size_t)wsf * 4);
+  if (!g.ws) return -1;
+  ProfScope ps(c, st, PC_GN, 0);
+  const int rc = launch_groupnorm(g, st);
+  c->arena.release(mk);   // stream-ordered: later kernels that reuse this memory run after the norm
+  return rc;
+}
+
+static const WMat* getW(agd_ctx* c, const std::string& k) {
+  auto it = c->W.find(k);
+  if (it == c->W.end()) { agd_set_error("missing weight '%s'", k.c_str()); return nullptr; }
+  return &it->second;
+}
+static const float* getV(agd_ctx* c, const std::string& k) {
+  auto it = c->V.find(k);
+  if (it == c->V.end()) { agd_set_error("missing tensor '%s'", k.c_str()); return nullptr; }
+  return it->second;
+}
+#define GETW(var, key) const WMat* var = getW(c, key); if (!var) return -1
+#define GETV(var, key) const float* var = getV(c, key); if (!var) return -1
+
+// ResnetBlock2D (norm1-silu-conv1 (+temb) - norm2-silu-conv2 + shortcut)
+static int resnet(agd_ctx* c, hipStream_t st, const std::string& pre, const Act& x0, const Act* x1, int Cout, float eps,
+                  bool has_temb, int groups, Act& out) {
+  const int B = x0.B, H = x0.H, Wd = x0.W, HW = H * Wd;
+  const int C1 = x1 ? x1->C : 0, Cin = x0.C + C1;
+  out = alloc_act(c, B, H, Wd, Cout); if (!out.p) return -1;
+  const size_t mk = c->arena.mark();
+  Act n1 = alloc_act(c, B, H, Wd, Cin); if (!n1.p) return -1;
+  GETV(g1, pre + "norm1.weight"); GETV(b1, pre + "norm1.bias");
+  CK(run_gn(c, st, x0.p, x0.C, x1 ? x1->p : nullptr, C1, B, HW, g1, b1, groups, eps, 1, n1.p));
+  Act h = alloc_act(c, B, H, Wd, Cout); if (!h.p) return -1;
+  GETW(w1, pre + "conv1.weight"); GETV(cb1, pre + "conv1.bias");
+  GemmOpt o1; o1.bias = cb1;
+  if (has_temb) {
+    auto it = c->tproj_off.find(pre);
+    if (it == c->tproj_off.end()) FAIL("no time_emb_proj for %s", pre.c_str());
+    o1.rowadd = c->tproj_out + it->second; o1.rowadd_ld = 0;
+  }
+  CK(run_conv(c, st, n1.p, Cin, nullptr, 0, B, H, Wd, *w1, 3, h.p, o1, c->zero_page));
+  Act n2 = alloc_act(c, B, H, Wd, Cout); if (!n2.p) return -1;
+  GETV(g2, pre + "norm2.weight"); GETV(b2, pre + "norm2.bias");
+  CK(run_gn(c, st, h.p, Cout, nullptr, 0, B, HW, g2, b2, groups, eps, 1, n2.p));
+  const bf16_t* res = x0.p;
+  if (c->W.count(pre + "conv_shortcut.weight")) {
+    GETW(ws, pre + "conv_shortcut.weight"); GETV(bs, pre + "conv_shortcut.bias");
+    GemmOpt os; os.bias = bs;
+    CK(run_conv(c, st, x0.p, x0.C, x1 ? x1->p : nullptr, C1, B, H, Wd, *ws, 1, h.p, os, c->zero_page));  // h is free again
+    res = h.p;
+  } else if (x1 || x0.C != Cout) {
+    FAIL("resnet %s: channel change %d->%d without conv_shortcut", pre.c_str(), Cin, Cout);
+  }
+  GETW(w2, pre + "conv2.weight"); GETV(cb2, pre + "conv2.bias");
+  GemmOpt o2; o2.bias = cb2; o2.residual = res;
+  CK(run_conv(c, st, n2.p, Cout, nullptr, 0, B, H, Wd, *w2, 3, out.p, o2, c->zero_page));
+  c->arena.release(mk);
+  return 0;
+}
+
+static int run_attention(agd_ctx* c, hipStream_t st, int cls, AttnP& a) {
+  const double fl = 4.0 * a.B * a.H * (double)a.Nq * a.Nk * a.D;
+  ProfScope ps(c, st, cls, fl);
+  return launch_attention(a, st);
+}
+
+// cross-attention attn2 body shared by the UNet walk and the agd_cross_attn seam
+static int cross_attention(agd_ctx* c, hipStream_t st, XLayer& xl, const bf16_t* q, int B2, int N, bf16_t* out, bool record) {
+  const int C = xl.C, D = C / xl.heads, T = c->ctx_T;
+  AttnP a{}; a.q = q; a.k = xl.kv; a.v = xl.kv + C; a.o = out;
+  a.ldq = C; a.ldk = 2 * C; a.ldv = 2 * C; a.ldo = C;
+  a.sq = (long long)N * C; a.sk = (long long)T * 2 * C; a.sv = a.sk; a.so = a.sq;
+  a.B = B2; a.H = xl.heads; a.D = D; a.Nq = N; a.Nk = T; a.scale = 1.0f / sqrtf((float)D);
+  a.record_mode = 0;
+  const int side = (int)lrintf(sqrtf((float)N));
+  bool hook_call = false;
+  if (record && c->rec_mode == 1 && !xl.mid && xl.acc) {
+    // daam: factor = latent_side / side; recorded iff factor != 8 (mid block); conditional half only
+    if (c->rec_L / side != 8 && side == xl.acc_side && B2 / 2 == c->rec_B) {
+      a.record_mode = 1; a.rec_b0 = B2 / 2; a.rec = xl.acc; a.rec_T = c->rec_T;
+      a.rec_head_stride = (long long)c->rec_T * N; a.rec_img_stride = a.rec_head_stride * xl.heads;
+    }
+  } else if (record && c->rec_mode == 2 && c->hook_scratch) {
+    const int b0 = c->rec_is_train ? 0 : B2 / 2;
+    if (B2 - b0 == c->hook_Bp) {
+      a.record_mode = 2; a.rec_b0 = b0; a.rec = c->hook_scratch; a.rec_T = T;
+      a.rec_img_stride = (long long)T * N; a.rec_head_stride = 0;
+      if (hipMemsetAsync(c->hook_scratch, 0, (size_t)c->hook_Bp * T * N * 4, st) != hipSuccess) FAIL("memset hook scratch");
+      hook_call = true;
+    }
+  }
+  CK(run_attention(c, st, PC_ATTN_CROSS, a));
+  if (hook_call) {
+    ProfScope ps(c, st, PC_HEAT, 0);
+    CK(launch_hook_accum(c->hook_scratch, c->hook_Bp, T, side, c->rec_L, c->hook_sum, st));
+    c->hook_count++;
+  }
+  return 0;
+}
+
+// Transformer2DModel with one BasicTransformerBlock
+static int transformer(agd_ctx* c, hipStream_t st, const std::string& pre, const Act& x, int heads, int groups, Act& out) {
+  const int B = x.B, HW = x.H * x.W, C = x.C, M = B * HW;
+  out = alloc_act(c, B, x.H, x.W, C); if (!out.p) return -1;
+  const size_t mk = c->arena.mark();
+  const std::string t = pre + "transformer_blocks.0.";
+  Act n = alloc_act(c, B, x.H, x.W, C); if (!n.p) return -1;
+  GETV(gg, pre + "norm.weight"); GETV(gb, pre + "norm.bias");
+  CK(run_gn(c, st, x.p, C, nullptr, 0, B, HW, gg, gb, groups, 1e-6f, 0, n.p));
+  Act h = alloc_act(c, B, x.H, x.W, C); if (!h.p) return -1;
+  { GETW(w, pre + "proj_in.weight"); GETV(b, pre + "proj_in.bias"); GemmOpt o; o.bias = b;
+    CK(run_conv(c, st, n.p, C, nullptr, 0, 1, 1, M, *w, 1, h.p, o, c->zero_page)); }
+  Act ln = n;  // reuse
+  bf16_t* qkv = (bf16_t*)c->arena.alloc((size_t)M * 3 * C * 2); if (!qkv) return -1;
+  bf16_t* att = (bf16_t*)c->arena.alloc((size_t)M * C * 2); if (!att) return -1;
+  // --- self attention ---
+  { GETV(g, t + "norm1.weight"); GETV(b, t + "norm1.bias");
+    { ProfScope ps(c, st, PC_LN, 0); CK(launch_layernorm(h.p, ln.p, g, b, M, C, 1e-5f, st)); }
+    GETW(w, t + "attn1.qkv"); GemmOpt o;
+    CK(run_conv(c, st, ln.p, C, nullptr, 0, 1, 1, M, *w, 1, qkv, o, c->zero_page));
+    AttnP a{}; a.q = qkv; a.k = qkv + C; a.v = qkv + 2 * C; a.o = att;
+    a.ldq = a.ldk = a.ldv = 3 * C; a.ldo = C; a.sq = a.sk = a.sv = (long long)HW * 3 * C; a.so = (long long)HW * C;
+    a.B = B; a.H = heads; a.D = C / heads; a.Nq = HW; a.Nk = HW; a.scale = 1.0f / sqrtf((float)(C / heads));
+    CK(run_attention(c, st, PC_ATTN_SELF, a));
+    GETW(wo, t + "attn1.to_out.0.weight"); GETV(bo, t + "attn1.to_out.0.bias");
+    GemmOpt oo; oo.bias = bo; oo.residual = h.p;
+    CK(run_conv(c, st, att, C, nullptr, 0, 1, 1, M, *wo, 1, h.p, oo, c->zero_page)); }
+  // --- cross attention (the processor seam) ---
+  { GETV(g, t + "norm2.weight"); GETV(b, t + "norm2.bias");
+    { ProfScope ps(c, st, PC_LN, 0); CK(launch_layernorm(h.p, ln.p, g, b, M, C, 1e-5f, st)); }
+    GETW(wq, t + "attn2.to_q.weight"); GemmOpt o;
+    bf16_t* q = qkv;
+    CK(run_conv(c, st, ln.p, C, nullptr, 0, 1, 1, M, *wq, 1, q, o, c->zero_page));
+    auto it = c->xl_idx.find(t + "attn2");
+    if (it == c->xl_idx.end()) FAIL("cross-attn layer %s not registered", (t + "attn2").c_str());
+    if (c->ctx_B2 != B) FAIL("context batch %d != unet batch %d (call agd_set_context)", c->ctx_B2, B);
+    CK(cross_attention(c, st, c->xl[it->second], q, B, HW, att, true));
+    GETW(wo, t + "attn2.to_out.0.weight"); GETV(bo, t + "attn2.to_out.0.bias");
+    GemmOpt oo; oo.bias = bo; oo.residual = h.p;
+    CK(run_conv(c, st, att, C, nullptr, 0, 1, 1, M, *wo, 1, h.p, oo, c->zero_page)); }
+  // --- GEGLU feed-forward ---
+  { GETV(g, t + "norm3.weight"); GETV(b, t + "norm3.bias");
+    { ProfScope ps(c, st, PC_LN, 0); CK(launch_layernorm(h.p, ln.p, g, b, M, C, 1e-5f, st)); }
+    bf16_t* ff = (bf16_t*)c->arena.alloc((size_t)M * 4 * C * 2); if (!ff) return -1;
+    GETW(w1, t + "ff.net.0.proj.weight"); GETV(b1, t + "ff.net.0.proj.bias");
+    GemmOpt o1; o1.bias = b1; o1.geglu = 1;
+    CK(run_conv(c, st, ln.p, C, nullptr, 0, 1, 1, M, *w1, 1, ff, o1, c->zero_page));
+    GETW(w2, t + "ff.net.2.weight"); GETV(b2, t + "ff.net.2.bias");
+    GemmOpt o2; o2.bias = b2; o2.residual = h.p;
+    CK(run_conv(c, st, ff, 4 * C, nullptr, 0, 1, 1, M, *w2, 1, h.p, o2, c->zero_page)); }
+  { GETW(w, pre + "proj_out.weight"); GETV(b, pre + "proj_out.bias"); GemmOpt o; o.bias = b; o.residual = x.p;
+    CK(run_conv(c, st, h.p, C, nullptr, 0, 1, 1, M, *w, 1, out.p, o, c->zero_page)); }
+  c->arena.release(mk);
+  return 0;
+}
+
+// time embedding for a single timestep (inference: identical for every batch row)
+static int time_embed(agd_ctx* c, hipStream_t st, float t) {
+  const int dim = c->cfg.block_out_channels[0], td = dim * 4;
+  ProfScope ps(c, st, PC_ELEM, 0);
+  float* e0 = c->temb_buf; float* e1 = e0 + dim; float* e2 = e1 + td;
+  CK(launch_timestep_embed(t, e0, dim, st));
+  GETW(w1, "unet.time_embedding.linear_1.weight"); GETV(b1, "unet.time_embedding.linear_1.bias");
+  GETW(w2, "unet.time_embedding.linear_2.weight"); GETV(b2, "unet.time_embedding.linear_2.bias");
+  CK(launch_small_linear(e0, w1->w, b1, e1, 1, td, w1->Cpad, 0, 1, st));     // linear_1 + SiLU
+  CK(launch_small_linear(e1, w2->w, b2, e2, 1, td, w2->Cpad, 0, 0, st));     // linear_2 -> temb
+  // every resnet's time_emb_proj(silu(temb)) in one launch
+  CK(launch_small_linear(e2, c->tproj_all.w, c->tproj_bias, c->tproj_out, 1, c->tproj_total, td, 1, 0, st));
+  return 0;
+}
+
+// x: [B2][L*L][64] bf16 (latent channels zero-padded) -> eps [B2][L*L][out_channels] fp32 NHWC
+static int unet_walk(agd_ctx* c, hipStream_t st, const bf16_t* xin, int B2, int L, float t, float* eps_out) {
+  const agd_config& g = c->cfg;
+  const int nl = g.n_levels, G = g.norm_num_groups;
+  const std::string u = "unet.";
+  c->arena.release(0);
+  CK(time_embed(c, st, t));
+  std::vector<Act> skips;
+  Act h = alloc_act(c, B2, L, L, g.block_out_channels[0]); if (!h.p) return -1;
+  { GETW(w, u + "conv_in.weight"); GETV(b, u + "conv_in.bias"); GemmOpt o; o.bias = b;
+    CK(run_conv(c, st, xin, 64, nullptr, 0, B2, L, L, *w, 3, h.p, o, c->zero_page)); }
+  skips.push_back(h);
+  for (int i = 0; i < nl; ++i) {
+    const int co = g.block_out_channels[i];
+    for (int j = 0; j < g.layers_per_block; ++j) {
+      Act r; CK(resnet(c, st, u + "down_blocks." + std::to_string(i) + ".resnets." + std::to_string(j) + ".", h, nullptr, co, 1e-5f, true, G, r));
+      h = r;
+      if (g.down_cross[i]) {
+        Act a; CK(transformer(c, st, u + "down_blocks." + std::to_string(i) + ".attentions." + std::to_string(j) + ".", h, g.num_heads[i], G, a));
+        h = a;
+      }
+      skips.push_back(h);
+    }
+    if (i != nl - 1) {
+      const std::string k = u + "down_blocks." + std::to_string(i) + ".downsamplers.0.conv.";
+      GETW(w, k + "weight"); GETV(b, k + "bias");
+      Act d = alloc_act(c, B2, h.H / 2, h.W / 2, co); if (!d.p) return -1;
+      GemmOpt o; o.bias = b; o.stride = 2;
+      CK(run_conv(c, st, h.p, co, nullptr, 0, B2, h.H, h.W, *w, 3, d.p, o, c->zero_page));
+      h = d; skips.push_back(h);
+    }
+  }
+  { const int cm = g.block_out_channels[nl - 1];
+    Act r; CK(resnet(c, st, u + "mid_block.resnets.0.", h, nullptr, cm, 1e-5f, true, G, r)); h = r;
+    Act a; CK(transformer(c, st, u + "mid_block.attentions.0.", h, g.num_heads[nl - 1], G, a)); h = a;
+    Act r2; CK(resnet(c, st, u + "mid_block.resnets.1.", h, nullptr, cm, 1e-5f, true, G, r2)); h = r2; }
+  for (int i = 0; i < nl; ++i) {
+    const int lvl = nl - 1 - i, co = g.block_out_channels[lvl];
+    for (int j = 0; j < g.layers_per_block + 1; ++j) {
+      Act sk = skips.back(); skips.pop_back();
+      Act r; CK(resnet(c, st, u + "up_blocks." + std::to_string(i) + ".resnets." + std::to_string(j) + ".", h, &sk, co, 1e-5f, true, G, r));
+      h = r;
+      if (g.down_cross[lvl]) {
+        Act a; CK(transformer(c, st, u + "up_blocks." + std::to_string(i) + ".attentions." + std::to_string(j) + ".", h, g.num_heads[lvl], G, a));
+        h = a;
+      }
+    }
+    if (i != nl - 1) {
+      const std::string k = u + "up_blocks." + std::to_string(i) + ".upsamplers.0.conv.";
+      GETW(w, k + "weight"); GETV(b, k + "bias");
+      Act d = alloc_act(c, B2, h.H * 2, h.W * 2, co); if (!d.p) return -1;
+      GemmOpt o; o.bias = b; o.up = 2;
+      CK(run_conv(c, st, h.p, co, nullptr, 0, B2, h.H, h.W, *w, 3, d.p, o, c->zero_page));
+      h = d;
+    }
+  }
+  { Act n = alloc_act(c, B2, L, L, h.C); if (!n.p) return -1;
+    GETV(gg, u + "conv_norm_out.weight"); GETV(gb, u + "conv_norm_out.bias");
+    CK(run_gn(c, st, h.p, h.C, nullptr, 0, B2, L * L, gg, gb, G, 1e-5f, 1, n.p));
+    GETW(w, u + "conv_out.weight"); GETV(b, u + "conv_out.bias");
+    GemmOpt o; o.bias = b; o.out_f32 = 1; o.ldo = g.out_channels;
+    CK(run_conv(c, st, n.p, h.C, nullptr, 0, B2, L, L, *w, 3, eps_out, o, c->zero_page)); }
+  return 0;
+}
+
+// AutoencoderKL.decode: z [B][L*L][64] bf16 (already divided by scaling factor) -> fp32 NHWC [B][8L*8L][ldo=4]
+static int vae_walk(agd_ctx* c, hipStream_t st, const bf16_t* zin, int B, int L, float* img_out) {
+  const agd_config& g = c->cfg;
+  const int nl = g.vae_n_levels, G = g.vae_norm_num_groups;
+  const std::string v = "vae.";
+  c->arena.release(0);
+  const int top = g.vae_block_out_channels[nl - 1];
+  // post_quant_conv (1x1, 4->4) written into a zeroed 64-channel buffer so conv_in sees padded input
+  bf16_t* pq = (bf16_t*)c->arena.alloc((size_t)B * L * L * 64 * 2); if (!pq) return -1;
+  if (hipMemsetAsync(pq, 0, (size_t)B * L * L * 64 * 2, st) != hipSuccess) FAIL("memset pq");
+  { GETW(w, v + "post_quant_conv.weight"); GETV(b, v + "post_quant_conv.bias"); GemmOpt o; o.bias = b; o.ldo = 64;
+    CK(run_conv(c, st, zin, 64, nullptr, 0, B, L, L, *w, 1, pq, o, c->zero_page)); }
+  Act h = alloc_act(c, B, L, L, top); if (!h.p) return -1;
+  { GETW(w, v + "decoder.conv_in.weight"); GETV(b, v + "decoder.conv_in.bias"); GemmOpt o; o.bias = b;
+    CK(run_conv(c, st, pq, 64, nullptr, 0, B, L, L, *w, 3, h.p, o, c->zero_page)); }
+  { Act r; CK(resnet(c, st, v + "decoder.mid_block.resnets.0.", h, nullptr, top, 1e-6f, false, G, r)); h = r; }
+  { // single-head attention over N = L*L tokens, C = top channels, through batched GEMMs
+    const std::string a = v + "decoder.mid_block.attentions.0.";
+    const int N = L * L, C = top, M = B * N;
+    Act out = alloc_act(c, B, L, L, C); if (!out.p) return -1;
+    const size_t mk = c->arena.mark();
+    Act n = alloc_act(c, B, L, L, C); if (!n.p) return -1;
+    GETV(gg, a + "group_norm.weight"); GETV(gb, a + "group_norm.bias");
+    CK(run_gn(c, st, h.p, C, nullptr, 0, B, N, gg, gb, G, 1e-6f, 0, n.p));
+    bf16_t* q = (bf16_t*)c->arena.alloc((size_t)M * C * 2); bf16_t* k = (bf16_t*)c->arena.alloc((size_t)M * C * 2);
+    bf16_t* vT = (bf16_t*)c->arena.alloc((size_t)M * C * 2); bf16_t* att = (bf16_t*)c->arena.alloc((size_t)M * C * 2);
+    float* S = (float*)c->arena.alloc((size_t)B * N * N * 4); bf16_t* P = (bf16_t*)c->arena.alloc((size_t)B * N * N * 2);
+    if (!q || !k || !vT || !att || !S || !P) return -1;
+    GETW(wq, a + "to_q.weight"); GETV(bq, a + "to_q.bias"); GETW(wk, a + "to_k.weight"); GETV(bk, a + "to_k.bias");
+    GETW(wv, a + "to_v.weight"); GETV(bv, a + "to_v.bias"); GETW(wo, a + "to_out.0.weight"); GETV(bo, a + "to_out.0.bias");
+    { GemmOpt o; o.bias = bq; CK(run_conv(c, st, n.p, C, nullptr, 0, 1, 1, M, *wq, 1, q, o, c->zero_page)); }
+    { GemmOpt o; o.bias = bk; CK(run_conv(c, st, n.p, C, nullptr, 0, 1, 1, M, *wk, 1, k, o, c->zero_page)); }
+    { // V^T[b] = Wv . X[b]^T  -> [C][N], bias per output row
+      IgemmP p{}; p.src0 = wv->w; p.C0 = C; p.Hin = 1; p.Win = C; p.Hout = 1; p.Wout = C; p.ksize = 1; p.stride = 1; p.up = 1;
+      p.W = n.p; p.bias = bv; p.bias_mode = 2; p.out = vT; p.ldo = N; p.ldr = N; p.M = C; p.N = N; p.K = C; p.alpha = 1.f;
+      p.batch = B; p.sA0 = 0; p.sW = (long long)N * C; p.sO = (long long)C * N; p.zero_page = c->zero_page;
+      ProfScope ps(c, st, PC_GEMM, 2.0 * B * C * (double)N * C); CK(launch_igemm(p, st)); }
+    { // S[b] = scale * Q[b] K[b]^T  (fp32)
+      IgemmP p{}; p.src0 = q; p.C0 = C; p.Hin = 1; p.Win = N; p.Hout = 1; p.Wout = N; p.ksize = 1; p.stride = 1; p.up = 1;
+      p.W = k; p.out = S; p.out_f32 = 1; p.ldo = N; p.ldr = N; p.M = N; p.N = N; p.K = C; p.alpha = 1.0f / sqrtf((float)C);
+      p.batch = B; p.sA0 = (long long)N * C; p.sW = (long long)N * C; p.sO = (long long)N * N; p.zero_page = c->zero_page;
+      ProfScope ps(c, st, PC_VAE_ATTN, 2.0 * B * N * (double)N * C); CK(launch_igemm(p, st)); }
+    { ProfScope ps(c, st, PC_VAE_ATTN, 0); CK(launch_softmax_rows(S, P, B * N, N, st)); }
+    { // O[b] = P[b] V[b]  via V^T as the [N=C][K=N] operand
+      IgemmP p{}; p.src0 = P; p.C0 = N; p.Hin = 1; p.Win = N; p.Hout = 1; p.Wout = N; p.ksize = 1; p.stride = 1; p.up = 1;
+      p.W = vT; p.out = att; p.ldo = C; p.ldr = C; p.M = N; p.N = C; p.K = N; p.alpha = 1.f;
+      p.batch = B; p.sA0 = (long long)N * N; p.sW = (long long)C * N; p.sO = (long long)N * C; p.zero_page = c->zero_page;
+      ProfScope ps(c, st, PC_VAE_ATTN, 2.0 * B * N * (double)N * C); CK(launch_igemm(p, st)); }
+    { GemmOpt o; o.bias = bo; o.residual = h.p; CK(run_conv(c, st, att, C, nullptr, 0, 1, 1, M, *wo, 1, out.p, o, c->zero_page)); }
+    c->arena.release(mk);
+    h = out; }
+  { Act r; CK(resnet(c, st, v + "decoder.mid_block.resnets.1.", h, nullptr, top, 1e-6f, false, G, r)); h = r; }
+  for (int i = 0; i < nl; ++i) {
+    const int co = g.vae_block_out_channels[nl - 1 - i];
+    for (int j = 0; j < g.vae_layers_per_block + 1; ++j) {
+      Act r; CK(resnet(c, st, v + "decoder.up_blocks." + std::to_string(i) + ".resnets." + std::to_string(j) + ".", h, nullptr, co, 1e-6f, false, G, r));
+      h = r;
+    }
+    if (i != nl - 1) {
+      const std::string k = v + "decoder.up_blocks." + std::to_string(i) + ".upsamplers.0.conv.";
+      GETW(w, k + "weight"); GETV(b, k + "bias");
+      Act d = alloc_act(c, B, h.H * 2, h.W * 2, co); if (!d.p) return -1;
+      GemmOpt o; o.bias = b; o.up = 2;
+      CK(run_conv(c, st, h.p, co, nullptr, 0, B, h.H, h.W, *w, 3, d.p, o, c->zero_page));
+      h = d;
+    }
+  }
+  { Act n = alloc_act(c, B, h.H, h.W, h.C); if (!n.p) return -1;
+    GETV(gg, v + "decoder.conv_norm_out.weight"); GETV(gb, v + "decoder.conv_norm_out.bias");
+    CK(run_gn(c, st, h.p, h.C, nullptr, 0, B, h.H * h.W, gg, gb, G, 1e-6f, 1, n.p));
+    GETW(w, v + "decoder.conv_out.weight"); GETV(b, v + "decoder.conv_out.bias");
+    GemmOpt o; o.bias = b; o.out_f32 = 1; o.ldo = 4;
+    CK(run_conv(c, st, n.p, h.C, nullptr, 0, B, h.H, h.W, *w, 3, img_out, o, c->zero_page)); }
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------
+extern "C" const char* agd_version(void) { return "agenda_hip 0.1 (gfx950)"; }
+extern "C" const char* agd_last_error(agd_ctx* c) { return (c && !c->err.empty()) ? c->err.c_str() : g_err; }
+extern "C" const char* agd_profile_class_name(int cls) { return (cls >= 0 && cls < AGD_N_CLASSES) ? kClassNames[cls] : ""; }
+
+extern "C" agd_ctx* agd_create(int device_id, const agd_config* cfg) {
+  if (!cfg || cfg->struct_size != (int)sizeof(agd_config)) { agd_set_error("agd_create: bad config (struct_size %d != %zu)", cfg ? cfg->struct_size : -1, sizeof(agd_config)); return nullptr; }
+  if (cfg->n_levels < 1 || cfg->n_levels > AGD_MAX_LEVELS || cfg->vae_n_levels < 1 || cfg->vae_n_levels > AGD_MAX_LEVELS) { agd_set_error("agd_create: bad level count"); return nullptr; }
+  for (int i = 0; i < cfg->n_levels; ++i)
+    if (cfg->block_out_channels[i] % 64) { agd_set_error("agd_create: UNet channels must be multiples of 64"); return nullptr; }
+  for (int i = 0; i < cfg->vae_n_levels; ++i)
+    if (cfg->vae_block_out_channels[i] % 64) { agd_set_error("agd_create: VAE channels must be multiples of 64"); return nullptr; }
+  if (cfg->cross_attention_dim % 64) { agd_set_error("agd_create: cross_attention_dim must be a multiple of 64"); return nullptr; }
+  if (hipSetDevice(device_id) != hipSuccess) { agd_set_error("hipSetDevice(%d) failed", device_id); return nullptr; }
+  agd_ctx* c = new agd_ctx(); c->device = device_id; c->cfg = *cfg;
+  const size_t ws = cfg->workspace_bytes > 0 ? (size_t)cfg->workspace_bytes : ((size_t)8 << 30);
+  if (hipMalloc((void**)&c->arena.base, ws) != hipSuccess) { agd_set_error("arena hipMalloc(%zu) failed", ws); delete c; return nullptr; }
+  c->arena.cap = ws;
+  c->zero_page = dmalloc<bf16_t>(c, 2048);
+  c->t_dev = dmalloc<float>(c, 64);
+  if (!c->zero_page || !c->t_dev) { delete c; return nullptr; }
+  hipMemset(c->zero_page, 0, 4096);
+  return c;
+}
+
+extern "C" void agd_destroy(agd_ctx* c) {
+  if (!c) return;
+  hipSetDevice(c->device);
+  hipDeviceSynchronize();
+  for (void* p : c->owned) hipFree(p);
+  if (c->arena.base) hipFree(c->arena.base);
+  if (c->stage) hipFree(c->stage);
+  for (auto e : c->ev_pool) hipEventDestroy(e);
+  delete c;
+}
+
+static bool ends_with(const std::string& s, const char* suf) { const size_t n = strlen(suf); return s.size() >= n && s.compare(s.size() - n, n, suf) == 0; }
+
+extern "C" int agd_load_tensor(agd_ctx* c, const char* name, const void* ptr, int dtype, int ndim, const long long* shape) {
+  if (!c || !name || !ptr || !shape) { agd_set_error("agd_load_tensor: null argument"); return fail_ctx(c); }
+  if (dtype != 0) { agd_set_error("agd_load_tensor: only float32 (dtype 0) supported"); return fail_ctx(c); }
+  hipSetDevice(c->device);
+  long long n = 1; for (int i = 0; i < ndim; ++i) n *= shape[i];
+  const size_t bytes = (size_t)n * 4;
+  if (bytes > c->stage_bytes) {
+    if (c->stage) hipFree(c->stage);
+    if (hipMalloc((void**)&c->stage, bytes) != hipSuccess) { c->stage = nullptr; c->stage_bytes = 0; agd_set_error("stage alloc failed"); return fail_ctx(c); }
+    c->stage_bytes = bytes;
+  }
+  if (hipMemcpy(c->stage, ptr, bytes, hipMemcpyDefault) != hipSuccess) { agd_set_error("copy of '%s' failed", name); return fail_ctx(c); }
+  const std::string k(name);
+  if (ndim == 1) {
+    float* d = dmalloc<float>(c, (size_t)n); if (!d) return fail_ctx(c);
+    hipMemcpy(d, c->stage, bytes, hipMemcpyDeviceToDevice);
+    c->V[k] = d; c->Vn[k] = (int)n;
+  } else if (ndim == 2 || ndim == 4) {
+    WMat w; w.N = (int)shape[0]; w.Cin = (int)shape[1]; w.taps = ndim == 4 ? (int)(shape[2] * shape[3]) : 1;
+    if (w.taps != 1 && w.taps != 9) { agd_set_error("'%s': only 1x1 / 3x3 kernels", name); return fail_ctx(c); }
+    w.Cpad = (w.Cin + 63) / 64 * 64;
+    w.w = dmalloc<bf16_t>(c, (size_t)w.N * w.taps * w.Cpad); if (!w.w) return fail_ctx(c);
+    const int geglu_bn = ends_with(k, "ff.net.0.proj.weight") ? 128 : 0;
+    if (geglu_bn && (w.N % 128)) { agd_set_error("'%s': GEGLU projection rows %d not a multiple of 128", name, w.N); return fail_ctx(c); }
+    API_CK(c, launch_convert_weight(c->stage, w.w, w.N, w.Cin, w.taps, w.Cpad, geglu_bn, 0));
+    hipDeviceSynchronize();
+    c->W[k] = w;
+  } else { agd_set_error("'%s': unsupported ndim %d", name, ndim); return fail_ctx(c); }
+  return 0;
+}
+
+static int concat_rows(agd_ctx* c, const std::vector<const WMat*>& parts, WMat& out) {
+  out = WMat(); out.Cin = parts[0]->Cin; out.Cpad = parts[0]->Cpad; out.taps = parts[0]->taps;
+  for (auto* p : parts) { if (p->Cpad != out.Cpad || p->taps != out.taps) FAIL("concat_rows: mismatched K"); out.N += p->N; }
+  out.w = dmalloc<bf16_t>(c, (size_t)out.N * out.taps * out.Cpad); if (!out.w) return -1;
+  size_t off = 0;
+  for (auto* p : parts) { const size_t nb = (size_t)p->N * p->taps * p->Cpad; hipMemcpy(out.w + off, p->w, nb * 2, hipMemcpyDeviceToDevice); off += nb; }
+  return 0;
+}
+
+extern "C" int agd_finalize(agd_ctx* c) {
+  if (!c) return -1;
+  hipSetDevice(c->device);
+  const agd_config& g = c->cfg;
+  // ---- enumerate transformer blocks: fused QKV + cross K/V weights, recorder layers (daam order: up, down, mid)
+  std::vector<std::pair<std::string, int>> tf;   // (prefix, level)
+  const int nl = g.n_levels;
+  for (int i = 0; i < nl; ++i) { const int lvl = nl - 1 - i;
+    if (g.down_cross[lvl]) for (int j = 0; j < g.layers_per_block + 1; ++j) tf.push_back({"unet.up_blocks." + std::to_string(i) + ".attentions." + std::to_string(j) + ".", lvl}); }
+  for (int i = 0; i < nl; ++i)
+    if (g.down_cross[i]) for (int j = 0; j < g.layers_per_block; ++j) tf.push_back({"unet.down_blocks." + std::to_string(i) + ".attentions." + std::to_string(j) + ".", i});
+  tf.push_back({"unet.mid_block.attentions.0.", nl - 1});
+  for (auto& pr : tf) {
+    const std::string t = pr.first + "transformer_blocks.0.";
+    const WMat* q = getW(c, t + "attn1.to_q.weight"); const WMat* k = getW(c, t + "attn1.to_k.weight"); const WMat* v = getW(c, t + "attn1.to_v.weight");
+    if (!q || !k || !v) return fail_ctx(c);
+    WMat qkv; API_CK(c, concat_rows(c, {q, k, v}, qkv)); c->W[t + "attn1.qkv"] = qkv;
+    const WMat* ck = getW(c, t + "attn2.to_k.weight"); const WMat* cv = getW(c, t + "attn2.to_v.weight");
+    if (!ck || !cv) return fail_ctx(c);
+    XLayer xl; xl.name = t + "attn2"; xl.C = q->N; xl.level = pr.second; xl.heads = g.num_heads[pr.second];
+    xl.mid = pr.first.find("mid_block") != std::string::npos;
+    API_CK(c, concat_rows(c, {ck, cv}, xl.wkv));
+    if (xl.C % xl.heads) { agd_set_error("%s: C %d not divisible by heads %d", xl.name.c_str(), xl.C, xl.heads); return fail_ctx(c); }
+    c->xl_idx[xl.name] = (int)c->xl.size(); c->xl.push_back(xl);
+  }
+  // ---- all time_emb_proj stacked into one [sum Cout][4*dim] matrix
+  { std::vector<const WMat*> parts; std::vector<std::string> pres; int total = 0;
+    for (auto& kv : c->W) if (ends_with(kv.first, "time_emb_proj.weight")) pres.push_back(kv.first.substr(0, kv.first.size() - strlen("time_emb_proj.weight")));
+    std::sort(pres.begin(), pres.end());
+    for (auto& p : pres) { const WMat* w = getW(c, p + "time_emb_proj.weight"); parts.push_back(w); c->tproj_off[p] = total; total += w->N; }
+    if (!parts.empty()) {
+      API_CK(c, concat_rows(c, parts, c->tproj_all)); c->tproj_total = total;
+      c->tproj_bias = dmalloc<float>(c, total); c->tproj_out = dmalloc<float>(c, total);
+      if (!c->tproj_bias || !c->tproj_out) return fail_ctx(c);
+      for (auto& p : pres) { const float* b = getV(c, p + "time_emb_proj.bias"); if (!b) return fail_ctx(c);
+        hipMemcpy(c->tproj_bias + c->tproj_off[p], b, (size_t)c->Vn[p + "time_emb_proj.bias"] * 4, hipMemcpyDeviceToDevice); }
+    }
+    const int dim = g.block_out_channels[0];
+    c->temb_buf = dmalloc<float>(c, (size_t)dim * 9); if (!c->temb_buf) return fail_ctx(c); }
+  hipDeviceSynchronize();
+  c->finalized = true;
+  return 0;
+}
+
+static hipStream_t S(void* s) { return (hipStream_t)s; }
+static int need_final(agd_ctx* c) { if (!c) { agd_set_error("null ctx"); return -1; } if (!c->finalized) { agd_set_error("agd_finalize not called"); return -1; } hipSetDevice(c->device); return 0; }
+
+extern "C" int agd_set_context(agd_ctx* c, const float* ctx_emb, int batch2, int tokens, void* stream) {
+  API_CK(c, need_final(c));
+  hipStream_t st = S(stream);
+  const int Dc = c->cfg.cross_attention_dim;
+  if (tokens > 96) { agd_set_error("set_context: tokens %d > 96 unsupported", tokens); return fail_ctx(c); }
+  if (batch2 != c->ctx_B2 || tokens != c->ctx_T) {
+    c->ctx_bf16 = dmalloc<bf16_t>(c, (size_t)batch2 * tokens * Dc); if (!c->ctx_bf16) return fail_ctx(c);
+    for (auto& xl : c->xl) { xl.kv = dmalloc<bf16_t>(c, (size_t)batch2 * tokens * 2 * xl.C); if (!xl.kv) return fail_ctx(c); }
+    c->ctx_B2 = batch2; c->ctx_T = tokens;
+  }
+  API_CK(c, launch_f32_to_bf16(ctx_emb, c->ctx_bf16, (long long)batch2 * tokens * Dc, st));
+  for (auto& xl : c->xl) {
+    GemmOpt o;
+    API_CK(c, run_conv(c, st, c->ctx_bf16, Dc, nullptr, 0, 1, 1, batch2 * tokens, xl.wkv, 1, xl.kv, o, c->zero_page));
+  }
+  return 0;
+}
+
+static int ensure_lat(agd_ctx* c, int B2, int L) {
+  const size_t need = (size_t)B2 * L * L * 64;
+  if (need > c->lat_cap) {
+    c->lat_bf16 = dmalloc<bf16_t>(c, need); c->eps_nhwc = dmalloc<float>(c, (size_t)B2 * L * L * 4 * 4);
+    if (!c->lat_bf16 || !c->eps_nhwc) return -1;
+    c->lat_cap = need;
+  }
+  return 0;
+}
+
+extern "C" int agd_unet_forward(agd_ctx* c, const float* sample, int batch2, int L, float timestep, float* out, void* stream) {
+  API_CK(c, need_final(c));
+  hipStream_t st = S(stream);
+  API_CK(c, ensure_lat(c, batch2, L));
+  const int Cl = c->cfg.in_channels;
+  { ProfScope ps(c, st, PC_ELEM, 0); API_CK(c, launch_prep_latents(sample, c->lat_bf16, batch2, Cl, L * L, 64, 1, 1.0f, st)); }
+  API_CK(c, unet_walk(c, st, c->lat_bf16, batch2, L, timestep, c->eps_nhwc));
+  { ProfScope ps(c, st, PC_ELEM, 0); API_CK(c, launch_nchw_from_nhwc_f32(c->eps_nhwc, c->cfg.out_channels, out, batch2, c->cfg.out_channels, L * L, st)); }
+  return 0;
+}
+
+// eps strides for cfg_ddim: NCHW eps handled by transposing through the NHWC kernel's stride form
+extern "C" int agd_cfg_ddim_step(agd_ctx* c, const float* eps, float* latents, int batch, int L, float guidance, float alpha_t,
+                                 float alpha_prev, void* stream) {
+  API_CK(c, need_final(c));
+  hipStream_t st = S(stream);
+  API_CK(c, ensure_lat(c, 2 * batch, L));
+  // NCHW eps -> NHWC scratch (tiny), then the fused kernel
+  const int C = c->cfg.out_channels, HW = L * L;
+  // reuse nchw_from_nhwc in the reverse direction: treat eps as "NHWC with ldc=HW" is not valid; do an explicit pass
+  float* tmp = c->eps_nhwc;
+  // out[b][p][c] = eps[b][c][p]  == nchw_from_nhwc with (C,HW) swapped
+  API_CK(c, launch_nchw_from_nhwc_f32(eps, HW, tmp, 2 * batch, HW, C, st));
+  ProfScope ps(c, st, PC_ELEM, 0);
+  API_CK(c, launch_cfg_ddim(tmp, C, latents, batch, C, HW, guidance, alpha_t, alpha_prev, c->cfg.prediction_type, st));
+  return 0;
+}
+
+extern "C" int agd_denoise(agd_ctx* c, float* latents, int batch, int L, int n_steps, const float* timesteps, const float* alpha_t,
+                           const float* alpha_prev, float guidance, void* stream) {
+  API_CK(c, need_final(c));
+  hipStream_t st = S(stream);
+  const int B2 = 2 * batch, Cl = c->cfg.in_channels, HW = L * L;
+  API_CK(c, ensure_lat(c, B2, L));
+  if (c->ctx_B2 != B2) { agd_set_error("denoise: context batch %d != 2*batch %d", c->ctx_B2, B2); return fail_ctx(c); }
+  for (int s = 0; s < n_steps; ++s) {
+    { ProfScope ps(c, st, PC_ELEM, 0); API_CK(c, launch_prep_latents(latents, c->lat_bf16, batch, Cl, HW, 64, 2, 1.0f, st)); }
+    API_CK(c, unet_walk(c, st, c->lat_bf16, B2, L, timesteps[s], c->eps_nhwc));
+    { ProfScope ps(c, st, PC_ELEM, 0);
+      API_CK(c, launch_cfg_ddim(c->eps_nhwc, c->cfg.out_channels, latents, batch, Cl, HW, guidance, alpha_t[s], alpha_prev[s], c->cfg.prediction_type, st)); }
+  }
+  return 0;
+}
+
+extern "C" int agd_vae_decode(agd_ctx* c, const float* latents, int batch, int L, unsigned char* out_u8, float* out_f32, void* stream) {
+  API_CK(c, need_final(c));
+  hipStream_t st = S(stream);
+  API_CK(c, ensure_lat(c, batch, L));
+  const int S8 = L << (c->cfg.vae_n_levels - 1);
+  const long long npix = (long long)batch * S8 * S8;
+  { ProfScope ps(c, st, PC_ELEM, 0);
+    API_CK(c, launch_prep_latents(latents, c->lat_bf16, batch, c->cfg.vae_latent_channels, L * L, 64, 1, 1.0f / c->cfg.vae_scaling_factor, st)); }
+  float* img = nullptr;
+  if (hipMalloc((void**)&img, (size_t)npix * 4 * 4) != hipSuccess) { agd_set_error("vae image alloc failed"); return fail_ctx(c); }
+  int rc = vae_walk(c, st, c->lat_bf16, batch, L, img);
+  if (rc == 0 && out_u8) { ProfScope ps(c, st, PC_ELEM, 0); rc = launch_image_u8(img, 4, out_u8, npix, c->cfg.vae_out_channels, st); }
+  if (rc == 0 && out_f32) {
+    // [npix][4] -> [npix][3] : "NCHW from NHWC" with HW=1 does exactly that per pixel
+    rc = launch_nchw_from_nhwc_f32(img, 4, out_f32, (int)npix, c->cfg.vae_out_channels, 1, st);
+  }
+  hipStreamSynchronize(st);
+  hipFree(img);
+  return rc ? fail_ctx(c) : 0;
+}
+
+// ---- recorder -------------------------------------------------------------------------
+extern "C" int agd_record_config(agd_ctx* c, int mode, int is_train, int rec_tokens) {
+  if (!c) return -1;
+  if (mode < 0 || mode > 2) { agd_set_error("record_config: mode %d", mode); return fail_ctx(c); }
+  c->rec_mode = mode; c->rec_is_train = is_train; c->rec_T = rec_tokens;
+  return 0;
+}
+
+extern "C" int agd_record_reset(agd_ctx* c, int batch, int L, void* stream) {
+  API_CK(c, need_final(c));
+  hipStream_t st = S(stream);
+  const int T = c->rec_T > 0 ? c->rec_T : c->cfg.max_tokens;
+  c->rec_T = T;
+  if (c->rec_mode == 1) {
+    for (auto& xl : c->xl) {
+      if (xl.mid) continue;
+      const int side = L >> xl.level;
+      if (side < 1 || (L / side) == 8) continue;
+      const size_t n = (size_t)batch * xl.heads * T * side * side;
+      if (!xl.acc || xl.acc_side != side || c->rec_B != batch) { xl.acc = dmalloc<float>(c, n); if (!xl.acc) return fail_ctx(c); xl.acc_side = side; }
+      if (hipMemsetAsync(xl.acc, 0, n * 4, st) != hipSuccess) { agd_set_error("memset acc"); return fail_ctx(c); }
+    }
+  } else if (c->rec_mode == 2) {
+    const int Bp = c->rec_is_train ? 2 * batch : batch;   // `batch` = images; UNet batch is 2*batch under CFG
+    const int Tc = c->ctx_T > 0 ? c->ctx_T : c->cfg.max_tokens;
+    if (!c->hook_sum || c->hook_Bp != Bp || c->rec_L != L) {
+      c->hook_sum = dmalloc<float>(c, (size_t)Bp * Tc * L * L); c->hook_scratch = dmalloc<float>(c, (size_t)Bp * Tc * L * L);
+      if (!c->hook_sum || !c->hook_scratch) return fail_ctx(c);
+      c->hook_Bp = Bp;
+    }
+    if (hipMemsetAsync(c->hook_sum, 0, (size_t)Bp * Tc * L * L * 4, st) != hipSuccess) { agd_set_error("memset hook"); return fail_ctx(c); }
+    c->hook_count = 0;
+  }
+  c->rec_B = batch; c->rec_L = L;
+  return 0;
+}
+
+extern "C" int agd_daam_global(agd_ctx* c, int img, int rows, float* out, void* stream) {
+  API_CK(c, need_final(c));
+  hipStream_t st = S(stream);
+  std::vector<HeatLayer> hl; int total = 0;
+  for (auto& xl : c->xl) {
+    if (!xl.acc || xl.mid) continue;
+    HeatLayer h; h.acc = xl.acc; h.side = xl.acc_side; h.heads = xl.heads;
+    h.head_stride = (long long)c->rec_T * xl.acc_side * xl.acc_side; h.img_stride = h.head_stride * xl.heads;
+    hl.push_back(h); total += xl.heads;
+  }
+  if (hl.empty() || c->rec_mode != 1) { agd_set_error("No heat maps found. Did you forget to call `with trace(...)`?"); c->err = g_err; return -2; }
+  if (rows > c->rec_T || img >= c->rec_B) { agd_set_error("daam_global: rows %d > recorded %d or img %d >= %d", rows, c->rec_T, img, c->rec_B); return fail_ctx(c); }
+  { ProfScope ps(c, st, PC_HEAT, 0); API_CK(c, launch_daam_global(hl.data(), (int)hl.size(), total, rows, c->rec_L, img, out, st)); }
+  hipStreamSynchronize(st);
+  return 0;
+}
+
+extern "C" int agd_hook_count(agd_ctx* c) { return c ? c->hook_count : 0; }
+
+extern "C" int agd_hook_global(agd_ctx* c, float* out, void* stream) {
+  API_CK(c, need_final(c));
+  hipStream_t st = S(stream);
+  if (c->hook_count == 0 || !c->hook_sum) { agd_set_error("No heat maps found."); c->err = g_err; return -2; }
+  const long long n = (long long)c->hook_Bp * c->ctx_T * c->rec_L * c->rec_L;
+  hipMemcpyAsync(out, c->hook_sum, (size_t)n * 4, hipMemcpyDeviceToDevice, st);
+  API_CK(c, launch_scale(out, n, 1.0f / (float)c->hook_count, st));
+  hipStreamSynchronize(st);
+  return 0;
+}
+
+extern "C" int agd_cross_attn(agd_ctx* c, const char* layer, const float* hidden, const float* ctx_emb, int batch2, int n_query,
+                              int tokens, float* out, int record, void* stream) {
+  API_CK(c, need_final(c));
+  hipStream_t st = S(stream);
+  auto it = c->xl_idx.find(std::string("unet.") + layer);
+  if (it == c->xl_idx.end()) it = c->xl_idx.find(layer);
+  if (it == c->xl_idx.end()) { agd_set_error("cross_attn: unknown layer '%s'", layer); return fail_ctx(c); }
+  XLayer& xl = c->xl[it->second];
+  if (ctx_emb) API_CK(c, agd_set_context(c, ctx_emb, batch2, tokens, stream));
+  if (c->ctx_B2 != batch2) { agd_set_error("cross_attn: context batch mismatch"); return fail_ctx(c); }
+  const int C = xl.C, M = batch2 * n_query;
+  c->arena.release(0);
+  bf16_t* x = (bf16_t*)c->arena.alloc((size_t)M * C * 2); bf16_t* q = (bf16_t*)c->arena.alloc((size_t)M * C * 2);
+  bf16_t* att = (bf16_t*)c->arena.alloc((size_t)M * C * 2); float* o32 = out;
+  if (!x || !q || !att) return fail_ctx(c);
+  API_CK(c, launch_f32_to_bf16(hidden, x, (long long)M * C, st));
+  const std::string t = xl.name.substr(0, xl.name.size() - 5);   // strip "attn2"
+  const WMat* wq = getW(c, t + "attn2.to_q.weight"); const WMat* wo = getW(c, t + "attn2.to_out.0.weight"); const float* bo = getV(c, t + "attn2.to_out.0.bias");
+  if (!wq || !wo || !bo) return fail_ctx(c);
+  { GemmOpt o; API_CK(c, run_conv(c, st, x, C, nullptr, 0, 1, 1, M, *wq, 1, q, o, c->zero_page)); }
+  API_CK(c, cross_attention(c, st, xl, q, batch2, n_query, att, record != 0));
+  { GemmOpt o; o.bias = bo; o.out_f32 = 1; API_CK(c, run_conv(c, st, att, C, nullptr, 0, 1, 1, M, *wo, 1, o32, o, c->zero_page)); }
+  return 0;
+}
+
+// ---- profiling ------------------------------------------------------------------------
+extern "C" int agd_profile_begin(agd_ctx* c) {
+  if (!c) return -1;
+  c->prof.clear(); c->ev_used = 0; c->prof_on = true;
+  for (int i = 0; i < AGD_N_CLASSES; ++i) c->launches[i] = 0;
+  return 0;
+}
+extern "C" int agd_profile_end(agd_ctx* c, double* ms, double* flops, long long* launches) {
+  if (!c) return -1;
+  hipSetDevice(c->device);
+  hipDeviceSynchronize();
+  for (int i = 0; i < AGD_N_CLASSES; ++i) { ms[i] = 0; flops[i] = 0; launches[i] = c->launches[i]; }
+  for (auto& pe : c->prof) { float t = 0; hipEventElapsedTime(&t, pe.a, pe.b); ms[pe.cls] += t; flops[pe.cls] += pe.flops; }
+  c->prof_on = false; c->prof.clear(); c->ev_used = 0;
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// single-op entry points (fp32 in/out; temp device buffers per call; used by parity tests)
+// ---------------------------------------------------------------------------------------
+struct Tmp {
+  std::vector<void*> v;
+  template <typename T> T* get(size_t n) { void* p = nullptr; if (hipMalloc(&p, n * sizeof(T) + 256) != hipSuccess) { agd_set_error("tmp alloc failed"); return nullptr; } v.push_back(p); return (T*)p; }
+  ~Tmp() { for (void* p : v) hipFree(p); }
+};
+static bf16_t* op_zero_page() {
+  static bf16_t* z = nullptr;
+  if (!z) { hipMalloc((void**)&z, 4096); hipMemset(z, 0, 4096); }
+  return z;
+}
+
+// NCHW fp32 <-> NHWC bf16 (padded) helpers built from the library kernels
+static int to_nhwc_bf16(const float* x, bf16_t* y, int B, int C, int HW, int Cpad, hipStream_t st) { return launch_prep_latents(x, y, B, C, HW, Cpad, 1, 1.0f, st); }
+
+extern "C" int agd_op_conv2d(const float* x, const float* w, const float* bias, float* y, int B, int Cin, int H, int W, int Cout,
+                             int ksize, int stride, int pad, int upsample, void* stream) {
+  hipStream_t st = S(stream); Tmp tmp;
+  if (pad != (ksize == 3 ? 1 : 0)) { agd_set_error("op_conv2d: pad must be 1 for 3x3, 0 for 1x1"); return -1; }
+  const int Cpad = (Cin + 63) / 64 * 64, taps = ksize * ksize, up = upsample ? 2 : 1;
+  const int Ho = (H * up + 2 * pad - ksize) / stride + 1, Wo = (W * up + 2 * pad - ksize) / stride + 1;
+  bf16_t* xb = tmp.get<bf16_t>((size_t)B * H * W * Cpad); bf16_t* wb = tmp.get<bf16_t>((size_t)Cout * taps * Cpad);
+  float* yn = tmp.get<float>((size_t)B * Ho * Wo * Cout);
+  if (!xb || !wb || !yn) return -1;
+  CK(to_nhwc_bf16(x, xb, B, Cin, H * W, Cpad, st));
+  CK(launch_convert_weight(w, wb, Cout, Cin, taps, Cpad, 0, st));
+  WMat wm; wm.w = wb; wm.N = Cout; wm.Cin = Cin; wm.Cpad = Cpad; wm.taps = taps;
+  GemmOpt o; o.bias = bias; o.stride = stride; o.up = up; o.out_f32 = 1;
+  CK(run_conv(nullptr, st, xb, Cpad, nullptr, 0, B, H, W, wm, ksize, yn, o, op_zero_page()));
+  CK(launch_nchw_from_nhwc_f32(yn, Cout, y, B, Cout, Ho * Wo, st));
+  hipStreamSynchronize(st);
+  return 0;
+}
+
+extern "C" int agd_op_linear(const float* x, const float* w, const float* bias, const float* residual, float* y, int M, int K, int N,
+                             int geglu, void* stream) {
+  hipStream_t st = S(stream); Tmp tmp;
+  if (K % 64) { agd_set_error("op_linear: K must be a multiple of 64"); return -1; }
+  const int Nout = geglu ? N / 2 : N;
+  bf16_t* xb = tmp.get<bf16_t>((size_t)M * K); bf16_t* wb = tmp.get<bf16_t>((size_t)N * K);
+  bf16_t* rb = residual ? tmp.get<bf16_t>((size_t)M * Nout) : nullptr;
+  if (!xb || !wb || (residual && !rb)) return -1;
+  CK(launch_f32_to_bf16(x, xb, (long long)M * K, st));
+  CK(launch_convert_weight(w, wb, N, K, 1, K, geglu ? 128 : 0, st));
+  if (residual) CK(launch_f32_to_bf16(residual, rb, (long long)M * Nout, st));
+  WMat wm; wm.w = wb; wm.N = N; wm.Cin = K; wm.Cpad = K; wm.taps = 1;
+  GemmOpt o; o.bias = bias; o.residual = rb; o.geglu = geglu; o.out_f32 = 1;
+  CK(run_conv(nullptr, st, xb, K, nullptr, 0, 1, 1, M, wm, 1, y, o, op_zero_page()));
+  hipStreamSynchronize(st);
+  return 0;
+}
+
+extern "C" int agd_op_groupnorm(const float* x, const float* gamma, const float* beta, float* y, int B, int C, int HW, int groups,
+                                float eps, int silu, void* stream) {
+  hipStream_t st = S(stream); Tmp tmp;
+  bf16_t* xb = tmp.get<bf16_t>((size_t)B * HW * C); bf16_t* yb = tmp.get<bf16_t>((size_t)B * HW * C);
+  float* ws = tmp.get<float>((size_t)agd_groupnorm_ws_floats(B, C, HW, groups)); float* yf = tmp.get<float>((size_t)B * HW * C);
+  if (!xb || !yb || !ws || !yf) return -1;
+  CK(to_nhwc_bf16(x, xb, B, C, HW, C, st));
+  GroupNormP g{}; g.x0 = xb; g.C0 = C; g.y = yb; g.gamma = gamma; g.beta = beta; g.B = B; g.HW = HW; g.groups = groups; g.eps = eps; g.silu = silu; g.ws = ws;
+  CK(launch_groupnorm(g, st));
+  CK(launch_bf16_to_f32(yb, yf, (long long)B * HW * C, st));
+  CK(launch_nchw_from_nhwc_f32(yf, C, y, B, C, HW, st));
+  hipStreamSynchronize(st);
+  return 0;
+}
+
+extern "C" int agd_op_layernorm(const float* x, const float* gamma, const float* beta, float* y, int rows, int C, float eps, void* stream) {
+  hipStream_t st = S(stream); Tmp tmp;
+  bf16_t* xb = tmp.get<bf16_t>((size_t)rows * C); bf16_t* yb = tmp.get<bf16_t>((size_t)rows * C);
+  if (!xb || !yb) return -1;
+  CK(launch_f32_to_bf16(x, xb, (long long)rows * C, st));
+  CK(launch_layernorm(xb, yb, gamma, beta, rows, C, eps, st));
+  CK(launch_bf16_to_f32(yb, y, (long long)rows * C, st));
+  hipStreamSynchronize(st);
+  return 0;
+}
+
+extern "C" int agd_op_attention(const float* q, const float* k, const float* v, float* o, int B, int H, int D, int Nq, int Nk,
+                                float scale, float* probs_out, void* stream) {
+  hipStream_t st = S(stream); Tmp tmp;
+  const int C = H * D;
+  bf16_t* qb = tmp.get<bf16_t>((size_t)B * Nq * C); bf16_t* kb = tmp.get<bf16_t>((size_t)B * Nk * C);
+  bf16_t* vb = tmp.get<bf16_t>((size_t)B * Nk * C); bf16_t* ob = tmp.get<bf16_t>((size_t)B * Nq * C);
+  if (!qb || !kb || !vb || !ob) return -1;
+  CK(launch_f32_to_bf16(q, qb, (long long)B * Nq * C, st));
+  CK(launch_f32_to_bf16(k, kb, (long long)B * Nk * C, st));
+  CK(launch_f32_to_bf16(v, vb, (long long)B * Nk * C, st));
+  AttnP a{}; a.q = qb; a.k = kb; a.v = vb; a.o = ob; a.ldq = a.ldk = a.ldv = a.ldo = C;
+  a.sq = (long long)Nq * C; a.so = a.sq; a.sk = (long long)Nk * C; a.sv = a.sk;
+  a.B = B; a.H = H; a.D = D; a.Nq = Nq; a.Nk = Nk; a.scale = scale;
+  if (probs_out) {
+    if (hipMemsetAsync(probs_out, 0, (size_t)B * H * Nk * Nq * 4, st) != hipSuccess) { agd_set_error("memset probs"); return -1; }
+    a.record_mode = 1; a.rec_b0 = 0; a.rec = probs_out; a.rec_T = Nk;
+    a.rec_head_stride = (long long)Nk * Nq; a.rec_img_stride = a.rec_head_stride * H;
+  }
+  CK(launch_attention(a, st));
+  CK(launch_bf16_to_f32(ob, o, (long long)B * Nq * C, st));
+  hipStreamSynchronize(st);
+  return 0;
+}
+
+extern "C" int agd_op_bicubic_clamp_mean(const float* maps, int n_maps, int T, int side, int S_, float* out, void* stream) {
+  hipStream_t st = S(stream);
+  // n_maps accumulators of [T][side][side]: treat as one layer with n_maps "heads"
+  HeatLayer h; h.acc = maps; h.side = side; h.heads = n_maps; h.head_stride = (long long)T * side * side; h.img_stride = 0;
+  CK(launch_daam_global(&h, 1, n_maps, T, S_, 0, out, st));
+  hipStreamSynchronize(st);
+  return 0;
+}

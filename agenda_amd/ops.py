@@ -1,0 +1,92 @@
+"""Single-op bindings (fp32 torch tensors on the GPU -> HIP kernels -> fp32).  These mirror the
+torch.nn.functional calls that diffusers makes on the reference path so each HIP kernel can be
+parity-tested in isolation through the C ABI (`agd_op_*` in include/agenda_hip.h)."""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+
+
+def _f32c(t):
+    assert t.is_cuda, "ops run on the GPU only (no CPU fallback)"
+    return t.detach().to(torch.float32).contiguous()
+
+
+def conv2d(x, w, bias=None, stride=1, padding=None, upsample=False):
+    lib = _lib.load()
+    x, w = _f32c(x), _f32c(w)
+    b = _f32c(bias) if bias is not None else None
+    B, Cin, H, W = x.shape
+    Cout, _, k, _ = w.shape
+    pad = (1 if k == 3 else 0) if padding is None else padding
+    up = 2 if upsample else 1
+    Ho = (H * up + 2 * pad - k) // stride + 1
+    Wo = (W * up + 2 * pad - k) // stride + 1
+    y = torch.empty(B, Cout, Ho, Wo, device=x.device, dtype=torch.float32)
+    _lib.check(lib.agd_op_conv2d(_lib.ptr(x), _lib.ptr(w), _lib.ptr(b), _lib.ptr(y), B, Cin, H, W, Cout, k, stride,
+                                 pad, int(upsample), _lib.current_stream_ptr()), None, "agd_op_conv2d")
+    return y
+
+
+def linear(x, w, bias=None, residual=None, geglu=False):
+    lib = _lib.load()
+    x2 = _f32c(x).reshape(-1, x.shape[-1])
+    w = _f32c(w)
+    M, K = x2.shape
+    N = w.shape[0]
+    Nout = N // 2 if geglu else N
+    b = _f32c(bias) if bias is not None else None
+    r = _f32c(residual).reshape(M, Nout) if residual is not None else None
+    y = torch.empty(M, Nout, device=x.device, dtype=torch.float32)
+    _lib.check(lib.agd_op_linear(_lib.ptr(x2), _lib.ptr(w), _lib.ptr(b), _lib.ptr(r), _lib.ptr(y), M, K, N, int(geglu),
+                                 _lib.current_stream_ptr()), None, "agd_op_linear")
+    return y.reshape(*x.shape[:-1], Nout)
+
+
+def group_norm(x, groups, gamma, beta, eps=1e-5, silu=False):
+    lib = _lib.load()
+    x = _f32c(x)
+    B, Cc = x.shape[:2]
+    HW = x[0, 0].numel()
+    y = torch.empty_like(x)
+    _lib.check(lib.agd_op_groupnorm(_lib.ptr(x), _lib.ptr(_f32c(gamma)), _lib.ptr(_f32c(beta)), _lib.ptr(y), B, Cc, HW,
+                                    groups, float(eps), int(silu), _lib.current_stream_ptr()), None, "agd_op_groupnorm")
+    return y
+
+
+def layer_norm(x, gamma, beta, eps=1e-5):
+    lib = _lib.load()
+    x = _f32c(x)
+    Cc = x.shape[-1]
+    rows = x.numel() // Cc
+    y = torch.empty_like(x)
+    _lib.check(lib.agd_op_layernorm(_lib.ptr(x), _lib.ptr(_f32c(gamma)), _lib.ptr(_f32c(beta)), _lib.ptr(y), rows, Cc,
+                                    float(eps), _lib.current_stream_ptr()), None, "agd_op_layernorm")
+    return y
+
+
+def attention(q, k, v, heads, scale=None, return_probs=False):
+    """q [B,Nq,H*D], k/v [B,Nk,H*D] -> o [B,Nq,H*D] (+ probs [B,H,Nk,Nq] token-major if asked, Nk<=96)."""
+    lib = _lib.load()
+    q, k, v = _f32c(q), _f32c(k), _f32c(v)
+    B, Nq, Cc = q.shape
+    Nk = k.shape[1]
+    D = Cc // heads
+    scale = D ** -0.5 if scale is None else scale
+    o = torch.empty_like(q)
+    probs = torch.empty(B, heads, Nk, Nq, device=q.device, dtype=torch.float32) if return_probs else None
+    _lib.check(lib.agd_op_attention(_lib.ptr(q), _lib.ptr(k), _lib.ptr(v), _lib.ptr(o), B, heads, D, Nq, Nk, float(scale),
+                                    _lib.ptr(probs), _lib.current_stream_ptr()), None, "agd_op_attention")
+    return (o, probs) if return_probs else o
+
+
+def bicubic_clamp_mean(maps, out_side):
+    """maps [n_maps, T, side, side] -> mean_n clamp(bicubic(maps[n]), 0) : [T, S, S]"""
+    lib = _lib.load()
+    maps = _f32c(maps)
+    n, T, side, _ = maps.shape
+    out = torch.empty(T, out_side, out_side, device=maps.device, dtype=torch.float32)
+    _lib.check(lib.agd_op_bicubic_clamp_mean(_lib.ptr(maps), n, T, side, out_side, _lib.ptr(out),
+                                             _lib.current_stream_ptr()), None, "agd_op_bicubic_clamp_mean")
+    return out

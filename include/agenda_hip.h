@@ -1,0 +1,125 @@
+/* agenda_hip.h -- C ABI of libagenda_hip.so: the MI355X (gfx950) implementation of the AGenDA
+ * data-generation hot path (Stable-Diffusion UNet denoise loop + DAAM cross-attention heat maps +
+ * VAE decode).
+ *
+ * The reference (humansensinglab/AGenDA) has no FFI: the path sits behind three PYTHON surfaces
+ * (SURVEY.md §8b).  Each entry point below names the reference interface it stands under:
+ *   - diffusers `StableDiffusionPipeline.__call__`   reference data_generation/data_generation.py:59
+ *   - `daam.trace(pipe)` / `compute_global_heat_map`  reference data_generation/data_generation.py:57,64
+ *   - diffusers attention-processor protocol          reference data_generation/hook.py:83-122
+ * The Python shim in agenda_amd/ binds these with ctypes.
+ *
+ * Conventions: plain pointers + sizes, no torch types.  Every call returns 0 on success, nonzero on
+ * error (message via agd_last_error).  Tensors are caller-owned DEVICE pointers unless noted; the
+ * library owns only its weights, workspace and heat-map accumulators.  `stream` is a hipStream_t
+ * (NULL = default stream); calls are stream-ordered with no hidden syncs except where noted.
+ * One ctx per GPU per process; calls on one ctx must be serialised by the caller.
+ */
+#ifndef AGENDA_HIP_H
+#define AGENDA_HIP_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct agd_ctx agd_ctx;
+
+#define AGD_MAX_LEVELS 8
+
+/* Architecture description == the fields of unet/config.json + vae/config.json that
+ * `StableDiffusionPipeline.from_pretrained` (data_generation.py:30) reads. */
+typedef struct agd_config {
+  int struct_size;                 /* sizeof(agd_config), ABI guard */
+  int in_channels, out_channels, n_levels;
+  int block_out_channels[AGD_MAX_LEVELS];
+  int down_cross[AGD_MAX_LEVELS];  /* 1 = CrossAttnDownBlock2D at this level */
+  int num_heads[AGD_MAX_LEVELS];
+  int layers_per_block, cross_attention_dim, use_linear_projection, norm_num_groups;
+  int vae_latent_channels, vae_out_channels, vae_n_levels;
+  int vae_block_out_channels[AGD_MAX_LEVELS];
+  int vae_layers_per_block, vae_norm_num_groups;
+  float vae_scaling_factor;
+  int max_tokens;                  /* 77 */
+  int prediction_type;             /* 0 epsilon, 1 v_prediction */
+  long long workspace_bytes;       /* activation arena; 0 = default (8 GiB) */
+} agd_config;
+
+/* ---- lifetime ------------------------------------------------------------------------- */
+agd_ctx* agd_create(int device_id, const agd_config* cfg);
+void agd_destroy(agd_ctx* ctx);
+const char* agd_last_error(agd_ctx* ctx);          /* ctx may be NULL (last global error) */
+
+/* ---- weights: names are the diffusers state-dict keys, UNet keys prefixed "unet.", VAE keys
+ * "vae." (`pipeline.unet` / `pipeline.vae`, data_generation.py:30).  `ptr` may be host or
+ * device memory; dtype 0 = float32.  Synchronous. */
+int agd_load_tensor(agd_ctx* ctx, const char* name, const void* ptr, int dtype, int ndim, const long long* shape);
+int agd_finalize(agd_ctx* ctx);                    /* after the last agd_load_tensor */
+
+/* ---- text context: `encoder_hidden_states` [2B, T, ctx_dim] fp32, rows [0,B) unconditional,
+ * [B,2B) conditional (CFG order assumed by hook.py:48-49).  Projects K/V of every attn2 once. */
+int agd_set_context(agd_ctx* ctx, const float* ctx_emb, int batch2, int tokens, void* stream);
+
+/* ---- `unet(sample, t, encoder_hidden_states).sample`: sample/out fp32 NCHW [B2,4,L,L] */
+int agd_unet_forward(agd_ctx* ctx, const float* sample, int batch2, int latent_side, float timestep, float* out,
+                     void* stream);
+
+/* ---- CFG combine + DDIM (eta 0) step on fp32 NCHW latents [B,4,L,L] in place;
+ * eps is [2B,4,L,L] NCHW.  (`scheduler.step` inside pipeline.__call__) */
+int agd_cfg_ddim_step(agd_ctx* ctx, const float* eps, float* latents, int batch, int latent_side, float guidance,
+                      float alpha_t, float alpha_prev, void* stream);
+
+/* ---- the whole denoise loop of `pipeline(prompt, num_inference_steps=..)` on device:
+ * latents [B,4,L,L] fp32 in/out; per-step timesteps and alpha_cumprod (t, prev) from the host
+ * scheduler.  Heat-map recording follows agd_record_config. */
+int agd_denoise(agd_ctx* ctx, float* latents, int batch, int latent_side, int n_steps, const float* timesteps,
+                const float* alpha_t, const float* alpha_prev, float guidance, void* stream);
+
+/* ---- `vae.decode(latents / scaling_factor)` + image post-process.
+ * out_u8: [B, 8L, 8L, 3] uint8 (may be NULL); out_f32: [B, 8L, 8L, 3] fp32 in [-1,1] (may be NULL) */
+int agd_vae_decode(agd_ctx* ctx, const float* latents, int batch, int latent_side, unsigned char* out_u8,
+                   float* out_f32, void* stream);
+
+/* ---- heat-map recording (daam.trace / hook.py UNetCrossAttentionHooker state)
+ * mode 0 off; 1 DAAM (per-layer/head time sums, mid block excluded, conditional half);
+ * 2 HOOK (hook.py: head-mean per call, every attn2 incl. mid; is_train=1 keeps all batch rows).
+ * rec_tokens: token rows recorded (<= tokens; rows beyond len(prompt)+2 are never read by daam). */
+int agd_record_config(agd_ctx* ctx, int mode, int is_train, int rec_tokens);
+int agd_record_reset(agd_ctx* ctx, int batch, int latent_side, void* stream);   /* hooker.clear() / new trace */
+/* daam `compute_global_heat_map()` for image `img`: out [rows, S, S] fp32 (rows <= rec_tokens). Syncs. */
+int agd_daam_global(agd_ctx* ctx, int img, int rows, float* out, void* stream);
+/* hook.py `compute_global_heat_map()`: out [B', T, S, S]; returns -2 if nothing was recorded. Syncs. */
+int agd_hook_global(agd_ctx* ctx, float* out, void* stream);
+int agd_hook_count(agd_ctx* ctx);
+
+/* ---- the processor seam: one attn2 call (hook.py:91-120) for UNet cross-attention layer
+ * `layer` (module path, e.g. "down_blocks.0.attentions.0.transformer_blocks.0.attn2").
+ * hidden/out fp32 [B2, N, C]; ctx_emb fp32 [B2, T, ctx_dim]; record != 0 feeds the recorder. */
+int agd_cross_attn(agd_ctx* ctx, const char* layer, const float* hidden, const float* ctx_emb, int batch2,
+                   int n_query, int tokens, float* out, int record, void* stream);
+
+/* ---- single-op entry points (fp32 in/out, converted to the bf16 NHWC compute layout inside);
+ * used by the parity tests, mirror torch.nn.functional signatures the oracle uses. */
+int agd_op_conv2d(const float* x_nchw, const float* w, const float* bias, float* y_nchw, int B, int Cin, int H, int W,
+                  int Cout, int ksize, int stride, int pad, int upsample, void* stream);
+int agd_op_linear(const float* x, const float* w, const float* bias, const float* residual, float* y, int M, int K,
+                  int N, int geglu, void* stream);
+int agd_op_groupnorm(const float* x_nchw, const float* gamma, const float* beta, float* y_nchw, int B, int C, int HW,
+                     int groups, float eps, int silu, void* stream);
+int agd_op_layernorm(const float* x, const float* gamma, const float* beta, float* y, int rows, int C, float eps,
+                     void* stream);
+/* q [B,Nq,H*D], k/v [B,Nk,H*D] fp32 -> o [B,Nq,H*D]; probs_out (may be NULL): [B,H,Nk,Nq] fp32, needs Nk<=96 */
+int agd_op_attention(const float* q, const float* k, const float* v, float* o, int B, int H, int D, int Nq, int Nk,
+                     float scale, float* probs_out, void* stream);
+int agd_op_bicubic_clamp_mean(const float* maps, int n_maps, int T, int side, int S, float* out, void* stream);
+
+/* ---- per-kernel-class timing (HIP events on the launch stream) */
+#define AGD_N_CLASSES 10
+int agd_profile_begin(agd_ctx* ctx);
+int agd_profile_end(agd_ctx* ctx, double* ms, double* flops, long long* launches);  /* arrays of AGD_N_CLASSES; syncs */
+const char* agd_profile_class_name(int cls);
+
+const char* agd_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,158 @@
+"""Per-kernel parity: HIP kernels (through the C ABI) vs the fp32 torch ops the oracle is built
+from.  Inputs are rounded to bf16 first so the comparison measures kernel arithmetic
+(bf16 operands, fp32 accumulate, one rounding on output) -- tolerance 2^-7 relative to the
+output scale."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+REL = 2.0 ** -7
+
+
+def bfr(t):
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+def rel_err(got, want):
+    return float((got.cpu() - want).abs().max() / (want.abs().max() + 1e-12))
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from agenda_amd import ops as _ops
+    return _ops
+
+
+@pytest.mark.parametrize("B,Cin,H,Cout,k,stride,up", [
+    (2, 64, 16, 64, 3, 1, False),
+    (2, 128, 16, 320, 3, 1, False),      # N tail (320 = 2.5 tiles of 128)
+    (1, 64, 8, 128, 3, 2, False),        # downsample
+    (1, 64, 8, 64, 3, 1, True),          # nearest-2x upsample fused in the gather
+    (2, 4, 16, 64, 3, 1, False),         # conv_in: 4 channels zero-padded to 64
+    (1, 64, 16, 4, 3, 1, False),         # conv_out: N=4
+    (1, 192, 12, 64, 1, 1, False),       # 1x1
+    (8, 320, 32, 320, 3, 1, False),      # 128x128-tile path (many tiles)
+    (3, 64, 9, 64, 3, 1, False),         # ragged M (243 rows)
+])
+def test_conv2d(ops, B, Cin, H, Cout, k, stride, up):
+    g = torch.Generator().manual_seed(B * 1000 + Cin + Cout + k)
+    x = bfr(torch.randn(B, Cin, H, H, generator=g))
+    w = bfr(torch.randn(Cout, Cin, k, k, generator=g) / math.sqrt(Cin * k * k))
+    b = torch.randn(Cout, generator=g) * 0.1
+    xi = F.interpolate(x, scale_factor=2.0, mode="nearest") if up else x
+    want = F.conv2d(xi, w, b, stride=stride, padding=1 if k == 3 else 0)
+    got = ops.conv2d(x.cuda(), w.cuda(), b.cuda(), stride=stride, upsample=up)
+    assert got.shape == want.shape
+    assert rel_err(got, want) < 1e-4      # fp32 output, bf16-exact inputs: only accumulation order differs
+
+
+@pytest.mark.parametrize("M,K,N,geglu,res", [
+    (256, 320, 320, False, True),
+    (616, 768, 640, False, False),       # M = 8*77 ragged
+    (512, 320, 2560, True, False),       # GEGLU
+    (100, 64, 128, True, True),
+    (2, 1280, 1280, False, False),       # tiny M
+    (4096, 1280, 320, False, True),
+])
+def test_linear(ops, M, K, N, geglu, res):
+    g = torch.Generator().manual_seed(M + K + N)
+    x = bfr(torch.randn(M, K, generator=g))
+    w = bfr(torch.randn(N, K, generator=g) / math.sqrt(K))
+    b = torch.randn(N, generator=g) * 0.1
+    y = F.linear(x, w, b)
+    if geglu:
+        val, gate = y.chunk(2, dim=-1)
+        y = val * F.gelu(gate)
+    r = bfr(torch.randn(M, y.shape[1], generator=g)) if res else None
+    if res:
+        y = y + r
+    got = ops.linear(x.cuda(), w.cuda(), b.cuda(), r.cuda() if res else None, geglu=geglu)
+    assert rel_err(got, y) < 1e-4
+
+
+@pytest.mark.parametrize("B,C,H,groups,silu,eps", [
+    (2, 320, 16, 32, True, 1e-5), (1, 1920, 8, 32, True, 1e-5), (2, 2560, 4, 32, False, 1e-6),
+    (1, 128, 64, 32, True, 1e-6), (2, 64, 8, 32, False, 1e-5), (1, 960, 16, 32, True, 1e-5),
+])
+def test_groupnorm(ops, B, C, H, groups, silu, eps):
+    g = torch.Generator().manual_seed(C + H)
+    x = bfr(torch.randn(B, C, H, H, generator=g) * 2 + 0.5)
+    ga = torch.randn(C, generator=g) * 0.2 + 1
+    be = torch.randn(C, generator=g) * 0.2
+    want = F.group_norm(x, groups, ga, be, eps)
+    if silu:
+        want = F.silu(want)
+    got = ops.group_norm(x.cuda(), groups, ga.cuda(), be.cuda(), eps, silu)
+    assert rel_err(got, want) < REL
+
+
+@pytest.mark.parametrize("rows,C", [(64, 320), (10, 1280), (7, 64), (33, 640)])
+def test_layernorm(ops, rows, C):
+    g = torch.Generator().manual_seed(rows + C)
+    x = bfr(torch.randn(rows, C, generator=g) * 3 + 1)
+    ga = torch.randn(C, generator=g) * 0.2 + 1
+    be = torch.randn(C, generator=g) * 0.2
+    want = F.layer_norm(x, (C,), ga, be, 1e-5)
+    got = ops.layer_norm(x.cuda(), ga.cuda(), be.cuda())
+    assert rel_err(got, want) < REL
+
+
+def _attn_ref(q, k, v, heads):
+    from oracle import sd_oracle as O
+    d = q.shape[-1] // heads
+    qh, kh, vh = (O.head_to_batch_dim(t, heads) for t in (q, k, v))
+    p = O.attention_scores(qh, kh, d ** -0.5)
+    return O.batch_to_head_dim(torch.bmm(p, vh), heads), p
+
+
+@pytest.mark.parametrize("B,H,D,Nq,Nk", [
+    (2, 8, 40, 256, 256), (1, 8, 80, 64, 64), (1, 8, 160, 64, 64), (2, 2, 64, 128, 128),
+    (1, 2, 32, 256, 256), (1, 4, 40, 144, 144),   # ragged query/key tails (768-px mid block)
+    (1, 8, 40, 1024, 1024), (1, 2, 128, 64, 64),
+])
+def test_self_attention(ops, B, H, D, Nq, Nk):
+    g = torch.Generator().manual_seed(D + Nq)
+    q, k, v = (bfr(torch.randn(B, n, H * D, generator=g)) for n in (Nq, Nk, Nk))
+    want, _ = _attn_ref(q, k, v, H)
+    got = ops.attention(q.cuda(), k.cuda(), v.cuda(), H)
+    assert rel_err(got, want) < REL
+
+
+def test_self_attention_online_softmax_rescale(ops):
+    """Force the running max to jump at a later KV tile (a spike key) so the rescale branch runs."""
+    g = torch.Generator().manual_seed(5)
+    B, H, D, N = 1, 2, 64, 256
+    q, k, v = (bfr(torch.randn(B, N, H * D, generator=g)) for _ in range(3))
+    k[:, 200] = q[:, 7] * 4.0          # key 200 (4th tile) dominates query 7
+    k[:, 100] = q[:, 9] * 3.0
+    want, _ = _attn_ref(q, k, v, H)
+    got = ops.attention(q.cuda(), k.cuda(), v.cuda(), H)
+    assert rel_err(got, want) < REL
+
+
+@pytest.mark.parametrize("B,H,D,Nq,Nk", [(2, 8, 40, 256, 77), (2, 8, 80, 64, 77), (2, 8, 160, 16, 77), (2, 2, 64, 64, 77),
+                                          (2, 4, 40, 144, 77), (1, 2, 32, 64, 20)])
+def test_cross_attention_with_probs(ops, B, H, D, Nq, Nk):
+    g = torch.Generator().manual_seed(D + Nq + Nk)
+    q = bfr(torch.randn(B, Nq, H * D, generator=g))
+    k, v = (bfr(torch.randn(B, Nk, H * D, generator=g)) for _ in range(2))
+    want, p = _attn_ref(q, k, v, H)                       # p [B*H, Nq, Nk]
+    got, probs = ops.attention(q.cuda(), k.cuda(), v.cuda(), H, return_probs=True)
+    assert rel_err(got, want) < REL
+    want_p = p.reshape(B, H, Nq, Nk).permute(0, 1, 3, 2)  # token-major [B,H,Nk,Nq]
+    assert float((probs.cpu() - want_p).abs().max()) < 2e-3
+    assert float((probs.cpu().sum(2) - 1).abs().max()) < 1e-3   # rows of P sum to 1
+
+
+def test_bicubic_clamp_mean_matches_torch(ops):
+    g = torch.Generator().manual_seed(3)
+    for side in (8, 16, 32, 64):
+        m = torch.rand(5, 7, side, side, generator=g)
+        m[1] = (m[1] > 0.9).float() * 4      # undershoot -> clamp matters
+        want = torch.stack([F.interpolate(x[None], size=(64, 64), mode="bicubic")[0].clamp_(min=0) for x in m]).mean(0)
+        got = ops.bicubic_clamp_mean(m.cuda(), 64)
+        assert float((got.cpu() - want).abs().max()) < 2e-5
