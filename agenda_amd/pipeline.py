@@ -1,0 +1,423 @@
+"""`StableDiffusionPipeline`-shaped surface over libagenda_hip.so.
+
+Mirrors what the reference touches on `diffusers.StableDiffusionPipeline`
+(reference data_generation/data_generation.py:30-31,47-52,59): `from_pretrained`, `.to("cuda")`,
+`.tokenizer`, `.text_encoder`, `.unet`, `.vae`, `.scheduler`, `set_progress_bar_config`,
+`__call__(prompt, num_inference_steps=, generator=).images[0]`.
+
+Differences that are deliberate:
+ * batched prompts/seeds per call (the reference runs batch 1);
+ * DDIM (eta 0) instead of the checkpoint's default scheduler (BASELINE.json's metric);
+ * initial latents come from a CPU `torch.Generator` (or are passed explicitly) so the CPU oracle
+   and the GPU run share them; a CUDA generator cannot be reproduced on the host;
+ * no safety checker (no weights offline): nothing is ever blacked out.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import json
+import os
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Sequence, Union
+
+import numpy as np
+import torch
+
+from . import _lib
+from .config import SDConfig, CONFIGS, UNetConfig, VAEConfig, SchedulerConfig, cross_attn_layer_names
+from .scheduler import DDIMScheduler
+from .text import SimpleTokenizer, SyntheticTextEncoder
+
+
+@dataclass
+class PipelineOutput:
+    images: list
+    latents: Optional[torch.Tensor] = None
+    nsfw_content_detected: Optional[list] = None
+
+
+def _make_cfg(cfg: SDConfig, workspace_bytes: int) -> _lib.AgdConfig:
+    a = _lib.AgdConfig()
+    a.struct_size = C.sizeof(_lib.AgdConfig)
+    u, v = cfg.unet, cfg.vae
+    a.in_channels, a.out_channels, a.n_levels = u.in_channels, u.out_channels, len(u.block_out_channels)
+    for i, c in enumerate(u.block_out_channels):
+        a.block_out_channels[i] = c
+        a.down_cross[i] = int(u.down_cross[i])
+        a.num_heads[i] = u.num_heads[i]
+    a.layers_per_block, a.cross_attention_dim = u.layers_per_block, u.cross_attention_dim
+    a.use_linear_projection, a.norm_num_groups = int(u.use_linear_projection), u.norm_num_groups
+    a.vae_latent_channels, a.vae_out_channels, a.vae_n_levels = v.latent_channels, v.out_channels, len(v.block_out_channels)
+    for i, c in enumerate(v.block_out_channels):
+        a.vae_block_out_channels[i] = c
+    a.vae_layers_per_block, a.vae_norm_num_groups = v.layers_per_block, v.norm_num_groups
+    a.vae_scaling_factor = v.scaling_factor
+    a.max_tokens = cfg.max_tokens
+    a.prediction_type = 1 if cfg.sched.prediction_type == "v_prediction" else 0
+    a.workspace_bytes = workspace_bytes
+    return a
+
+
+class Engine:
+    """Owns one `agd_ctx` (one per GPU per process)."""
+
+    def __init__(self, cfg: SDConfig, device: int = 0, workspace_bytes: int = 0):
+        if not torch.cuda.is_available():
+            raise _lib.AgendaHipError("agenda_amd needs an MI355X (no CPU fallback)")
+        self.lib = _lib.load()
+        self.cfg = cfg
+        self.device = device
+        self._acfg = _make_cfg(cfg, workspace_bytes)
+        self.ctx = self.lib.agd_create(device, C.byref(self._acfg))
+        if not self.ctx:
+            raise _lib.AgendaHipError("agd_create failed: " + self.lib.agd_last_error(None).decode())
+        self.finalized = False
+
+    def close(self):
+        if getattr(self, "ctx", None):
+            self.lib.agd_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc, what):
+        _lib.check(rc, self.ctx, what)
+
+    def load_state_dict(self, sd: Dict[str, torch.Tensor], prefix: str):
+        for k, t in sd.items():
+            t = t.detach().to(torch.float32).contiguous()
+            shape = (C.c_longlong * t.ndim)(*t.shape)
+            self._ck(self.lib.agd_load_tensor(self.ctx, (prefix + k).encode(), C.c_void_p(t.data_ptr()), 0, t.ndim, shape),
+                     f"agd_load_tensor({prefix + k})")
+
+    def finalize(self):
+        self._ck(self.lib.agd_finalize(self.ctx), "agd_finalize")
+        self.finalized = True
+
+    @staticmethod
+    def _stream():
+        return _lib.current_stream_ptr()
+
+    def set_context(self, ctx_emb: torch.Tensor):
+        ctx_emb = ctx_emb.to(device=f"cuda:{self.device}", dtype=torch.float32).contiguous()
+        b2, t, _ = ctx_emb.shape
+        self._ck(self.lib.agd_set_context(self.ctx, _lib.ptr(ctx_emb), b2, t, self._stream()), "agd_set_context")
+        self._ctx_keepalive = ctx_emb
+
+    def unet_forward(self, sample: torch.Tensor, timestep: float) -> torch.Tensor:
+        sample = sample.to(device=f"cuda:{self.device}", dtype=torch.float32).contiguous()
+        out = torch.empty_like(sample)
+        b2, _, L, _ = sample.shape
+        self._ck(self.lib.agd_unet_forward(self.ctx, _lib.ptr(sample), b2, L, float(timestep), _lib.ptr(out), self._stream()),
+                 "agd_unet_forward")
+        return out
+
+    def denoise(self, latents: torch.Tensor, timesteps, a_t, a_p, guidance: float):
+        assert latents.is_cuda and latents.dtype == torch.float32 and latents.is_contiguous()
+        n = len(timesteps)
+        ts = (C.c_float * n)(*[float(t) for t in timesteps])
+        at = (C.c_float * n)(*[float(x) for x in a_t])
+        ap = (C.c_float * n)(*[float(x) for x in a_p])
+        b, _, L, _ = latents.shape
+        self._ck(self.lib.agd_denoise(self.ctx, _lib.ptr(latents), b, L, n, ts, at, ap, float(guidance), self._stream()),
+                 "agd_denoise")
+        return latents
+
+    def vae_decode(self, latents: torch.Tensor, want_f32: bool = False):
+        latents = latents.to(device=f"cuda:{self.device}", dtype=torch.float32).contiguous()
+        b, _, L, _ = latents.shape
+        S = L * (2 ** (len(self.cfg.vae.block_out_channels) - 1))
+        u8 = torch.empty(b, S, S, 3, device=latents.device, dtype=torch.uint8)
+        f32 = torch.empty(b, S, S, 3, device=latents.device, dtype=torch.float32) if want_f32 else None
+        self._ck(self.lib.agd_vae_decode(self.ctx, _lib.ptr(latents), b, L, _lib.ptr(u8), _lib.ptr(f32), self._stream()),
+                 "agd_vae_decode")
+        return (u8, f32) if want_f32 else u8
+
+    # recorder
+    def record_config(self, mode: int, is_train: bool = False, rec_tokens: int = 0):
+        self._ck(self.lib.agd_record_config(self.ctx, mode, int(is_train), rec_tokens), "agd_record_config")
+
+    def record_reset(self, batch: int, L: int):
+        self._ck(self.lib.agd_record_reset(self.ctx, batch, L, self._stream()), "agd_record_reset")
+
+    def daam_global(self, img: int, rows: int, S: int) -> torch.Tensor:
+        out = torch.empty(rows, S, S, device=f"cuda:{self.device}", dtype=torch.float32)
+        rc = self.lib.agd_daam_global(self.ctx, img, rows, _lib.ptr(out), self._stream())
+        if rc == -2:
+            raise RuntimeError(self.lib.agd_last_error(self.ctx).decode())
+        self._ck(rc, "agd_daam_global")
+        return out
+
+    def hook_global(self, bp: int, T: int, S: int) -> torch.Tensor:
+        out = torch.empty(bp, T, S, S, device=f"cuda:{self.device}", dtype=torch.float32)
+        rc = self.lib.agd_hook_global(self.ctx, _lib.ptr(out), self._stream())
+        if rc == -2:
+            raise RuntimeError("No heat maps found.")          # hook.py:74-77
+        self._ck(rc, "agd_hook_global")
+        return out
+
+    def hook_count(self) -> int:
+        return int(self.lib.agd_hook_count(self.ctx))
+
+    def cross_attn(self, layer: str, hidden: torch.Tensor, ctx_emb: Optional[torch.Tensor], record: bool) -> torch.Tensor:
+        hidden = hidden.to(device=f"cuda:{self.device}", dtype=torch.float32).contiguous()
+        b2, n, _ = hidden.shape
+        t = self.cfg.max_tokens
+        if ctx_emb is not None:
+            ctx_emb = ctx_emb.to(device=hidden.device, dtype=torch.float32).contiguous()
+            t = ctx_emb.shape[1]
+        out = torch.empty_like(hidden)
+        self._ck(self.lib.agd_cross_attn(self.ctx, layer.encode(), _lib.ptr(hidden), _lib.ptr(ctx_emb), b2, n, t,
+                                         _lib.ptr(out), int(record), self._stream()), "agd_cross_attn")
+        return out
+
+    def profile_begin(self):
+        self._ck(self.lib.agd_profile_begin(self.ctx), "agd_profile_begin")
+
+    def profile_end(self):
+        n = _lib.AGD_N_CLASSES
+        ms, fl, ln = (C.c_double * n)(), (C.c_double * n)(), (C.c_longlong * n)()
+        self._ck(self.lib.agd_profile_end(self.ctx, ms, fl, ln), "agd_profile_end")
+        return {self.lib.agd_profile_class_name(i).decode(): {"ms": ms[i], "flops": fl[i], "launches": ln[i]} for i in range(n)}
+
+
+class AttnHandle:
+    """Stand-in for a diffusers `Attention` module of the UNet: identifies the layer for the seam."""
+
+    def __init__(self, unet, name: str, heads: int, is_cross: bool):
+        self.unet, self.name, self.heads, self.is_cross = unet, name, heads, is_cross
+        self.norm_cross = None
+
+
+class UNetHandle:
+    """`pipeline.unet`: config + the attention-processor registry (`set_attn_processor`,
+    `attn_processors`; reference finetune_sd_token.py:755-757 installs hook.py's hooker this way)."""
+
+    def __init__(self, pipe):
+        self._pipe = pipe
+        self.config = pipe.cfg.unet
+        self._default = "AttnProcessor(fused-hip)"
+        names = cross_attn_layer_names(pipe.cfg.unet, include_mid=True)
+        self._attn2 = {n: AttnHandle(self, n, 0, True) for n in names}
+        self._procs = {}
+        for n in names:
+            self._procs[n + ".processor"] = self._default
+            self._procs[n.replace("attn2", "attn1") + ".processor"] = self._default
+
+    @property
+    def attn_processors(self):
+        return dict(self._procs)
+
+    def set_attn_processor(self, proc):
+        from .hook import UNetCrossAttentionHooker
+        if isinstance(proc, dict):
+            procs = proc
+        else:
+            procs = {k: proc for k in self._procs}
+        hookers = {id(p): p for p in procs.values() if isinstance(p, UNetCrossAttentionHooker)}
+        if len(hookers) > 1:
+            raise ValueError("only one UNetCrossAttentionHooker instance may be installed (it is shared by all layers)")
+        self._procs.update(procs)
+        hooker = next(iter(hookers.values()), None)
+        self._pipe._install_hooker(hooker)
+
+    def attn2(self, name: str) -> AttnHandle:
+        return self._attn2[name]
+
+    def __call__(self, sample, timestep, encoder_hidden_states=None):
+        if encoder_hidden_states is not None:
+            self._pipe.engine.set_context(encoder_hidden_states)
+        return self._pipe.engine.unet_forward(sample, float(timestep))
+
+
+class VAEHandle:
+    def __init__(self, pipe):
+        self._pipe = pipe
+        self.config = pipe.cfg.vae
+
+    def decode(self, z):
+        """`vae.decode(z)`: z already divided by scaling_factor by the caller (diffusers convention)."""
+        u8, f32 = self._pipe.engine.vae_decode(z * self.config.scaling_factor, want_f32=True)
+        return f32.permute(0, 3, 1, 2)
+
+
+class StableDiffusionPipeline:
+    def __init__(self, cfg: SDConfig, unet_sd: Dict[str, torch.Tensor], vae_sd: Dict[str, torch.Tensor],
+                 tokenizer=None, text_encoder=None, device: Union[int, str] = 0, workspace_bytes: int = 0):
+        self.cfg = cfg
+        dev = int(str(device).split(":")[-1]) if not isinstance(device, int) and ":" in str(device) else (device if isinstance(device, int) else 0)
+        self.engine = Engine(cfg, dev, workspace_bytes)
+        self.engine.load_state_dict(unet_sd, "unet.")
+        self.engine.load_state_dict(vae_sd, "vae.")
+        self.engine.finalize()
+        self.device = torch.device(f"cuda:{dev}")
+        self.tokenizer = tokenizer or SimpleTokenizer(cfg.max_tokens)
+        self.text_encoder = text_encoder or SyntheticTextEncoder(self.tokenizer, cfg.unet.cross_attention_dim)
+        self.scheduler = DDIMScheduler.from_config(cfg.sched)
+        self.unet = UNetHandle(self)
+        self.vae = VAEHandle(self)
+        self.vae_scale_factor = cfg.vae_scale_factor
+        self._trace = None
+        self._hooker = None
+        self._last_prompt = None
+        self._progress = {}
+
+    # ---- construction -------------------------------------------------------------------
+    @classmethod
+    def from_synthetic(cls, cfg: Union[str, SDConfig] = "sd15", seed: int = 1234, device=0, workspace_bytes: int = 0, **kw):
+        from . import synthetic
+        cfg = CONFIGS[cfg]() if isinstance(cfg, str) else cfg
+        return cls(cfg, synthetic.make_unet_weights(cfg, seed, **kw), synthetic.make_vae_weights(cfg, seed + 1, **kw),
+                   device=device, workspace_bytes=workspace_bytes)
+
+    @classmethod
+    def from_pretrained(cls, path: str, device=0, workspace_bytes: int = 0):
+        """Reads the diffusers on-disk layout (`unet/config.json`, `unet/diffusion_pytorch_model.safetensors`,
+        `vae/...`) that `save_pretrained` writes (reference finetune_sd_token.py:164-187)."""
+        from safetensors.torch import load_file
+
+        def jload(p):
+            with open(p) as f:
+                return json.load(f)
+
+        uc = jload(os.path.join(path, "unet", "config.json"))
+        vc = jload(os.path.join(path, "vae", "config.json"))
+        boc = tuple(uc["block_out_channels"])
+        ahd = uc.get("attention_head_dim", 8)
+        heads = tuple(ahd) if isinstance(ahd, (list, tuple)) else (ahd,) * len(boc)
+        ucfg = UNetConfig(in_channels=uc.get("in_channels", 4), out_channels=uc.get("out_channels", 4), block_out_channels=boc,
+                          down_cross=tuple("CrossAttn" in t for t in uc["down_block_types"]),
+                          layers_per_block=uc.get("layers_per_block", 2), num_heads=heads,
+                          cross_attention_dim=uc.get("cross_attention_dim", 768),
+                          use_linear_projection=uc.get("use_linear_projection", False),
+                          norm_num_groups=uc.get("norm_num_groups", 32))
+        vcfg = VAEConfig(latent_channels=vc.get("latent_channels", 4), out_channels=vc.get("out_channels", 3),
+                         block_out_channels=tuple(vc["block_out_channels"]), layers_per_block=vc.get("layers_per_block", 2),
+                         norm_num_groups=vc.get("norm_num_groups", 32), scaling_factor=vc.get("scaling_factor", 0.18215))
+        sc = SchedulerConfig()
+        sp = os.path.join(path, "scheduler", "scheduler_config.json")
+        if os.path.exists(sp):
+            sj = jload(sp)
+            sc = SchedulerConfig(sj.get("num_train_timesteps", 1000), sj.get("beta_start", 0.00085), sj.get("beta_end", 0.012),
+                                 sj.get("steps_offset", 1), sj.get("set_alpha_to_one", False), sj.get("prediction_type", "epsilon"))
+        cfg = SDConfig(name=os.path.basename(path.rstrip("/")), unet=ucfg, vae=vcfg, sched=sc,
+                       default_sample_size=uc.get("sample_size", 64))
+
+        def wload(sub):
+            for fn in ("diffusion_pytorch_model.safetensors", "model.safetensors"):
+                p = os.path.join(path, sub, fn)
+                if os.path.exists(p):
+                    return load_file(p)
+            raise FileNotFoundError(f"no safetensors weights under {path}/{sub}")
+
+        usd = wload("unet")
+        vsd = {k: v for k, v in wload("vae").items() if k.startswith(("decoder.", "post_quant_conv."))}
+        # pre-0.18 VAE attention naming
+        ren = {"query": "to_q", "key": "to_k", "value": "to_v", "proj_attn": "to_out.0"}
+        vsd = {(".".join(ren.get(p, p) for p in k.split(".")) if ".attentions." in k else k): v for k, v in vsd.items()}
+        tok = txt = None
+        try:  # real CLIP prompt side when the checkpoint carries it
+            from transformers import CLIPTokenizer, CLIPTextModel
+            tok = CLIPTokenizer.from_pretrained(os.path.join(path, "tokenizer"))
+            model = CLIPTextModel.from_pretrained(os.path.join(path, "text_encoder")).eval()
+
+            class _Enc:
+                def __init__(s, m, t):
+                    s.m, s.t = m, t
+
+                def resize_token_embeddings(s, n):
+                    return s.m.resize_token_embeddings(n)
+
+                def get_input_embeddings(s):
+                    return s.m.get_input_embeddings()
+
+                def __call__(s, prompts):
+                    ids = s.t(prompts, padding="max_length", max_length=s.t.model_max_length, truncation=True, return_tensors="pt").input_ids
+                    with torch.no_grad():
+                        return s.m(ids)[0].float()
+            txt = _Enc(model, tok)
+        except Exception:
+            tok = txt = None
+        return cls(cfg, usd, vsd, tokenizer=tok, text_encoder=txt, device=device, workspace_bytes=workspace_bytes)
+
+    def to(self, device):
+        if "cuda" not in str(device):
+            raise _lib.AgendaHipError("agenda_amd runs on the GPU only")
+        return self
+
+    def set_progress_bar_config(self, **kw):
+        self._progress = kw
+
+    # ---- recorder plumbing --------------------------------------------------------------
+    def _install_hooker(self, hooker):
+        self._hooker = hooker
+        if hooker is not None:
+            hooker._bind(self)
+        self._apply_record_mode()
+
+    def _apply_record_mode(self):
+        if self._trace is not None:
+            self.engine.record_config(1, False, self._trace.rec_tokens)
+        elif self._hooker is not None:
+            self.engine.record_config(2, self._hooker.is_train, 0)
+        else:
+            self.engine.record_config(0)
+
+    # ---- prompt -------------------------------------------------------------------------
+    def encode_prompt(self, prompts: List[str], negative: Optional[List[str]] = None) -> torch.Tensor:
+        """[uncond x B, cond x B] context, the CFG batch order (hook.py:48-49)."""
+        neg = negative if negative is not None else [""] * len(prompts)
+        self._last_prompt = prompts[0]
+        return torch.cat([self.text_encoder(neg), self.text_encoder(prompts)], 0)
+
+    # ---- txt2img ------------------------------------------------------------------------
+    @torch.no_grad()
+    def __call__(self, prompt: Union[str, List[str], None] = None, height: Optional[int] = None, width: Optional[int] = None,
+                 num_inference_steps: int = 50, guidance_scale: float = 7.5, negative_prompt=None,
+                 generator: Union[torch.Generator, Sequence[torch.Generator], None] = None, latents: Optional[torch.Tensor] = None,
+                 prompt_embeds: Optional[torch.Tensor] = None, output_type: str = "pil", num_images_per_prompt: int = 1):
+        side = self.cfg.default_sample_size * self.vae_scale_factor
+        height, width = height or side, width or side
+        if height != width or height % 64:
+            raise ValueError("height == width, multiple of 64 required")
+        L = height // self.vae_scale_factor
+        if prompt_embeds is None:
+            prompts = [prompt] if isinstance(prompt, str) else list(prompt)
+            prompts = [p for p in prompts for _ in range(num_images_per_prompt)]
+            negs = None if negative_prompt is None else ([negative_prompt] * len(prompts) if isinstance(negative_prompt, str) else list(negative_prompt))
+            prompt_embeds = self.encode_prompt(prompts, negs)
+        B = prompt_embeds.shape[0] // 2
+        if latents is None:
+            gens = generator if isinstance(generator, (list, tuple)) else [generator] * B
+            parts = []
+            for g in gens:
+                if g is not None and g.device.type != "cpu":
+                    raise ValueError("use a CPU torch.Generator (initial latents are an explicit, host-reproducible input)")
+                parts.append(torch.randn(1, self.cfg.unet.in_channels, L, L, generator=g))
+            latents = torch.cat(parts, 0)
+        lat = (latents.to(torch.float32) * self.scheduler.init_noise_sigma).to(self.device).contiguous().clone()
+        self.engine.set_context(prompt_embeds)
+        self._apply_record_mode()
+        if self._trace is not None or self._hooker is not None:
+            self.engine.record_reset(B, L)
+            if self._trace is not None:
+                self._trace._on_generate(B, L, self._last_prompt)
+            if self._hooker is not None:
+                self._hooker._on_generate(B, L, prompt_embeds.shape[1])
+        ts = self.scheduler.set_timesteps(num_inference_steps)
+        a_t, a_p = self.scheduler.step_coeffs()
+        self.engine.denoise(lat, ts, a_t, a_p, guidance_scale)
+        if output_type == "latent":
+            return PipelineOutput(images=[], latents=lat)
+        u8 = self.engine.vae_decode(lat)
+        if output_type == "pt":
+            return PipelineOutput(images=u8, latents=lat)
+        arr = u8.cpu().numpy()
+        if output_type == "np":
+            return PipelineOutput(images=arr, latents=lat, nsfw_content_detected=[False] * B)
+        from PIL import Image
+        return PipelineOutput(images=[Image.fromarray(a) for a in arr], latents=lat, nsfw_content_detected=[False] * B)

@@ -1,0 +1,133 @@
+"""End-to-end parity of the HIP UNet / VAE / denoise loop / heat maps vs the CPU oracle, through
+the C ABI.  Tolerances: single forward rel-err <= 2^-5 of the output scale after
+~60 stacked bf16 layers; multi-step images by PSNR; heat maps by max-abs on the min-max
+normalised map (<= 2/255)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(got, want):
+    got = got.detach().float().cpu()
+    return float((got - want).abs().max() / (want.abs().max() + 1e-12))
+
+
+def _rms_rel(got, want):
+    got = got.detach().float().cpu()
+    return float(((got - want) ** 2).mean().sqrt() / ((want ** 2).mean().sqrt() + 1e-12))
+
+
+def _psnr(a, b):
+    mse = np.mean((a.astype(np.float64) - b.astype(np.float64)) ** 2)
+    return 99.0 if mse == 0 else 10 * math.log10(255.0 ** 2 / mse)
+
+
+@pytest.fixture(scope="module")
+def tiny_pipe():
+    from agenda_amd import StableDiffusionPipeline, config, synthetic
+    cfg = config.tiny()
+    u = synthetic.make_unet_weights(cfg, 11, bias_std=0.05, perturb_norm=0.1)
+    v = synthetic.make_vae_weights(cfg, 12, bias_std=0.05, perturb_norm=0.1)
+    pipe = StableDiffusionPipeline(cfg, u, v, workspace_bytes=1 << 30)
+    return pipe, cfg, u, v
+
+
+@pytest.mark.parametrize("cfgname,L", [("tiny", 16), ("tiny40", 16)])
+def test_unet_forward_matches_oracle(cfgname, L):
+    from agenda_amd import StableDiffusionPipeline, config, synthetic
+    from oracle import sd_oracle as O
+    cfg = config.CONFIGS[cfgname]()
+    u = synthetic.make_unet_weights(cfg, 21, bias_std=0.05, perturb_norm=0.1)
+    v = synthetic.make_vae_weights(cfg, 22)
+    pipe = StableDiffusionPipeline(cfg, u, v, workspace_bytes=1 << 30)
+    ctx = synthetic.make_context(cfg, 2, seed=3)
+    x = synthetic.make_latents(cfg, [0, 1, 2, 3], L)
+    x = x.to(torch.bfloat16).float()
+    with torch.no_grad():
+        want = O.unet_forward(u, cfg.unet, x, torch.tensor(501), ctx)
+    pipe.engine.set_context(ctx)
+    got = pipe.engine.unet_forward(x, 501.0)
+    assert got.shape == want.shape
+    assert _rms_rel(got, want) < 2.0 ** -6, _rms_rel(got, want)
+    assert _rel(got, want) < 2.0 ** -4, _rel(got, want)
+    pipe.engine.close()
+
+
+def test_vae_decode_matches_oracle(tiny_pipe):
+    from agenda_amd import synthetic
+    from oracle import sd_oracle as O
+    pipe, cfg, u, v = tiny_pipe
+    z = synthetic.make_latents(cfg, [5, 6], 16).to(torch.bfloat16).float()
+    with torch.no_grad():
+        want = O.vae_decode(v, cfg.vae, z / cfg.vae.scaling_factor)          # [B,3,H,W]
+        want_u8 = O.postprocess_image(want)
+    u8, f32 = pipe.engine.vae_decode(z, want_f32=True)
+    got = f32.permute(0, 3, 1, 2)
+    assert _rms_rel(got, want) < 2.0 ** -6, _rms_rel(got, want)
+    assert _psnr(u8.cpu().numpy(), want_u8) > 35.0
+
+
+def test_generate_with_daam_matches_oracle(tiny_pipe):
+    from agenda_amd import synthetic, trace
+    from oracle import sd_oracle as O
+    pipe, cfg, u, v = tiny_pipe
+    B, L, steps = 2, 16, 4
+    ctx = synthetic.make_context(cfg, B, seed=9)
+    lat = synthetic.make_latents(cfg, [100, 101], L)
+    rec = O.DaamRecorder(L * L, context_size=cfg.max_tokens)
+    want_img, want_lat = O.generate(u, v, cfg, ctx, lat, steps, 7.5, recorder=rec)
+    with trace(pipe) as trc:
+        out = pipe(prompt_embeds=ctx, latents=lat, num_inference_steps=steps, output_type="np")
+        got_maps = [trc.compute_global_heat_map(prompt=None, image_index=i).heat_maps for i in range(B)]
+    assert _rms_rel(out.latents, want_lat) < 0.05, _rms_rel(out.latents, want_lat)
+    assert _psnr(out.images, want_img) > 30.0, _psnr(out.images, want_img)
+    want_maps = rec.compute_global_heat_map()            # [B, T, S, S]
+    assert len(rec.acc) > 0
+    for i in range(B):
+        g, w = got_maps[i].cpu(), want_maps[i]
+        assert g.shape == w.shape
+        # per-token min-max normalised maps (what data_generation.py:82 exports) within 2/255
+        for t in (0, 1, 5, 20, 76):
+            gn = (g[t] - g[t].min()) / (g[t].max() - g[t].min() + 1e-8)
+            wn = (w[t] - w[t].min()) / (w[t].max() - w[t].min() + 1e-8)
+            assert float((gn - wn).abs().max()) < 2.5 / 255 * 4, (i, t, float((gn - wn).abs().max()))
+        assert _rel(g, w) < 0.03, _rel(g, w)
+
+
+def test_trace_without_generation_raises(tiny_pipe):
+    from agenda_amd import trace
+    pipe = tiny_pipe[0]
+    with trace(pipe) as trc:
+        with pytest.raises(RuntimeError, match="No heat maps found"):
+            trc.compute_global_heat_map()
+
+
+def test_hook_mode_matches_oracle(tiny_pipe):
+    """hook.py semantics inside the fused UNet walk: head-mean per call, every attn2 (mid included),
+    conditional half only (is_train=False), mean over all calls of clamp(bicubic)."""
+    from agenda_amd import synthetic, UNetCrossAttentionHooker
+    from oracle import sd_oracle as O
+    pipe, cfg, u, v = tiny_pipe
+    B, L, steps = 2, 16, 2
+    ctx = synthetic.make_context(cfg, B, seed=19)
+    lat = synthetic.make_latents(cfg, [7, 8], L)
+    hk = UNetCrossAttentionHooker(is_train=False, latent_hw=L)
+    with pytest.raises(RuntimeError, match="No heat maps found."):
+        hk.compute_global_heat_map()
+    pipe.unet.set_attn_processor(hk)
+    try:
+        out = pipe(prompt_embeds=ctx, latents=lat, num_inference_steps=steps, output_type="latent")
+        got = hk.compute_global_heat_map()
+        n_calls = hk.num_recorded
+    finally:
+        pipe.unet.set_attn_processor("default")
+    rec = O.HookRecorder(is_train=False, latent_hw=L)
+    O.generate(u, v, cfg, ctx, lat, steps, 7.5, recorder=rec, decode=False)
+    want = rec.compute_global_heat_map()
+    assert n_calls == len(rec.cross_attn_maps)
+    assert got.shape == want.shape
+    assert _rel(got, want) < 0.03, _rel(got, want)
