@@ -1,0 +1,165 @@
+"""Driver for the generation hot loop, mirroring reference data_generation/data_generation.py:26-86
+(token selection, per-seed image + per-word DAAM heat-map export), batched and seed-sharded
+across ranks: images are independent per seed, so rank r takes seeds
+s = r (mod world); the only exchange is one all_gather of uint8 images + fp32 word heat maps per
+batch (RCCL over xGMI on GPUs; gloo in the CPU tests)."""
+from __future__ import annotations
+
+import argparse
+import os
+from typing import List, Optional, Sequence
+
+import numpy as np
+import torch
+
+
+def select_learned_tokens(prompt_template: str, initialize_token: Sequence[str], learned: Sequence[str],
+                          word_token_heatmaps: Optional[List[str]], store_learnable: bool):
+    """data_generation.py:36-43,54 -- a learned token is used iff its init word is a substring of the
+    UNFORMATTED template; the heat-map word list aliases the CLI list and is appended in place."""
+    words = word_token_heatmaps if word_token_heatmaps is not None else []
+    new_tokens = []
+    for t, n in zip(initialize_token, learned):
+        if t in prompt_template:
+            if store_learnable:
+                words.append(n)
+            new_tokens.append(n)
+    return new_tokens, words, prompt_template.format(*new_tokens)
+
+
+def inject_learned_tokens(pipe, embeds_dict, new_tokens):
+    """data_generation.py:45-52."""
+    if not new_tokens:
+        return []
+    emb = torch.stack([embeds_dict[t] for t in new_tokens])
+    pipe.tokenizer.add_tokens(list(new_tokens))
+    ids = pipe.tokenizer.convert_tokens_to_ids(list(new_tokens))
+    pipe.text_encoder.resize_token_embeddings(len(pipe.tokenizer))
+    with torch.no_grad():
+        w = pipe.text_encoder.get_input_embeddings().weight
+        w.data[ids] = emb.to(w.dtype)
+    return ids
+
+
+def shard_seeds(num_images: int, rank: int, world: int) -> List[int]:
+    return list(range(rank, num_images, world))
+
+
+def export_heatmap_u8(hm: np.ndarray) -> np.ndarray:
+    """data_generation.py:82-84: min-max (+1e-8), x255, truncating uint8 cast."""
+    hm = np.asarray(hm, dtype=np.float32)
+    hm = (hm - hm.min()) / (hm.max() - hm.min() + 1e-8) * 255
+    return hm.astype(np.uint8)
+
+
+def stack_heatmaps(obj: np.ndarray, fg: np.ndarray, bg: np.ndarray):
+    """postprocess_heatmap.py:44-48."""
+    inv = 255 - bg
+    return np.stack([obj, fg, inv], axis=-1), inv
+
+
+def generate_batch(pipe, seeds: Sequence[int], words: Sequence[str], prompt: Optional[str] = None,
+                   prompt_embeds: Optional[torch.Tensor] = None, num_inference_steps: int = 50,
+                   guidance_scale: float = 7.5, height: Optional[int] = None, rec_tokens: Optional[int] = None,
+                   word_rows: Optional[Sequence[Sequence[int]]] = None):
+    """One hot-path pass: len(seeds) images + per-word DAAM maps.
+    Returns (uint8 images [B,H,W,3] on GPU, fp32 heat maps [B, n_words, S, S] on GPU)."""
+    from .trace import trace
+    from . import synthetic
+    B = len(seeds)
+    side = height or pipe.cfg.default_sample_size * pipe.vae_scale_factor
+    L = side // pipe.vae_scale_factor
+    lat = synthetic.make_latents(pipe.cfg, seeds, L)      # CPU generator per image seed (data_generation.py:58)
+    with trace(pipe, rec_tokens=rec_tokens) as trc:
+        if prompt_embeds is None:
+            out = pipe([prompt] * B, num_inference_steps=num_inference_steps, guidance_scale=guidance_scale,
+                       latents=lat, height=side, width=side, output_type="pt")
+        else:
+            out = pipe(prompt_embeds=prompt_embeds, num_inference_steps=num_inference_steps, guidance_scale=guidance_scale,
+                       latents=lat, height=side, width=side, output_type="pt")
+        hms = []
+        for i in range(B):
+            g = trc.compute_global_heat_map(prompt=prompt, image_index=i)
+            if word_rows is not None:
+                hms.append(torch.stack([g.heat_maps[list(r)].mean(0) for r in word_rows]))
+            elif words:
+                hms.append(torch.stack([g.compute_word_heat_map(w).heatmap for w in words]))
+            else:
+                hms.append(g.heat_maps[:0])
+    return out.images, torch.stack(hms)
+
+
+def gather_outputs(images: torch.Tensor, heatmaps: torch.Tensor):
+    """The final exchange step: all_gather images + heat maps across ranks (no-op for world 1)."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return images, heatmaps
+    w = dist.get_world_size()
+    il = [torch.empty_like(images) for _ in range(w)]
+    hl = [torch.empty_like(heatmaps) for _ in range(w)]
+    dist.all_gather(il, images.contiguous())
+    dist.all_gather(hl, heatmaps.contiguous())
+    # interleave back to global seed order: seed = rank + world * local_index
+    return torch.stack(il, 1).flatten(0, 1), torch.stack(hl, 1).flatten(0, 1)
+
+
+def save_outputs(save_dir: str, seeds, images_u8: np.ndarray, heatmaps: np.ndarray, words, image_size: int):
+    """data_generation.py:60-62,66-86: resize, skip all-black, images/ + daam_<word>_heatmaps/ PNGs."""
+    from PIL import Image
+    os.makedirs(os.path.join(save_dir, "images"), exist_ok=True)
+    for i, seed in enumerate(seeds):
+        im = Image.fromarray(images_u8[i]).resize((image_size, image_size))
+        if np.max(np.asarray(im)) < 1e-5:       # NSFW content filter (black image)
+            continue
+        im.save(os.path.join(save_dir, "images", f"{seed}.png"))
+        for wi, word in enumerate(words):
+            d = os.path.join(save_dir, "daam_" + word + "_heatmaps")
+            os.makedirs(d, exist_ok=True)
+            Image.fromarray(export_heatmap_u8(heatmaps[i, wi])).resize((image_size, image_size)).save(os.path.join(d, f"{seed}.png"))
+
+
+def parse_args(argv=None):
+    p = argparse.ArgumentParser(description="Image and attention map generation (MI355X).")
+    p.add_argument("--save-dir", type=str, default="Data/Synthetic")
+    p.add_argument("--pretrained-model-path", type=str, default=None, help="diffusers-layout checkpoint; omit for synthetic weights")
+    p.add_argument("--learnable-tokens-embedding-path", type=str, default=None)
+    p.add_argument("--prompt", type=str, default="An aerial view image with {} cars in {} Utah")
+    p.add_argument("--initialize_token", type=str, default=["cars", "Utah", "New Zealand"], nargs="+")
+    p.add_argument("--word_token_heatmaps", type=str, default=None, nargs="+")
+    p.add_argument("--store_learnable_token_heatmaps", action="store_true")
+    p.add_argument("--num-images", type=int, default=10000)
+    p.add_argument("--image-size", type=int, default=112)
+    p.add_argument("--batch-size", type=int, default=4)
+    p.add_argument("--num-inference-steps", type=int, default=20)
+    return p.parse_args(argv)
+
+
+def main(argv=None):
+    import torch.distributed as dist
+    from . import StableDiffusionPipeline
+    args = parse_args(argv)
+    rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    torch.cuda.set_device(local)
+    if world > 1:
+        dist.init_process_group("nccl")
+    pipe = (StableDiffusionPipeline.from_pretrained(args.pretrained_model_path, device=local)
+            if args.pretrained_model_path else StableDiffusionPipeline.from_synthetic("sd15", device=local))
+    embeds = torch.load(args.learnable_tokens_embedding_path) if args.learnable_tokens_embedding_path else {}
+    new_tokens, words, prompt = select_learned_tokens(args.prompt, args.initialize_token, list(embeds.keys()),
+                                                     args.word_token_heatmaps, args.store_learnable_token_heatmaps)
+    inject_learned_tokens(pipe, embeds, new_tokens)
+    if not embeds:
+        prompt = args.prompt.replace("{}", "").replace("  ", " ")
+    seeds = shard_seeds(args.num_images, rank, world)
+    for i in range(0, len(seeds), args.batch_size):
+        chunk = seeds[i:i + args.batch_size]
+        imgs, hms = generate_batch(pipe, chunk, words, prompt=prompt, num_inference_steps=args.num_inference_steps)
+        save_outputs(args.save_dir, chunk, imgs.cpu().numpy(), hms.cpu().numpy(), words, args.image_size)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -268,11 +268,16 @@ class StableDiffusionPipeline:
 
     # ---- construction -------------------------------------------------------------------
     @classmethod
-    def from_synthetic(cls, cfg: Union[str, SDConfig] = "sd15", seed: int = 1234, device=0, workspace_bytes: int = 0, **kw):
+    def from_synthetic(cls, cfg: Union[str, SDConfig] = "sd15", seed: int = 1234, device=0, workspace_bytes: int = 0,
+                       weights_device: str = "cpu", keep_weights: bool = False, **kw):
         from . import synthetic
         cfg = CONFIGS[cfg]() if isinstance(cfg, str) else cfg
-        return cls(cfg, synthetic.make_unet_weights(cfg, seed, **kw), synthetic.make_vae_weights(cfg, seed + 1, **kw),
-                   device=device, workspace_bytes=workspace_bytes)
+        usd = synthetic.make_unet_weights(cfg, seed, device=weights_device, **kw)
+        vsd = synthetic.make_vae_weights(cfg, seed + 1, device=weights_device, **kw)
+        pipe = cls(cfg, usd, vsd, device=device, workspace_bytes=workspace_bytes)
+        if keep_weights:
+            pipe.synthetic_weights = (usd, vsd)
+        return pipe
 
     @classmethod
     def from_pretrained(cls, path: str, device=0, workspace_bytes: int = 0):

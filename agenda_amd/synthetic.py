@@ -22,35 +22,37 @@ def _bf16_round(t: torch.Tensor) -> torch.Tensor:
 def _fill(shapes: Dict[str, tuple], gen: torch.Generator, gain: float, bias_std: float,
           perturb_norm: float) -> Dict[str, torch.Tensor]:
     sd = {}
+    dev = gen.device
     for k, shp in shapes.items():
         is_norm = ("norm" in k.split(".")[-2]) or k.split(".")[-2] in ("norm", "group_norm")
         if k.endswith(".weight") and len(shp) >= 2:
             fan_in = 1
             for d in shp[1:]:
                 fan_in *= d
-            w = torch.randn(shp, generator=gen) * (gain / math.sqrt(fan_in))
+            w = torch.randn(shp, generator=gen, device=dev) * (gain / math.sqrt(fan_in))
         elif k.endswith(".weight"):
-            w = torch.ones(shp)
+            w = torch.ones(shp, device=dev)
             if is_norm and perturb_norm:
-                w = w + perturb_norm * torch.randn(shp, generator=gen)
+                w = w + perturb_norm * torch.randn(shp, generator=gen, device=dev)
         else:
             if is_norm:
-                w = perturb_norm * torch.randn(shp, generator=gen) if perturb_norm else torch.zeros(shp)
+                w = perturb_norm * torch.randn(shp, generator=gen, device=dev) if perturb_norm else torch.zeros(shp, device=dev)
             else:
-                w = bias_std * torch.randn(shp, generator=gen) if bias_std else torch.zeros(shp)
+                w = bias_std * torch.randn(shp, generator=gen, device=dev) if bias_std else torch.zeros(shp, device=dev)
         sd[k] = _bf16_round(w)
     return sd
 
 
 def make_unet_weights(cfg: SDConfig, seed: int = 1234, gain: float = 1.0, bias_std: float = 0.0,
-                      perturb_norm: float = 0.0) -> Dict[str, torch.Tensor]:
-    g = torch.Generator("cpu").manual_seed(seed)
+                      perturb_norm: float = 0.0, device: str = "cpu") -> Dict[str, torch.Tensor]:
+    """`device="cuda"` draws with a CUDA generator (fast; different values than the CPU stream)."""
+    g = torch.Generator(device).manual_seed(seed)
     return _fill(unet_param_shapes(cfg.unet), g, gain, bias_std, perturb_norm)
 
 
 def make_vae_weights(cfg: SDConfig, seed: int = 4321, gain: float = 1.0, bias_std: float = 0.0,
-                     perturb_norm: float = 0.0) -> Dict[str, torch.Tensor]:
-    g = torch.Generator("cpu").manual_seed(seed)
+                     perturb_norm: float = 0.0, device: str = "cpu") -> Dict[str, torch.Tensor]:
+    g = torch.Generator(device).manual_seed(seed)
     return _fill(vae_decoder_param_shapes(cfg.vae), g, gain, bias_std, perturb_norm)
 
 
