@@ -16,6 +16,9 @@
 //   of a half-wave hold 32 consecutive pixels -> 128-B coalesced read-modify-write.
 #include "kernels.h"
 
+int g_attn_qb = 1;   // queries per wave / 32 for the long self-attention shapes (tunable)
+extern "C" void agd_set_attn_qb(int v) { g_attn_qb = v; }
+
 template <int D> struct AttnCfg {
   static constexpr int KSTEPS = (D + 15) / 16;           // QK^T k-steps (d padded to 16)
   static constexpr int DBLK = (D + 31) / 32;             // PV output d-blocks (d padded to 32)
@@ -23,52 +26,64 @@ template <int D> struct AttnCfg {
   static constexpr int KPITCH = ((KCH | 1)) * 16;        // odd #chunks -> conflict-free b128 row reads
   static constexpr int VPITCH = ((DBLK | 1)) * 64;       // odd multiple of 64 B -> conflict-free tr reads
   static constexpr int CH = D / 8;                       // real 16-B chunks per row
+  // A spare (padded) V column exists when D is not a multiple of 32: column D is set to 1.0 so the
+  // PV MFMA also produces the softmax row sum (row D of O^T) -- no VALU adds for the denominator.
+  static constexpr bool ONES = (DBLK * 32 > D);
 };
 
-template <int D, int KB, int RECORD>
-__global__ __launch_bounds__(256) void attn_kernel(const AttnP p) {
+#define DEFER_THR 8.0f   // log2 units: rescale O only when a row max grows by more than 2^8
+
+template <int D, int KB, int QB, int RECORD>
+__global__ __launch_bounds__(256, ((QB == 1 && D <= 80) ? 2 : 1)) void attn_kernel(const AttnP p) {
   using C = AttnCfg<D>;
   constexpr int KEYS = KB * 32;
   constexpr int KSTEPS = C::KSTEPS, DBLK = C::DBLK, KPITCH = C::KPITCH, VPITCH = C::VPITCH, CH = C::CH;
+  constexpr bool ONES = C::ONES && !RECORD;
   constexpr int NCHUNK = KEYS * CH;                      // 16-B chunks per K (or V) tile
   constexpr int LD_IT = (NCHUNK + 255) / 256;
+  constexpr int STAGE = KEYS * (KPITCH + VPITCH);
+  constexpr int NSTAGE = RECORD ? 1 : 2;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* sK = smem;
-  char* sV = smem + KEYS * KPITCH;
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int c = lane & 31, hh = lane >> 5;
   const int head = blockIdx.y, b = blockIdx.z;
-  const int q0 = blockIdx.x * 128 + wid * 32;
+  const int q0 = blockIdx.x * (128 * QB) + wid * (32 * QB);
   const bf16_t* qp = p.q + b * p.sq + head * D;
   const bf16_t* kp = p.k + b * p.sk + head * D;
   const bf16_t* vp = p.v + b * p.sv + head * D;
 
-  // zero the K pad chunks once (never overwritten by tile loads)
-  if constexpr (C::KCH > CH) {
-    for (int i = tid; i < KEYS * (C::KCH - CH); i += 256) {
-      const int r = i / (C::KCH - CH), cc = CH + i % (C::KCH - CH);
-      *(u32x4*)(sK + r * KPITCH + cc * 16) = u32x4{0, 0, 0, 0};
+  // pad chunks (never overwritten by tile loads): K pad = 0; V pad = 0 except column D = 1.0 (ONES)
+#pragma unroll
+  for (int sidx = 0; sidx < NSTAGE; ++sidx) {
+    char* sK = smem + sidx * STAGE;
+    char* sV = sK + KEYS * KPITCH;
+    if constexpr (C::KCH > CH) {
+      for (int i = tid; i < KEYS * (C::KCH - CH); i += 256) {
+        const int r = i / (C::KCH - CH), cc = CH + i % (C::KCH - CH);
+        *(u32x4*)(sK + r * KPITCH + cc * 16) = u32x4{0, 0, 0, 0};
+      }
     }
-  }
-  if constexpr (DBLK * 4 > CH) {
-    for (int i = tid; i < KEYS * (DBLK * 4 - CH); i += 256) {
-      const int r = i / (DBLK * 4 - CH), cc = CH + i % (DBLK * 4 - CH);
-      *(u32x4*)(sV + r * VPITCH + cc * 16) = u32x4{0, 0, 0, 0};
+    if constexpr (DBLK * 4 > CH) {
+      for (int i = tid; i < KEYS * (DBLK * 4 - CH); i += 256) {
+        const int r = i / (DBLK * 4 - CH), cc = CH + i % (DBLK * 4 - CH);
+        *(u32x4*)(sV + r * VPITCH + cc * 16) = u32x4{(ONES && cc == CH) ? 0x3F80u : 0u, 0, 0, 0};
+      }
     }
   }
 
-  // Q fragments: lane (c, hh) holds Q[q0+c][16s + 8hh .. +8]
-  bf16x8 qf[KSTEPS];
-  {
-    const int qrow = q0 + c;
+  // Q fragments: lane (c, hh) holds Q[q0 + 32*qb + c][16s + 8hh .. +8]
+  bf16x8 qf[QB][KSTEPS];
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb) {
+    const int qrow = q0 + qb * 32 + c;
     const bool qok = qrow < p.Nq;
 #pragma unroll
     for (int s = 0; s < KSTEPS; ++s) {
       const int d0 = 16 * s + 8 * hh;
       u32x4 v = u32x4{0, 0, 0, 0};
       if (qok && d0 < D) v = *(const u32x4*)(qp + (long long)qrow * p.ldq + d0);
-      qf[s] = __builtin_bit_cast(bf16x8, v);
+      qf[qb][s] = __builtin_bit_cast(bf16x8, v);
     }
   }
 
@@ -87,7 +102,9 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnP p) {
       }
     }
   };
-  auto lstore = [&]() {
+  auto lstore = [&](int stage) {
+    char* sK = smem + stage * STAGE;
+    char* sV = sK + KEYS * KPITCH;
 #pragma unroll
     for (int it = 0; it < LD_IT; ++it) {
       const int idx = tid + it * 256;
@@ -99,18 +116,22 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnP p) {
     }
   };
 
-  f32x16 oacc[DBLK];
+  f32x16 oacc[QB][DBLK];
 #pragma unroll
-  for (int i = 0; i < DBLK; ++i)
+  for (int qb = 0; qb < QB; ++qb)
 #pragma unroll
-    for (int j = 0; j < 16; ++j) oacc[i][j] = 0.f;
-  float m_run = -INFINITY, l_run = 0.f;
+    for (int i = 0; i < DBLK; ++i)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) oacc[qb][i][j] = 0.f;
+  float m_run[QB], l_run[QB];
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb) { m_run[qb] = -INFINITY; l_run[qb] = 0.f; }
   const float sc = p.scale * 1.44269504088896340736f;   // exp(x) = exp2(x*log2e)
 
-  const int ntiles = (p.Nk + KEYS - 1) / KEYS;
+  const int ntiles = RECORD ? 1 : (p.Nk + KEYS - 1) / KEYS;   // RECORD: host guarantees Nk <= KEYS
+  const bool ragged = (p.Nk % KEYS) != 0;
   gload(0);
-  __syncthreads();            // pad zeroing done before first tile store (disjoint chunks, but keep ordering simple)
-  lstore();
+  lstore(0);
   __syncthreads();
 
   // V^T fragment addressing for ds_read_b64_tr_b16: lane supplies row (key) q, 4 columns at 4*pp
@@ -119,64 +140,107 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnP p) {
   const int tr_col = ((lane >> 4) & 1) * 16 + (gi & 3) * 4;  // + 32*db   (elements)
 
   for (int t = 0; t < ntiles; ++t) {
+    const int cur = RECORD ? 0 : (t & 1);
+    const char* sK = smem + cur * STAGE;
+    const char* sV = sK + KEYS * KPITCH;
     if (t + 1 < ntiles) gload(t + 1);
     // ---- S^T = K . Q^T ----
-    f32x16 sacc[KB];
+    f32x16 sacc[QB][KB];
 #pragma unroll
     for (int kb = 0; kb < KB; ++kb) {
 #pragma unroll
-      for (int j = 0; j < 16; ++j) sacc[kb][j] = 0.f;
+      for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) sacc[qb][kb][j] = 0.f;
 #pragma unroll
       for (int s = 0; s < KSTEPS; ++s) {
         const bf16x8 a = *(const bf16x8*)(sK + (kb * 32 + c) * KPITCH + (2 * s + hh) * 16);
-        sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[s], sacc[kb], 0, 0, 0);
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb)
+          sacc[qb][kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[qb][s], sacc[qb][kb], 0, 0, 0);
       }
     }
-    // ---- online softmax (query on the lane) ----
-    float mx = -INFINITY;
+    // ---- online softmax (query on the lane); keys beyond Nk masked on the last tile only ----
+    if (ragged && t == ntiles - 1) {
 #pragma unroll
-    for (int kb = 0; kb < KB; ++kb)
+      for (int qb = 0; qb < QB; ++qb)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int key = t * KEYS + kb * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
-        const float s = (key < p.Nk) ? sacc[kb][i] * sc : -INFINITY;
-        sacc[kb][i] = s;
-        mx = fmaxf(mx, s);
+        for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const int key = t * KEYS + kb * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+            if (key >= p.Nk) sacc[qb][kb][i] = -INFINITY;
+          }
+    }
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+      float mx = sacc[qb][0][0];
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) mx = fmaxf(mx, sacc[qb][kb][i]);
+      mx = fmaxf(mx, __shfl_xor(mx, 32)) * sc;
+      if constexpr (RECORD) {
+        m_run[qb] = mx;                                   // single tile: no running state to rescale
+      } else if (!__all(mx <= m_run[qb] + DEFER_THR)) {
+        const float m_new = fmaxf(m_run[qb], mx);
+        const float alpha = __builtin_amdgcn_exp2f(m_run[qb] - m_new);
+        m_run[qb] = m_new;
+        l_run[qb] *= alpha;
+#pragma unroll
+        for (int db = 0; db < DBLK; ++db)
+#pragma unroll
+          for (int j = 0; j < 16; ++j) oacc[qb][db][j] *= alpha;
       }
-    mx = fmaxf(mx, __shfl_xor(mx, 32));
-    const float m_new = fmaxf(m_run, mx);
-    const float alpha = exp2f(m_run - m_new);
-    float rs = 0.f;
+      const float nm = -m_run[qb];
+      if constexpr (ONES) {
 #pragma unroll
-    for (int kb = 0; kb < KB; ++kb)
+        for (int kb = 0; kb < KB; ++kb)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const float pv = exp2f(sacc[kb][i] - m_new);
-        sacc[kb][i] = pv;
-        rs += pv;
+          for (int i = 0; i < 16; ++i) sacc[qb][kb][i] = __builtin_amdgcn_exp2f(fmaf(sacc[qb][kb][i], sc, nm));
+      } else {
+        float rs = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const float pv = __builtin_amdgcn_exp2f(fmaf(sacc[qb][kb][i], sc, nm));
+            sacc[qb][kb][i] = pv;
+            rs += pv;
+          }
+        l_run[qb] += rs;
       }
-    l_run = l_run * alpha + rs;
-    m_run = m_new;
-#pragma unroll
-    for (int db = 0; db < DBLK; ++db)
-#pragma unroll
-      for (int j = 0; j < 16; ++j) oacc[db][j] *= alpha;
+    }
 
     if constexpr (RECORD) {
-      // single-tile case (host guarantees Nk <= KEYS): probabilities are final here
+      // single-tile case (host guarantees Nk <= KEYS): probabilities are final here.
+      // All old values are loaded first, then added, then stored: the RMW chains overlap.
       if (p.record_mode != 0 && b >= p.rec_b0 && (q0 + c) < p.Nq) {
-        const float lt = l_run + __shfl_xor(l_run, 32);
+        const float lt = l_run[0] + __shfl_xor(l_run[0], 32);
         const float inv = 1.0f / lt;
         const int img = b - p.rec_b0;
         if (p.record_mode == 1) {
-          float* rp = p.rec + img * p.rec_img_stride + head * p.rec_head_stride + (q0 + c);
+          // buffer RMW: wave-uniform base (this image/head slice), one 32-bit per-lane offset; the
+          // hardware range check (num_records = rec_T*Nq*4 B) drops token rows >= rec_T.
+          float* base = p.rec + img * p.rec_img_stride + head * p.rec_head_stride;
+          const unsigned nbytes = (unsigned)p.rec_T * (unsigned)p.Nq * 4u;
+          const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(base, 0, nbytes, 0x00020000);
+          const unsigned rowb = (unsigned)p.Nq * 4u;
+          const unsigned voff0 = (unsigned)(q0 + c) * 4u + (unsigned)(4 * hh) * rowb;
 #pragma unroll
-          for (int kb = 0; kb < KB; ++kb)
+          for (int kb = 0; kb < KB; ++kb) {
+            float old[16];
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-              const int tok = kb * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
-              if (tok < p.rec_T) rp[(long long)tok * p.Nq] += sacc[kb][i] * inv;
+              const unsigned off = voff0 + (unsigned)(kb * 32 + (i & 3) + 8 * (i >> 2)) * rowb;
+              old[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, off, 0, 0));
             }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+              const unsigned off = voff0 + (unsigned)(kb * 32 + (i & 3) + 8 * (i >> 2)) * rowb;
+              __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, old[i] + sacc[0][kb][i] * inv), rsrc, off, 0, 0);
+            }
+          }
         } else {
           float* rp = p.rec + img * p.rec_img_stride + (q0 + c);
           const float invh = inv / (float)p.H;
@@ -185,11 +249,9 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnP p) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
               const int tok = kb * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
-              if (tok < p.rec_T) atomicAdd(rp + (long long)tok * p.Nq, sacc[kb][i] * invh);
+              if (tok < p.rec_T) atomicAdd(rp + (long long)tok * p.Nq, sacc[0][kb][i] * invh);
             }
         }
-      } else {
-        (void)__shfl_xor(l_run, 32);
       }
     }
 
@@ -198,9 +260,11 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnP p) {
     for (int kb = 0; kb < KB; ++kb)
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
-        bf16x8 pf;
+        bf16x8 pf[QB];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) pf[j] = (__bf16)sacc[kb][8 * s + j];
+        for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) pf[qb][j] = (__bf16)sacc[qb][kb][8 * s + j];
         const char* vb = sV + (kb * 32 + 16 * s + tr_row) * VPITCH + tr_col * 2;
 #pragma unroll
         for (int db = 0; db < DBLK; ++db) {
@@ -209,43 +273,56 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnP p) {
           s16x8 a8;
           a8[0] = lo[0]; a8[1] = lo[1]; a8[2] = lo[2]; a8[3] = lo[3];
           a8[4] = hi[0]; a8[5] = hi[1]; a8[6] = hi[2]; a8[7] = hi[3];
-          oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a8), pf, oacc[db], 0, 0, 0);
+#pragma unroll
+          for (int qb = 0; qb < QB; ++qb)
+            oacc[qb][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a8), pf[qb], oacc[qb][db], 0, 0, 0);
         }
       }
     if (t + 1 < ntiles) {
-      __syncthreads();
-      lstore();
+      lstore(cur ^ 1);      // the other stage was last read in iteration t-1 (all waves passed its barrier)
       __syncthreads();
     }
   }
 
   // ---- finalize + store O[query][d] ----
-  const float lt = l_run + __shfl_xor(l_run, 32);
-  const float inv = 1.0f / lt;
-  const int qrow = q0 + c;
-  if (qrow < p.Nq) {
-    bf16_t* op = p.o + b * p.so + (long long)qrow * p.ldo + head * D;
 #pragma unroll
-    for (int db = 0; db < DBLK; ++db)
+  for (int qb = 0; qb < QB; ++qb) {
+    float lt;
+    if constexpr (ONES) {
+      constexpr int ld = D % 32;
+      const float lv = oacc[qb][D / 32][4 * (ld / 8)];     // row D of O^T lives in lanes 0..31 (hh = 0)
+      lt = __shfl(lv, c);
+    } else {
+      lt = l_run[qb] + __shfl_xor(l_run[qb], 32);
+    }
+    const float inv = 1.0f / lt;
+    const int qrow = q0 + qb * 32 + c;
+    if (qrow < p.Nq) {
+      bf16_t* op = p.o + b * p.so + (long long)qrow * p.ldo + head * D;
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int d0 = db * 32 + 8 * g + 4 * hh;
-        if (d0 < D) {
-          u32x2 pk;
-          pk[0] = pack_bf2(oacc[db][4 * g + 0] * inv, oacc[db][4 * g + 1] * inv);
-          pk[1] = pack_bf2(oacc[db][4 * g + 2] * inv, oacc[db][4 * g + 3] * inv);
-          *(u32x2*)(op + d0) = pk;
+      for (int db = 0; db < DBLK; ++db)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int d0 = db * 32 + 8 * g + 4 * hh;
+          if (d0 < D) {
+            u32x2 pk;
+            pk[0] = pack_bf2(oacc[qb][db][4 * g + 0] * inv, oacc[qb][db][4 * g + 1] * inv);
+            pk[1] = pack_bf2(oacc[qb][db][4 * g + 2] * inv, oacc[qb][db][4 * g + 3] * inv);
+            *(u32x2*)(op + d0) = pk;
+          }
         }
-      }
+    }
   }
 }
 
-template <int D, int KB, int RECORD>
+template <int D, int KB, int QB, int RECORD>
 static int launch_attn_t(const AttnP& p, hipStream_t st) {
   using C = AttnCfg<D>;
-  constexpr int lds = KB * 32 * (C::KPITCH + C::VPITCH);
-  dim3 grid((p.Nq + 127) / 128, p.H, p.B);
-  auto kfn = attn_kernel<D, KB, RECORD>;
+  constexpr int lds = (RECORD ? 1 : 2) * KB * 32 * (C::KPITCH + C::VPITCH);
+  dim3 grid((p.Nq + 128 * QB - 1) / (128 * QB), p.H, p.B);
+  auto kfn = attn_kernel<D, KB, QB, RECORD>;
+  static bool attr = false;
+  if (!attr && lds > 65536) { HIP_CHECK_RET(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); attr = true; }
   hipLaunchKernelGGL(kfn, grid, dim3(256), lds, st, p);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
@@ -255,10 +332,11 @@ template <int D>
 static int launch_attn_d(const AttnP& p, hipStream_t st) {
   if (p.record_mode != 0) {
     if (p.Nk > 96) { agd_set_error("attention: recording needs Nk <= 96 (got %d)", p.Nk); return -1; }
-    return launch_attn_t<D, 3, 1>(p, st);
+    return launch_attn_t<D, 3, 1, 1>(p, st);
   }
-  if (p.Nk <= 96 && p.Nk > 64) return launch_attn_t<D, 3, 0>(p, st);
-  return launch_attn_t<D, 2, 0>(p, st);
+  if (p.Nk <= 96 && p.Nk > 64) return launch_attn_t<D, 3, 1, 0>(p, st);
+  if constexpr (D <= 80) { if (p.Nq >= 1024 && g_attn_qb == 2) return launch_attn_t<D, 2, 2, 0>(p, st); }
+  return launch_attn_t<D, 2, 1, 0>(p, st);
 }
 
 int launch_attention(const AttnP& p, hipStream_t st) {

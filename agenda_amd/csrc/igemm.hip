@@ -19,8 +19,9 @@
 //    time-embedding row add / residual / GEGLU / SiLU fused, one rounding to bf16;
 //  * block->tile map is XCD-aware (tiles sharing an A panel share an L2).
 #include "kernels.h"
+#define CK0(expr) do { if ((expr) != 0) return -1; } while (0)
 
-template <int BM, int BN, int WM, int WN, int KS>
+template <int BM, int BN, int WM, int WN, int KS, int GEGLU, int SPLITK>
 __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(const IgemmP p) {
   constexpr int NT = WM * WN * 64;
   constexpr int NW = WM * WN;
@@ -74,24 +75,44 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(const IgemmP p) {
   }
   const bf16_t* aptr[A_IT];
   unsigned a_ok = 0;
-  int seg_left = 0, tap = -1, cursrc = 1;           // first new_segment() -> tap 0, src 0
+  int seg_left = 0, tap = 0, cursrc = 0;
 
-  auto new_segment = [&]() {
-    if (cursrc == 0 && p.C1 > 0) cursrc = 1; else { cursrc = 0; ++tap; }
+  // K-steps of this block: [ks0, ks0 + nk)  (split-K: grid.z slices the K range)
+  const int nk_total = p.K >> 6;
+  int ks0 = 0, nk = nk_total;
+  if constexpr (SPLITK) {
+    const int per = (nk_total + (int)gridDim.z - 1) / (int)gridDim.z;
+    ks0 = (int)blockIdx.z * per;
+    nk = nk_total - ks0 < per ? nk_total - ks0 : per;
+    if (nk < 0) nk = 0;
+  }
+
+  auto set_segment = [&](int tap_, int src_, int off_steps) {
+    tap = tap_; cursrc = src_;
     const int kh = (KS == 3) ? tap / 3 : 0, kw = (KS == 3) ? tap - kh * 3 : 0;
     const bf16_t* base = cursrc ? src1 : src0;
     const int Cs = cursrc ? p.C1 : p.C0;
-    seg_left = Cs >> 6;
+    seg_left = (Cs >> 6) - off_steps;
     a_ok = 0;
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
       const int iy = a_y[i] + kh, ix = a_x[i] + kw;
       const bool ok = ((a_rowok >> i) & 1) && (unsigned)iy < (unsigned)Hup && (unsigned)ix < (unsigned)Wup;
       const long long pix = ((long long)a_b[i] * p.Hin + (iy >> ush)) * p.Win + (ix >> ush);
-      aptr[i] = base + (ok ? pix * Cs : 0) + lchunk * 8;
+      aptr[i] = base + (ok ? pix * Cs : 0) + lchunk * 8 + off_steps * 64;
       a_ok |= (ok ? 1u : 0u) << i;
     }
   };
+  auto new_segment = [&]() {
+    if (cursrc == 0 && p.C1 > 0) set_segment(tap, 1, 0); else set_segment(tap + 1, 0, 0);
+  };
+  {
+    const int spt = (p.C0 + p.C1) >> 6;              // k-steps per tap
+    const int t0 = ks0 / spt, r0 = ks0 - t0 * spt;
+    if (r0 < (p.C0 >> 6)) set_segment(t0, 0, r0); else set_segment(t0, 1, r0 - (p.C0 >> 6));
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) bptr[i] += (long long)ks0 * 64;
+  }
 
   auto issue = [&](int stage) {
     if (seg_left == 0) new_segment();
@@ -124,8 +145,7 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(const IgemmP p) {
 #pragma unroll
   for (int kk = 0; kk < 2; ++kk) foff[kk] = frow * 128 + ((((kk << 2) + (lane >> 4)) ^ (lane & 7)) << 4);
 
-  const int nk = p.K >> 6;
-  issue(0);
+  if (nk > 0) issue(0);
   for (int ks = 0; ks < nk; ++ks) {
     const int cur = ks & 1;
     asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
@@ -147,126 +167,230 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(const IgemmP p) {
     }
   }
 
-  // ---- epilogue: acc -> LDS fp32 [BM][BN] -> coalesced row chunks -------------------------
-  __syncthreads();
-  float* stg = (float*)smem;
-#pragma unroll
-  for (int i = 0; i < MI; ++i)
-#pragma unroll
-    for (int j = 0; j < NI; ++j)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int ml = wm * WTM + i * 16 + (lane >> 4) * 4 + r;
-        const int nl = wn * WTN + j * 16 + (lane & 15);
-        stg[ml * BN + nl] = acc[i][j][r] * p.alpha;
-      }
-  __syncthreads();
+  // ---- epilogue: acc -> LDS fp32 [BM][BN] -> coalesced 16-B row chunks -----------------------
+  // Residual chunks are prefetched into registers before the LDS round trip so their HBM latency
+  // overlaps the staging; all trip counts are compile-time.
+  constexpr int OW = GEGLU ? BN / 2 : BN;           // output columns produced by this tile
+  constexpr int CPR = OW / 8;                       // 8-column chunks per output row
+  constexpr int EP_IT = (BM * CPR + NT - 1) / NT;
+  const int Nout = GEGLU ? p.N / 2 : p.N;
+  const int no0 = GEGLU ? tn * (BN / 2) : n0;
 
-  const int OW = p.geglu ? BN / 2 : BN;            // output columns produced by this tile
-  const int Nout = p.geglu ? p.N / 2 : p.N;
-  const int no0 = p.geglu ? tn * (BN / 2) : n0;
-  const int cpr = OW / 8;
-  const bool vec_ok = ((p.ldo & 7) == 0) && (!p.residual || (p.ldr & 7) == 0);
-  for (int c = tid; c < BM * cpr; c += NT) {
-    const int r = c / cpr, cc = c - r * cpr;
-    const int m = m0 + r;
-    const int no = no0 + cc * 8;
-    if (m >= p.M || no >= Nout) continue;
-    float v[8];
-    const float* sp = stg + r * BN + cc * 8;
-    *(f32x4*)&v[0] = *(const f32x4*)sp;
-    *(f32x4*)&v[4] = *(const f32x4*)(sp + 4);
-    const int nvalid = (Nout - no) < 8 ? (Nout - no) : 8;
-    if (p.geglu) {
-      float g[8];
-      *(f32x4*)&g[0] = *(const f32x4*)(sp + BN / 2);
-      *(f32x4*)&g[4] = *(const f32x4*)(sp + BN / 2 + 4);
-      if (p.bias) {
+  auto stage_acc = [&]() {
+    __syncthreads();
+    float* stg_ = (float*)smem;
 #pragma unroll
-        for (int e = 0; e < 8; ++e)
-          if (e < nvalid) { v[e] += p.bias[no + e]; g[e] += p.bias[Nout + no + e]; }
-      }
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = v[e] * gelu_erf_f(g[e]);
-    } else {
-      if (p.bias_mode == 1) {
+      for (int j = 0; j < NI; ++j)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) if (e < nvalid) v[e] += p.bias[no + e];
-      } else if (p.bias_mode == 2) {
-        const float bm = p.bias[m];
+        for (int r = 0; r < 4; ++r)
+          stg_[(wm * WTM + i * 16 + (lane >> 4) * 4 + r) * BN + wn * WTN + j * 16 + (lane & 15)] = acc[i][j][r] * p.alpha;
+    __syncthreads();
+  };
+  const float* stg = (const float*)smem;
+
+  if constexpr (SPLITK) {
+    stage_acc();
+    float* part = p.splitk_ws + ((long long)blockIdx.z * p.M) * p.N;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] += bm;
-      }
-      if (p.rowadd) {
-        const float* ra = p.rowadd + (long long)(m / HWo) * p.rowadd_ld + no;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) if (e < nvalid) v[e] += ra[e];
+    for (int it = 0; it < EP_IT; ++it) {
+      const int idx = tid + it * NT;
+      const int r = idx / CPR, cc = idx - r * CPR;
+      const int m = m0 + r, no = no0 + cc * 8;
+      const int nvalid = (Nout - no) < 8 ? (Nout - no) : 8;
+      if (idx < BM * CPR && m < p.M && nvalid > 0) {
+        const float* sp = stg + r * BN + cc * 8;
+        float* op = part + (long long)m * p.N + no;
+        if (nvalid == 8) { *(f32x4*)op = *(const f32x4*)sp; *(f32x4*)(op + 4) = *(const f32x4*)(sp + 4); }
+        else for (int e = 0; e < nvalid; ++e) op[e] = sp[e];
       }
     }
-    if (p.residual) {
-      const bf16_t* rp = p.residual + bz * p.sR + (long long)m * p.ldr + no;
-      if (vec_ok && nvalid == 8) {
-        const s16x8 rv = *(const s16x8*)rp;
+    return;
+  } else {
+    const bool vec_all = ((p.ldo & 7) == 0) && (!p.residual || (p.ldr & 7) == 0);
+    s16x8 rres[EP_IT];
+    if (p.residual && vec_all) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] += bf2f((bf16_t)rv[e]);
-      } else {
-        for (int e = 0; e < nvalid; ++e) v[e] += bf2f(rp[e]);
+      for (int it = 0; it < EP_IT; ++it) {
+        const int idx = tid + it * NT;
+        const int r = idx / CPR, cc = idx - r * CPR;
+        const int m = m0 + r, no = no0 + cc * 8;
+        if (idx < BM * CPR && m < p.M && no + 8 <= Nout) rres[it] = *(const s16x8*)(p.residual + bz * p.sR + (long long)m * p.ldr + no);
       }
     }
-    if (p.act == 1) {
+    stage_acc();
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = silu_f(v[e]);
-    }
-    if (p.out_f32) {
-      float* op = (float*)p.out + bz * p.sO + (long long)m * p.ldo + no;
-      if (((p.ldo & 3) == 0) && nvalid == 8) {
-        *(f32x4*)op = *(f32x4*)&v[0];
-        *(f32x4*)(op + 4) = *(f32x4*)&v[4];
+    for (int it = 0; it < EP_IT; ++it) {
+      const int idx = tid + it * NT;
+      const int r = idx / CPR, cc = idx - r * CPR;
+      const int m = m0 + r, no = no0 + cc * 8;
+      const int nvalid = (Nout - no) < 8 ? (Nout - no) : 8;
+      if (idx >= BM * CPR || m >= p.M || nvalid <= 0) continue;
+      const bool vec_ok = vec_all && nvalid == 8;
+      float v[8];
+      const float* sp = stg + r * BN + cc * 8;
+      *(f32x4*)&v[0] = *(const f32x4*)sp;
+      *(f32x4*)&v[4] = *(const f32x4*)(sp + 4);
+      if constexpr (GEGLU) {
+        float g[8], bv[8], gv[8];
+        *(f32x4*)&g[0] = *(const f32x4*)(sp + BN / 2);
+        *(f32x4*)&g[4] = *(const f32x4*)(sp + BN / 2 + 4);
+        *(f32x4*)&bv[0] = *(const f32x4*)(p.bias + no); *(f32x4*)&bv[4] = *(const f32x4*)(p.bias + no + 4);
+        *(f32x4*)&gv[0] = *(const f32x4*)(p.bias + Nout + no); *(f32x4*)&gv[4] = *(const f32x4*)(p.bias + Nout + no + 4);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (v[e] + bv[e]) * gelu_erf_f(g[e] + gv[e]);
       } else {
-        for (int e = 0; e < nvalid; ++e) op[e] = v[e];
+        if (p.bias_mode == 1) {
+          if (nvalid == 8) {
+            float bv[8];
+            *(f32x4*)&bv[0] = *(const f32x4*)(p.bias + no); *(f32x4*)&bv[4] = *(const f32x4*)(p.bias + no + 4);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += bv[e];
+          } else {
+            for (int e = 0; e < nvalid; ++e) v[e] += p.bias[no + e];
+          }
+        } else if (p.bias_mode == 2) {
+          const float bm = p.bias[m];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += bm;
+        }
+        if (p.rowadd) {
+          const float* ra = p.rowadd + (long long)(m / HWo) * p.rowadd_ld + no;
+          if (nvalid == 8) {
+            float rv[8];
+            *(f32x4*)&rv[0] = *(const f32x4*)ra; *(f32x4*)&rv[4] = *(const f32x4*)(ra + 4);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += rv[e];
+          } else {
+            for (int e = 0; e < nvalid; ++e) v[e] += ra[e];
+          }
+        }
       }
-    } else {
-      bf16_t* op = (bf16_t*)p.out + bz * p.sO + (long long)m * p.ldo + no;
-      if (vec_ok && nvalid == 8) {
-        u32x4 pk;
-        pk[0] = pack_bf2(v[0], v[1]); pk[1] = pack_bf2(v[2], v[3]);
-        pk[2] = pack_bf2(v[4], v[5]); pk[3] = pack_bf2(v[6], v[7]);
-        *(u32x4*)op = pk;
+      if (p.residual) {
+        if (vec_ok) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += bf2f((bf16_t)rres[it][e]);
+        } else {
+          const bf16_t* rp = p.residual + bz * p.sR + (long long)m * p.ldr + no;
+          for (int e = 0; e < nvalid; ++e) v[e] += bf2f(rp[e]);
+        }
+      }
+      if (p.act == 1) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = silu_f(v[e]);
+      }
+      if (p.out_f32) {
+        float* op = (float*)p.out + bz * p.sO + (long long)m * p.ldo + no;
+        if (((p.ldo & 3) == 0) && nvalid == 8) {
+          *(f32x4*)op = *(f32x4*)&v[0];
+          *(f32x4*)(op + 4) = *(f32x4*)&v[4];
+        } else {
+          for (int e = 0; e < nvalid; ++e) op[e] = v[e];
+        }
       } else {
-        for (int e = 0; e < nvalid; ++e) op[e] = f2bf(v[e]);
+        bf16_t* op = (bf16_t*)p.out + bz * p.sO + (long long)m * p.ldo + no;
+        if (vec_ok) {
+          u32x4 pk;
+          pk[0] = pack_bf2(v[0], v[1]); pk[1] = pack_bf2(v[2], v[3]);
+          pk[2] = pack_bf2(v[4], v[5]); pk[3] = pack_bf2(v[6], v[7]);
+          *(u32x4*)op = pk;
+        } else {
+          for (int e = 0; e < nvalid; ++e) op[e] = f2bf(v[e]);
+        }
       }
     }
   }
 }
 
-template <int BM, int BN, int WM, int WN>
-static int launch_cfg(const IgemmP& p, hipStream_t st) {
+// split-K second pass: out = epilogue(sum_s partial[s])   (deterministic slab sum, no atomics)
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const IgemmP p, int S) {
+  const int HWo = p.Hout * p.Wout;
+  const long long total = (long long)p.M * (p.N >> 2);
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int m = (int)(i / (p.N >> 2)), n = (int)(i % (p.N >> 2)) * 4;
+    f32x4 a = *(const f32x4*)(p.splitk_ws + (long long)m * p.N + n);
+    for (int s = 1; s < S; ++s) a += *(const f32x4*)(p.splitk_ws + ((long long)s * p.M + m) * p.N + n);
+    float v[4] = {a[0], a[1], a[2], a[3]};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (p.bias_mode == 1) v[e] += p.bias[n + e]; else if (p.bias_mode == 2) v[e] += p.bias[m];
+      if (p.rowadd) v[e] += p.rowadd[(long long)(m / HWo) * p.rowadd_ld + n + e];
+      if (p.residual) v[e] += bf2f(p.residual[(long long)m * p.ldr + n + e]);
+      if (p.act == 1) v[e] = silu_f(v[e]);
+    }
+    if (p.out_f32) { float* op = (float*)p.out + (long long)m * p.ldo + n; for (int e = 0; e < 4; ++e) op[e] = v[e]; }
+    else { bf16_t* op = (bf16_t*)p.out + (long long)m * p.ldo + n; u32x2 pk; pk[0] = pack_bf2(v[0], v[1]); pk[1] = pack_bf2(v[2], v[3]);
+           if ((p.ldo & 3) == 0) *(u32x2*)op = pk; else for (int e = 0; e < 4; ++e) op[e] = f2bf(v[e]); }
+  }
+}
+
+template <int BM, int BN, int WM, int WN, int KS, int GEGLU, int SPLITK>
+static int launch_one(const IgemmP& p, int splits, hipStream_t st) {
   constexpr int NT = WM * WN * 64;
   constexpr int stage = (BM + BN) * 128;
   constexpr int lds = (2 * stage > BM * BN * 4) ? 2 * stage : BM * BN * 4;
   const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
-  dim3 grid(tiles, p.batch > 0 ? p.batch : 1);
-  if (p.ksize == 3) {
-    auto kfn = igemm_kernel<BM, BN, WM, WN, 3>;
-    static bool attr3 = false;
-    if (!attr3) { HIP_CHECK_RET(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); attr3 = true; }
-    hipLaunchKernelGGL(kfn, grid, dim3(NT), lds, st, p);
-  } else {
-    auto kfn = igemm_kernel<BM, BN, WM, WN, 1>;
-    static bool attr1 = false;
-    if (!attr1) { HIP_CHECK_RET(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); attr1 = true; }
-    hipLaunchKernelGGL(kfn, grid, dim3(NT), lds, st, p);
-  }
+  dim3 grid(tiles, p.batch > 0 ? p.batch : 1, splits);
+  auto kfn = igemm_kernel<BM, BN, WM, WN, KS, GEGLU, SPLITK>;
+  static bool attr = false;
+  if (!attr) { HIP_CHECK_RET(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); attr = true; }
+  hipLaunchKernelGGL(kfn, grid, dim3(NT), lds, st, p);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }
 
-int launch_igemm(const IgemmP& p, hipStream_t st) {
+template <int BM, int BN, int WM, int WN>
+static int launch_cfg(const IgemmP& p, int splits, hipStream_t st) {
+  if (splits > 1) {
+    int rc = (p.ksize == 3) ? launch_one<BM, BN, WM, WN, 3, 0, 1>(p, splits, st) : launch_one<BM, BN, WM, WN, 1, 0, 1>(p, splits, st);
+    if (rc) return rc;
+    const long long total = (long long)p.M * (p.N >> 2);
+    const int grid = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid), dim3(256), 0, st, p, splits);
+    HIP_CHECK_RET(hipGetLastError());
+    return 0;
+  }
+  if (p.geglu) {
+    if constexpr (BN == 128) { if (p.ksize == 1) return launch_one<BM, BN, WM, WN, 1, 1, 0>(p, 1, st); }
+    agd_set_error("igemm: geglu only on 1x1 with the 128-wide tile"); return -1;
+  }
+  if (p.ksize == 3) return launch_one<BM, BN, WM, WN, 3, 0, 0>(p, 1, st);
+  return launch_one<BM, BN, WM, WN, 1, 0, 0>(p, 1, st);
+}
+
+static float* g_splitk_ws = nullptr; static size_t g_splitk_cap = 0;
+
+int launch_igemm(const IgemmP& p_in, hipStream_t st) {
+  IgemmP p = p_in;
   if (p.K & 63 || p.C0 & 63 || p.C1 & 63) { agd_set_error("igemm: K/C0/C1 must be multiples of 64 (K=%d C0=%d C1=%d)", p.K, p.C0, p.C1); return -1; }
   if (p.K != p.ksize * p.ksize * (p.C0 + p.C1)) { agd_set_error("igemm: K=%d != ks^2*(C0+C1)=%d", p.K, p.ksize * p.ksize * (p.C0 + p.C1)); return -1; }
   if (p.ksize != 1 && p.ksize != 3) { agd_set_error("igemm: ksize %d", p.ksize); return -1; }
   if (p.geglu && (p.N % 128)) { agd_set_error("igemm: geglu needs N %% 128 == 0"); return -1; }
-  const long long t128 = (long long)((p.M + 127) / 128) * ((p.N + 127) / 128) * (p.batch > 0 ? p.batch : 1);
-  if (t128 >= 192 || p.geglu) return launch_cfg<128, 128, 2, 2>(p, st);
-  return launch_cfg<64, 64, 2, 2>(p, st);
+  const int batch = p.batch > 0 ? p.batch : 1;
+  const long long t128 = (long long)((p.M + 127) / 128) * ((p.N + 127) / 128) * batch;
+  const int nk = p.K >> 6;
+  if (p.geglu) return launch_cfg<128, 128, 2, 2>(p, 1, st);
+  // split-K for small-M problems (8x8 / 16x16 feature maps): fill the 256 CUs with K slices
+  if (batch == 1 && t128 <= 160 && nk >= 64 && (p.N & 3) == 0 && p.M >= 128) {
+    int S = (int)((384 + t128 - 1) / t128);
+    if (S > 8) S = 8;
+    if (S > nk / 8) S = nk / 8;
+    if (S >= 2) {
+      const size_t need = (size_t)S * p.M * p.N * 4;
+      if (need > g_splitk_cap) {
+        if (g_splitk_ws) hipFree(g_splitk_ws);
+        const size_t cap = need > ((size_t)64 << 20) ? need : ((size_t)64 << 20);
+        if (hipMalloc((void**)&g_splitk_ws, cap) != hipSuccess) { g_splitk_ws = nullptr; g_splitk_cap = 0; agd_set_error("split-K workspace alloc failed"); return -1; }
+        g_splitk_cap = cap;
+      }
+      p.splitk_ws = g_splitk_ws;
+      return launch_cfg<128, 128, 2, 2>(p, S, st);
+    }
+  }
+  if (t128 >= 192) {
+    if ((p.N % 160) == 0 && (p.N % 128) != 0) return launch_cfg<128, 160, 2, 2>(p, 1, st);
+    return launch_cfg<128, 128, 2, 2>(p, 1, st);
+  }
+  return launch_cfg<64, 64, 2, 2>(p, 1, st);
 }

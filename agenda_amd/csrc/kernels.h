@@ -25,6 +25,7 @@ struct IgemmP {
   int batch;                        // grid.y
   long long sA0, sA1, sW, sO, sR;   // per-batch element strides
   const bf16_t* zero_page;          // >= 256 B of zeros
+  float* splitk_ws;                 // set by the launcher: fp32 partial slabs [S][M][N]
 };
 int launch_igemm(const IgemmP& p, hipStream_t st);
 

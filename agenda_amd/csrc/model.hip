@@ -890,3 +890,89 @@ extern "C" int agd_op_bicubic_clamp_mean(const float* maps, int n_maps, int T, i
   hipStreamSynchronize(st);
   return 0;
 }
+
+// ---------------------------------------------------------------------------------------
+// kernel micro-benchmarks (random bf16 operands; HIP-event timing on the launch stream)
+// ---------------------------------------------------------------------------------------
+__global__ void fill_random_bf16(bf16_t* p, long long n, unsigned seed, float scale) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    unsigned h = (unsigned)i * 2654435761u ^ seed; h ^= h >> 15; h *= 2246822519u; h ^= h >> 13; h *= 3266489917u; h ^= h >> 16;
+    p[i] = f2bf(((float)(h & 0xFFFF) / 32768.0f - 1.0f) * scale);
+  }
+}
+static void fill_rand(bf16_t* p, long long n, unsigned seed, float scale) {
+  hipLaunchKernelGGL(fill_random_bf16, dim3(4096), dim3(256), 0, 0, p, n, seed, scale);
+}
+
+extern "C" int agd_bench_conv(int B, int H, int W, int C0, int C1, int Cout, int ksize, int stride, int up, int geglu,
+                              int with_residual, int iters, double* ms_out) {
+  Tmp tmp;
+  const int Ctot = C0 + C1, taps = ksize * ksize, pad = ksize == 3 ? 1 : 0;
+  const int Ho = (H * up + 2 * pad - ksize) / stride + 1, Wo = (W * up + 2 * pad - ksize) / stride + 1;
+  const long long M = (long long)B * Ho * Wo;
+  const int Nout = geglu ? Cout / 2 : Cout;
+  bf16_t* x0 = tmp.get<bf16_t>((size_t)B * H * W * C0); bf16_t* x1 = C1 ? tmp.get<bf16_t>((size_t)B * H * W * C1) : nullptr;
+  bf16_t* w = tmp.get<bf16_t>((size_t)Cout * taps * Ctot); bf16_t* y = tmp.get<bf16_t>((size_t)M * Nout);
+  bf16_t* r = with_residual ? tmp.get<bf16_t>((size_t)M * Nout) : nullptr;
+  float* bias = tmp.get<float>(Cout);
+  if (!x0 || !w || !y || !bias || (C1 && !x1) || (with_residual && !r)) return -1;
+  fill_rand(x0, (long long)B * H * W * C0, 1, 1.0f); if (x1) fill_rand(x1, (long long)B * H * W * C1, 2, 1.0f);
+  fill_rand(w, (long long)Cout * taps * Ctot, 3, 0.05f); if (r) fill_rand(r, M * Nout, 4, 1.0f);
+  hipMemset(bias, 0, Cout * 4);
+  WMat wm; wm.w = w; wm.N = Cout; wm.Cin = Ctot; wm.Cpad = Ctot; wm.taps = taps;
+  GemmOpt o; o.bias = bias; o.stride = stride; o.up = up; o.geglu = geglu; o.residual = r;
+  hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+  for (int i = 0; i < 2; ++i) CK(run_conv(nullptr, 0, x0, C0, x1, C1, B, H, W, wm, ksize, y, o, op_zero_page()));
+  hipEventRecord(a, 0);
+  for (int i = 0; i < iters; ++i) CK(run_conv(nullptr, 0, x0, C0, x1, C1, B, H, W, wm, ksize, y, o, op_zero_page()));
+  hipEventRecord(b, 0); hipEventSynchronize(b);
+  float t = 0; hipEventElapsedTime(&t, a, b);
+  *ms_out = t / iters;
+  hipEventDestroy(a); hipEventDestroy(b);
+  return 0;
+}
+
+extern "C" int agd_bench_attention(int B, int H, int D, int Nq, int Nk, int record, int iters, double* ms_out) {
+  Tmp tmp;
+  const int C = H * D;
+  const bool self = (Nq == Nk);
+  // self: packed qkv rows [3C]; cross: q [C], kv [2C]
+  bf16_t* q = tmp.get<bf16_t>((size_t)B * Nq * (self ? 3 * C : C)); bf16_t* kv = self ? nullptr : tmp.get<bf16_t>((size_t)B * Nk * 2 * C);
+  bf16_t* o = tmp.get<bf16_t>((size_t)B * Nq * C);
+  float* rec = record ? tmp.get<float>((size_t)B * H * Nk * Nq) : nullptr;
+  if (!q || !o || (!self && !kv) || (record && !rec)) return -1;
+  fill_rand(q, (long long)B * Nq * (self ? 3 * C : C), 5, 1.0f); if (kv) fill_rand(kv, (long long)B * Nk * 2 * C, 6, 1.0f);
+  if (rec) hipMemset(rec, 0, (size_t)B * H * Nk * Nq * 4);
+  AttnP a{};
+  if (self) { a.q = q; a.k = q + C; a.v = q + 2 * C; a.ldq = a.ldk = a.ldv = 3 * C; a.sq = a.sk = a.sv = (long long)Nq * 3 * C; }
+  else { a.q = q; a.k = kv; a.v = kv + C; a.ldq = C; a.ldk = a.ldv = 2 * C; a.sq = (long long)Nq * C; a.sk = a.sv = (long long)Nk * 2 * C; }
+  a.o = o; a.ldo = C; a.so = (long long)Nq * C; a.B = B; a.H = H; a.D = D; a.Nq = Nq; a.Nk = Nk; a.scale = 1.0f / sqrtf((float)D);
+  if (record) { a.record_mode = 1; a.rec_b0 = B / 2; a.rec = rec; a.rec_T = Nk; a.rec_head_stride = (long long)Nk * Nq; a.rec_img_stride = a.rec_head_stride * H; }
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  for (int i = 0; i < 2; ++i) CK(launch_attention(a, 0));
+  hipEventRecord(e0, 0);
+  for (int i = 0; i < iters; ++i) CK(launch_attention(a, 0));
+  hipEventRecord(e1, 0); hipEventSynchronize(e1);
+  float t = 0; hipEventElapsedTime(&t, e0, e1);
+  *ms_out = t / iters;
+  hipEventDestroy(e0); hipEventDestroy(e1);
+  return 0;
+}
+
+extern "C" int agd_bench_groupnorm(int B, int HW, int C, int iters, double* ms_out) {
+  Tmp tmp;
+  bf16_t* x = tmp.get<bf16_t>((size_t)B * HW * C); bf16_t* y = tmp.get<bf16_t>((size_t)B * HW * C);
+  float* ws = tmp.get<float>((size_t)agd_groupnorm_ws_floats(B, C, HW, 32)); float* g = tmp.get<float>(2 * C);
+  if (!x || !y || !ws || !g) return -1;
+  fill_rand(x, (long long)B * HW * C, 7, 1.0f); hipMemset(g, 0, 2 * C * 4);
+  GroupNormP p{}; p.x0 = x; p.C0 = C; p.y = y; p.gamma = g; p.beta = g + C; p.B = B; p.HW = HW; p.groups = 32; p.eps = 1e-5f; p.silu = 1; p.ws = ws;
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  for (int i = 0; i < 2; ++i) CK(launch_groupnorm(p, 0));
+  hipEventRecord(e0, 0);
+  for (int i = 0; i < iters; ++i) CK(launch_groupnorm(p, 0));
+  hipEventRecord(e1, 0); hipEventSynchronize(e1);
+  float t = 0; hipEventElapsedTime(&t, e0, e1);
+  *ms_out = t / iters;
+  hipEventDestroy(e0); hipEventDestroy(e1);
+  return 0;
+}

@@ -118,8 +118,9 @@ class HookRecorder:
 class DaamRecorder:
     """Per-(layer, head) time-summed heat maps, one set per image.
 
-    daam semantics: `factor = sqrt(latent_area / N)`; a call is recorded iff keys == 77 context
-    tokens and `factor != 8` (mid block excluded); the conditional half of the B*H axis is
+    daam semantics: its locator hooks the attn2 of up/down blocks only (mid block never hooked,
+    `locate_middle_block=False`); `factor = sqrt(latent_area / N)`; a hooked call is recorded iff
+    keys == 77 context tokens and `factor != 8`; the conditional half of the B*H axis is
     reshaped to [H, T, h, w] and added into `acc[(factor, layer, head)]`.  Upstream assumes one
     image per call; a batch here is treated as independent images (image-major on the B axis),
     i.e. exactly what running daam once per image would give.
@@ -132,6 +133,8 @@ class DaamRecorder:
 
     def __call__(self, p: Tensor, heads: int, layer: str = ""):
         bh, n, t = p.shape
+        if "mid_block" in layer:                               # locator: mid block is not hooked
+            return
         factor = int(math.sqrt(self.latent_area // n))
         if t != self.context_size or factor == 8:
             return

@@ -37,6 +37,9 @@ def ops():
     (1, 192, 12, 64, 1, 1, False),       # 1x1
     (8, 320, 32, 320, 3, 1, False),      # 128x128-tile path (many tiles)
     (3, 64, 9, 64, 3, 1, False),         # ragged M (243 rows)
+    (8, 1280, 8, 1280, 3, 1, False),     # split-K path (M=512, K=11520)
+    (2, 640, 16, 1280, 3, 1, False),     # split-K, M=512, ragged K split
+    (8, 320, 32, 320, 3, 2, False),      # stride-2 at 128-tile size
 ])
 def test_conv2d(ops, B, Cin, H, Cout, k, stride, up):
     g = torch.Generator().manual_seed(B * 1000 + Cin + Cout + k)
@@ -57,6 +60,9 @@ def test_conv2d(ops, B, Cin, H, Cout, k, stride, up):
     (100, 64, 128, True, True),
     (2, 1280, 1280, False, False),       # tiny M
     (4096, 1280, 320, False, True),
+    (8192, 320, 320, False, True),       # BN=160 tile path
+    (8192, 320, 960, False, False),      # BN=160, fused qkv width
+    (512, 5120, 1280, False, True),      # split-K linear
 ])
 def test_linear(ops, M, K, N, geglu, res):
     g = torch.Generator().manual_seed(M + K + N)
