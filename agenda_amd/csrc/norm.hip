@@ -5,7 +5,18 @@
 // (per-block partials -> fp64 finalize), affine folded into per-(image,channel) scale/shift.
 #include "kernels.h"
 
-// ws layout (floats): [0, B*nchunk*32*2) block partials ; then B*C scale ; then B*C shift
+// ws layout (floats): [0, B*nchunk*groups*2) block partials ; then B*C scale ; then B*C shift
+// Thread t owns channel vector (t % nvec) and pixel-row (t / nvec) of its block's pixel chunk, so no
+// index division happens inside the streaming loops.
+struct GnGeom { int nvec, PR, ppb, nchunk; };
+static GnGeom gn_geom(int B, int C, int HW) {
+  GnGeom g; g.nvec = C / 8; g.PR = 512 / g.nvec;
+  const long long target = ((long long)HW * B + 511) / 512;          // pixels per block for ~512 blocks
+  int it = (int)((target + g.PR - 1) / g.PR); if (it < 1) it = 1; if (it > 16) it = 16;
+  g.ppb = it * g.PR; g.nchunk = (HW + g.ppb - 1) / g.ppb;
+  return g;
+}
+
 __global__ __launch_bounds__(512) void gn_stats_kernel(const bf16_t* __restrict__ x0, const bf16_t* __restrict__ x1,
                                                        int C0, int C1, int HW, int groups, int ppb, int nchunk,
                                                        float* __restrict__ part) {
@@ -24,7 +35,17 @@ __global__ __launch_bounds__(512) void gn_stats_kernel(const bf16_t* __restrict_
     const bf16_t* base; int Cs, cc;
     if (ch < C0) { base = x0; Cs = C0; cc = ch; } else { base = x1; Cs = C1; cc = ch - C0; }
     base += (long long)b * HW * Cs + cc;
-    for (int px = p0 + prow; px < p1; px += PR) {
+    int px = p0 + prow;
+    for (; px + 3 * PR < p1; px += 4 * PR) {          // 4 independent loads in flight
+      s16x8 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = *(const s16x8*)(base + (long long)(px + u * PR) * Cs);
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float f = bf2f((bf16_t)v[u][e]); s[e] += f; ss[e] += f * f; }
+    }
+    for (; px < p1; px += PR) {
       const s16x8 v = *(const s16x8*)(base + (long long)px * Cs);
 #pragma unroll
       for (int e = 0; e < 8; ++e) { const float f = bf2f((bf16_t)v[e]); s[e] += f; ss[e] += f * f; }
@@ -39,12 +60,16 @@ __global__ __launch_bounds__(512) void gn_stats_kernel(const bf16_t* __restrict_
   }
   __syncthreads();
   const int cpg = C / groups;
-  // one thread per group: sum over its channels and pixel-rows (small)
-  if (tid < groups) {
-    float a = 0.f, q = 0.f;
-    for (int r = 0; r < PR; ++r)
-      for (int cch = tid * cpg; cch < (tid + 1) * cpg; ++cch) { a += ls[r * C + cch]; q += lss[r * C + cch]; }
-    float* o = part + (((long long)b * nchunk + chunk) * groups + tid) * 2;
+  // 8 threads per group: strided partial sums then a shuffle reduce
+  const int g = tid >> 3, l = tid & 7;
+  float a = 0.f, q = 0.f;
+  if (g < groups) {
+    const int n = PR * cpg;
+    for (int i = l; i < n; i += 8) { const int r = i / cpg, cch = g * cpg + (i - r * cpg); a += ls[r * C + cch]; q += lss[r * C + cch]; }
+  }
+  for (int o = 4; o >= 1; o >>= 1) { a += __shfl_xor(a, o); q += __shfl_xor(q, o); }
+  if (g < groups && l == 0) {
+    float* o = part + (((long long)b * nchunk + chunk) * groups + g) * 2;
     o[0] = a; o[1] = q;
   }
 }
@@ -82,31 +107,42 @@ __global__ void gn_finalize_kernel(const float* __restrict__ part, int nchunk, i
   }
 }
 
-__global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict__ x0, const bf16_t* __restrict__ x1,
-                                                       int C0, int C1, int HW, long long nvec_total,
+__global__ __launch_bounds__(512) void gn_apply_kernel(const bf16_t* __restrict__ x0, const bf16_t* __restrict__ x1,
+                                                       int C0, int C1, int HW, int ppb,
                                                        const float* __restrict__ scale, const float* __restrict__ shift,
                                                        int silu, bf16_t* __restrict__ y) {
   const int C = C0 + C1, nvec = C >> 3;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nvec_total; i += (long long)gridDim.x * 256) {
-    const long long px = i / nvec;            // global pixel index (b*HW + p)
-    const int vc = (int)(i - px * nvec);
-    const int ch = vc * 8;
-    const int b = (int)(px / HW);
-    const bf16_t* src = (ch < C0) ? x0 + px * C0 + ch : x1 + px * C1 + (ch - C0);
-    const s16x8 v = *(const s16x8*)src;
-    const f32x4 sc0 = *(const f32x4*)(scale + (long long)b * C + ch), sc1 = *(const f32x4*)(scale + (long long)b * C + ch + 4);
-    const f32x4 sh0 = *(const f32x4*)(shift + (long long)b * C + ch), sh1 = *(const f32x4*)(shift + (long long)b * C + ch + 4);
+  const int PR = 512 / nvec;
+  const int tid = threadIdx.x;
+  const int vcol = tid % nvec, prow = tid / nvec;
+  if (prow >= PR) return;
+  const int b = blockIdx.y;
+  const int p0 = blockIdx.x * ppb, p1 = min(HW, p0 + ppb);
+  const int ch = vcol * 8;
+  const bf16_t* base; int Cs, cc;
+  if (ch < C0) { base = x0; Cs = C0; cc = ch; } else { base = x1; Cs = C1; cc = ch - C0; }
+  base += (long long)b * HW * Cs + cc;
+  bf16_t* yb = y + (long long)b * HW * C + ch;
+  float sc[8], sh[8];
+  *(f32x4*)&sc[0] = *(const f32x4*)(scale + (long long)b * C + ch); *(f32x4*)&sc[4] = *(const f32x4*)(scale + (long long)b * C + ch + 4);
+  *(f32x4*)&sh[0] = *(const f32x4*)(shift + (long long)b * C + ch); *(f32x4*)&sh[4] = *(const f32x4*)(shift + (long long)b * C + ch + 4);
+  auto one = [&](const s16x8 v, int px) {
     float o[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const float f = bf2f((bf16_t)v[e]);
-      float r = f * (e < 4 ? sc0[e] : sc1[e - 4]) + (e < 4 ? sh0[e] : sh1[e - 4]);
-      o[e] = silu ? silu_f(r) : r;
-    }
+    for (int e = 0; e < 8; ++e) { const float r = fmaf(bf2f((bf16_t)v[e]), sc[e], sh[e]); o[e] = silu ? silu_f(r) : r; }
     u32x4 pk;
     pk[0] = pack_bf2(o[0], o[1]); pk[1] = pack_bf2(o[2], o[3]); pk[2] = pack_bf2(o[4], o[5]); pk[3] = pack_bf2(o[6], o[7]);
-    *(u32x4*)(y + px * C + ch) = pk;
+    *(u32x4*)(yb + (long long)px * C) = pk;
+  };
+  int px = p0 + prow;
+  for (; px + 3 * PR < p1; px += 4 * PR) {
+    s16x8 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = *(const s16x8*)(base + (long long)(px + u * PR) * Cs);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) one(v[u], px + u * PR);
   }
+  for (; px < p1; px += PR) one(*(const s16x8*)(base + (long long)px * Cs), px);
 }
 
 int launch_groupnorm(const GroupNormP& p, hipStream_t st) {
@@ -115,70 +151,72 @@ int launch_groupnorm(const GroupNormP& p, hipStream_t st) {
   if (C % 8 || p.C0 % 8 || nvec > 512 || C % p.groups || p.groups > 64) {
     agd_set_error("groupnorm: unsupported C0=%d C1=%d groups=%d", p.C0, p.C1, p.groups); return -1;
   }
-  const int PR = 512 / nvec;
-  const int ppb = PR * 8;
-  const int nchunk = (p.HW + ppb - 1) / ppb;
+  const GnGeom g = gn_geom(p.B, C, p.HW);
   float* part = p.ws;
-  float* scale = part + (long long)p.B * nchunk * p.groups * 2;
+  float* scale = part + (long long)p.B * g.nchunk * p.groups * 2;
   float* shift = scale + (long long)p.B * C;
-  const int lds = 2 * PR * C * 4;
-  hipLaunchKernelGGL(gn_stats_kernel, dim3(nchunk, p.B), dim3(512), lds, st, p.x0, p.x1, p.C0, p.C1, p.HW, p.groups, ppb, nchunk, part);
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3(p.B), dim3(512), 0, st, part, nchunk, p.groups, C, p.HW, p.eps, p.gamma, p.beta, scale, shift);
-  const long long nv = (long long)p.B * p.HW * nvec;
-  const int grid = (int)((nv + 255) / 256 < 4096 ? (nv + 255) / 256 : 4096);
-  hipLaunchKernelGGL(gn_apply_kernel, dim3(grid), dim3(256), 0, st, p.x0, p.x1, p.C0, p.C1, p.HW, nv, scale, shift, p.silu, p.y);
+  const int lds = 2 * g.PR * C * 4;
+  hipLaunchKernelGGL(gn_stats_kernel, dim3(g.nchunk, p.B), dim3(512), lds, st, p.x0, p.x1, p.C0, p.C1, p.HW, p.groups, g.ppb, g.nchunk, part);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(p.B), dim3(512), 0, st, part, g.nchunk, p.groups, C, p.HW, p.eps, p.gamma, p.beta, scale, shift);
+  hipLaunchKernelGGL(gn_apply_kernel, dim3(g.nchunk, p.B), dim3(512), 0, st, p.x0, p.x1, p.C0, p.C1, p.HW, g.ppb, scale, shift, p.silu, p.y);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }
 
 // required workspace floats for a groupnorm call (host helper)
 extern "C" long long agd_groupnorm_ws_floats(int B, int C, int HW, int groups) {
-  const int nvec = C / 8; const int PR = 512 / nvec; const int ppb = PR * 8;
-  const int nchunk = (HW + ppb - 1) / ppb;
-  return (long long)B * nchunk * groups * 2 + 2LL * B * C;
+  const GnGeom g = gn_geom(B, C, HW);
+  return (long long)B * g.nchunk * groups * 2 + 2LL * B * C;
 }
 
 // ---------------------------------------------------------------------------------------
-// LayerNorm: one wave per row, values held in registers (C <= 2048), two-pass variance.
+// LayerNorm: LPR lanes per row (16 -> 4 rows per wave for C <= 1280, else 64), values held in
+// registers, two-pass variance, 16-B loads/stores.
 // ---------------------------------------------------------------------------------------
+template <int LPR, int MAXV>
 __global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y,
                                                         const float* __restrict__ g, const float* __restrict__ bta,
                                                         int rows, int C, float eps) {
-  const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= rows) return;
+  constexpr int RPB = 256 / LPR;                    // rows per block
+  const int l = threadIdx.x % LPR;
+  const int row = blockIdx.x * RPB + threadIdx.x / LPR;
+  const bool rok = row < rows;
   const int nvec = C >> 3;
-  float v[4][8];
+  float v[MAXV][8];
   float s = 0.f;
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const int vi = lane + k * 64;
-    if (vi < nvec) {
+  for (int k = 0; k < MAXV; ++k) {
+    const int vi = l + k * LPR;
+    if (rok && vi < nvec) {
       const s16x8 r = *(const s16x8*)(x + (long long)row * C + vi * 8);
 #pragma unroll
       for (int e = 0; e < 8; ++e) { v[k][e] = bf2f((bf16_t)r[e]); s += v[k][e]; }
     }
   }
-  for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
+#pragma unroll
+  for (int o = LPR / 2; o >= 1; o >>= 1) s += __shfl_xor(s, o);
   const float mean = s / (float)C;
   float q = 0.f;
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const int vi = lane + k * 64;
-    if (vi < nvec) {
+  for (int k = 0; k < MAXV; ++k) {
+    const int vi = l + k * LPR;
+    if (rok && vi < nvec) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) { const float d = v[k][e] - mean; q += d * d; }
     }
   }
-  for (int o = 32; o >= 1; o >>= 1) q += __shfl_xor(q, o);
+#pragma unroll
+  for (int o = LPR / 2; o >= 1; o >>= 1) q += __shfl_xor(q, o);
   const float rstd = rsqrtf(q / (float)C + eps);
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const int vi = lane + k * 64;
-    if (vi < nvec) {
-      float o8[8];
+  for (int k = 0; k < MAXV; ++k) {
+    const int vi = l + k * LPR;
+    if (rok && vi < nvec) {
+      float gm[8], bt[8], o8[8];
+      *(f32x4*)&gm[0] = *(const f32x4*)(g + vi * 8); *(f32x4*)&gm[4] = *(const f32x4*)(g + vi * 8 + 4);
+      *(f32x4*)&bt[0] = *(const f32x4*)(bta + vi * 8); *(f32x4*)&bt[4] = *(const f32x4*)(bta + vi * 8 + 4);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) o8[e] = (v[k][e] - mean) * rstd * g[vi * 8 + e] + bta[vi * 8 + e];
+      for (int e = 0; e < 8; ++e) o8[e] = (v[k][e] - mean) * rstd * gm[e] + bt[e];
       u32x4 pk;
       pk[0] = pack_bf2(o8[0], o8[1]); pk[1] = pack_bf2(o8[2], o8[3]); pk[2] = pack_bf2(o8[4], o8[5]); pk[3] = pack_bf2(o8[6], o8[7]);
       *(u32x4*)(y + (long long)row * C + vi * 8) = pk;
@@ -188,7 +226,9 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* __restrict
 
 int launch_layernorm(const bf16_t* x, bf16_t* y, const float* g, const float* b, int rows, int C, float eps, hipStream_t st) {
   if (C % 8 || C > 2048) { agd_set_error("layernorm: unsupported C=%d", C); return -1; }
-  hipLaunchKernelGGL(layernorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, x, y, g, b, rows, C, eps);
+  if (C <= 640) hipLaunchKernelGGL((layernorm_kernel<16, 5>), dim3((rows + 15) / 16), dim3(256), 0, st, x, y, g, b, rows, C, eps);
+  else if (C <= 1280) hipLaunchKernelGGL((layernorm_kernel<16, 10>), dim3((rows + 15) / 16), dim3(256), 0, st, x, y, g, b, rows, C, eps);
+  else hipLaunchKernelGGL((layernorm_kernel<64, 4>), dim3((rows + 3) / 4), dim3(256), 0, st, x, y, g, b, rows, C, eps);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }

@@ -13,10 +13,10 @@ class DDIMScheduler:
         self.num_train_timesteps = num_train_timesteps
         self.steps_offset = steps_offset
         self.prediction_type = prediction_type
-        # float32 arithmetic, like torch.linspace(...)**2 -> cumprod in diffusers
-        betas = np.linspace(np.float32(beta_start) ** 0.5, np.float32(beta_end) ** 0.5, num_train_timesteps,
-                            dtype=np.float32) ** 2
-        self.alphas_cumprod = np.cumprod((1.0 - betas).astype(np.float32), dtype=np.float32)
+        # the same torch float32 ops diffusers uses (scaled_linear betas -> cumprod), so the table is bit-identical
+        import torch
+        betas = torch.linspace(beta_start ** 0.5, beta_end ** 0.5, num_train_timesteps, dtype=torch.float32) ** 2
+        self.alphas_cumprod = torch.cumprod(1.0 - betas, dim=0).numpy()
         self.final_alpha_cumprod = np.float32(1.0) if set_alpha_to_one else self.alphas_cumprod[0]
         self.init_noise_sigma = 1.0
         self.timesteps = None

@@ -122,7 +122,9 @@ def main():
         usd, vsd = pipe.synthetic_weights
         usd = {k: v.cpu() for k, v in usd.items()}
         vsd = {k: v.cpu() for k, v in vsd.items()}
-        cpu = cpu_baseline(cfg, usd, vsd, ctx, os.cpu_count() or 1)
+        # a 1-GPU box grants 16 host cores; never oversubscribe past that share
+        threads = int(os.environ.get("AGD_CPU_THREADS", min(os.cpu_count() or 1, 16)))
+        cpu = cpu_baseline(cfg, usd, vsd, ctx, threads)
     if world > 1:
         dist.barrier()
     if rank == 0:
