@@ -42,6 +42,14 @@ AGD_DEV void glds16(const void* gsrc, void* lds_wave_base) {
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
+// LDS-DMA through a buffer descriptor: `base` must be wave-uniform; `voff` is the per-lane byte offset
+// (>= 0x7FFFFFF0 -> out of range -> the hardware writes zeros: conv padding / tile tails for free);
+// `soff` is a wave-uniform (SGPR) byte offset.  LDS destination = wave-uniform base + lane*16.
+AGD_DEV void bufdma16(const void* base, void* lds_wave_base, unsigned voff, unsigned soff) {
+  const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x7FFFFFF0, 0x00020000);
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voff, soff, 0, 0);
+}
+
 // XCD-aware bijective block remap: consecutive logical ids land on the same XCD (8 XCDs,
 // round-robin dispatch), so tiles that share an operand panel share an L2.  Speed only.
 AGD_DEV int xcd_remap(int bid, int nwg) {

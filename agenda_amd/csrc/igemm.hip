@@ -9,8 +9,10 @@
 //  * activations live NHWC bf16, so a conv tap is a contiguous 128-B channel run per pixel and a
 //    transformer token row IS a pixel row -- no NCHW<->NHWC transposes anywhere;
 //  * A (im2col rows) and B (weights [N][K], K = tap-major) tiles go global->LDS by LDS-DMA
-//    (global_load_lds_dwordx4, per-lane source address = free gather; padding pixels read a zero
-//    page), double-buffered, one barrier per 64-deep K step;
+//    (buffer_load_dwordx4 ... lds): wave-uniform buffer descriptors, a per-lane 32-bit byte offset
+//    that is fixed for a whole (tap, source) segment = the im2col gather, and the K advance in an
+//    SGPR soffset -- zero VALU per load in steady state; padding pixels get an out-of-range offset
+//    and the hardware range check writes zeros; STAGES-deep ring, one barrier per 64-deep K step;
 //  * LDS rows are 128 B with the 16-B chunk index XOR (row&7): conflict-free ds_read_b128 for the
 //    16x16x32 MFMA operand fetch; the XOR is applied on the SOURCE address (LDS-DMA writes
 //    lane-linear);
@@ -21,7 +23,11 @@
 #include "kernels.h"
 #define CK0(expr) do { if ((expr) != 0) return -1; } while (0)
 
-template <int BM, int BN, int WM, int WN, int KS, int GEGLU, int SPLITK>
+template <int N> AGD_DEV void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory"); }
+
+#define OOB_OFF 0x80000000u      // >= num_records (0x7FFFFFF0): buffer range check returns zeros
+
+template <int BM, int BN, int WM, int WN, int KS, int STAGES, int GEGLU, int SPLITK>
 __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(const IgemmP p) {
   constexpr int NT = WM * WN * 64;
   constexpr int NW = WM * WN;
@@ -30,6 +36,9 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(const IgemmP p) {
   constexpr int A_IT = BM * 8 / NT, B_IT = BN * 8 / NT;
   constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
   static_assert(A_IT >= 1 && B_IT >= 1, "tile too small for thread count");
+  static_assert((BM * 8) % NT == 0 && (BN * 8) % NT == 0, "tile rows must split evenly over the DMA lanes");
+  constexpr int LPS = A_IT + B_IT;                   // LDS-DMA instructions per stage per wave
+  static_assert(STAGES >= 2 && STAGES <= 4 && (STAGES - 2) * LPS < 64, "vmcnt field");
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -41,10 +50,10 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(const IgemmP p) {
   const int bz = blockIdx.y;
   const int m0 = tm * BM, n0 = tn * BN;
 
-  const bf16_t* src0 = p.src0 + bz * p.sA0;
-  const bf16_t* src1 = p.src1 ? p.src1 + bz * p.sA1 : nullptr;
-  const bf16_t* Wp = p.W + bz * p.sW;
-  const bf16_t* zp = p.zero_page;
+  // wave-uniform buffer descriptors (kernel args + blockIdx only)
+  const bf16_t* base0 = p.src0 + bz * p.sA0;
+  const bf16_t* base1 = p.src1 ? p.src1 + bz * p.sA1 : p.src0;
+  const bf16_t* baseW = p.W + bz * p.sW;
 
   // ---- per-thread gather state ---------------------------------------------------------
   const int lrow = lane >> 3;                       // row within the 8-row DMA group
@@ -64,17 +73,14 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(const IgemmP p) {
     a_b[i] = b; a_y[i] = oy * p.stride - p.pad; a_x[i] = ox * p.stride - p.pad;
     a_rowok |= (ok ? 1u : 0u) << i;
   }
-  const bf16_t* bptr[B_IT];
-  unsigned b_ok = 0;
+  unsigned bvoff[B_IT];                              // fixed for the whole kernel
 #pragma unroll
   for (int i = 0; i < B_IT; ++i) {
     const int n = n0 + (i * NW + wid) * 8 + lrow;
-    const bool ok = n < p.N;
-    bptr[i] = Wp + (long long)(ok ? n : 0) * p.K + lchunk * 8;
-    b_ok |= (ok ? 1u : 0u) << i;
+    bvoff[i] = (n < p.N) ? (unsigned)(((long long)n * p.K + lchunk * 8) * 2) : OOB_OFF;
   }
-  const bf16_t* aptr[A_IT];
-  unsigned a_ok = 0;
+  unsigned avoff[A_IT];                              // fixed within a (tap, source) segment
+  unsigned asoff = 0, bsoff = 0;                     // SGPR byte offsets: K advance
   int seg_left = 0, tap = 0, cursrc = 0;
 
   // K-steps of this block: [ks0, ks0 + nk)  (split-K: grid.z slices the K range)
@@ -90,17 +96,15 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(const IgemmP p) {
   auto set_segment = [&](int tap_, int src_, int off_steps) {
     tap = tap_; cursrc = src_;
     const int kh = (KS == 3) ? tap / 3 : 0, kw = (KS == 3) ? tap - kh * 3 : 0;
-    const bf16_t* base = cursrc ? src1 : src0;
     const int Cs = cursrc ? p.C1 : p.C0;
     seg_left = (Cs >> 6) - off_steps;
-    a_ok = 0;
+    asoff = (unsigned)off_steps * 128u;
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
       const int iy = a_y[i] + kh, ix = a_x[i] + kw;
       const bool ok = ((a_rowok >> i) & 1) && (unsigned)iy < (unsigned)Hup && (unsigned)ix < (unsigned)Wup;
-      const long long pix = ((long long)a_b[i] * p.Hin + (iy >> ush)) * p.Win + (ix >> ush);
-      aptr[i] = base + (ok ? pix * Cs : 0) + lchunk * 8 + off_steps * 64;
-      a_ok |= (ok ? 1u : 0u) << i;
+      const int pix = (a_b[i] * p.Hin + (iy >> ush)) * p.Win + (ix >> ush);
+      avoff[i] = ok ? (unsigned)(((long long)pix * Cs + lchunk * 8) * 2) : OOB_OFF;
     }
   };
   auto new_segment = [&]() {
@@ -110,26 +114,28 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(const IgemmP p) {
     const int spt = (p.C0 + p.C1) >> 6;              // k-steps per tap
     const int t0 = ks0 / spt, r0 = ks0 - t0 * spt;
     if (r0 < (p.C0 >> 6)) set_segment(t0, 0, r0); else set_segment(t0, 1, r0 - (p.C0 >> 6));
-#pragma unroll
-    for (int i = 0; i < B_IT; ++i) bptr[i] += (long long)ks0 * 64;
+    bsoff = (unsigned)ks0 * 128u;
   }
 
-  auto issue = [&](int stage) {
+  auto issue = [&](int slot) {
     if (seg_left == 0) new_segment();
-    char* sA = smem + stage * STAGE;
+    char* sA = smem + slot * STAGE;
     char* sB = sA + A_BYTES;
+    // make the scalar operands provably wave-uniform (else hipcc wraps every load in a waterfall loop)
+    const unsigned aso = __builtin_amdgcn_readfirstlane(asoff), bso = __builtin_amdgcn_readfirstlane(bsoff);
+    if (__builtin_amdgcn_readfirstlane(cursrc)) {
 #pragma unroll
-    for (int i = 0; i < A_IT; ++i) {
-      const bf16_t* g = ((a_ok >> i) & 1) ? aptr[i] : zp;
-      glds16(g, sA + (i * NW + wid) * 1024);
-      aptr[i] += 64;
+      for (int i = 0; i < A_IT; ++i)
+        bufdma16(base1, sA + (i * NW + wid) * 1024, avoff[i], aso);
+    } else {
+#pragma unroll
+      for (int i = 0; i < A_IT; ++i)
+        bufdma16(base0, sA + (i * NW + wid) * 1024, avoff[i], aso);
     }
 #pragma unroll
-    for (int i = 0; i < B_IT; ++i) {
-      const bf16_t* g = ((b_ok >> i) & 1) ? bptr[i] : zp;
-      glds16(g, sB + (i * NW + wid) * 1024);
-      bptr[i] += 64;
-    }
+    for (int i = 0; i < B_IT; ++i)
+      bufdma16(baseW, sB + (i * NW + wid) * 1024, bvoff[i], bso);
+    asoff += 128u; bsoff += 128u;
     --seg_left;
   };
 
@@ -145,13 +151,22 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(const IgemmP p) {
 #pragma unroll
   for (int kk = 0; kk < 2; ++kk) foff[kk] = frow * 128 + ((((kk << 2) + (lane >> 4)) ^ (lane & 7)) << 4);
 
-  if (nk > 0) issue(0);
+  // ---- main loop: STAGES-deep ring, counted vmcnt, one barrier per K step ----------------------
+#pragma unroll
+  for (int s_ = 0; s_ < STAGES - 1; ++s_)
+    if (s_ < nk) issue(s_);
+  int slot = 0, islot = STAGES - 1;
   for (int ks = 0; ks < nk; ++ks) {
-    const int cur = ks & 1;
-    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-    if (ks + 1 < nk) issue(cur ^ 1);
-    const char* sA = smem + cur * STAGE + wm * WTM * 128;
-    const char* sB = smem + cur * STAGE + A_BYTES + wn * WTN * 128;
+    const int newer = (nk - 1 - ks) < (STAGES - 2) ? (nk - 1 - ks) : (STAGES - 2);   // stages allowed in flight
+    if (STAGES >= 4 && newer == 2) wait_vmcnt<2 * LPS>();
+    else if (STAGES >= 3 && newer == 1) wait_vmcnt<LPS>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (ks + STAGES - 1 < nk) { issue(islot); islot = (islot + 1 == STAGES) ? 0 : islot + 1; }
+    const char* sA = smem + slot * STAGE + wm * WTM * 128;
+    const char* sB = smem + slot * STAGE + A_BYTES + wn * WTN * 128;
+    slot = (slot + 1 == STAGES) ? 0 : slot + 1;
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
       bf16x8 af[MI], bfr[NI];
@@ -325,14 +340,14 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const IgemmP p, int 
   }
 }
 
-template <int BM, int BN, int WM, int WN, int KS, int GEGLU, int SPLITK>
+template <int BM, int BN, int WM, int WN, int KS, int STAGES, int GEGLU, int SPLITK>
 static int launch_one(const IgemmP& p, int splits, hipStream_t st) {
   constexpr int NT = WM * WN * 64;
   constexpr int stage = (BM + BN) * 128;
-  constexpr int lds = (2 * stage > BM * BN * 4) ? 2 * stage : BM * BN * 4;
+  constexpr int lds = (STAGES * stage > BM * BN * 4) ? STAGES * stage : BM * BN * 4;
   const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
   dim3 grid(tiles, p.batch > 0 ? p.batch : 1, splits);
-  auto kfn = igemm_kernel<BM, BN, WM, WN, KS, GEGLU, SPLITK>;
+  auto kfn = igemm_kernel<BM, BN, WM, WN, KS, STAGES, GEGLU, SPLITK>;
   static bool attr = false;
   if (!attr) { HIP_CHECK_RET(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); attr = true; }
   hipLaunchKernelGGL(kfn, grid, dim3(NT), lds, st, p);
@@ -340,10 +355,10 @@ static int launch_one(const IgemmP& p, int splits, hipStream_t st) {
   return 0;
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int STAGES = 2>
 static int launch_cfg(const IgemmP& p, int splits, hipStream_t st) {
   if (splits > 1) {
-    int rc = (p.ksize == 3) ? launch_one<BM, BN, WM, WN, 3, 0, 1>(p, splits, st) : launch_one<BM, BN, WM, WN, 1, 0, 1>(p, splits, st);
+    int rc = (p.ksize == 3) ? launch_one<BM, BN, WM, WN, 3, STAGES, 0, 1>(p, splits, st) : launch_one<BM, BN, WM, WN, 1, STAGES, 0, 1>(p, splits, st);
     if (rc) return rc;
     const long long total = (long long)p.M * (p.N >> 2);
     const int grid = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
@@ -352,12 +367,15 @@ static int launch_cfg(const IgemmP& p, int splits, hipStream_t st) {
     return 0;
   }
   if (p.geglu) {
-    if constexpr (BN == 128) { if (p.ksize == 1) return launch_one<BM, BN, WM, WN, 1, 1, 0>(p, 1, st); }
+    if constexpr (BN == 128) { if (p.ksize == 1) return launch_one<BM, BN, WM, WN, 1, STAGES, 1, 0>(p, 1, st); }
     agd_set_error("igemm: geglu only on 1x1 with the 128-wide tile"); return -1;
   }
-  if (p.ksize == 3) return launch_one<BM, BN, WM, WN, 3, 0, 0>(p, 1, st);
-  return launch_one<BM, BN, WM, WN, 1, 0, 0>(p, 1, st);
+  if (p.ksize == 3) return launch_one<BM, BN, WM, WN, 3, STAGES, 0, 0>(p, 1, st);
+  return launch_one<BM, BN, WM, WN, 1, STAGES, 0, 0>(p, 1, st);
 }
+
+int g_igemm_cfg = 0;   // experiment knob
+extern "C" void agd_set_igemm_cfg(int v) { g_igemm_cfg = v; }
 
 static float* g_splitk_ws = nullptr; static size_t g_splitk_cap = 0;
 

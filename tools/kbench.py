@@ -45,6 +45,9 @@ def gn(B, HW, Cc, iters=20, cnt=1):
 
 
 what = sys.argv[1] if len(sys.argv) > 1 else "all"
+if len(sys.argv) > 2:
+    lib.agd_set_igemm_cfg(int(sys.argv[2]))
+    print("igemm cfg", sys.argv[2])
 B = 8
 tot = 0
 if what in ("conv", "all"):
