@@ -15,6 +15,7 @@
 //   recorded probabilities are stored token-major [T][h*w]: for a fixed register the 32 lanes
 //   of a half-wave hold 32 consecutive pixels -> 128-B coalesced read-modify-write.
 #include "kernels.h"
+#include <type_traits>
 
 int g_attn_qb = 1;   // queries per wave / 32 for the long self-attention shapes (tunable)
 extern "C" void agd_set_attn_qb(int v) { g_attn_qb = v; }
@@ -34,7 +35,7 @@ template <int D> struct AttnCfg {
 #define DEFER_THR 8.0f   // log2 units: rescale O only when a row max grows by more than 2^8
 
 template <int D, int KB, int QB, int RECORD>
-__global__ __launch_bounds__(256, ((QB == 1 && D <= 80) ? 2 : 1)) void attn_kernel(const AttnP p) {
+__global__ __launch_bounds__(256, ((QB == 1 && D <= 40 && !RECORD) ? 4 : (QB == 1 && D <= 80) ? 2 : 1)) void attn_kernel(const AttnP p) {
   using C = AttnCfg<D>;
   constexpr int KEYS = KB * 32;
   constexpr int KSTEPS = C::KSTEPS, DBLK = C::DBLK, KPITCH = C::KPITCH, VPITCH = C::VPITCH, CH = C::CH;
@@ -87,19 +88,27 @@ __global__ __launch_bounds__(256, ((QB == 1 && D <= 80) ? 2 : 1)) void attn_kern
     }
   }
 
+  // K/V tile prefetch through buffer descriptors: per-lane 32-bit offset fixed for the kernel, the tile
+  // advance in an SGPR soffset; rows >= Nk fall outside num_records and read as zeros.
   u32x4 kreg[LD_IT], vreg[LD_IT];
+  unsigned kvoff[LD_IT], vvoff[LD_IT];
+#pragma unroll
+  for (int it = 0; it < LD_IT; ++it) {
+    const int idx = tid + it * 256;
+    const int r = idx / CH, cc = idx - r * CH;
+    kvoff[it] = (idx < NCHUNK) ? (unsigned)((r * p.ldk + cc * 8) * 2) : 0x80000000u;
+    vvoff[it] = (idx < NCHUNK) ? (unsigned)((r * p.ldv + cc * 8) * 2) : 0x80000000u;
+  }
+  const unsigned k_bytes = (unsigned)(((long long)(p.Nk - 1) * p.ldk + D) * 2), v_bytes = (unsigned)(((long long)(p.Nk - 1) * p.ldv + D) * 2);
+  const auto krs = __builtin_amdgcn_make_buffer_rsrc((void*)kp, 0, k_bytes, 0x00020000);
+  const auto vrs = __builtin_amdgcn_make_buffer_rsrc((void*)vp, 0, v_bytes, 0x00020000);
   auto gload = [&](int tile) {
+    const unsigned ks_ = __builtin_amdgcn_readfirstlane((unsigned)(tile * KEYS * p.ldk * 2));
+    const unsigned vs_ = __builtin_amdgcn_readfirstlane((unsigned)(tile * KEYS * p.ldv * 2));
 #pragma unroll
     for (int it = 0; it < LD_IT; ++it) {
-      const int idx = tid + it * 256;
-      const int r = idx / CH, cc = idx - r * CH;
-      const int key = tile * KEYS + r;
-      kreg[it] = u32x4{0, 0, 0, 0};
-      vreg[it] = u32x4{0, 0, 0, 0};
-      if (idx < NCHUNK && key < p.Nk) {
-        kreg[it] = *(const u32x4*)(kp + (long long)key * p.ldk + cc * 8);
-        vreg[it] = *(const u32x4*)(vp + (long long)key * p.ldv + cc * 8);
-      }
+      kreg[it] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(krs, kvoff[it], ks_, 0));
+      vreg[it] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(vrs, vvoff[it], vs_, 0));
     }
   };
   auto lstore = [&](int stage) {
@@ -139,7 +148,8 @@ __global__ __launch_bounds__(256, ((QB == 1 && D <= 80) ? 2 : 1)) void attn_kern
   const int tr_row = (gi >> 2) + 4 * hh;                 // + 16*s (+8 second half) + 32*kb
   const int tr_col = ((lane >> 4) & 1) * 16 + (gi & 3) * 4;  // + 32*db   (elements)
 
-  for (int t = 0; t < ntiles; ++t) {
+  auto tile_body = [&](int t, auto mask_tag) {
+    constexpr bool MASK = decltype(mask_tag)::value;
     const int cur = RECORD ? 0 : (t & 1);
     const char* sK = smem + cur * STAGE;
     const char* sV = sK + KEYS * KPITCH;
@@ -149,19 +159,18 @@ __global__ __launch_bounds__(256, ((QB == 1 && D <= 80) ? 2 : 1)) void attn_kern
 #pragma unroll
     for (int kb = 0; kb < KB; ++kb) {
 #pragma unroll
-      for (int qb = 0; qb < QB; ++qb)
-#pragma unroll
-        for (int j = 0; j < 16; ++j) sacc[qb][kb][j] = 0.f;
-#pragma unroll
       for (int s = 0; s < KSTEPS; ++s) {
         const bf16x8 a = *(const bf16x8*)(sK + (kb * 32 + c) * KPITCH + (2 * s + hh) * 16);
 #pragma unroll
-        for (int qb = 0; qb < QB; ++qb)
-          sacc[qb][kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[qb][s], sacc[qb][kb], 0, 0, 0);
+        for (int qb = 0; qb < QB; ++qb) {
+          if (s == 0) { const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                        sacc[qb][kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[qb][s], z, 0, 0, 0); }
+          else sacc[qb][kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[qb][s], sacc[qb][kb], 0, 0, 0);
+        }
       }
     }
     // ---- online softmax (query on the lane); keys beyond Nk masked on the last tile only ----
-    if (ragged && t == ntiles - 1) {
+    if constexpr (MASK) {
 #pragma unroll
       for (int qb = 0; qb < QB; ++qb)
 #pragma unroll
@@ -179,7 +188,7 @@ __global__ __launch_bounds__(256, ((QB == 1 && D <= 80) ? 2 : 1)) void attn_kern
       for (int kb = 0; kb < KB; ++kb)
 #pragma unroll
         for (int i = 0; i < 16; ++i) mx = fmaxf(mx, sacc[qb][kb][i]);
-      mx = fmaxf(mx, __shfl_xor(mx, 32)) * sc;
+      mx = xhalf_max(mx) * sc;
       if constexpr (RECORD) {
         m_run[qb] = mx;                                   // single tile: no running state to rescale
       } else if (!__all(mx <= m_run[qb] + DEFER_THR)) {
@@ -216,7 +225,7 @@ __global__ __launch_bounds__(256, ((QB == 1 && D <= 80) ? 2 : 1)) void attn_kern
       // single-tile case (host guarantees Nk <= KEYS): probabilities are final here.
       // All old values are loaded first, then added, then stored: the RMW chains overlap.
       if (p.record_mode != 0 && b >= p.rec_b0 && (q0 + c) < p.Nq) {
-        const float lt = l_run[0] + __shfl_xor(l_run[0], 32);
+        const float lt = xhalf_sum(l_run[0]);
         const float inv = 1.0f / lt;
         const int img = b - p.rec_b0;
         if (p.record_mode == 1) {
@@ -270,17 +279,25 @@ __global__ __launch_bounds__(256, ((QB == 1 && D <= 80) ? 2 : 1)) void attn_kern
         for (int db = 0; db < DBLK; ++db) {
           const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vb + db * 64));
           const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vb + 8 * VPITCH + db * 64));
-          s16x8 a8;
-          a8[0] = lo[0]; a8[1] = lo[1]; a8[2] = lo[2]; a8[3] = lo[3];
-          a8[4] = hi[0]; a8[5] = hi[1]; a8[6] = hi[2]; a8[7] = hi[3];
+          const u32x2 lo2 = __builtin_bit_cast(u32x2, lo), hi2 = __builtin_bit_cast(u32x2, hi);
+          const u32x4 a4 = u32x4{lo2[0], lo2[1], hi2[0], hi2[1]};
 #pragma unroll
           for (int qb = 0; qb < QB; ++qb)
-            oacc[qb][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a8), pf[qb], oacc[qb][db], 0, 0, 0);
+            oacc[qb][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a4), pf[qb], oacc[qb][db], 0, 0, 0);
         }
       }
     if (t + 1 < ntiles) {
       lstore(cur ^ 1);      // the other stage was last read in iteration t-1 (all waves passed its barrier)
       __syncthreads();
+    }
+  };
+  {
+    using T_ = std::integral_constant<bool, true>; using F_ = std::integral_constant<bool, false>;
+    if constexpr (RECORD) {
+      tile_body(0, T_{});                              // single (always key-masked) tile
+    } else {
+      for (int t = 0; t < ntiles - 1; ++t) tile_body(t, F_{});
+      if (ragged) tile_body(ntiles - 1, T_{}); else tile_body(ntiles - 1, F_{});
     }
   }
 
@@ -293,7 +310,7 @@ __global__ __launch_bounds__(256, ((QB == 1 && D <= 80) ? 2 : 1)) void attn_kern
       const float lv = oacc[qb][D / 32][4 * (ld / 8)];     // row D of O^T lives in lanes 0..31 (hh = 0)
       lt = __shfl(lv, c);
     } else {
-      lt = l_run[qb] + __shfl_xor(l_run[qb], 32);
+      lt = xhalf_sum(l_run[qb]);
     }
     const float inv = 1.0f / lt;
     const int qrow = q0 + qb * 32 + c;

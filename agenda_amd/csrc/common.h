@@ -36,6 +36,16 @@ AGD_DEV float erf_fast(float x) {
 }
 AGD_DEV float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erf_fast(x * 0.70710678118654752440f)); }
 
+// value held by lane (l ^ 32) combined with own: one VALU v_permlane32_swap instead of a ds_bpermute round trip
+AGD_DEV float xhalf_max(float x) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+AGD_DEV float xhalf_sum(float x) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
 // global -> LDS direct (LDS-DMA), 16 B per lane; LDS destination = wave-uniform base + lane*16.
 AGD_DEV void glds16(const void* gsrc, void* lds_wave_base) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
@@ -45,8 +55,8 @@ AGD_DEV void glds16(const void* gsrc, void* lds_wave_base) {
 // LDS-DMA through a buffer descriptor: `base` must be wave-uniform; `voff` is the per-lane byte offset
 // (>= 0x7FFFFFF0 -> out of range -> the hardware writes zeros: conv padding / tile tails for free);
 // `soff` is a wave-uniform (SGPR) byte offset.  LDS destination = wave-uniform base + lane*16.
-AGD_DEV void bufdma16(const void* base, void* lds_wave_base, unsigned voff, unsigned soff) {
-  const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x7FFFFFF0, 0x00020000);
+AGD_DEV void bufdma16(const void* base, void* lds_wave_base, unsigned voff, unsigned soff, unsigned nrec = 0x7FFFFFF0u) {
+  const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, nrec, 0x00020000);
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voff, soff, 0, 0);
 }
 

@@ -33,10 +33,11 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(const IgemmP p) {
   constexpr int NW = WM * WN;
   constexpr int WTM = BM / WM, WTN = BN / WN;
   constexpr int MI = WTM / 16, NI = WTN / 16;
-  constexpr int A_IT = BM * 8 / NT, B_IT = BN * 8 / NT;
+  constexpr int A_IT = (BM * 8 + NT - 1) / NT, B_IT = (BN * 8 + NT - 1) / NT;   // DMA instructions per wave (last may be partial)
+  constexpr int A_Q = BM / 8, B_Q = BN / 8;          // 8-row DMA groups per tile
   constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
   static_assert(A_IT >= 1 && B_IT >= 1, "tile too small for thread count");
-  static_assert((BM * 8) % NT == 0 && (BN * 8) % NT == 0, "tile rows must split evenly over the DMA lanes");
+  static_assert(STAGES == 2 || ((BM * 8) % NT == 0 && (BN * 8) % NT == 0), "counted vmcnt needs equal DMA counts per wave");
   constexpr int LPS = A_IT + B_IT;                   // LDS-DMA instructions per stage per wave
   static_assert(STAGES >= 2 && STAGES <= 4 && (STAGES - 2) * LPS < 64, "vmcnt field");
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -54,6 +55,8 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(const IgemmP p) {
   const bf16_t* base0 = p.src0 + bz * p.sA0;
   const bf16_t* base1 = p.src1 ? p.src1 + bz * p.sA1 : p.src0;
   const bf16_t* baseW = p.W + bz * p.sW;
+  // timing experiments only (p.dbg): zero-record descriptors drop the loads but keep the instruction stream
+  const unsigned nrecA = (p.dbg & 1) ? 0u : 0x7FFFFFF0u, nrecB = (p.dbg & 2) ? 0u : 0x7FFFFFF0u;
 
   // ---- per-thread gather state ---------------------------------------------------------
   const int lrow = lane >> 3;                       // row within the 8-row DMA group
@@ -118,6 +121,7 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(const IgemmP p) {
   }
 
   auto issue = [&](int slot) {
+    if (p.dbg & 4) return;                      // timing experiment: no DMA instructions at all
     if (seg_left == 0) new_segment();
     char* sA = smem + slot * STAGE;
     char* sB = sA + A_BYTES;
@@ -126,15 +130,15 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(const IgemmP p) {
     if (__builtin_amdgcn_readfirstlane(cursrc)) {
 #pragma unroll
       for (int i = 0; i < A_IT; ++i)
-        bufdma16(base1, sA + (i * NW + wid) * 1024, avoff[i], aso);
+        if (i * NW + wid < A_Q) bufdma16(base1, sA + (i * NW + wid) * 1024, avoff[i], aso, nrecA);
     } else {
 #pragma unroll
       for (int i = 0; i < A_IT; ++i)
-        bufdma16(base0, sA + (i * NW + wid) * 1024, avoff[i], aso);
+        if (i * NW + wid < A_Q) bufdma16(base0, sA + (i * NW + wid) * 1024, avoff[i], aso, nrecA);
     }
 #pragma unroll
     for (int i = 0; i < B_IT; ++i)
-      bufdma16(baseW, sB + (i * NW + wid) * 1024, bvoff[i], bso);
+      if (i * NW + wid < B_Q) bufdma16(baseW, sB + (i * NW + wid) * 1024, bvoff[i], bso, nrecB);
     asoff += 128u; bsoff += 128u;
     --seg_left;
   };
@@ -151,35 +155,60 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(const IgemmP p) {
 #pragma unroll
   for (int kk = 0; kk < 2; ++kk) foff[kk] = frow * 128 + ((((kk << 2) + (lane >> 4)) ^ (lane & 7)) << 4);
 
-  // ---- main loop: STAGES-deep ring, counted vmcnt, one barrier per K step ----------------------
-#pragma unroll
-  for (int s_ = 0; s_ < STAGES - 1; ++s_)
-    if (s_ < nk) issue(s_);
-  int slot = 0, islot = STAGES - 1;
+  // ---- main loop (2-stage ring): ONE basic block per K step, hand-interleaved so the LDS-DMA issue of
+  // the next stage hides under this stage's MFMAs inside the same wave:
+  //   [barrier] kk0 fragment reads | { 2 MFMA, 1 LDS-DMA, 1 kk1 fragment read } x n | remaining MFMAs
+  // Memory ops keep source order (the compiler cannot prove DMA stores and fragment loads disjoint);
+  // sched_group_barrier pins the register-only MFMAs in between.  The last step issues its DMAs
+  // through a zero-record descriptor (dropped) so there is no branch in the loop body.
+  static_assert(STAGES == 2, "hand-interleaved loop is written for the 2-stage ring");
+  static_assert((BM * 8) % NT == 0 && (BN * 8) % NT == 0, "tile rows must split evenly over the DMA lanes");
+  constexpr int NF = MI + NI, ND = A_IT + B_IT, NG = NF > ND ? NF : ND;
+  if (nk > 0) issue(0);
   for (int ks = 0; ks < nk; ++ks) {
-    const int newer = (nk - 1 - ks) < (STAGES - 2) ? (nk - 1 - ks) : (STAGES - 2);   // stages allowed in flight
-    if (STAGES >= 4 && newer == 2) wait_vmcnt<2 * LPS>();
-    else if (STAGES >= 3 && newer == 1) wait_vmcnt<LPS>();
-    else wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    if (ks + STAGES - 1 < nk) { issue(islot); islot = (islot + 1 == STAGES) ? 0 : islot + 1; }
-    const char* sA = smem + slot * STAGE + wm * WTM * 128;
-    const char* sB = smem + slot * STAGE + A_BYTES + wn * WTN * 128;
-    slot = (slot + 1 == STAGES) ? 0 : slot + 1;
+    const int cur = ks & 1;
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    const bool more = ks + 1 < nk;
+    if (more && seg_left == 0) new_segment();
+    const unsigned nrA = more ? nrecA : 0u, nrB = more ? nrecB : 0u;
+    const bf16_t* baseA = __builtin_amdgcn_readfirstlane(cursrc) ? base1 : base0;
+    const unsigned aso = __builtin_amdgcn_readfirstlane(asoff), bso = __builtin_amdgcn_readfirstlane(bsoff);
+    char* dA = smem + (cur ^ 1) * STAGE;
+    char* dB = dA + A_BYTES;
+    const char* sA = smem + cur * STAGE + wm * WTM * 128;
+    const char* sB = smem + cur * STAGE + A_BYTES + wn * WTN * 128;
+    bf16x8 a0[MI], b0[NI], a1[MI], b1[NI];
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      bf16x8 af[MI], bfr[NI];
+    for (int i = 0; i < MI; ++i) a0[i] = *(const bf16x8*)(sA + i * 2048 + foff[0]);
 #pragma unroll
-      for (int i = 0; i < MI; ++i) af[i] = *(const bf16x8*)(sA + i * 2048 + foff[kk]);
+    for (int j = 0; j < NI; ++j) b0[j] = *(const bf16x8*)(sB + j * 2048 + foff[0]);
 #pragma unroll
-      for (int j = 0; j < NI; ++j) bfr[j] = *(const bf16x8*)(sB + j * 2048 + foff[kk]);
-#pragma unroll
-      for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < NI; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    for (int g = 0; g < NG; ++g) {
+      if (g < A_IT) bufdma16(baseA, dA + (g * NW + wid) * 1024, avoff[g < A_IT ? g : 0], aso, nrA);
+      else if (g < ND) bufdma16(baseW, dB + ((g - A_IT) * NW + wid) * 1024, bvoff[(g >= A_IT && g < ND) ? g - A_IT : 0], bso, nrB);
+      if (g < MI) a1[g] = *(const bf16x8*)(sA + g * 2048 + foff[1]);
+      else if (g < NF) b1[g - MI] = *(const bf16x8*)(sB + (g - MI) * 2048 + foff[1]);
     }
+    if (more) { asoff += 128u; bsoff += 128u; --seg_left; }
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NI; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0[i], b0[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NI; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[i], b1[j], acc[i][j], 0, 0, 0);
+    // pin the interleave (masks: MFMA 0x8, VMEM_READ 0x20, DS_READ 0x100)
+    __builtin_amdgcn_sched_group_barrier(0x100, NF, 0);
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      __builtin_amdgcn_sched_group_barrier(0x8, 2, 0);
+      if (g < ND) __builtin_amdgcn_sched_group_barrier(0x20, 1, 0);
+      if (g < NF) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x8, 2 * MI * NI - 2 * NG, 0);
   }
 
   // ---- epilogue: acc -> LDS fp32 [BM][BN] -> coalesced 16-B row chunks -----------------------
@@ -381,6 +410,7 @@ static float* g_splitk_ws = nullptr; static size_t g_splitk_cap = 0;
 
 int launch_igemm(const IgemmP& p_in, hipStream_t st) {
   IgemmP p = p_in;
+  p.dbg = g_igemm_cfg >> 4;
   if (p.K & 63 || p.C0 & 63 || p.C1 & 63) { agd_set_error("igemm: K/C0/C1 must be multiples of 64 (K=%d C0=%d C1=%d)", p.K, p.C0, p.C1); return -1; }
   if (p.K != p.ksize * p.ksize * (p.C0 + p.C1)) { agd_set_error("igemm: K=%d != ks^2*(C0+C1)=%d", p.K, p.ksize * p.ksize * (p.C0 + p.C1)); return -1; }
   if (p.ksize != 1 && p.ksize != 3) { agd_set_error("igemm: ksize %d", p.ksize); return -1; }
@@ -407,7 +437,8 @@ int launch_igemm(const IgemmP& p_in, hipStream_t st) {
     }
   }
   if (t128 >= 192) {
-    if ((p.N % 160) == 0 && (p.N % 128) != 0) return launch_cfg<128, 160, 2, 2>(p, 1, st);
+    const bool n160 = (p.N % 160) == 0 && (p.N % 128) != 0;
+    if (n160) return launch_cfg<128, 160, 2, 2>(p, 1, st);
     return launch_cfg<128, 128, 2, 2>(p, 1, st);
   }
   return launch_cfg<64, 64, 2, 2>(p, 1, st);

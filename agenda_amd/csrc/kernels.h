@@ -26,6 +26,7 @@ struct IgemmP {
   long long sA0, sA1, sW, sO, sR;   // per-batch element strides
   const bf16_t* zero_page;          // >= 256 B of zeros
   float* splitk_ws;                 // set by the launcher: fp32 partial slabs [S][M][N]
+  int dbg;                          // timing experiments only
 };
 int launch_igemm(const IgemmP& p, hipStream_t st);
 

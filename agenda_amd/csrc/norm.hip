@@ -74,58 +74,55 @@ __global__ __launch_bounds__(512) void gn_stats_kernel(const bf16_t* __restrict_
   }
 }
 
-__global__ void gn_finalize_kernel(const float* __restrict__ part, int nchunk, int groups, int C, int HW, float eps,
-                                   const float* __restrict__ gamma, const float* __restrict__ beta,
-                                   float* __restrict__ scale, float* __restrict__ shift) {
-  // block = one image; thread t: group g = t / 8, lane-in-group l = t % 8 strides over chunks
-  __shared__ float smean[64], srstd[64];
-  const int b = blockIdx.x, tid = threadIdx.x;
-  const int g = tid >> 3, l = tid & 7;
-  double a = 0.0, q = 0.0;
-  if (g < groups) {
-    for (int ck = l; ck < nchunk; ck += 8) {
-      const float* pp = part + (((long long)b * nchunk + ck) * groups + g) * 2;
-      a += (double)pp[0]; q += (double)pp[1];
-    }
-  }
-  for (int o = 4; o >= 1; o >>= 1) { a += __shfl_xor(a, o); q += __shfl_xor(q, o); }
-  if (g < groups && l == 0) {
-    const double n = (double)HW * (C / groups);
-    const double mean = a / n;
-    double var = q / n - mean * mean;
-    if (var < 0) var = 0;
-    smean[g] = (float)mean;
-    srstd[g] = (float)(1.0 / sqrt(var + (double)eps));
-  }
-  __syncthreads();
-  const int cpg = C / groups;
-  for (int cch = tid; cch < C; cch += blockDim.x) {
-    const int gg = cch / cpg;
-    const float sc = srstd[gg] * gamma[cch];
-    scale[(long long)b * C + cch] = sc;
-    shift[(long long)b * C + cch] = beta[cch] - smean[gg] * sc;
-  }
-}
-
+// apply: every block first reduces the per-chunk partials of ITS image (deterministic fixed order,
+// fp64) into group mean/rstd in LDS -- the "finalize" step costs ~nchunk*groups*8 B of L2 reads per
+// block and saves a dependent kernel launch -- then streams y = silu?(x*scale + shift).
 __global__ __launch_bounds__(512) void gn_apply_kernel(const bf16_t* __restrict__ x0, const bf16_t* __restrict__ x1,
-                                                       int C0, int C1, int HW, int ppb,
-                                                       const float* __restrict__ scale, const float* __restrict__ shift,
+                                                       int C0, int C1, int HW, int ppb, int nchunk, int groups, float eps,
+                                                       const float* __restrict__ part,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        int silu, bf16_t* __restrict__ y) {
+  __shared__ float smean[64], srstd[64];
   const int C = C0 + C1, nvec = C >> 3;
   const int PR = 512 / nvec;
   const int tid = threadIdx.x;
+  const int b = blockIdx.y;
+  {
+    const int g = tid >> 3, l = tid & 7;
+    double a = 0.0, q = 0.0;
+    if (g < groups) {
+      for (int ck = l; ck < nchunk; ck += 8) {
+        const float* pp = part + (((long long)b * nchunk + ck) * groups + g) * 2;
+        a += (double)pp[0]; q += (double)pp[1];
+      }
+    }
+    for (int o = 4; o >= 1; o >>= 1) { a += __shfl_xor(a, o); q += __shfl_xor(q, o); }
+    if (g < groups && l == 0) {
+      const double n = (double)HW * (C / groups);
+      const double mean = a / n;
+      double var = q / n - mean * mean;
+      if (var < 0) var = 0;
+      smean[g] = (float)mean;
+      srstd[g] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+  }
+  __syncthreads();
   const int vcol = tid % nvec, prow = tid / nvec;
   if (prow >= PR) return;
-  const int b = blockIdx.y;
   const int p0 = blockIdx.x * ppb, p1 = min(HW, p0 + ppb);
   const int ch = vcol * 8;
   const bf16_t* base; int Cs, cc;
   if (ch < C0) { base = x0; Cs = C0; cc = ch; } else { base = x1; Cs = C1; cc = ch - C0; }
   base += (long long)b * HW * Cs + cc;
   bf16_t* yb = y + (long long)b * HW * C + ch;
+  const int cpg = C / groups;
   float sc[8], sh[8];
-  *(f32x4*)&sc[0] = *(const f32x4*)(scale + (long long)b * C + ch); *(f32x4*)&sc[4] = *(const f32x4*)(scale + (long long)b * C + ch + 4);
-  *(f32x4*)&sh[0] = *(const f32x4*)(shift + (long long)b * C + ch); *(f32x4*)&sh[4] = *(const f32x4*)(shift + (long long)b * C + ch + 4);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int gg = (ch + e) / cpg;
+    sc[e] = srstd[gg] * gamma[ch + e];
+    sh[e] = beta[ch + e] - smean[gg] * sc[e];
+  }
   auto one = [&](const s16x8 v, int px) {
     float o[8];
 #pragma unroll
@@ -153,12 +150,10 @@ int launch_groupnorm(const GroupNormP& p, hipStream_t st) {
   }
   const GnGeom g = gn_geom(p.B, C, p.HW);
   float* part = p.ws;
-  float* scale = part + (long long)p.B * g.nchunk * p.groups * 2;
-  float* shift = scale + (long long)p.B * C;
   const int lds = 2 * g.PR * C * 4;
   hipLaunchKernelGGL(gn_stats_kernel, dim3(g.nchunk, p.B), dim3(512), lds, st, p.x0, p.x1, p.C0, p.C1, p.HW, p.groups, g.ppb, g.nchunk, part);
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3(p.B), dim3(512), 0, st, part, g.nchunk, p.groups, C, p.HW, p.eps, p.gamma, p.beta, scale, shift);
-  hipLaunchKernelGGL(gn_apply_kernel, dim3(g.nchunk, p.B), dim3(512), 0, st, p.x0, p.x1, p.C0, p.C1, p.HW, g.ppb, scale, shift, p.silu, p.y);
+  hipLaunchKernelGGL(gn_apply_kernel, dim3(g.nchunk, p.B), dim3(512), 0, st, p.x0, p.x1, p.C0, p.C1, p.HW, g.ppb, g.nchunk, p.groups, p.eps,
+                     part, p.gamma, p.beta, p.silu, p.y);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }
