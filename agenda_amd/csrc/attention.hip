@@ -48,8 +48,20 @@ __global__ __launch_bounds__(256, ((QB == 1 && D <= 40 && !RECORD) ? 4 : (QB == 
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int c = lane & 31, hh = lane >> 5;
-  const int head = blockIdx.y, b = blockIdx.z;
-  const int q0 = blockIdx.x * (128 * QB) + wid * (32 * QB);
+  // XCD-aware 1-D grid: blocks are dealt round-robin over the 8 XCDs, so give every (batch, head) pair --
+  // whose query tiles all stream the same K/V -- to ONE XCD (its L2 then serves K/V after the first tile).
+  const int nqt = p.nqt, nbh = p.B * p.H;
+  int bh, qt;
+  {
+    const int id = blockIdx.x, x = id & 7, j = id >> 3;
+    const int per = (nbh + 7) >> 3;                    // (b,h) pairs per XCD group
+    const int lb = j / nqt;
+    qt = j - lb * nqt;
+    bh = x * per + lb;                                 // may exceed nbh for the last groups: exit
+  }
+  if (bh >= nbh) return;
+  const int head = bh % p.H, b = bh / p.H;
+  const int q0 = qt * (128 * QB) + wid * (32 * QB);
   const bf16_t* qp = p.q + b * p.sq + head * D;
   const bf16_t* kp = p.k + b * p.sk + head * D;
   const bf16_t* vp = p.v + b * p.sv + head * D;
@@ -336,11 +348,14 @@ template <int D, int KB, int QB, int RECORD>
 static int launch_attn_t(const AttnP& p, hipStream_t st) {
   using C = AttnCfg<D>;
   constexpr int lds = (RECORD ? 1 : 2) * KB * 32 * (C::KPITCH + C::VPITCH);
-  dim3 grid((p.Nq + 128 * QB - 1) / (128 * QB), p.H, p.B);
+  AttnP pp = p;
+  pp.nqt = (p.Nq + 128 * QB - 1) / (128 * QB);
+  const int per = (p.B * p.H + 7) / 8;
+  dim3 grid(8 * per * pp.nqt);
   auto kfn = attn_kernel<D, KB, QB, RECORD>;
   static bool attr = false;
   if (!attr && lds > 65536) { HIP_CHECK_RET(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); attr = true; }
-  hipLaunchKernelGGL(kfn, grid, dim3(256), lds, st, p);
+  hipLaunchKernelGGL(kfn, grid, dim3(256), lds, st, pp);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }

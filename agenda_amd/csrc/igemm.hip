@@ -21,6 +21,7 @@
 //    time-embedding row add / residual / GEGLU / SiLU fused, one rounding to bf16;
 //  * block->tile map is XCD-aware (tiles sharing an A panel share an L2).
 #include "kernels.h"
+#include <cstdlib>
 #define CK0(expr) do { if ((expr) != 0) return -1; } while (0)
 
 template <int N> AGD_DEV void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory"); }
@@ -90,7 +91,8 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(const IgemmP p) {
   const int nk_total = p.K >> 6;
   int ks0 = 0, nk = nk_total;
   if constexpr (SPLITK) {
-    const int per = (nk_total + (int)gridDim.z - 1) / (int)gridDim.z;
+    constexpr int Q = (KS == 3) ? 9 : 1;             // 3x3: slice on whole channel chunks (9 taps each)
+    const int per = ((nk_total / Q + (int)gridDim.z - 1) / (int)gridDim.z) * Q;
     ks0 = (int)blockIdx.z * per;
     nk = nk_total - ks0 < per ? nk_total - ks0 : per;
     if (nk < 0) nk = 0;
@@ -164,15 +166,9 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(const IgemmP p) {
   static_assert(STAGES == 2, "hand-interleaved loop is written for the 2-stage ring");
   static_assert((BM * 8) % NT == 0 && (BN * 8) % NT == 0, "tile rows must split evenly over the DMA lanes");
   constexpr int NF = MI + NI, ND = A_IT + B_IT, NG = NF > ND ? NF : ND;
-  if (nk > 0) issue(0);
-  for (int ks = 0; ks < nk; ++ks) {
-    const int cur = ks & 1;
-    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-    const bool more = ks + 1 < nk;
-    if (more && seg_left == 0) new_segment();
-    const unsigned nrA = more ? nrecA : 0u, nrB = more ? nrecB : 0u;
-    const bf16_t* baseA = __builtin_amdgcn_readfirstlane(cursrc) ? base1 : base0;
-    const unsigned aso = __builtin_amdgcn_readfirstlane(asoff), bso = __builtin_amdgcn_readfirstlane(bsoff);
+
+  // one K step: barrier, then {kk0 fragment reads | (2 MFMA, 1 DMA, 1 kk1 read) x n | remaining MFMAs}
+  auto kstep = [&](int cur, const bf16_t* baseA, const unsigned (&av)[A_IT], unsigned aso, unsigned bso, unsigned nrA, unsigned nrB) {
     char* dA = smem + (cur ^ 1) * STAGE;
     char* dB = dA + A_BYTES;
     const char* sA = smem + cur * STAGE + wm * WTM * 128;
@@ -184,12 +180,11 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(const IgemmP p) {
     for (int j = 0; j < NI; ++j) b0[j] = *(const bf16x8*)(sB + j * 2048 + foff[0]);
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
-      if (g < A_IT) bufdma16(baseA, dA + (g * NW + wid) * 1024, avoff[g < A_IT ? g : 0], aso, nrA);
+      if (g < A_IT) bufdma16(baseA, dA + (g * NW + wid) * 1024, av[g < A_IT ? g : 0], aso, nrA);
       else if (g < ND) bufdma16(baseW, dB + ((g - A_IT) * NW + wid) * 1024, bvoff[(g >= A_IT && g < ND) ? g - A_IT : 0], bso, nrB);
       if (g < MI) a1[g] = *(const bf16x8*)(sA + g * 2048 + foff[1]);
       else if (g < NF) b1[g - MI] = *(const bf16x8*)(sB + (g - MI) * 2048 + foff[1]);
     }
-    if (more) { asoff += 128u; bsoff += 128u; --seg_left; }
 #pragma unroll
     for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -209,6 +204,84 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(const IgemmP p) {
       if (g < NF) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
     }
     __builtin_amdgcn_sched_group_barrier(0x8, 2 * MI * NI - 2 * NG, 0);
+  };
+
+  if (KS == 3 && p.up == 1 && (p.dbg & 8)) {     // opt-in (AGD_IGEMM_CFG=128): measured slower, see DESIGN.md §4
+    // K order = channel-chunk major, tap minor: the 9 taps of one 64-channel chunk run back to back, so the
+    // shifted re-reads of the same pixels hit in L2 (tap-major order sweeps every chunk between two uses of a
+    // pixel: ~9x the algorithmic fetch, measured with FETCH_SIZE).  Gather offset of tap (kh,kw) =
+    // per-row base (pixel (oy*s-1, ox*s-1), may wrap) + scalar delta (kh*Win + kw)*Cs*2; a 9-bit mask per row
+    // marks the taps that fall inside the image (the others get the out-of-range offset -> zeros).
+    unsigned abase[A_IT], amask[A_IT];
+    auto fill_base = [&](int src) {
+      const int Cs = src ? p.C1 : p.C0;
+#pragma unroll
+      for (int i = 0; i < A_IT; ++i) {
+        const int pix = (a_b[i] * p.Hin + a_y[i]) * p.Win + a_x[i];
+        abase[i] = (unsigned)(pix * Cs * 2 + lchunk * 16);
+      }
+    };
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+      unsigned mk = 0;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int iy = a_y[i] + t / 3, ix = a_x[i] + t % 3;
+        const bool ok = ((a_rowok >> i) & 1) && (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win;
+        mk |= (ok ? 1u : 0u) << t;
+      }
+      amask[i] = mk;
+    }
+    const int Ctot = p.C0 + p.C1, nch0 = p.C0 >> 6;
+    int isrc, ichunk;                                   // coordinates of the NEXT stage to issue
+    { const int c0 = ks0 / 9; if (c0 < nch0) { isrc = 0; ichunk = c0; } else { isrc = 1; ichunk = c0 - nch0; } }
+    fill_base(isrc);
+    auto tap_offsets = [&](int t, unsigned (&av)[A_IT]) {
+      const int Cs = isrc ? p.C1 : p.C0;
+      const unsigned delta = __builtin_amdgcn_readfirstlane((unsigned)(((t / 3) * p.Win + (t % 3)) * Cs * 2));
+#pragma unroll
+      for (int i = 0; i < A_IT; ++i) av[i] = ((amask[i] >> t) & 1u) ? abase[i] + delta : OOB_OFF;
+    };
+    if (nk > 0) {   // prologue: stage 0 = (isrc, ichunk, tap 0)
+      const unsigned aso = (unsigned)ichunk * 128u, bso = (unsigned)(((isrc ? p.C0 : 0) + ichunk * 64) * 2);
+      unsigned av[A_IT]; tap_offsets(0, av);
+      char* dA = smem; char* dB = dA + A_BYTES;
+#pragma unroll
+      for (int i = 0; i < A_IT; ++i) bufdma16(isrc ? base1 : base0, dA + (i * NW + wid) * 1024, av[i], aso, nrecA);
+#pragma unroll
+      for (int i = 0; i < B_IT; ++i) bufdma16(baseW, dB + (i * NW + wid) * 1024, bvoff[i], bso, nrecB);
+    }
+    const int niter = nk / 9;
+    int gs = 0;                                         // k-step counter within this block
+    for (int it = 0; it < niter; ++it) {
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        const bool more = gs + 1 < nk;
+        if (t == 8 && more) {                           // next stage starts a new chunk (maybe the second source)
+          ++ichunk;
+          if (isrc == 0 && ichunk == nch0) { isrc = 1; ichunk = 0; fill_base(1); }
+        }
+        const int nt = (t + 1) % 9;
+        unsigned av[A_IT]; tap_offsets(nt, av);
+        const unsigned aso = __builtin_amdgcn_readfirstlane((unsigned)ichunk * 128u);
+        const unsigned bso = __builtin_amdgcn_readfirstlane((unsigned)((nt * Ctot + (isrc ? p.C0 : 0) + ichunk * 64) * 2));
+        const bf16_t* baseA = __builtin_amdgcn_readfirstlane(isrc) ? base1 : base0;
+        kstep(gs & 1, baseA, av, aso, bso, more ? nrecA : 0u, more ? nrecB : 0u);
+        ++gs;
+      }
+    }
+  } else {
+    if (nk > 0) issue(0);
+    for (int ks = 0; ks < nk; ++ks) {
+      asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+      const bool more = ks + 1 < nk;
+      if (more && seg_left == 0) new_segment();
+      const bf16_t* baseA = __builtin_amdgcn_readfirstlane(cursrc) ? base1 : base0;
+      const unsigned aso = __builtin_amdgcn_readfirstlane(asoff), bso = __builtin_amdgcn_readfirstlane(bsoff);
+      kstep(ks & 1, baseA, avoff, aso, bso, more ? nrecA : 0u, more ? nrecB : 0u);
+      if (more) { asoff += 128u; bsoff += 128u; --seg_left; }
+    }
   }
 
   // ---- epilogue: acc -> LDS fp32 [BM][BN] -> coalesced 16-B row chunks -----------------------
@@ -263,6 +336,19 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(const IgemmP p) {
         if (idx < BM * CPR && m < p.M && no + 8 <= Nout) rres[it] = *(const s16x8*)(p.residual + bz * p.sR + (long long)m * p.ldr + no);
       }
     }
+    // when the thread count is a multiple of the chunks per row, each thread keeps ONE column chunk for all its
+    // rows: per-column epilogue operands (bias vectors) are loaded once, before the staging barriers
+    constexpr bool FIXED_CC = (NT % CPR) == 0;
+    float hb[8], hg[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { hb[e] = 0.f; hg[e] = 0.f; }
+    if constexpr (FIXED_CC) {
+      const int no_ = no0 + (tid % CPR) * 8;
+      if (p.bias && p.bias_mode != 2 && no_ + 8 <= Nout) {
+        *(f32x4*)&hb[0] = *(const f32x4*)(p.bias + no_); *(f32x4*)&hb[4] = *(const f32x4*)(p.bias + no_ + 4);
+        if constexpr (GEGLU) { *(f32x4*)&hg[0] = *(const f32x4*)(p.bias + Nout + no_); *(f32x4*)&hg[4] = *(const f32x4*)(p.bias + Nout + no_ + 4); }
+      }
+    }
     stage_acc();
 #pragma unroll
     for (int it = 0; it < EP_IT; ++it) {
@@ -277,20 +363,21 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(const IgemmP p) {
       *(f32x4*)&v[0] = *(const f32x4*)sp;
       *(f32x4*)&v[4] = *(const f32x4*)(sp + 4);
       if constexpr (GEGLU) {
-        float g[8], bv[8], gv[8];
+        float g[8];
         *(f32x4*)&g[0] = *(const f32x4*)(sp + BN / 2);
         *(f32x4*)&g[4] = *(const f32x4*)(sp + BN / 2 + 4);
-        *(f32x4*)&bv[0] = *(const f32x4*)(p.bias + no); *(f32x4*)&bv[4] = *(const f32x4*)(p.bias + no + 4);
-        *(f32x4*)&gv[0] = *(const f32x4*)(p.bias + Nout + no); *(f32x4*)&gv[4] = *(const f32x4*)(p.bias + Nout + no + 4);
+        if constexpr (!FIXED_CC) {
+          *(f32x4*)&hb[0] = *(const f32x4*)(p.bias + no); *(f32x4*)&hb[4] = *(const f32x4*)(p.bias + no + 4);
+          *(f32x4*)&hg[0] = *(const f32x4*)(p.bias + Nout + no); *(f32x4*)&hg[4] = *(const f32x4*)(p.bias + Nout + no + 4);
+        }
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = (v[e] + bv[e]) * gelu_erf_f(g[e] + gv[e]);
+        for (int e = 0; e < 8; ++e) v[e] = (v[e] + hb[e]) * gelu_erf_f(g[e] + hg[e]);
       } else {
         if (p.bias_mode == 1) {
           if (nvalid == 8) {
-            float bv[8];
-            *(f32x4*)&bv[0] = *(const f32x4*)(p.bias + no); *(f32x4*)&bv[4] = *(const f32x4*)(p.bias + no + 4);
+            if constexpr (!FIXED_CC) { *(f32x4*)&hb[0] = *(const f32x4*)(p.bias + no); *(f32x4*)&hb[4] = *(const f32x4*)(p.bias + no + 4); }
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] += bv[e];
+            for (int e = 0; e < 8; ++e) v[e] += hb[e];
           } else {
             for (int e = 0; e < nvalid; ++e) v[e] += p.bias[no + e];
           }
@@ -410,6 +497,8 @@ static float* g_splitk_ws = nullptr; static size_t g_splitk_cap = 0;
 
 int launch_igemm(const IgemmP& p_in, hipStream_t st) {
   IgemmP p = p_in;
+  static bool env_read = false;
+  if (!env_read) { env_read = true; const char* e = getenv("AGD_IGEMM_CFG"); if (e) g_igemm_cfg = atoi(e); }
   p.dbg = g_igemm_cfg >> 4;
   if (p.K & 63 || p.C0 & 63 || p.C1 & 63) { agd_set_error("igemm: K/C0/C1 must be multiples of 64 (K=%d C0=%d C1=%d)", p.K, p.C0, p.C1); return -1; }
   if (p.K != p.ksize * p.ksize * (p.C0 + p.C1)) { agd_set_error("igemm: K=%d != ks^2*(C0+C1)=%d", p.K, p.ksize * p.ksize * (p.C0 + p.C1)); return -1; }
@@ -436,7 +525,7 @@ int launch_igemm(const IgemmP& p_in, hipStream_t st) {
       return launch_cfg<128, 128, 2, 2>(p, S, st);
     }
   }
-  if (t128 >= 192) {
+  if (t128 >= ((g_igemm_cfg & 15) == 3 ? 128 : 192)) {
     const bool n160 = (p.N % 160) == 0 && (p.N % 128) != 0;
     if (n160) return launch_cfg<128, 160, 2, 2>(p, 1, st);
     return launch_cfg<128, 128, 2, 2>(p, 1, st);

@@ -44,6 +44,7 @@ struct AttnP {
   int record_mode; int rec_b0;      // first batch row that records (B/2 for CFG inference, 0 for train)
   float* rec; long long rec_img_stride; long long rec_head_stride;  // DAAM: [img][head][T][Nq]
   int rec_T;                        // number of token rows to record (<= Nk)
+  int nqt;                          // set by the launcher: query tiles per (batch, head)
 };
 int launch_attention(const AttnP& p, hipStream_t st);
 

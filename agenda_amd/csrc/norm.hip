@@ -221,9 +221,11 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* __restrict
 
 int launch_layernorm(const bf16_t* x, bf16_t* y, const float* g, const float* b, int rows, int C, float eps, hipStream_t st) {
   if (C % 8 || C > 2048) { agd_set_error("layernorm: unsupported C=%d", C); return -1; }
-  if (C <= 640) hipLaunchKernelGGL((layernorm_kernel<16, 5>), dim3((rows + 15) / 16), dim3(256), 0, st, x, y, g, b, rows, C, eps);
-  else if (C <= 1280) hipLaunchKernelGGL((layernorm_kernel<16, 10>), dim3((rows + 15) / 16), dim3(256), 0, st, x, y, g, b, rows, C, eps);
-  else hipLaunchKernelGGL((layernorm_kernel<64, 4>), dim3((rows + 3) / 4), dim3(256), 0, st, x, y, g, b, rows, C, eps);
+  // few rows (16x16 / 8x8 feature maps): one wave per row so the grid still covers the 256 CUs
+  const bool few = rows < 16 * 512;
+  if (few || C > 1280) hipLaunchKernelGGL((layernorm_kernel<64, 4>), dim3((rows + 3) / 4), dim3(256), 0, st, x, y, g, b, rows, C, eps);
+  else if (C <= 640) hipLaunchKernelGGL((layernorm_kernel<16, 5>), dim3((rows + 15) / 16), dim3(256), 0, st, x, y, g, b, rows, C, eps);
+  else hipLaunchKernelGGL((layernorm_kernel<16, 10>), dim3((rows + 15) / 16), dim3(256), 0, st, x, y, g, b, rows, C, eps);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }

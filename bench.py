@@ -63,10 +63,18 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", 0))
     if world != args.gpus and world > 1:
         raise SystemExit(f"WORLD_SIZE {world} != --gpus {args.gpus}")
+    # AGD_FORCE_DEVICE / AGD_DIST_BACKEND exist only to rehearse the multi-rank path on a 1-GPU box
+    # (ranks share cuda:0, gloo instead of RCCL); the driver's real runs use one GPU per rank + nccl.
+    if "AGD_FORCE_DEVICE" in os.environ:
+        local = int(os.environ["AGD_FORCE_DEVICE"])
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+        backend = os.environ.get("AGD_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+        else:
+            dist.init_process_group(backend)
 
     from agenda_amd import StableDiffusionPipeline, synthetic
     from agenda_amd.generation import generate_batch, gather_outputs
@@ -128,10 +136,10 @@ def main():
     if world > 1:
         dist.barrier()
     if rank == 0:
-        line = {"metric": "512x512 images/sec + DAAM heatmaps, 50 DDIM steps, SD-1.5", "value": round(value, 4), "unit": "images/sec",
+        line = {"metric": f"512x512 images/sec + DAAM heatmaps, {args.ddim_steps} DDIM steps, SD-1.5", "value": round(value, 4), "unit": "images/sec",
                 "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2),
                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-                "config": {"workload": "SD-1.5 512x512 batch=4/GPU, 50 DDIM steps (eta 0, CFG 7.5), DAAM heat maps on (77 rows recorded, 2 word maps), VAE decode",
+                "config": {"workload": f"SD-1.5 512x512 batch={B}/GPU, {args.ddim_steps} DDIM steps (eta 0, CFG 7.5), DAAM heat maps on (77 rows recorded, 2 word maps), VAE decode",
                            "global_batch": world * B, "ddim_steps": args.ddim_steps, "parallelism": f"seed-sharded x{world} + all_gather"},
                 "roofline": roof, "cpu_baseline": cpu}
         if classes:
