@@ -55,6 +55,7 @@ _SIGS = {
     "agd_daam_global": (C.c_int, [_P, C.c_int, C.c_int, _P, _P]),
     "agd_hook_global": (C.c_int, [_P, _P, _P]),
     "agd_hook_count": (C.c_int, [_P]),
+    "agd_hook_last_map": (C.c_int, [_P, _P, C.c_int, _P]),
     "agd_cross_attn": (C.c_int, [_P, C.c_char_p, _P, _P, C.c_int, C.c_int, C.c_int, _P, C.c_int, _P]),
     "agd_op_conv2d": (C.c_int, [_P, _P, _P, _P] + [C.c_int] * 9 + [_P]),
     "agd_op_linear": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),

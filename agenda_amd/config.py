@@ -102,7 +102,20 @@ def tiny40() -> SDConfig:
     )
 
 
-CONFIGS = {"sd15": sd15, "sd21": sd21, "tiny": tiny, "tiny40": tiny40}
+def tiny21() -> SDConfig:
+    """SD-2.1-style small config: linear proj_in/out, head dim 64, v-prediction (run it at latent 24 to get
+    the ragged 768-px-like token counts 576 / 144 / 36 / 9)."""
+    return SDConfig(
+        name="tiny21",
+        unet=UNetConfig(block_out_channels=(64, 128, 128, 128), num_heads=(1, 2, 2, 2), cross_attention_dim=128,
+                        use_linear_projection=True),
+        vae=VAEConfig(block_out_channels=(64, 64, 128, 128)),
+        sched=SchedulerConfig(prediction_type="v_prediction"),
+        default_sample_size=24,
+    )
+
+
+CONFIGS = {"sd15": sd15, "sd21": sd21, "tiny": tiny, "tiny40": tiny40, "tiny21": tiny21}
 
 
 # ------------------------------------------------------------------------------------------

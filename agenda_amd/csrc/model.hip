@@ -725,6 +725,16 @@ extern "C" int agd_daam_global(agd_ctx* c, int img, int rows, float* out, void* 
 
 extern "C" int agd_hook_count(agd_ctx* c) { return c ? c->hook_count : 0; }
 
+extern "C" int agd_hook_last_map(agd_ctx* c, float* out, int n_query, void* stream) {
+  API_CK(c, need_final(c));
+  hipStream_t st = S(stream);
+  if (c->hook_count == 0 || !c->hook_scratch) { agd_set_error("No heat maps found."); c->err = g_err; return -2; }
+  const size_t n = (size_t)c->hook_Bp * c->ctx_T * n_query;
+  if (hipMemcpyAsync(out, c->hook_scratch, n * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) { agd_set_error("hook_last_map copy"); return fail_ctx(c); }
+  hipStreamSynchronize(st);
+  return 0;
+}
+
 extern "C" int agd_hook_global(agd_ctx* c, float* out, void* stream) {
   API_CK(c, need_final(c));
   hipStream_t st = S(stream);

@@ -18,6 +18,7 @@ class UNetCrossAttentionHooker:
     def __init__(self, is_train: bool = True, latent_hw: int = 64):
         self.is_train = is_train
         self.latent_hw = latent_hw
+        self.cross_attn_maps = []          # hook.py:19 -- filled by direct (seam) calls; the fused UNet walk streams instead
         self._pipe = None
         self._bp = 0
         self._tokens = 0
@@ -38,6 +39,7 @@ class UNetCrossAttentionHooker:
     # -- reference surface ----------------------------------------------------------------
     def clear(self):
         """hook.py:25-26"""
+        self.cross_attn_maps.clear()
         if self._pipe is not None and self._bp:
             self._pipe._apply_record_mode()
             self._pipe.engine.record_reset(self._bp // 2 if self.is_train else self._bp, self._side)
@@ -70,4 +72,6 @@ class UNetCrossAttentionHooker:
             self._pipe._apply_record_mode()
             self._pipe.engine.set_context(encoder_hidden_states)
             self._pipe.engine.record_reset(bp // 2 if self.is_train else bp, self.latent_hw)
-        return self._pipe.engine.cross_attn(attn.name, hidden_states, encoder_hidden_states, record=True)
+        out = self._pipe.engine.cross_attn(attn.name, hidden_states, encoder_hidden_states, record=True)
+        self.cross_attn_maps.append(self._pipe.engine.hook_last_map(bp, self._tokens, n))     # hook.py:110-112
+        return out

@@ -160,6 +160,12 @@ class Engine:
         self._ck(rc, "agd_hook_global")
         return out
 
+    def hook_last_map(self, bp: int, T: int, n_query: int) -> torch.Tensor:
+        side = int(round(n_query ** 0.5))
+        out = torch.empty(bp, T, side, side, device=f"cuda:{self.device}", dtype=torch.float32)
+        self._ck(self.lib.agd_hook_last_map(self.ctx, _lib.ptr(out), n_query, self._stream()), "agd_hook_last_map")
+        return out
+
     def hook_count(self) -> int:
         return int(self.lib.agd_hook_count(self.ctx))
 

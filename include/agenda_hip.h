@@ -89,6 +89,8 @@ int agd_daam_global(agd_ctx* ctx, int img, int rows, float* out, void* stream);
 /* hook.py `compute_global_heat_map()`: out [B', T, S, S]; returns -2 if nothing was recorded. Syncs. */
 int agd_hook_global(agd_ctx* ctx, float* out, void* stream);
 int agd_hook_count(agd_ctx* ctx);
+/* the map hook.py:110-112 appends for the most recent recorded call: out [B', T, h, w] (h*w = n_query). Syncs. */
+int agd_hook_last_map(agd_ctx* ctx, float* out, int n_query, void* stream);
 
 /* ---- the processor seam: one attn2 call (hook.py:91-120) for UNet cross-attention layer
  * `layer` (module path, e.g. "down_blocks.0.attentions.0.transformer_blocks.0.attn2").

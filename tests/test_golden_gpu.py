@@ -1,0 +1,86 @@
+"""Pin the HIP attention + recorder kernel DIRECTLY to the reference's own outputs: golden vectors
+produced by running /root/reference/data_generation/hook.py (tests/golden/make_golden_hook.py).
+The projections (tiny Linear layers of the fixture, C=160) run in torch; the attention core
+(hook.py:104-115) and the `_unravel_attn` map (hook.py:28-56) come from the HIP kernel."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name,N", [("call_hw64", 64), ("call_hw144", 144)])
+@pytest.mark.parametrize("is_train", [True, False])
+def test_attention_kernel_matches_reference_hook_call(golden_dir, name, N, is_train):
+    from agenda_amd import ops
+    z = np.load(os.path.join(golden_dir, "hook_call.npz"))
+    heads = 4
+    x, ctx = torch.from_numpy(z[name + "_x"]), torch.from_numpy(z[name + "_ctx"])
+    w = {k: torch.from_numpy(z[f"{name}_cross_{k}"]) for k in ("wq", "wk", "wv", "wo", "bo")}
+    q, k, v = F.linear(x, w["wq"]), F.linear(ctx, w["wk"]), F.linear(ctx, w["wv"])
+    o, probs = ops.attention(q.cuda(), k.cuda(), v.cuda(), heads, return_probs=True)       # probs [B,H,T,N]
+    y = F.linear(o.cpu(), w["wo"], w["bo"])
+    want_y = torch.from_numpy(z[f"{name}_cross_y_train{int(is_train)}"])
+    assert float((y - want_y).abs().max() / want_y.abs().max()) < 2.0 ** -6
+    # hook.py:28-56: keep the conditional half in inference mode, mean over heads, [B', T, h, w]
+    side = int(N ** 0.5)
+    p = probs.cpu()
+    if not is_train:
+        p = p[p.shape[0] // 2:]
+    maps = p.mean(1).reshape(p.shape[0], p.shape[2], side, side)
+    want_m = torch.from_numpy(z[f"{name}_map_train{int(is_train)}"])
+    assert maps.shape == want_m.shape
+    assert float((maps - want_m).abs().max()) < 2e-3
+    # self-attention path (hook.py:95-99 with encoder_hidden_states None): output only
+    ws = {k: torch.from_numpy(z[f"{name}_self_{k}"]) for k in ("wq", "wk", "wv", "wo", "bo")}
+    qs, ks, vs = F.linear(x, ws["wq"]), F.linear(x, ws["wk"]), F.linear(x, ws["wv"])
+    ys = F.linear(ops.attention(qs.cuda(), ks.cuda(), vs.cuda(), heads).cpu(), ws["wo"], ws["bo"])
+    want_ys = torch.from_numpy(z[f"{name}_self_y_train{int(is_train)}"])
+    assert float((ys - want_ys).abs().max() / want_ys.abs().max()) < 2.0 ** -6
+
+
+def test_bicubic_clamp_mean_matches_reference_global_heat_map(golden_dir):
+    """hook.py:59-81 on the reference's own fixture (mixed resolutions, clamp exercised)."""
+    from agenda_amd import ops
+    z = np.load(os.path.join(golden_dir, "hook_global.npz"))
+    want = torch.from_numpy(z["global_out"])[0]                      # [T, 64, 64]
+    acc = None
+    for i in range(6):
+        m = torch.from_numpy(z[f"global_in{i}"])                     # [1, T, r, r]
+        part = ops.bicubic_clamp_mean(m.cuda(), 64).cpu()            # n_maps = 1
+        acc = part if acc is None else acc + part
+    got = acc / 6
+    assert float((got - want).abs().max()) < 2e-5
+
+
+def test_hooker_seam_records_per_call_maps():
+    """Direct processor call through the C-ABI seam (agd_cross_attn): output + appended map (hook.py:110-112)."""
+    from agenda_amd import StableDiffusionPipeline, UNetCrossAttentionHooker, config, synthetic
+    from oracle import sd_oracle as O
+    cfg = config.tiny()
+    u, v = synthetic.make_unet_weights(cfg, 11), synthetic.make_vae_weights(cfg, 12)
+    pipe = StableDiffusionPipeline(cfg, u, v, workspace_bytes=1 << 30)
+    name = "down_blocks.0.attentions.0.transformer_blocks.0.attn2"
+    C, heads, L = 64, 2, 16
+    g = torch.Generator().manual_seed(1)
+    hidden = torch.randn(2, L * L, C, generator=g).to(torch.bfloat16).float()
+    ctx = synthetic.make_context(cfg, 1, seed=2)
+    hk = UNetCrossAttentionHooker(is_train=False, latent_hw=L)
+    pipe.unet.set_attn_processor(hk)
+    y = hk(pipe.unet.attn2(name), hidden, ctx)
+    rec = O.HookRecorder(is_train=False, latent_hw=L)
+    t = name.rsplit("attn2", 1)[0]
+    want = O.explicit_attention_processor(hidden, ctx, u[t + "attn2.to_q.weight"], u[t + "attn2.to_k.weight"],
+                                          u[t + "attn2.to_v.weight"], u[t + "attn2.to_out.0.weight"],
+                                          u[t + "attn2.to_out.0.bias"], heads, recorder=rec)
+    assert float((y.cpu() - want).abs().max() / want.abs().max()) < 2.0 ** -6
+    assert len(hk.cross_attn_maps) == 1 and hk.cross_attn_maps[0].shape == rec.cross_attn_maps[0].shape
+    assert float((hk.cross_attn_maps[0].cpu() - rec.cross_attn_maps[0]).abs().max()) < 2e-3
+    got = hk.compute_global_heat_map()
+    assert float((got.cpu() - rec.compute_global_heat_map()).abs().max()) < 2e-3
+    hk.clear()
+    assert hk.cross_attn_maps == []
+    pipe.engine.close()

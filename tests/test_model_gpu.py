@@ -140,3 +140,64 @@ def test_hook_mode_matches_oracle(tiny_pipe):
     assert n_calls == len(rec.cross_attn_maps)
     assert got.shape == want.shape
     assert _rel(got, want) < 0.03, _rel(got, want)
+
+
+def test_sd21_style_config_ragged_sizes():
+    """Linear proj_in/out, head dim 64, v-prediction, latent 24 -> token counts 576/144/36/9 (768-px-like tails)."""
+    from agenda_amd import StableDiffusionPipeline, config, synthetic, trace
+    from oracle import sd_oracle as O
+    cfg = config.tiny21()
+    u = synthetic.make_unet_weights(cfg, 31, bias_std=0.05, perturb_norm=0.1)
+    v = synthetic.make_vae_weights(cfg, 32, bias_std=0.05, perturb_norm=0.1)
+    pipe = StableDiffusionPipeline(cfg, u, v, workspace_bytes=2 << 30)
+    B, L, steps = 1, 24, 2
+    ctx = synthetic.make_context(cfg, B, seed=5)
+    lat = synthetic.make_latents(cfg, [42], L)
+    rec = O.DaamRecorder(L * L, cfg.max_tokens)
+    want_img, want_lat = O.generate(u, v, cfg, ctx, lat, steps, 7.5, recorder=rec)
+    with trace(pipe) as trc:
+        out = pipe(prompt_embeds=ctx, latents=lat, num_inference_steps=steps, height=L * 8, width=L * 8, output_type="np")
+        hm = trc.compute_global_heat_map(image_index=0).heat_maps.cpu()
+    assert out.images.shape == want_img.shape == (1, 192, 192, 3)
+    assert _rms_rel(out.latents, want_lat) < 0.06, _rms_rel(out.latents, want_lat)
+    assert _psnr(out.images, want_img) > 30.0
+    assert _rel(hm, rec.compute_global_heat_map()[0]) < 0.05
+    pipe.engine.close()
+
+
+def test_from_pretrained_roundtrip(tmp_path, tiny_pipe):
+    """diffusers on-disk layout (what `save_pretrained` writes, reference finetune_sd_token.py:164-187)."""
+    import json
+    from safetensors.torch import save_file
+    from agenda_amd import StableDiffusionPipeline, synthetic
+    pipe, cfg, u, v = tiny_pipe
+    (tmp_path / "unet").mkdir(); (tmp_path / "vae").mkdir(); (tmp_path / "scheduler").mkdir()
+    uc = {"in_channels": 4, "out_channels": 4, "block_out_channels": list(cfg.unet.block_out_channels),
+          "down_block_types": ["CrossAttnDownBlock2D" if c else "DownBlock2D" for c in cfg.unet.down_cross],
+          "layers_per_block": cfg.unet.layers_per_block, "attention_head_dim": list(cfg.unet.num_heads),
+          "cross_attention_dim": cfg.unet.cross_attention_dim, "use_linear_projection": False, "norm_num_groups": 32,
+          "sample_size": cfg.default_sample_size}
+    vc = {"latent_channels": 4, "out_channels": 3, "block_out_channels": list(cfg.vae.block_out_channels),
+          "layers_per_block": cfg.vae.layers_per_block, "norm_num_groups": 32, "scaling_factor": cfg.vae.scaling_factor}
+    json.dump(uc, open(tmp_path / "unet" / "config.json", "w"))
+    json.dump(vc, open(tmp_path / "vae" / "config.json", "w"))
+    json.dump({"num_train_timesteps": 1000, "beta_start": 0.00085, "beta_end": 0.012, "steps_offset": 1,
+               "set_alpha_to_one": False, "prediction_type": "epsilon"}, open(tmp_path / "scheduler" / "scheduler_config.json", "w"))
+    save_file({k: t.contiguous() for k, t in u.items()}, str(tmp_path / "unet" / "diffusion_pytorch_model.safetensors"))
+    # store the VAE attention with the pre-0.18 names to exercise the renaming, plus an encoder key that must be ignored
+    old = {"to_q": "query", "to_k": "key", "to_v": "value", "to_out.0": "proj_attn"}
+    vsd = {}
+    for k, t in v.items():
+        if ".attentions." in k:
+            for new, o in old.items():
+                k = k.replace("." + new + ".", "." + o + ".")
+        vsd[k] = t.contiguous()
+    vsd["encoder.conv_in.weight"] = torch.zeros(8, 3, 3, 3)
+    save_file(vsd, str(tmp_path / "vae" / "diffusion_pytorch_model.safetensors"))
+    p2 = StableDiffusionPipeline.from_pretrained(str(tmp_path), workspace_bytes=1 << 30)
+    ctx = synthetic.make_context(cfg, 1, seed=3)
+    lat = synthetic.make_latents(cfg, [9], 16)
+    a = pipe(prompt_embeds=ctx, latents=lat, num_inference_steps=2, output_type="pt")
+    b = p2(prompt_embeds=ctx, latents=lat, num_inference_steps=2, output_type="pt")
+    assert torch.equal(a.images, b.images)
+    p2.engine.close()
