@@ -20,6 +20,22 @@ UNET_GF, VAE_GF = 803.3, 2514.5
 MFMA_PEAK_TF = 2500.0                  # bf16 dense, MI355X_MICROARCH.md
 
 
+def pmc_traffic_mb():
+    """HBM-side MB per launch of the dominant kernel class (3x3 igemm), from the committed rocprofv3 --pmc
+    passes (profiles/r01_pmc_traffic_summary.csv: FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE);
+    PMC counters cannot be sampled from inside this process, so this is the offline figure or None."""
+    p = os.path.join(ROOT, "profiles", "r01_pmc_traffic_summary.csv")
+    try:
+        n = mb = 0.0
+        for line in open(p).read().splitlines()[1:]:
+            f = line.rsplit(",", 5)
+            if "igemm_kernel" in f[0] and ", 3, 2, 0," in f[0]:
+                n += float(f[1]); mb += float(f[1]) * (float(f[3]) + float(f[4]))
+        return {"MB_per_launch": round(mb / n, 1), "source": "profiles/r01_pmc_traffic_summary.csv"} if n else None
+    except Exception:
+        return None
+
+
 def cpu_baseline(cfg, usd, vsd, ctx, threads):
     """Oracle (fp32 PyTorch CPU restatement, kind 'port') on a bounded sample of the same workload:
     one CFG denoise step (UNet batch 2 at 512 px, DAAM recording on) + one VAE decode for ONE
@@ -122,7 +138,7 @@ def main():
         conv = classes["igemm_conv3x3"]
         ach = conv["flops"] / (conv["ms"] * 1e-3) / 1e12
         roof = {"bound": "mfma", "kernel": "igemm_kernel<3x3>", "achieved": round(ach, 1), "peak": MFMA_PEAK_TF, "unit": "TFLOP/s",
-                "frac": round(ach / MFMA_PEAK_TF, 4), "traffic": None,
+                "frac": round(ach / MFMA_PEAK_TF, 4), "traffic": pmc_traffic_mb(),
                 "launches": conv["launches"], "avg_launch_us": round(conv["ms"] * 1e3 / max(conv["launches"], 1), 1),
                 "end_to_end_frac": round(value / world * TFLOP_PER_IMAGE.get(args.ddim_steps, (2 * args.ddim_steps * UNET_GF + VAE_GF) / 1e3) / MFMA_PEAK_TF, 4)}
     cpu = None
