@@ -63,6 +63,9 @@ _SIGS = {
     "agd_op_layernorm": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_float, _P]),
     "agd_op_attention": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _P, _P]),
     "agd_op_bicubic_clamp_mean": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
+    "agd_op_heatmap_u8": (C.c_int, [_P, C.c_int, C.c_int, _P, _P]),
+    "agd_op_resize_u8_pil": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
+    "agd_op_stack_heatmaps": (C.c_int, [_P, _P, _P, C.c_longlong, _P, _P, _P]),
     "agd_profile_begin": (C.c_int, [_P]),
     "agd_profile_end": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_longlong)]),
     "agd_profile_class_name": (C.c_char_p, [C.c_int]),

@@ -364,7 +364,8 @@ int launch_igemm(const IgemmP& p_in, hipStream_t st) {
   if (p.geglu) return launch_cfg<128, 128, 2, 2>(p, 1, st);
   // split-K for small-M problems (8x8 / 16x16 feature maps): fill the 256 CUs with K slices
   if (batch == 1 && t128 <= 160 && nk >= 64 && (p.N & 3) == 0 && p.M >= 128) {
-    int S = (int)((384 + t128 - 1) / t128);
+    const int target = (g_igemm_cfg & 15) == 7 ? 256 : (g_igemm_cfg & 15) == 8 ? 512 : 384;
+    int S = (int)((target + t128 - 1) / t128);
     if (S > 8) S = 8;
     if (S > nk / 8) S = nk / 8;
     if (S >= 2) {

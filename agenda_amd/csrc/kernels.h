@@ -82,3 +82,10 @@ struct HeatLayer { const float* acc; int side; int heads; long long img_stride; 
 int launch_daam_global(const HeatLayer* layers, int n_layers, int total_maps, int T, int S, int img, float* out, hipStream_t st);
 int launch_hook_accum(const float* map, int B, int T, int side, int S, float* sum, hipStream_t st);
 int launch_scale(float* x, long long n, float s, hipStream_t st);
+
+// export path (bit-exact with numpy min-max/astype and PIL Image.resize BICUBIC on uint8)
+int launch_heatmap_u8(const float* hm, int n, int npix, unsigned char* out, hipStream_t st);
+int launch_pil_resample(const unsigned char* in, unsigned char* out, const int* bounds, const int* kk, int ksize,
+                        long long n_outer, int in_len, int out_len, int inner, hipStream_t st);
+int launch_stack_heatmaps(const unsigned char* obj, const unsigned char* fg, const unsigned char* bg, long long npix,
+                          unsigned char* rgb, unsigned char* inv, hipStream_t st);

@@ -280,3 +280,73 @@ int launch_scale(float* x, long long n, float s, hipStream_t st) {
   hipLaunchKernelGGL(scale_kernel, dim3(grid_for(n)), dim3(256), 0, st, x, n, s);
   HIP_CHECK_RET(hipGetLastError()); return 0;
 }
+
+// ---------------------------------------------------------------------------------------
+// Export path on device, bit-exact with the reference's host code:
+//   data_generation.py:82-84  (x - min) / (max - min + 1e-8) * 255 -> astype(uint8) (truncation)
+//   data_generation.py:60,85  PIL Image.resize (default BICUBIC): Pillow Resample.c 8-bit path --
+//       22-bit fixed-point coefficients (computed on the host in double, like Pillow), horizontal
+//       pass then vertical pass, each rounded through clip8
+//   postprocess_heatmap.py:44-48  stack [obj, fg, 255 - bg]
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void heatmap_u8_kernel(const float* __restrict__ hm, int npix, unsigned char* __restrict__ out) {
+  __shared__ float smn[4], smx[4];
+  const float* x = hm + (long long)blockIdx.x * npix;
+  float mn = INFINITY, mx = -INFINITY;
+  for (int i = threadIdx.x; i < npix; i += 256) { const float v = x[i]; mn = fminf(mn, v); mx = fmaxf(mx, v); }
+  for (int o = 32; o >= 1; o >>= 1) { mn = fminf(mn, __shfl_xor(mn, o)); mx = fmaxf(mx, __shfl_xor(mx, o)); }
+  if ((threadIdx.x & 63) == 0) { smn[threadIdx.x >> 6] = mn; smx[threadIdx.x >> 6] = mx; }
+  __syncthreads();
+  mn = fminf(fminf(smn[0], smn[1]), fminf(smn[2], smn[3]));
+  mx = fmaxf(fmaxf(smx[0], smx[1]), fmaxf(smx[2], smx[3]));
+  const float den = (mx - mn) + 1e-8f;                       // float32 arithmetic, as numpy does on a float32 array
+  for (int i = threadIdx.x; i < npix; i += 256) {
+    const float v = __fmul_rn(__fdiv_rn(__fsub_rn(x[i], mn), den), 255.0f);   // no contraction: match numpy op by op
+    out[(long long)blockIdx.x * npix + i] = (unsigned char)(int)v;            // truncation toward zero
+  }
+}
+int launch_heatmap_u8(const float* hm, int n, int npix, unsigned char* out, hipStream_t st) {
+  hipLaunchKernelGGL(heatmap_u8_kernel, dim3(n), dim3(256), 0, st, hm, npix, out);
+  HIP_CHECK_RET(hipGetLastError()); return 0;
+}
+
+// one resampling pass along `axis_len` (stride `astride` elements between taps); `inner` = elements per tap group
+__global__ void pil_resample_kernel(const unsigned char* __restrict__ in, unsigned char* __restrict__ out,
+                                    const int* __restrict__ bounds, const int* __restrict__ kk, int ksize,
+                                    long long n_outer, int in_len, int out_len, int inner) {
+  // layout: [outer][len][inner]
+  const long long total = n_outer * out_len * inner;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % inner);
+    const int o = (int)((i / inner) % out_len);
+    const long long ou = i / ((long long)inner * out_len);
+    const int xmin = bounds[2 * o], cnt = bounds[2 * o + 1];
+    const unsigned char* src = in + (ou * in_len + xmin) * inner + c;
+    const int* k = kk + (long long)o * ksize;
+    int ss = 1 << 21;                                        // 1 << (PRECISION_BITS - 1)
+    for (int t = 0; t < cnt; ++t) ss += (int)src[(long long)t * inner] * k[t];
+    ss >>= 22;
+    out[i] = (unsigned char)(ss < 0 ? 0 : (ss > 255 ? 255 : ss));
+  }
+}
+int launch_pil_resample(const unsigned char* in, unsigned char* out, const int* bounds, const int* kk, int ksize,
+                        long long n_outer, int in_len, int out_len, int inner, hipStream_t st) {
+  const long long total = n_outer * out_len * inner;
+  hipLaunchKernelGGL(pil_resample_kernel, dim3(grid_for(total)), dim3(256), 0, st, in, out, bounds, kk, ksize, n_outer, in_len, out_len, inner);
+  HIP_CHECK_RET(hipGetLastError()); return 0;
+}
+
+__global__ void stack_heatmaps_kernel(const unsigned char* __restrict__ obj, const unsigned char* __restrict__ fg,
+                                      const unsigned char* __restrict__ bg, long long npix, unsigned char* __restrict__ rgb,
+                                      unsigned char* __restrict__ inv) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += (long long)gridDim.x * blockDim.x) {
+    const unsigned char ib = (unsigned char)(255 - bg[i]);
+    rgb[3 * i] = obj[i]; rgb[3 * i + 1] = fg[i]; rgb[3 * i + 2] = ib;
+    if (inv) inv[i] = ib;
+  }
+}
+int launch_stack_heatmaps(const unsigned char* obj, const unsigned char* fg, const unsigned char* bg, long long npix,
+                          unsigned char* rgb, unsigned char* inv, hipStream_t st) {
+  hipLaunchKernelGGL(stack_heatmaps_kernel, dim3(grid_for(npix)), dim3(256), 0, st, obj, fg, bg, npix, rgb, inv);
+  HIP_CHECK_RET(hipGetLastError()); return 0;
+}

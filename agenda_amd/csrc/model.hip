@@ -986,3 +986,83 @@ extern "C" int agd_bench_groupnorm(int B, int HW, int C, int iters, double* ms_o
   hipEventDestroy(e0); hipEventDestroy(e1);
   return 0;
 }
+
+
+// ---------------------------------------------------------------------------------------
+// export entry points
+// ---------------------------------------------------------------------------------------
+namespace {
+struct PilCoeffs { int in = 0, out = 0, ksize = 0; int* bounds = nullptr; int* kk = nullptr; };
+double pil_bicubic(double x) {
+  const double a = -0.5;
+  if (x < 0.0) x = -x;
+  if (x < 1.0) return ((a + 2.0) * x - (a + 3.0)) * x * x + 1;
+  if (x < 2.0) return (((x - 5) * x + 8) * x - 4) * a;
+  return 0.0;
+}
+// Pillow Resample.c precompute_coeffs + normalize_coeffs_8bpc (PRECISION_BITS = 22), cached per (in, out)
+const PilCoeffs* pil_coeffs(int in_size, int out_size) {
+  static std::vector<PilCoeffs> cache;
+  for (auto& c : cache) if (c.in == in_size && c.out == out_size) return &c;
+  const double scale = (double)in_size / out_size;
+  const double filterscale = scale < 1.0 ? 1.0 : scale;
+  const double support = 2.0 * filterscale;
+  const int ksize = (int)ceil(support) * 2 + 1;
+  std::vector<int> bounds(2 * out_size), kk((size_t)out_size * ksize, 0);
+  std::vector<double> w(ksize);
+  const double ss = 1.0 / filterscale;
+  for (int xx = 0; xx < out_size; ++xx) {
+    const double center = (xx + 0.5) * scale;
+    int xmin = (int)(center - support + 0.5); if (xmin < 0) xmin = 0;
+    int xmax = (int)(center + support + 0.5); if (xmax > in_size) xmax = in_size;
+    xmax -= xmin;
+    double ww = 0.0;
+    for (int x = 0; x < xmax; ++x) { w[x] = pil_bicubic((x + xmin - center + 0.5) * ss); ww += w[x]; }
+    for (int x = 0; x < xmax; ++x) {
+      const double v = ww != 0.0 ? w[x] / ww : w[x];
+      kk[(size_t)xx * ksize + x] = v < 0 ? (int)(-0.5 + v * (1 << 22)) : (int)(0.5 + v * (1 << 22));
+    }
+    bounds[2 * xx] = xmin; bounds[2 * xx + 1] = xmax;
+  }
+  PilCoeffs c; c.in = in_size; c.out = out_size; c.ksize = ksize;
+  if (hipMalloc((void**)&c.bounds, bounds.size() * 4) != hipSuccess || hipMalloc((void**)&c.kk, kk.size() * 4) != hipSuccess) return nullptr;
+  hipMemcpy(c.bounds, bounds.data(), bounds.size() * 4, hipMemcpyHostToDevice);
+  hipMemcpy(c.kk, kk.data(), kk.size() * 4, hipMemcpyHostToDevice);
+  cache.push_back(c);
+  return &cache.back();
+}
+}  // namespace
+
+extern "C" int agd_op_heatmap_u8(const float* hm, int n, int npix, unsigned char* out, void* stream) {
+  CK(launch_heatmap_u8(hm, n, npix, out, S(stream)));
+  return 0;
+}
+
+// in [n][H][W][C] uint8 -> out [n][oh][ow][C], == PIL Image.resize((ow, oh)) per image (default BICUBIC)
+extern "C" int agd_op_resize_u8_pil(const unsigned char* in, int n, int H, int W, int C, int oh, int ow, unsigned char* out, void* stream) {
+  hipStream_t st = S(stream);
+  const unsigned char* src = in;
+  unsigned char* tmp = nullptr;
+  if (W != ow) {                                            // horizontal pass first
+    const PilCoeffs* ch = pil_coeffs(W, ow); if (!ch) FAIL("resize: coefficient upload failed");
+    unsigned char* dst = out;
+    if (H != oh) { if (hipMalloc((void**)&tmp, (size_t)n * H * ow * C) != hipSuccess) FAIL("resize: tmp alloc"); dst = tmp; }
+    CK(launch_pil_resample(src, dst, ch->bounds, ch->kk, ch->ksize, (long long)n * H, W, ow, C, st));
+    src = dst;
+  }
+  if (H != oh) {                                            // then vertical
+    const PilCoeffs* cv = pil_coeffs(H, oh); if (!cv) FAIL("resize: coefficient upload failed");
+    CK(launch_pil_resample(src, out, cv->bounds, cv->kk, cv->ksize, n, H, oh, ow * C, st));
+  } else if (W == ow) {
+    hipMemcpyAsync(out, in, (size_t)n * H * W * C, hipMemcpyDeviceToDevice, st);
+  }
+  hipStreamSynchronize(st);
+  if (tmp) hipFree(tmp);
+  return 0;
+}
+
+extern "C" int agd_op_stack_heatmaps(const unsigned char* obj, const unsigned char* fg, const unsigned char* bg, long long npix,
+                                     unsigned char* rgb, unsigned char* inv, void* stream) {
+  CK(launch_stack_heatmaps(obj, fg, bg, npix, rgb, inv, S(stream)));
+  return 0;
+}

@@ -103,19 +103,37 @@ def gather_outputs(images: torch.Tensor, heatmaps: torch.Tensor):
     return torch.stack(il, 1).flatten(0, 1), torch.stack(hl, 1).flatten(0, 1)
 
 
-def save_outputs(save_dir: str, seeds, images_u8: np.ndarray, heatmaps: np.ndarray, words, image_size: int):
-    """data_generation.py:60-62,66-86: resize, skip all-black, images/ + daam_<word>_heatmaps/ PNGs."""
+def save_outputs(save_dir: str, seeds, images_u8, heatmaps, words, image_size: int, stack_words=None):
+    """data_generation.py:60-62,66-86: resize, skip all-black, images/ + daam_<word>_heatmaps/ PNGs.
+    CUDA tensors take the device export path (agenda_amd/export.py: min-max -> uint8 -> PIL-exact bicubic resize on
+    the GPU, one D2H copy of the finished buffers); numpy inputs take the reference's literal host code.  Both
+    produce identical bytes (tests/test_export.py).  `stack_words=(obj, fg, bg)` additionally writes
+    daam_stack_heatmaps/ + daam_inv_heatmaps/ as postprocess_heatmap.py:44-50 would."""
     from PIL import Image
     os.makedirs(os.path.join(save_dir, "images"), exist_ok=True)
+    if torch.is_tensor(images_u8) and images_u8.is_cuda:
+        from . import export
+        small, hm = export.export_batch(images_u8, heatmaps, image_size)
+        small, hm = small.cpu().numpy(), hm.cpu().numpy()
+    else:
+        images_u8, heatmaps = np.asarray(images_u8), np.asarray(heatmaps)
+        small = np.stack([np.asarray(Image.fromarray(im).resize((image_size, image_size))) for im in images_u8])
+        hm = np.stack([np.stack([np.asarray(Image.fromarray(export_heatmap_u8(h)).resize((image_size, image_size)))
+                                 for h in hs]) if len(hs) else np.zeros((0, image_size, image_size), np.uint8) for hs in heatmaps])
     for i, seed in enumerate(seeds):
-        im = Image.fromarray(images_u8[i]).resize((image_size, image_size))
-        if np.max(np.asarray(im)) < 1e-5:       # NSFW content filter (black image)
+        if np.max(small[i]) < 1e-5:             # NSFW content filter (black image), data_generation.py:61-62
             continue
-        im.save(os.path.join(save_dir, "images", f"{seed}.png"))
+        Image.fromarray(small[i]).save(os.path.join(save_dir, "images", f"{seed}.png"))
         for wi, word in enumerate(words):
             d = os.path.join(save_dir, "daam_" + word + "_heatmaps")
             os.makedirs(d, exist_ok=True)
-            Image.fromarray(export_heatmap_u8(heatmaps[i, wi])).resize((image_size, image_size)).save(os.path.join(d, f"{seed}.png"))
+            Image.fromarray(hm[i, wi]).save(os.path.join(d, f"{seed}.png"))
+        if stack_words is not None:
+            o, f, b = (hm[i, list(words).index(w)] for w in stack_words)
+            rgb, inv = stack_heatmaps(o, f, b)
+            for sub, arr in (("daam_stack_heatmaps", rgb), ("daam_inv_heatmaps", inv)):
+                os.makedirs(os.path.join(save_dir, sub), exist_ok=True)
+                Image.fromarray(arr).save(os.path.join(save_dir, sub, f"{seed}.png"))
 
 
 def parse_args(argv=None):
@@ -155,7 +173,7 @@ def main(argv=None):
     for i in range(0, len(seeds), args.batch_size):
         chunk = seeds[i:i + args.batch_size]
         imgs, hms = generate_batch(pipe, chunk, words, prompt=prompt, num_inference_steps=args.num_inference_steps)
-        save_outputs(args.save_dir, chunk, imgs.cpu().numpy(), hms.cpu().numpy(), words, args.image_size)
+        save_outputs(args.save_dir, chunk, imgs, hms, words, args.image_size)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -113,6 +113,16 @@ int agd_op_attention(const float* q, const float* k, const float* v, float* o, i
                      float scale, float* probs_out, void* stream);
 int agd_op_bicubic_clamp_mean(const float* maps, int n_maps, int T, int side, int S, float* out, void* stream);
 
+/* ---- export path on device, bit-exact with the reference's host code:
+ * heat map fp32 [n][npix] -> uint8 by per-map min-max (+1e-8), x255, truncation   (data_generation.py:82-84) */
+int agd_op_heatmap_u8(const float* hm, int n, int npix, unsigned char* out, void* stream);
+/* uint8 [n][H][W][C] -> [n][oh][ow][C], identical to PIL `Image.resize((ow, oh))` (default BICUBIC) per image
+ * (data_generation.py:60,85).  Syncs. */
+int agd_op_resize_u8_pil(const unsigned char* in, int n, int H, int W, int C, int oh, int ow, unsigned char* out, void* stream);
+/* rgb [npix][3] = [obj, fg, 255 - bg]; inv [npix] = 255 - bg (may be NULL)        (postprocess_heatmap.py:44-48) */
+int agd_op_stack_heatmaps(const unsigned char* obj, const unsigned char* fg, const unsigned char* bg, long long npix,
+                          unsigned char* rgb, unsigned char* inv, void* stream);
+
 /* ---- per-kernel-class timing (HIP events on the launch stream) */
 #define AGD_N_CLASSES 10
 int agd_profile_begin(agd_ctx* ctx);

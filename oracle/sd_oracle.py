@@ -443,3 +443,68 @@ def generate(unet_sd, vae_sd, cfg, ctx: Tensor, latents: Tensor, num_inference_s
         if decode:
             img = postprocess_image(vae_decode(vae_sd, cfg.vae, x / cfg.vae.scaling_factor))
     return img, x
+
+
+# ==========================================================================================
+# 8. PIL `Image.resize` (default BICUBIC) on uint8, restated  (reference data_generation.py:60,85)
+#    Pillow's Resample.c: double-precision coefficients (bicubic a=-0.5, support scaled by the
+#    downscale factor), normalised, converted to 22-bit fixed point, horizontal pass then vertical
+#    pass, each rounding through clip8.  Pinned bit-exactly against PIL itself in the tests.
+# ==========================================================================================
+PIL_PRECISION_BITS = 32 - 8 - 2
+
+
+def _pil_bicubic(x: float) -> float:
+    a = -0.5
+    x = abs(x)
+    if x < 1.0:
+        return ((a + 2.0) * x - (a + 3.0)) * x * x + 1
+    if x < 2.0:
+        return (((x - 5) * x + 8) * x - 4) * a
+    return 0.0
+
+
+def pil_resample_coeffs(in_size: int, out_size: int):
+    """-> (bounds [out,2] int32 (xmin, count), kk [out, ksize] int32 fixed-point weights)."""
+    scale = in_size / out_size
+    filterscale = max(scale, 1.0)
+    support = 2.0 * filterscale
+    ksize = int(math.ceil(support)) * 2 + 1
+    bounds = np.zeros((out_size, 2), np.int32)
+    kk = np.zeros((out_size, ksize), np.int32)
+    ss = 1.0 / filterscale
+    for xx in range(out_size):
+        center = (xx + 0.5) * scale
+        xmin = max(int(center - support + 0.5), 0)
+        xmax = min(int(center + support + 0.5), in_size) - xmin
+        w = [_pil_bicubic((x + xmin - center + 0.5) * ss) for x in range(xmax)]
+        ww = sum(w)
+        for x in range(xmax):
+            v = w[x] / ww if ww != 0.0 else w[x]
+            kk[xx, x] = int(-0.5 + v * (1 << PIL_PRECISION_BITS)) if v < 0 else int(0.5 + v * (1 << PIL_PRECISION_BITS))
+        bounds[xx] = (xmin, xmax)
+    return bounds, kk
+
+
+def pil_resize_u8(img: np.ndarray, out_hw: Tuple[int, int]) -> np.ndarray:
+    """img uint8 [H,W] or [H,W,C] -> uint8 [oh,ow(,C)], bit-exact with `PIL.Image.resize((ow,oh))`."""
+    squeeze = img.ndim == 2
+    x = img[..., None] if squeeze else img
+    H, W, C = x.shape
+    oh, ow = out_hw
+
+    def one_pass(src, in_size, out_size, axis):
+        if in_size == out_size:
+            return src
+        b, kk = pil_resample_coeffs(in_size, out_size)
+        src = np.moveaxis(src, axis, 0).astype(np.int64)
+        out = np.empty((out_size,) + src.shape[1:], np.int64)
+        for o in range(out_size):
+            xmin, n = b[o]
+            acc = np.tensordot(kk[o, :n].astype(np.int64), src[xmin:xmin + n], axes=(0, 0)) + (1 << (PIL_PRECISION_BITS - 1))
+            out[o] = np.clip(acc >> PIL_PRECISION_BITS, 0, 255)
+        return np.moveaxis(out, 0, axis).astype(np.uint8)
+
+    y = one_pass(x, W, ow, 1)           # horizontal first
+    y = one_pass(y, H, oh, 0)           # then vertical
+    return y[..., 0] if squeeze else y

@@ -214,3 +214,29 @@ def test_param_inventory_counts():
     assert abs(n - 859.52e6) < 0.05e6                               # SD-1.x UNet: 859.5 M parameters
     names = config.cross_attn_layer_names(config.sd15().unet)
     assert len(names) == 16 and names[-1].startswith("mid_block")   # 9 up + 6 down + 1 mid attn2
+
+
+def test_save_outputs_and_postprocess_roundtrip(tmp_path):
+    """Host export path + postprocess CLI produce the reference's directory layout and stacked RGB."""
+    from PIL import Image
+    from agenda_amd.generation import save_outputs, export_heatmap_u8
+    from agenda_amd import postprocess
+    rng = np.random.default_rng(1)
+    imgs = rng.integers(1, 256, size=(2, 64, 64, 3), dtype=np.uint8)
+    imgs[1] = 0                                                      # all-black image is skipped (data_generation.py:61-62)
+    hms = rng.random((2, 3, 16, 16), dtype=np.float32)
+    words = ["cars", "new_token_v0", "new_token_v2"]
+    save_outputs(str(tmp_path), [7, 8], imgs, hms, words, 28)
+    assert sorted(os.listdir(tmp_path / "images")) == ["7.png"]
+    for wi, w in enumerate(words):
+        got = np.asarray(Image.open(tmp_path / f"daam_{w}_heatmaps" / "7.png"))
+        want = np.asarray(Image.fromarray(export_heatmap_u8(hms[0, wi])).resize((28, 28)))
+        np.testing.assert_array_equal(got, want)
+        assert not (tmp_path / f"daam_{w}_heatmaps" / "8.png").exists()
+    n = postprocess.main(["--save-dir", str(tmp_path), "--object-heatmap-path", "daam_cars_heatmaps",
+                          "--fg-heatmap-path", "daam_new_token_v0_heatmaps", "--bg-heatmap-path", "daam_new_token_v2_heatmaps"])
+    assert n == 1
+    rgb = np.asarray(Image.open(tmp_path / "daam_stack_heatmaps" / "7.png"))
+    o, f, b = (np.asarray(Image.open(tmp_path / f"daam_{w}_heatmaps" / "7.png")) for w in words)
+    np.testing.assert_array_equal(rgb, np.stack([o, f, 255 - b], -1))
+    np.testing.assert_array_equal(np.asarray(Image.open(tmp_path / "daam_inv_heatmaps" / "7.png")), 255 - b)
