@@ -149,6 +149,9 @@ def parse_args(argv=None):
     p.add_argument("--image-size", type=int, default=112)
     p.add_argument("--batch-size", type=int, default=4)
     p.add_argument("--num-inference-steps", type=int, default=20)
+    p.add_argument("--synthetic-config", type=str, default="sd15", help="architecture for synthetic weights when no checkpoint is given")
+    p.add_argument("--stack", type=str, default=None, nargs=3, metavar=("OBJ", "FG", "BG"),
+                   help="also write daam_stack_heatmaps/ + daam_inv_heatmaps/ for these three words (postprocess_heatmap.py)")
     return p.parse_args(argv)
 
 
@@ -162,18 +165,20 @@ def main(argv=None):
     if world > 1:
         dist.init_process_group("nccl")
     pipe = (StableDiffusionPipeline.from_pretrained(args.pretrained_model_path, device=local)
-            if args.pretrained_model_path else StableDiffusionPipeline.from_synthetic("sd15", device=local))
+            if args.pretrained_model_path else StableDiffusionPipeline.from_synthetic(args.synthetic_config, device=local))
     embeds = torch.load(args.learnable_tokens_embedding_path) if args.learnable_tokens_embedding_path else {}
-    new_tokens, words, prompt = select_learned_tokens(args.prompt, args.initialize_token, list(embeds.keys()),
-                                                     args.word_token_heatmaps, args.store_learnable_token_heatmaps)
-    inject_learned_tokens(pipe, embeds, new_tokens)
-    if not embeds:
-        prompt = args.prompt.replace("{}", "").replace("  ", " ")
+    if embeds:
+        new_tokens, words, prompt = select_learned_tokens(args.prompt, args.initialize_token, list(embeds.keys()),
+                                                         args.word_token_heatmaps, args.store_learnable_token_heatmaps)
+        inject_learned_tokens(pipe, embeds, new_tokens)
+    else:       # no learned-token file (the reference requires one): plain prompt, placeholders dropped
+        words = args.word_token_heatmaps if args.word_token_heatmaps is not None else []
+        prompt = " ".join(args.prompt.replace("{}", " ").split())
     seeds = shard_seeds(args.num_images, rank, world)
     for i in range(0, len(seeds), args.batch_size):
         chunk = seeds[i:i + args.batch_size]
         imgs, hms = generate_batch(pipe, chunk, words, prompt=prompt, num_inference_steps=args.num_inference_steps)
-        save_outputs(args.save_dir, chunk, imgs, hms, words, args.image_size)
+        save_outputs(args.save_dir, chunk, imgs, hms, words, args.image_size, stack_words=args.stack)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -201,3 +201,33 @@ def test_from_pretrained_roundtrip(tmp_path, tiny_pipe):
     b = p2(prompt_embeds=ctx, latents=lat, num_inference_steps=2, output_type="pt")
     assert torch.equal(a.images, b.images)
     p2.engine.close()
+
+
+def test_generation_driver_cli_layout_and_device_export(tmp_path):
+    """`python -m agenda_amd.generation` equivalent: directory layout of data_generation.py:66-86, and the device
+    export path writes the same bytes as the reference's host code on the same tensors."""
+    import os
+    from PIL import Image
+    from agenda_amd import generation, StableDiffusionPipeline
+    from agenda_amd.generation import generate_batch, save_outputs
+    out = tmp_path / "run"
+    generation.main(["--save-dir", str(out), "--num-images", "3", "--batch-size", "2", "--num-inference-steps", "2",
+                     "--synthetic-config", "tiny", "--word_token_heatmaps", "cars", "utah", "view", "--image-size", "56",
+                     "--stack", "cars", "utah", "view"])
+    assert sorted(os.listdir(out / "images")) == ["0.png", "1.png", "2.png"]
+    for d in ("daam_cars_heatmaps", "daam_utah_heatmaps", "daam_view_heatmaps", "daam_stack_heatmaps", "daam_inv_heatmaps"):
+        assert sorted(os.listdir(out / d)) == ["0.png", "1.png", "2.png"], d
+    im = np.asarray(Image.open(out / "images" / "1.png"))
+    assert im.shape == (56, 56, 3) and im.dtype == np.uint8
+    st = np.asarray(Image.open(out / "daam_stack_heatmaps" / "1.png"))
+    o, f, b = (np.asarray(Image.open(out / f"daam_{w}_heatmaps" / "1.png")) for w in ("cars", "utah", "view"))
+    np.testing.assert_array_equal(st, np.stack([o, f, 255 - b], -1))
+    # device export == host export on identical tensors
+    pipe = StableDiffusionPipeline.from_synthetic("tiny", workspace_bytes=1 << 30)
+    imgs, hms = generate_batch(pipe, [0, 1], ["cars"], prompt="An aerial view image with cars in Utah", num_inference_steps=2)
+    save_outputs(str(tmp_path / "dev"), [0, 1], imgs, hms, ["cars"], 56)
+    save_outputs(str(tmp_path / "host"), [0, 1], imgs.cpu().numpy(), hms.cpu().numpy(), ["cars"], 56)
+    for sub in ("images", "daam_cars_heatmaps"):
+        for n in ("0.png", "1.png"):
+            np.testing.assert_array_equal(np.asarray(Image.open(tmp_path / "dev" / sub / n)), np.asarray(Image.open(tmp_path / "host" / sub / n)))
+    pipe.engine.close()
