@@ -30,6 +30,8 @@ class AgdConfig(C.Structure):
         ("max_tokens", C.c_int),
         ("prediction_type", C.c_int),
         ("workspace_bytes", C.c_longlong),
+        ("text_hidden", C.c_int), ("text_layers", C.c_int), ("text_heads", C.c_int), ("text_intermediate", C.c_int),
+        ("text_vocab", C.c_int), ("text_max_pos", C.c_int), ("text_act", C.c_int), ("text_eps", C.c_float),
     ]
 
 
@@ -45,6 +47,8 @@ _SIGS = {
     "agd_load_tensor": (C.c_int, [_P, C.c_char_p, _P, C.c_int, C.c_int, C.POINTER(C.c_longlong)]),
     "agd_finalize": (C.c_int, [_P]),
     "agd_set_context": (C.c_int, [_P, _P, C.c_int, C.c_int, _P]),
+    "agd_text_encode": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P]),
+    "agd_text_set_embedding_row": (C.c_int, [_P, C.c_int, _P]),
     "agd_unet_forward": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_float, _P, _P]),
     "agd_cfg_ddim_step": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, _P]),
     "agd_denoise": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float),

@@ -54,6 +54,19 @@ class SchedulerConfig:
 
 
 @dataclass
+class TextConfig:
+    """CLIP text encoder (`pipeline.text_encoder`; transformers CLIPTextConfig fields). Defaults = SD-1.x ViT-L/14."""
+    hidden_size: int = 768
+    num_hidden_layers: int = 12
+    num_attention_heads: int = 12
+    intermediate_size: int = 3072
+    vocab_size: int = 49408
+    max_position_embeddings: int = 77
+    hidden_act: str = "quick_gelu"       # "gelu" for the OpenCLIP encoder of SD-2.x
+    layer_norm_eps: float = 1e-5
+
+
+@dataclass
 class SDConfig:
     name: str = "sd15"
     unet: UNetConfig = field(default_factory=UNetConfig)
@@ -62,6 +75,7 @@ class SDConfig:
     max_tokens: int = 77
     vae_scale_factor: int = 8
     default_sample_size: int = 64
+    text: "TextConfig | None" = None     # None: no device text encoder (synthetic / external embeddings)
 
     def to_dict(self):
         return asdict(self)
@@ -116,6 +130,26 @@ def tiny21() -> SDConfig:
 
 
 CONFIGS = {"sd15": sd15, "sd21": sd21, "tiny": tiny, "tiny40": tiny40, "tiny21": tiny21}
+
+
+def text_param_shapes(t: TextConfig) -> Dict[str, tuple]:
+    """transformers CLIPTextModel state-dict keys (without the `text_model.` prefix of transformers 4.x)."""
+    H, I = t.hidden_size, t.intermediate_size
+    p: Dict[str, tuple] = {"embeddings.token_embedding.weight": (t.vocab_size, H),
+                           "embeddings.position_embedding.weight": (t.max_position_embeddings, H)}
+    for l in range(t.num_hidden_layers):
+        L = f"encoder.layers.{l}."
+        for n in ("q_proj", "k_proj", "v_proj", "out_proj"):
+            p[L + f"self_attn.{n}.weight"] = (H, H)
+            p[L + f"self_attn.{n}.bias"] = (H,)
+        for n in ("layer_norm1", "layer_norm2"):
+            p[L + n + ".weight"] = (H,)
+            p[L + n + ".bias"] = (H,)
+        p[L + "mlp.fc1.weight"] = (I, H); p[L + "mlp.fc1.bias"] = (I,)
+        p[L + "mlp.fc2.weight"] = (H, I); p[L + "mlp.fc2.bias"] = (H,)
+    p["final_layer_norm.weight"] = (H,)
+    p["final_layer_norm.bias"] = (H,)
+    return p
 
 
 # ------------------------------------------------------------------------------------------

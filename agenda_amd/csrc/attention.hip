@@ -150,7 +150,7 @@ __global__ __launch_bounds__(256, ((QB == 1 && D <= 40 && !RECORD) ? 4 : (QB == 
   const float sc = p.scale * 1.44269504088896340736f;   // exp(x) = exp2(x*log2e)
 
   const int ntiles = RECORD ? 1 : (p.Nk + KEYS - 1) / KEYS;   // RECORD: host guarantees Nk <= KEYS
-  const bool ragged = (p.Nk % KEYS) != 0;
+  const bool ragged = (p.Nk % KEYS) != 0 || p.causal;   // causal: every tile takes the masked path
   gload(0);
   lstore(0);
   __syncthreads();
@@ -190,7 +190,7 @@ __global__ __launch_bounds__(256, ((QB == 1 && D <= 40 && !RECORD) ? 4 : (QB == 
 #pragma unroll
           for (int i = 0; i < 16; ++i) {
             const int key = t * KEYS + kb * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
-            if (key >= p.Nk) sacc[qb][kb][i] = -INFINITY;
+            if (key >= p.Nk || (p.causal && key > q0 + qb * 32 + c)) sacc[qb][kb][i] = -INFINITY;
           }
     }
 #pragma unroll
@@ -308,7 +308,8 @@ __global__ __launch_bounds__(256, ((QB == 1 && D <= 40 && !RECORD) ? 4 : (QB == 
     if constexpr (RECORD) {
       tile_body(0, T_{});                              // single (always key-masked) tile
     } else {
-      for (int t = 0; t < ntiles - 1; ++t) tile_body(t, F_{});
+      if (p.causal) { for (int t = 0; t < ntiles - 1; ++t) tile_body(t, T_{}); }
+      else { for (int t = 0; t < ntiles - 1; ++t) tile_body(t, F_{}); }
       if (ragged) tile_body(ntiles - 1, T_{}); else tile_body(ntiles - 1, F_{});
     }
   }

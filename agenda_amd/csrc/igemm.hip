@@ -302,7 +302,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const IgemmP p, int 
       if (p.bias_mode == 1) v[e] += p.bias[n + e]; else if (p.bias_mode == 2) v[e] += p.bias[m];
       if (p.rowadd) v[e] += p.rowadd[(long long)(m / HWo) * p.rowadd_ld + n + e];
       if (p.residual) v[e] += bf2f(p.residual[(long long)m * p.ldr + n + e]);
-      if (p.act == 1) v[e] = silu_f(v[e]);
+      if (p.act == 1) v[e] = silu_f(v[e]); else if (p.act == 2) v[e] = v[e] / (1.0f + __expf(-1.702f * v[e])); else if (p.act == 3) v[e] = gelu_erf_f(v[e]);
     }
     if (p.out_f32) { float* op = (float*)p.out + (long long)m * p.ldo + n; for (int e = 0; e < 4; ++e) op[e] = v[e]; }
     else { bf16_t* op = (bf16_t*)p.out + (long long)m * p.ldo + n; u32x2 pk; pk[0] = pack_bf2(v[0], v[1]); pk[1] = pack_bf2(v[2], v[3]);

@@ -136,6 +136,12 @@ AGD_DEV void igemm_epilogue(const IgemmP& p, f32x4 (&acc)[BM / WM / 16][BN / WN 
       if (p.act == 1) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = silu_f(v[e]);
+      } else if (p.act == 2) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = v[e] / (1.0f + __expf(-1.702f * v[e]));
+      } else if (p.act == 3) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = gelu_erf_f(v[e]);
       }
       if (p.out_f32) {
         float* op = (float*)p.out + bz * p.sO + (long long)m * p.ldo + no;

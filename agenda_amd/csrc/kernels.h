@@ -21,7 +21,7 @@ struct IgemmP {
   int M, N, K;
   float alpha;
   int geglu;                        // 1: tile columns are [val half | gate half] -> val*gelu(gate)
-  int act;                          // 0 none, 1 silu on the output
+  int act;                          // 0 none, 1 silu, 2 quick_gelu x*sigmoid(1.702x), 3 gelu(erf) on the output
   int batch;                        // grid.y
   long long sA0, sA1, sW, sO, sR;   // per-batch element strides
   const bf16_t* zero_page;          // >= 256 B of zeros
@@ -45,6 +45,7 @@ struct AttnP {
   float* rec; long long rec_img_stride; long long rec_head_stride;  // DAAM: [img][head][T][Nq]
   int rec_T;                        // number of token rows to record (<= Nk)
   int nqt;                          // set by the launcher: query tiles per (batch, head)
+  int causal;                       // 1: key j attends only to queries i >= j (CLIP text encoder)
 };
 int launch_attention(const AttnP& p, hipStream_t st);
 
@@ -89,3 +90,5 @@ int launch_pil_resample(const unsigned char* in, unsigned char* out, const int* 
                         long long n_outer, int in_len, int out_len, int inner, hipStream_t st);
 int launch_stack_heatmaps(const unsigned char* obj, const unsigned char* fg, const unsigned char* bg, long long npix,
                           unsigned char* rgb, unsigned char* inv, hipStream_t st);
+
+int launch_embed_gather(const int* ids, const bf16_t* tok, const bf16_t* pos, bf16_t* out, int B, int T, int H, int vocab_cap, hipStream_t st);

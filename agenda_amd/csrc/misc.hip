@@ -350,3 +350,23 @@ int launch_stack_heatmaps(const unsigned char* obj, const unsigned char* fg, con
   hipLaunchKernelGGL(stack_heatmaps_kernel, dim3(grid_for(npix)), dim3(256), 0, st, obj, fg, bg, npix, rgb, inv);
   HIP_CHECK_RET(hipGetLastError()); return 0;
 }
+
+// CLIP embeddings: out[b*T+t] = token_embedding[ids[b][t]] + position_embedding[t]   (bf16 tables, fp32 add)
+__global__ void embed_gather_kernel(const int* __restrict__ ids, const bf16_t* __restrict__ tok, const bf16_t* __restrict__ pos,
+                                    bf16_t* __restrict__ out, int BT, int T, int H, int vocab_cap) {
+  const int nv = H >> 3;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < (long long)BT * nv; i += (long long)gridDim.x * blockDim.x) {
+    const int row = (int)(i / nv), v = (int)(i % nv);
+    int id = ids[row]; id = id < 0 ? 0 : (id >= vocab_cap ? vocab_cap - 1 : id);
+    const s16x8 a = *(const s16x8*)(tok + (long long)id * H + v * 8);
+    const s16x8 b = *(const s16x8*)(pos + (long long)(row % T) * H + v * 8);
+    u32x4 pk;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) pk[e] = pack_bf2(bf2f((bf16_t)a[2 * e]) + bf2f((bf16_t)b[2 * e]), bf2f((bf16_t)a[2 * e + 1]) + bf2f((bf16_t)b[2 * e + 1]));
+    *(u32x4*)(out + (long long)row * H + v * 8) = pk;
+  }
+}
+int launch_embed_gather(const int* ids, const bf16_t* tok, const bf16_t* pos, bf16_t* out, int B, int T, int H, int vocab_cap, hipStream_t st) {
+  hipLaunchKernelGGL(embed_gather_kernel, dim3(grid_for((long long)B * T * (H / 8))), dim3(256), 0, st, ids, tok, pos, out, B * T, T, H, vocab_cap);
+  HIP_CHECK_RET(hipGetLastError()); return 0;
+}

@@ -114,6 +114,7 @@ struct GemmOpt {
   const bf16_t* residual = nullptr; int ldr = 0; int geglu = 0; int act = 0; int out_f32 = 0; int ldo = 0;
   int stride = 1, up = 1; float alpha = 1.f;
 };
+static const int kTextExtraRows = 256;   // room for tokenizer.add_tokens() (learned tokens)
 
 static int run_conv(agd_ctx* c, hipStream_t st, const bf16_t* s0, int C0, const bf16_t* s1, int C1, int B, int Hin, int Win,
                     const WMat& w, int ksize, void* out, const GemmOpt& o, const bf16_t* zero_page) {
@@ -510,7 +511,9 @@ extern "C" int agd_load_tensor(agd_ctx* c, const char* name, const void* ptr, in
     WMat w; w.N = (int)shape[0]; w.Cin = (int)shape[1]; w.taps = ndim == 4 ? (int)(shape[2] * shape[3]) : 1;
     if (w.taps != 1 && w.taps != 9) { agd_set_error("'%s': only 1x1 / 3x3 kernels", name); return fail_ctx(c); }
     w.Cpad = (w.Cin + 63) / 64 * 64;
-    w.w = dmalloc<bf16_t>(c, (size_t)w.N * w.taps * w.Cpad); if (!w.w) return fail_ctx(c);
+    const bool is_tok_emb = ends_with(k, "token_embedding.weight");
+    w.w = dmalloc<bf16_t>(c, (size_t)(w.N + (is_tok_emb ? kTextExtraRows : 0)) * w.taps * w.Cpad); if (!w.w) return fail_ctx(c);
+    if (is_tok_emb) hipMemset(w.w + (size_t)w.N * w.Cpad, 0, (size_t)kTextExtraRows * w.Cpad * 2);
     const int geglu_bn = ends_with(k, "ff.net.0.proj.weight") ? 128 : 0;
     if (geglu_bn && (w.N % 128)) { agd_set_error("'%s': GEGLU projection rows %d not a multiple of 128", name, w.N); return fail_ctx(c); }
     API_CK(c, launch_convert_weight(c->stage, w.w, w.N, w.Cin, w.taps, w.Cpad, geglu_bn, 0));
@@ -568,6 +571,18 @@ extern "C" int agd_finalize(agd_ctx* c) {
     }
     const int dim = g.block_out_channels[0];
     c->temb_buf = dmalloc<float>(c, (size_t)dim * 9); if (!c->temb_buf) return fail_ctx(c); }
+  // ---- CLIP text encoder: fused q/k/v projection per layer
+  for (int l = 0; l < g.text_layers; ++l) {
+    const std::string a = "text.encoder.layers." + std::to_string(l) + ".self_attn.";
+    const WMat* q = getW(c, a + "q_proj.weight"); const WMat* k = getW(c, a + "k_proj.weight"); const WMat* v = getW(c, a + "v_proj.weight");
+    const float* bq = getV(c, a + "q_proj.bias"); const float* bk = getV(c, a + "k_proj.bias"); const float* bv = getV(c, a + "v_proj.bias");
+    if (!q || !k || !v || !bq || !bk || !bv) return fail_ctx(c);
+    WMat qkv; API_CK(c, concat_rows(c, {q, k, v}, qkv)); c->W[a + "qkv.weight"] = qkv;
+    float* b = dmalloc<float>(c, (size_t)3 * q->N); if (!b) return fail_ctx(c);
+    hipMemcpy(b, bq, (size_t)q->N * 4, hipMemcpyDeviceToDevice); hipMemcpy(b + q->N, bk, (size_t)q->N * 4, hipMemcpyDeviceToDevice);
+    hipMemcpy(b + 2 * q->N, bv, (size_t)q->N * 4, hipMemcpyDeviceToDevice);
+    c->V[a + "qkv.bias"] = b; c->Vn[a + "qkv.bias"] = 3 * q->N;
+  }
   hipDeviceSynchronize();
   c->finalized = true;
   return 0;
@@ -1064,5 +1079,65 @@ extern "C" int agd_op_resize_u8_pil(const unsigned char* in, int n, int H, int W
 extern "C" int agd_op_stack_heatmaps(const unsigned char* obj, const unsigned char* fg, const unsigned char* bg, long long npix,
                                      unsigned char* rgb, unsigned char* inv, void* stream) {
   CK(launch_stack_heatmaps(obj, fg, bg, npix, rgb, inv, S(stream)));
+  return 0;
+}
+
+
+// ---------------------------------------------------------------------------------------
+// CLIP text encoder: `pipeline.text_encoder(input_ids)[0]`
+// ---------------------------------------------------------------------------------------
+extern "C" int agd_text_set_embedding_row(agd_ctx* c, int token_id, const float* row) {
+  API_CK(c, need_final(c));
+  const WMat* te = getW(c, "text.embeddings.token_embedding.weight"); if (!te) return fail_ctx(c);
+  if (token_id < 0 || token_id >= te->N + kTextExtraRows) { agd_set_error("text: token id %d out of range (vocab %d + %d)", token_id, te->N, kTextExtraRows); return fail_ctx(c); }
+  Tmp tmp; float* d = tmp.get<float>(te->Cpad); if (!d) return fail_ctx(c);
+  if (hipMemcpy(d, row, (size_t)te->Cin * 4, hipMemcpyDefault) != hipSuccess) { agd_set_error("text: row copy failed"); return fail_ctx(c); }
+  API_CK(c, launch_f32_to_bf16(d, te->w + (size_t)token_id * te->Cpad, te->Cin, 0));
+  hipDeviceSynchronize();
+  return 0;
+}
+
+extern "C" int agd_text_encode(agd_ctx* c, const int* input_ids, int B, int T, float* out, void* stream) {
+  API_CK(c, need_final(c));
+  hipStream_t st = S(stream);
+  const agd_config& g = c->cfg;
+  if (g.text_layers <= 0) { agd_set_error("text encoder not configured"); return fail_ctx(c); }
+  const int H = g.text_hidden, heads = g.text_heads, D = H / heads, M = B * T;
+  if (T > g.text_max_pos || T > 96) { agd_set_error("text: %d tokens unsupported (max %d)", T, g.text_max_pos < 96 ? g.text_max_pos : 96); return fail_ctx(c); }
+  const std::string tx = "text.";
+  const WMat* te = getW(c, tx + "embeddings.token_embedding.weight"); const WMat* pe = getW(c, tx + "embeddings.position_embedding.weight");
+  if (!te || !pe) return fail_ctx(c);
+  c->arena.release(0);
+  int* ids = (int*)c->arena.alloc((size_t)M * 4);
+  bf16_t* x = (bf16_t*)c->arena.alloc((size_t)M * H * 2); bf16_t* h = (bf16_t*)c->arena.alloc((size_t)M * H * 2);
+  bf16_t* qkv = (bf16_t*)c->arena.alloc((size_t)M * 3 * H * 2); bf16_t* att = (bf16_t*)c->arena.alloc((size_t)M * H * 2);
+  bf16_t* ff = (bf16_t*)c->arena.alloc((size_t)M * g.text_intermediate * 2);
+  if (!ids || !x || !h || !qkv || !att || !ff) return fail_ctx(c);
+  if (hipMemcpyAsync(ids, input_ids, (size_t)M * 4, hipMemcpyDefault, st) != hipSuccess) { agd_set_error("text: ids copy failed"); return fail_ctx(c); }
+  API_CK(c, launch_embed_gather(ids, te->w, pe->w, x, B, T, H, te->N + kTextExtraRows, st));
+  for (int l = 0; l < g.text_layers; ++l) {
+    const std::string L = tx + "encoder.layers." + std::to_string(l) + ".";
+    const float* g1 = getV(c, L + "layer_norm1.weight"); const float* b1 = getV(c, L + "layer_norm1.bias");
+    const float* g2 = getV(c, L + "layer_norm2.weight"); const float* b2 = getV(c, L + "layer_norm2.bias");
+    const WMat* wqkv = getW(c, L + "self_attn.qkv.weight"); const float* bqkv = getV(c, L + "self_attn.qkv.bias");
+    const WMat* wo = getW(c, L + "self_attn.out_proj.weight"); const float* bo = getV(c, L + "self_attn.out_proj.bias");
+    const WMat* w1 = getW(c, L + "mlp.fc1.weight"); const float* bf1 = getV(c, L + "mlp.fc1.bias");
+    const WMat* w2 = getW(c, L + "mlp.fc2.weight"); const float* bf2 = getV(c, L + "mlp.fc2.bias");
+    if (!g1 || !b1 || !g2 || !b2 || !wqkv || !bqkv || !wo || !bo || !w1 || !bf1 || !w2 || !bf2) return fail_ctx(c);
+    API_CK(c, launch_layernorm(x, h, g1, b1, M, H, g.text_eps, st));
+    { GemmOpt o; o.bias = bqkv; API_CK(c, run_conv(c, st, h, H, nullptr, 0, 1, 1, M, *wqkv, 1, qkv, o, c->zero_page)); }
+    { AttnP a{}; a.q = qkv; a.k = qkv + H; a.v = qkv + 2 * H; a.o = att; a.ldq = a.ldk = a.ldv = 3 * H; a.ldo = H;
+      a.sq = a.sk = a.sv = (long long)T * 3 * H; a.so = (long long)T * H; a.B = B; a.H = heads; a.D = D; a.Nq = T; a.Nk = T;
+      a.scale = 1.0f / sqrtf((float)D); a.causal = 1;
+      API_CK(c, run_attention(c, st, PC_OTHER, a)); }
+    { GemmOpt o; o.bias = bo; o.residual = x; API_CK(c, run_conv(c, st, att, H, nullptr, 0, 1, 1, M, *wo, 1, x, o, c->zero_page)); }
+    API_CK(c, launch_layernorm(x, h, g2, b2, M, H, g.text_eps, st));
+    { GemmOpt o; o.bias = bf1; o.act = g.text_act == 0 ? 2 : 3; API_CK(c, run_conv(c, st, h, H, nullptr, 0, 1, 1, M, *w1, 1, ff, o, c->zero_page)); }
+    { GemmOpt o; o.bias = bf2; o.residual = x; API_CK(c, run_conv(c, st, ff, g.text_intermediate, nullptr, 0, 1, 1, M, *w2, 1, x, o, c->zero_page)); }
+  }
+  { const float* gf = getV(c, tx + "final_layer_norm.weight"); const float* bfn = getV(c, tx + "final_layer_norm.bias");
+    if (!gf || !bfn) return fail_ctx(c);
+    API_CK(c, launch_layernorm(x, h, gf, bfn, M, H, g.text_eps, st));
+    API_CK(c, launch_bf16_to_f32(h, out, (long long)M * H, st)); }
   return 0;
 }

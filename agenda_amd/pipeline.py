@@ -55,6 +55,12 @@ def _make_cfg(cfg: SDConfig, workspace_bytes: int) -> _lib.AgdConfig:
     a.max_tokens = cfg.max_tokens
     a.prediction_type = 1 if cfg.sched.prediction_type == "v_prediction" else 0
     a.workspace_bytes = workspace_bytes
+    t = getattr(cfg, "text", None)
+    if t is not None:
+        a.text_hidden, a.text_layers, a.text_heads = t.hidden_size, t.num_hidden_layers, t.num_attention_heads
+        a.text_intermediate, a.text_vocab, a.text_max_pos = t.intermediate_size, t.vocab_size, t.max_position_embeddings
+        a.text_act = 0 if t.hidden_act == "quick_gelu" else 1
+        a.text_eps = t.layer_norm_eps
     return a
 
 
@@ -107,6 +113,19 @@ class Engine:
         b2, t, _ = ctx_emb.shape
         self._ck(self.lib.agd_set_context(self.ctx, _lib.ptr(ctx_emb), b2, t, self._stream()), "agd_set_context")
         self._ctx_keepalive = ctx_emb
+
+    def text_encode(self, input_ids: torch.Tensor) -> torch.Tensor:
+        """`text_encoder(input_ids)[0]`: int [B,T] -> fp32 [B,T,H] (cuda)."""
+        ids = input_ids.to(torch.int32).contiguous()
+        b, t = ids.shape
+        out = torch.empty(b, t, self.cfg.text.hidden_size, device=f"cuda:{self.device}", dtype=torch.float32)
+        self._ck(self.lib.agd_text_encode(self.ctx, C.c_void_p(ids.data_ptr()), b, t, _lib.ptr(out), self._stream()), "agd_text_encode")
+        torch.cuda.synchronize()          # `ids` may be a host tensor: keep it alive until the copy ran
+        return out
+
+    def text_set_embedding_row(self, token_id: int, row: torch.Tensor):
+        row = row.detach().to(torch.float32).contiguous()
+        self._ck(self.lib.agd_text_set_embedding_row(self.ctx, int(token_id), C.c_void_p(row.data_ptr())), "agd_text_set_embedding_row")
 
     def unet_forward(self, sample: torch.Tensor, timestep: float) -> torch.Tensor:
         sample = sample.to(device=f"cuda:{self.device}", dtype=torch.float32).contiguous()
@@ -253,15 +272,24 @@ class VAEHandle:
 
 class StableDiffusionPipeline:
     def __init__(self, cfg: SDConfig, unet_sd: Dict[str, torch.Tensor], vae_sd: Dict[str, torch.Tensor],
-                 tokenizer=None, text_encoder=None, device: Union[int, str] = 0, workspace_bytes: int = 0):
+                 tokenizer=None, text_encoder=None, device: Union[int, str] = 0, workspace_bytes: int = 0,
+                 text_sd: Optional[Dict[str, torch.Tensor]] = None):
         self.cfg = cfg
         dev = int(str(device).split(":")[-1]) if not isinstance(device, int) and ":" in str(device) else (device if isinstance(device, int) else 0)
         self.engine = Engine(cfg, dev, workspace_bytes)
         self.engine.load_state_dict(unet_sd, "unet.")
         self.engine.load_state_dict(vae_sd, "vae.")
+        if text_sd is not None:
+            if cfg.text is None:
+                raise ValueError("text_sd given but cfg.text is None")
+            self.engine.load_state_dict({k[len("text_model."):] if k.startswith("text_model.") else k: v
+                                         for k, v in text_sd.items() if "position_ids" not in k}, "text.")
         self.engine.finalize()
         self.device = torch.device(f"cuda:{dev}")
         self.tokenizer = tokenizer or SimpleTokenizer(cfg.max_tokens)
+        if text_encoder is None and text_sd is not None:
+            from .text import HipCLIPTextEncoder
+            text_encoder = HipCLIPTextEncoder(self.engine, self.tokenizer, text_sd)
         self.text_encoder = text_encoder or SyntheticTextEncoder(self.tokenizer, cfg.unet.cross_attention_dim)
         self.scheduler = DDIMScheduler.from_config(cfg.sched)
         self.unet = UNetHandle(self)
@@ -330,30 +358,26 @@ class StableDiffusionPipeline:
         # pre-0.18 VAE attention naming
         ren = {"query": "to_q", "key": "to_k", "value": "to_v", "proj_attn": "to_out.0"}
         vsd = {(".".join(ren.get(p, p) for p in k.split(".")) if ".attentions." in k else k): v for k, v in vsd.items()}
-        tok = txt = None
-        try:  # real CLIP prompt side when the checkpoint carries it
-            from transformers import CLIPTokenizer, CLIPTextModel
-            tok = CLIPTokenizer.from_pretrained(os.path.join(path, "tokenizer"))
-            model = CLIPTextModel.from_pretrained(os.path.join(path, "text_encoder")).eval()
+        # prompt side: text_encoder/ runs on the device (agd_text_encode); tokenizer/ via transformers when present
+        tok = None
+        tsd = None
+        tcj = os.path.join(path, "text_encoder", "config.json")
+        if os.path.exists(tcj):
+            from .config import TextConfig
+            tj = jload(tcj)
+            cfg.text = TextConfig(hidden_size=tj.get("hidden_size", 768), num_hidden_layers=tj.get("num_hidden_layers", 12),
+                                  num_attention_heads=tj.get("num_attention_heads", 12), intermediate_size=tj.get("intermediate_size", 3072),
+                                  vocab_size=tj.get("vocab_size", 49408), max_position_embeddings=tj.get("max_position_embeddings", 77),
+                                  hidden_act=tj.get("hidden_act", "quick_gelu"), layer_norm_eps=tj.get("layer_norm_eps", 1e-5))
+            tsd = wload("text_encoder")
+        if os.path.isdir(os.path.join(path, "tokenizer")):
+            try:
+                from transformers import CLIPTokenizer
+                tok = CLIPTokenizer.from_pretrained(os.path.join(path, "tokenizer"))
+            except Exception:
+                tok = None
+        return cls(cfg, usd, vsd, tokenizer=tok, device=device, workspace_bytes=workspace_bytes, text_sd=tsd)
 
-            class _Enc:
-                def __init__(s, m, t):
-                    s.m, s.t = m, t
-
-                def resize_token_embeddings(s, n):
-                    return s.m.resize_token_embeddings(n)
-
-                def get_input_embeddings(s):
-                    return s.m.get_input_embeddings()
-
-                def __call__(s, prompts):
-                    ids = s.t(prompts, padding="max_length", max_length=s.t.model_max_length, truncation=True, return_tensors="pt").input_ids
-                    with torch.no_grad():
-                        return s.m(ids)[0].float()
-            txt = _Enc(model, tok)
-        except Exception:
-            tok = txt = None
-        return cls(cfg, usd, vsd, tokenizer=tok, text_encoder=txt, device=device, workspace_bytes=workspace_bytes)
 
     def to(self, device):
         if "cuda" not in str(device):

@@ -12,7 +12,7 @@ from typing import Dict
 
 import torch
 
-from .config import SDConfig, unet_param_shapes, vae_decoder_param_shapes
+from .config import SDConfig, unet_param_shapes, vae_decoder_param_shapes, text_param_shapes
 
 
 def _bf16_round(t: torch.Tensor) -> torch.Tensor:
@@ -73,3 +73,21 @@ def make_latents(cfg: SDConfig, seeds, latent_side: int) -> torch.Tensor:
         g = torch.Generator("cpu").manual_seed(int(s))
         out.append(torch.randn(1, cfg.unet.in_channels, latent_side, latent_side, generator=g))
     return torch.cat(out, 0)
+
+
+def make_text_weights(cfg: SDConfig, seed: int = 99, device: str = "cpu") -> Dict[str, torch.Tensor]:
+    """Random CLIP text-encoder weights (transformers key names): linears ~ N(0, 1/fan_in), embeddings ~ N(0, 0.02),
+    LayerNorm gamma ~ 1, small biases; bf16-representable."""
+    g = torch.Generator(device).manual_seed(seed)
+    sd = {}
+    for k, shp in text_param_shapes(cfg.text).items():
+        if "embedding" in k:
+            w = torch.randn(shp, generator=g, device=device) * 0.02
+        elif k.endswith(".weight") and len(shp) == 2:
+            w = torch.randn(shp, generator=g, device=device) / math.sqrt(shp[1])
+        elif k.endswith(".weight"):
+            w = 1.0 + 0.1 * torch.randn(shp, generator=g, device=device)
+        else:
+            w = 0.05 * torch.randn(shp, generator=g, device=device)
+        sd[k] = _bf16_round(w)
+    return sd

@@ -108,3 +108,46 @@ class SyntheticTextEncoder:
             rows.append(self._table[torch.tensor(ids)] + self._pos)
         x = torch.stack(rows)
         return x.to(torch.bfloat16).to(torch.float32)
+
+
+class HipCLIPTextEncoder:
+    """`pipeline.text_encoder` on the GPU (agd_text_encode: CLIP text transformer as HIP kernels).  Keeps the
+    surface the reference touches (data_generation.py:49-52): `resize_token_embeddings(n)`,
+    `get_input_embeddings().weight.data[ids] = rows`; rows of added tokens are pushed to the device before each
+    encode.  Works with a real CLIPTokenizer (has `__call__` returning input_ids) or the SimpleTokenizer stand-in."""
+
+    def __init__(self, engine, tokenizer, text_sd):
+        self.engine, self.tokenizer = engine, tokenizer
+        key = next(k for k in text_sd if k.endswith("embeddings.token_embedding.weight"))
+        self.base_vocab = text_sd[key].shape[0]
+        self.max_len = engine.cfg.text.max_position_embeddings
+        self._emb = _Emb(text_sd[key].detach().float().clone())     # host master copy (fp32), like nn.Embedding.weight
+
+    def resize_token_embeddings(self, n: int):
+        cur = self._emb.weight.shape[0]
+        if n > cur:
+            if n > self.base_vocab + 256:
+                raise ValueError("at most 256 added tokens")
+            self._emb.weight = torch.cat([self._emb.weight, torch.zeros(n - cur, self._emb.weight.shape[1])])
+            self._emb.weight.data = self._emb.weight
+        return self._emb
+
+    def get_input_embeddings(self):
+        return self._emb
+
+    def _ids(self, prompts):
+        tok = self.tokenizer
+        if hasattr(tok, "encode") and isinstance(tok, SimpleTokenizer):
+            vocab = self._emb.weight.shape[0]
+            rows = []
+            for p in prompts:
+                ids = tok.encode(p)
+                rows.append([min(i, vocab - 1) for i in ids])
+            return torch.tensor(rows, dtype=torch.int32)
+        enc = tok(prompts, padding="max_length", max_length=self.max_len, truncation=True, return_tensors="pt")
+        return enc.input_ids.to(torch.int32)
+
+    def __call__(self, prompts):
+        for tid in range(self.base_vocab, self._emb.weight.shape[0]):        # learned / added tokens
+            self.engine.text_set_embedding_row(tid, self._emb.weight[tid])
+        return self.engine.text_encode(self._ids(prompts)).cpu()

@@ -41,6 +41,10 @@ typedef struct agd_config {
   int max_tokens;                  /* 77 */
   int prediction_type;             /* 0 epsilon, 1 v_prediction */
   long long workspace_bytes;       /* activation arena; 0 = default (8 GiB) */
+  /* CLIP text encoder (`pipeline.text_encoder`, data_generation.py:47-52); text_layers == 0: none loaded */
+  int text_hidden, text_layers, text_heads, text_intermediate, text_vocab, text_max_pos;
+  int text_act;                    /* 0 quick_gelu (SD-1.x CLIP ViT-L/14), 1 gelu (OpenCLIP, SD-2.x) */
+  float text_eps;
 } agd_config;
 
 /* ---- lifetime ------------------------------------------------------------------------- */
@@ -57,6 +61,12 @@ int agd_finalize(agd_ctx* ctx);                    /* after the last agd_load_te
 /* ---- text context: `encoder_hidden_states` [2B, T, ctx_dim] fp32, rows [0,B) unconditional,
  * [B,2B) conditional (CFG order assumed by hook.py:48-49).  Projects K/V of every attn2 once. */
 int agd_set_context(agd_ctx* ctx, const float* ctx_emb, int batch2, int tokens, void* stream);
+
+/* ---- `text_encoder(input_ids)[0]` (CLIPTextModel.last_hidden_state): ids int32 [B, T] (host or device) ->
+ * out fp32 [B, T, text_hidden].  Weights: "text." + transformers state-dict key.  Rows of the token embedding can
+ * be (over)written -- the learned-token injection of data_generation.py:45-52 -- ids up to text_vocab + 255. */
+int agd_text_encode(agd_ctx* ctx, const int* input_ids, int batch, int tokens, float* out, void* stream);
+int agd_text_set_embedding_row(agd_ctx* ctx, int token_id, const float* row);
 
 /* ---- `unet(sample, t, encoder_hidden_states).sample`: sample/out fp32 NCHW [B2,4,L,L] */
 int agd_unet_forward(agd_ctx* ctx, const float* sample, int batch2, int latent_side, float timestep, float* out,

@@ -50,6 +50,7 @@ def test_config_struct_matches_header_size():
     n_int = 4 + 3 * 8 + 4 + 3 + 8 + 2      # ints before the float
     expect = (n_int + 1 + 2) * 4           # + float + max_tokens + prediction_type
     expect = (expect + 7) // 8 * 8 + 8     # align + long long
+    expect += 8 * 4                        # text encoder: 7 ints + float
     assert ctypes.sizeof(_lib.AgdConfig) == expect
 
 

@@ -194,7 +194,20 @@ def test_from_pretrained_roundtrip(tmp_path, tiny_pipe):
         vsd[k] = t.contiguous()
     vsd["encoder.conv_in.weight"] = torch.zeros(8, 3, 3, 3)
     save_file(vsd, str(tmp_path / "vae" / "diffusion_pytorch_model.safetensors"))
+    # text_encoder/ in transformers-4.x naming (text_model. prefix + position_ids buffer) -> device CLIP encoder
+    from agenda_amd import config as _config
+    from agenda_amd.text import HipCLIPTextEncoder
+    tcfg = _config.tiny(); tcfg.text = _config.TextConfig(hidden_size=64, num_hidden_layers=1, num_attention_heads=1, intermediate_size=128, vocab_size=300)
+    (tmp_path / "text_encoder").mkdir()
+    json.dump({"hidden_size": 64, "num_hidden_layers": 1, "num_attention_heads": 1, "intermediate_size": 128, "vocab_size": 300,
+               "max_position_embeddings": 77, "hidden_act": "quick_gelu", "layer_norm_eps": 1e-5}, open(tmp_path / "text_encoder" / "config.json", "w"))
+    tsd = {"text_model." + k: t.contiguous() for k, t in synthetic.make_text_weights(tcfg, 3).items()}
+    tsd["text_model.embeddings.position_ids"] = torch.arange(77)[None].float()
+    save_file(tsd, str(tmp_path / "text_encoder" / "model.safetensors"))
     p2 = StableDiffusionPipeline.from_pretrained(str(tmp_path), workspace_bytes=1 << 30)
+    assert isinstance(p2.text_encoder, HipCLIPTextEncoder) and p2.cfg.text.hidden_size == 64
+    e = p2.text_encoder(["an aerial view image with cars"])
+    assert e.shape == (1, 77, 64) and torch.isfinite(e).all()
     ctx = synthetic.make_context(cfg, 1, seed=3)
     lat = synthetic.make_latents(cfg, [9], 16)
     a = pipe(prompt_embeds=ctx, latents=lat, num_inference_steps=2, output_type="pt")
