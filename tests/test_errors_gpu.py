@@ -1,0 +1,63 @@
+"""Error behaviour at the C-ABI boundary: every failure is a status code + message that the shim raises as a Python
+exception (no exceptions across the ABI, no silent fallback)."""
+import ctypes as C
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_bad_config_and_missing_weights_raise():
+    from agenda_amd import StableDiffusionPipeline, config, synthetic, _lib
+    lib = _lib.load()
+    bad = _lib.AgdConfig()
+    bad.struct_size = 12                                    # ABI guard
+    assert not lib.agd_create(0, C.byref(bad))
+    assert b"struct_size" in lib.agd_last_error(None)
+    cfg = config.tiny()
+    u, v = synthetic.make_unet_weights(cfg), synthetic.make_vae_weights(cfg)
+    u2 = dict(u); del u2["mid_block.attentions.0.transformer_blocks.0.attn1.to_k.weight"]
+    with pytest.raises(_lib.AgendaHipError, match="missing weight"):
+        StableDiffusionPipeline(cfg, u2, v, workspace_bytes=1 << 28)
+    cfg_bad = config.tiny(); cfg_bad.unet.block_out_channels = (48, 96, 96, 96)
+    with pytest.raises(_lib.AgendaHipError, match="multiples of 64"):
+        StableDiffusionPipeline(cfg_bad, u, v, workspace_bytes=1 << 28)
+
+
+def test_call_order_and_argument_errors():
+    from agenda_amd import StableDiffusionPipeline, config, synthetic, trace, _lib
+    cfg = config.tiny()
+    pipe = StableDiffusionPipeline.from_synthetic(cfg, workspace_bytes=1 << 28)
+    x = synthetic.make_latents(cfg, [0, 1], 16)
+    with pytest.raises(_lib.AgendaHipError, match="context batch"):
+        pipe.engine.unet_forward(x, 10.0)                    # agd_set_context not called yet
+    ctx = synthetic.make_context(cfg, 1)
+    pipe.engine.set_context(ctx)
+    assert torch.isfinite(pipe.engine.unet_forward(x, 10.0)).all()
+    with pytest.raises(_lib.AgendaHipError, match="unknown layer"):
+        pipe.engine.cross_attn("no.such.layer", torch.zeros(2, 16, 64), ctx, record=False)
+    with pytest.raises(_lib.AgendaHipError, match="text encoder not configured"):
+        pipe.engine.cfg.text = config.TextConfig(hidden_size=64)          # python-side only; the ctx has none
+        pipe.engine.text_encode(torch.zeros(1, 77, dtype=torch.int32))
+    with pytest.raises(ValueError, match="CPU torch.Generator"):
+        pipe(prompt_embeds=ctx, generator=torch.Generator(device="cuda").manual_seed(0), num_inference_steps=1)
+    with pytest.raises(ValueError, match="not found in prompt"):
+        with trace(pipe) as trc:
+            pipe(["a photo of cars"], num_inference_steps=1, output_type="latent")
+            trc.compute_global_heat_map().compute_word_heat_map("boat")
+    with pytest.raises(RuntimeError, match="already active"):
+        with trace(pipe):
+            with trace(pipe):
+                pass
+    pipe.engine.close()
+
+
+def test_workspace_exhaustion_is_reported():
+    from agenda_amd import StableDiffusionPipeline, config, synthetic, _lib
+    cfg = config.tiny()
+    pipe = StableDiffusionPipeline.from_synthetic(cfg, workspace_bytes=1 << 20)      # 1 MiB arena: far too small
+    pipe.engine.set_context(synthetic.make_context(cfg, 1))
+    with pytest.raises(_lib.AgendaHipError, match="arena exhausted"):
+        pipe.engine.unet_forward(synthetic.make_latents(cfg, [0, 1], 16), 10.0)
+    pipe.engine.close()
