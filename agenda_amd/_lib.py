@@ -54,6 +54,7 @@ _SIGS = {
     "agd_denoise": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float),
                               C.POINTER(C.c_float), C.c_float, _P]),
     "agd_vae_decode": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P, _P]),
+    "agd_vae_encode": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P, _P]),
     "agd_record_config": (C.c_int, [_P, C.c_int, C.c_int, C.c_int]),
     "agd_record_reset": (C.c_int, [_P, C.c_int, C.c_int, _P]),
     "agd_daam_global": (C.c_int, [_P, C.c_int, C.c_int, _P, _P]),

@@ -278,6 +278,37 @@ def vae_decoder_param_shapes(cfg: VAEConfig) -> Dict[str, tuple]:
     return p
 
 
+def vae_encoder_param_shapes(cfg: VAEConfig) -> Dict[str, tuple]:
+    """Keys of `AutoencoderKL` that `encode()` touches (encoder.* + quant_conv) -- the img2img front end."""
+    p: Dict[str, tuple] = {}
+    lc, boc = cfg.latent_channels, cfg.block_out_channels
+    p["encoder.conv_in.weight"] = (boc[0], cfg.out_channels, 3, 3)
+    p["encoder.conv_in.bias"] = (boc[0],)
+    ch = boc[0]
+    for i, co in enumerate(boc):
+        for j in range(cfg.layers_per_block):
+            _resnet(p, f"encoder.down_blocks.{i}.resnets.{j}.", ch, co, None)
+            ch = co
+        if i != len(boc) - 1:
+            p[f"encoder.down_blocks.{i}.downsamplers.0.conv.weight"] = (co, co, 3, 3)
+            p[f"encoder.down_blocks.{i}.downsamplers.0.conv.bias"] = (co,)
+    _resnet(p, "encoder.mid_block.resnets.0.", ch, ch, None)
+    a = "encoder.mid_block.attentions.0."
+    p[a + "group_norm.weight"] = (ch,)
+    p[a + "group_norm.bias"] = (ch,)
+    for n in ("to_q", "to_k", "to_v", "to_out.0"):
+        p[a + n + ".weight"] = (ch, ch)
+        p[a + n + ".bias"] = (ch,)
+    _resnet(p, "encoder.mid_block.resnets.1.", ch, ch, None)
+    p["encoder.conv_norm_out.weight"] = (ch,)
+    p["encoder.conv_norm_out.bias"] = (ch,)
+    p["encoder.conv_out.weight"] = (2 * lc, ch, 3, 3)
+    p["encoder.conv_out.bias"] = (2 * lc,)
+    p["quant_conv.weight"] = (2 * lc, 2 * lc, 1, 1)
+    p["quant_conv.bias"] = (2 * lc,)
+    return p
+
+
 def cross_attn_layer_names(cfg: UNetConfig, include_mid: bool = True) -> List[str]:
     """Module paths of every `attn2`, in daam's locator order (up blocks, then down blocks, then
     mid) [upstream-knowledge, SURVEY.md §8a row D1]."""

@@ -113,6 +113,8 @@ struct GemmOpt {
   const float* bias = nullptr; const float* rowadd = nullptr; int rowadd_ld = 0;
   const bf16_t* residual = nullptr; int ldr = 0; int geglu = 0; int act = 0; int out_f32 = 0; int ldo = 0;
   int stride = 1, up = 1; float alpha = 1.f;
+  int pad = -1;                 // -1: 1 for 3x3, 0 for 1x1
+  int hout = 0, wout = 0;       // >0: override (asymmetric (0,1,0,1) padding of the VAE encoder's stride-2 convs)
 };
 static const int kTextExtraRows = 256;   // room for tokenizer.add_tokens() (learned tokens)
 
@@ -120,9 +122,9 @@ static int run_conv(agd_ctx* c, hipStream_t st, const bf16_t* s0, int C0, const 
                     const WMat& w, int ksize, void* out, const GemmOpt& o, const bf16_t* zero_page) {
   IgemmP p{};
   p.src0 = s0; p.src1 = s1; p.C0 = C0; p.C1 = C1; p.Hin = Hin; p.Win = Win;
-  p.ksize = ksize; p.stride = o.stride; p.pad = ksize == 3 ? 1 : 0; p.up = o.up;
-  p.Hout = (Hin * o.up + 2 * p.pad - ksize) / o.stride + 1;
-  p.Wout = (Win * o.up + 2 * p.pad - ksize) / o.stride + 1;
+  p.ksize = ksize; p.stride = o.stride; p.pad = o.pad >= 0 ? o.pad : (ksize == 3 ? 1 : 0); p.up = o.up;
+  p.Hout = o.hout > 0 ? o.hout : (Hin * o.up + 2 * p.pad - ksize) / o.stride + 1;
+  p.Wout = o.wout > 0 ? o.wout : (Win * o.up + 2 * p.pad - ksize) / o.stride + 1;
   p.W = w.w; p.bias = o.bias; p.bias_mode = o.bias ? 1 : 0; p.rowadd = o.rowadd; p.rowadd_ld = o.rowadd_ld;
   p.residual = o.residual; p.N = w.N; p.K = w.taps * w.Cpad; p.M = B * p.Hout * p.Wout;
   const int nout = o.geglu ? w.N / 2 : w.N;
@@ -374,24 +376,8 @@ static int unet_walk(agd_ctx* c, hipStream_t st, const bf16_t* xin, int B2, int 
   return 0;
 }
 
-// AutoencoderKL.decode: z [B][L*L][64] bf16 (already divided by scaling factor) -> fp32 NHWC [B][8L*8L][ldo=4]
-static int vae_walk(agd_ctx* c, hipStream_t st, const bf16_t* zin, int B, int L, float* img_out) {
-  const agd_config& g = c->cfg;
-  const int nl = g.vae_n_levels, G = g.vae_norm_num_groups;
-  const std::string v = "vae.";
-  c->arena.release(0);
-  const int top = g.vae_block_out_channels[nl - 1];
-  // post_quant_conv (1x1, 4->4) written into a zeroed 64-channel buffer so conv_in sees padded input
-  bf16_t* pq = (bf16_t*)c->arena.alloc((size_t)B * L * L * 64 * 2); if (!pq) return -1;
-  if (hipMemsetAsync(pq, 0, (size_t)B * L * L * 64 * 2, st) != hipSuccess) FAIL("memset pq");
-  { GETW(w, v + "post_quant_conv.weight"); GETV(b, v + "post_quant_conv.bias"); GemmOpt o; o.bias = b; o.ldo = 64;
-    CK(run_conv(c, st, zin, 64, nullptr, 0, B, L, L, *w, 1, pq, o, c->zero_page)); }
-  Act h = alloc_act(c, B, L, L, top); if (!h.p) return -1;
-  { GETW(w, v + "decoder.conv_in.weight"); GETV(b, v + "decoder.conv_in.bias"); GemmOpt o; o.bias = b;
-    CK(run_conv(c, st, pq, 64, nullptr, 0, B, L, L, *w, 3, h.p, o, c->zero_page)); }
-  { Act r; CK(resnet(c, st, v + "decoder.mid_block.resnets.0.", h, nullptr, top, 1e-6f, false, G, r)); h = r; }
-  { // single-head attention over N = L*L tokens, C = top channels, through batched GEMMs
-    const std::string a = v + "decoder.mid_block.attentions.0.";
+// AutoencoderKL mid-block attention: single head over N = L*L tokens, C channels, through batched GEMMs
+static int vae_mid_attention(agd_ctx* c, hipStream_t st, const std::string& a, int G, int B, int L, int top, Act& h) {
     const int N = L * L, C = top, M = B * N;
     Act out = alloc_act(c, B, L, L, C); if (!out.p) return -1;
     const size_t mk = c->arena.mark();
@@ -424,7 +410,27 @@ static int vae_walk(agd_ctx* c, hipStream_t st, const bf16_t* zin, int B, int L,
       ProfScope ps(c, st, PC_VAE_ATTN, 2.0 * B * N * (double)N * C); CK(launch_igemm(p, st)); }
     { GemmOpt o; o.bias = bo; o.residual = h.p; CK(run_conv(c, st, att, C, nullptr, 0, 1, 1, M, *wo, 1, out.p, o, c->zero_page)); }
     c->arena.release(mk);
-    h = out; }
+    h = out;
+  return 0;
+}
+
+// AutoencoderKL.decode: z [B][L*L][64] bf16 (already divided by scaling factor) -> fp32 NHWC [B][8L*8L][ldo=4]
+static int vae_walk(agd_ctx* c, hipStream_t st, const bf16_t* zin, int B, int L, float* img_out) {
+  const agd_config& g = c->cfg;
+  const int nl = g.vae_n_levels, G = g.vae_norm_num_groups;
+  const std::string v = "vae.";
+  c->arena.release(0);
+  const int top = g.vae_block_out_channels[nl - 1];
+  // post_quant_conv (1x1, 4->4) written into a zeroed 64-channel buffer so conv_in sees padded input
+  bf16_t* pq = (bf16_t*)c->arena.alloc((size_t)B * L * L * 64 * 2); if (!pq) return -1;
+  if (hipMemsetAsync(pq, 0, (size_t)B * L * L * 64 * 2, st) != hipSuccess) FAIL("memset pq");
+  { GETW(w, v + "post_quant_conv.weight"); GETV(b, v + "post_quant_conv.bias"); GemmOpt o; o.bias = b; o.ldo = 64;
+    CK(run_conv(c, st, zin, 64, nullptr, 0, B, L, L, *w, 1, pq, o, c->zero_page)); }
+  Act h = alloc_act(c, B, L, L, top); if (!h.p) return -1;
+  { GETW(w, v + "decoder.conv_in.weight"); GETV(b, v + "decoder.conv_in.bias"); GemmOpt o; o.bias = b;
+    CK(run_conv(c, st, pq, 64, nullptr, 0, B, L, L, *w, 3, h.p, o, c->zero_page)); }
+  { Act r; CK(resnet(c, st, v + "decoder.mid_block.resnets.0.", h, nullptr, top, 1e-6f, false, G, r)); h = r; }
+  CK(vae_mid_attention(c, st, v + "decoder.mid_block.attentions.0.", G, B, L, top, h));
   { Act r; CK(resnet(c, st, v + "decoder.mid_block.resnets.1.", h, nullptr, top, 1e-6f, false, G, r)); h = r; }
   for (int i = 0; i < nl; ++i) {
     const int co = g.vae_block_out_channels[nl - 1 - i];
@@ -447,6 +453,47 @@ static int vae_walk(agd_ctx* c, hipStream_t st, const bf16_t* zin, int B, int L,
     GETW(w, v + "decoder.conv_out.weight"); GETV(b, v + "decoder.conv_out.bias");
     GemmOpt o; o.bias = b; o.out_f32 = 1; o.ldo = 4;
     CK(run_conv(c, st, n.p, h.C, nullptr, 0, B, h.H, h.W, *w, 3, img_out, o, c->zero_page)); }
+  return 0;
+}
+
+// AutoencoderKL.encode: x [B][S*S][64] bf16 (3 image channels zero-padded) -> moments fp32 NHWC [B][L*L][2*lc]
+static int vae_encode_walk(agd_ctx* c, hipStream_t st, const bf16_t* xin, int B, int S_, float* moments) {
+  const agd_config& g = c->cfg;
+  const int nl = g.vae_n_levels, G = g.vae_norm_num_groups, lc = g.vae_latent_channels;
+  const std::string v = "vae.";
+  c->arena.release(0);
+  Act h = alloc_act(c, B, S_, S_, g.vae_block_out_channels[0]); if (!h.p) return -1;
+  { GETW(w, v + "encoder.conv_in.weight"); GETV(b, v + "encoder.conv_in.bias"); GemmOpt o; o.bias = b;
+    CK(run_conv(c, st, xin, 64, nullptr, 0, B, S_, S_, *w, 3, h.p, o, c->zero_page)); }
+  for (int i = 0; i < nl; ++i) {
+    const int co = g.vae_block_out_channels[i];
+    for (int j = 0; j < g.vae_layers_per_block; ++j) {
+      Act r; CK(resnet(c, st, v + "encoder.down_blocks." + std::to_string(i) + ".resnets." + std::to_string(j) + ".", h, nullptr, co, 1e-6f, false, G, r));
+      h = r;
+    }
+    if (i != nl - 1) {   // Downsample2D(padding=0) after F.pad(x, (0,1,0,1)): taps beyond the bottom/right edge read zeros
+      const std::string k = v + "encoder.down_blocks." + std::to_string(i) + ".downsamplers.0.conv.";
+      GETW(w, k + "weight"); GETV(b, k + "bias");
+      Act d = alloc_act(c, B, h.H / 2, h.W / 2, co); if (!d.p) return -1;
+      GemmOpt o; o.bias = b; o.stride = 2; o.pad = 0; o.hout = h.H / 2; o.wout = h.W / 2;
+      CK(run_conv(c, st, h.p, co, nullptr, 0, B, h.H, h.W, *w, 3, d.p, o, c->zero_page));
+      h = d;
+    }
+  }
+  const int top = g.vae_block_out_channels[nl - 1], L = h.H;
+  { Act r; CK(resnet(c, st, v + "encoder.mid_block.resnets.0.", h, nullptr, top, 1e-6f, false, G, r)); h = r; }
+  CK(vae_mid_attention(c, st, v + "encoder.mid_block.attentions.0.", G, B, L, top, h));
+  { Act r; CK(resnet(c, st, v + "encoder.mid_block.resnets.1.", h, nullptr, top, 1e-6f, false, G, r)); h = r; }
+  Act n = alloc_act(c, B, L, L, top); if (!n.p) return -1;
+  GETV(gg, v + "encoder.conv_norm_out.weight"); GETV(gb, v + "encoder.conv_norm_out.bias");
+  CK(run_gn(c, st, h.p, top, nullptr, 0, B, L * L, gg, gb, G, 1e-6f, 1, n.p));
+  // conv_out (top -> 2*lc) into a zeroed 64-channel buffer, then quant_conv 1x1 (2*lc -> 2*lc) in fp32 out
+  bf16_t* co64 = (bf16_t*)c->arena.alloc((size_t)B * L * L * 64 * 2); if (!co64) return -1;
+  if (hipMemsetAsync(co64, 0, (size_t)B * L * L * 64 * 2, st) != hipSuccess) FAIL("memset enc");
+  { GETW(w, v + "encoder.conv_out.weight"); GETV(b, v + "encoder.conv_out.bias"); GemmOpt o; o.bias = b; o.ldo = 64;
+    CK(run_conv(c, st, n.p, top, nullptr, 0, B, L, L, *w, 3, co64, o, c->zero_page)); }
+  { GETW(w, v + "quant_conv.weight"); GETV(b, v + "quant_conv.bias"); GemmOpt o; o.bias = b; o.out_f32 = 1; o.ldo = 2 * lc;
+    CK(run_conv(c, st, co64, 64, nullptr, 0, B, L, L, *w, 1, moments, o, c->zero_page)); }
   return 0;
 }
 
@@ -1139,5 +1186,27 @@ extern "C" int agd_text_encode(agd_ctx* c, const int* input_ids, int B, int T, f
     if (!gf || !bfn) return fail_ctx(c);
     API_CK(c, launch_layernorm(x, h, gf, bfn, M, H, g.text_eps, st));
     API_CK(c, launch_bf16_to_f32(h, out, (long long)M * H, st)); }
+  return 0;
+}
+
+
+// `vae.encode(image).latent_dist` moments: image fp32 NCHW [B,3,S,S] in [-1,1] -> mean, logvar fp32 NCHW [B,lc,L,L]
+extern "C" int agd_vae_encode(agd_ctx* c, const float* image, int batch, int side, float* mean_out, float* logvar_out, void* stream) {
+  API_CK(c, need_final(c));
+  hipStream_t st = S(stream);
+  const int lc = c->cfg.vae_latent_channels, L = side >> (c->cfg.vae_n_levels - 1);
+  if (side % (1 << (c->cfg.vae_n_levels - 1)) || side % 8) { agd_set_error("vae_encode: side %d not divisible", side); return fail_ctx(c); }
+  Tmp tmp;
+  bf16_t* x = tmp.get<bf16_t>((size_t)batch * side * side * 64); float* mom = tmp.get<float>((size_t)batch * L * L * 2 * lc);
+  float* mom_nchw = tmp.get<float>((size_t)batch * L * L * 2 * lc);
+  if (!x || !mom || !mom_nchw) return fail_ctx(c);
+  API_CK(c, launch_prep_latents(image, x, batch, c->cfg.vae_out_channels, side * side, 64, 1, 1.0f, st));
+  API_CK(c, vae_encode_walk(c, st, x, batch, side, mom));
+  API_CK(c, launch_nchw_from_nhwc_f32(mom, 2 * lc, mom_nchw, batch, 2 * lc, L * L, st));
+  for (int b = 0; b < batch; ++b) {
+    hipMemcpyAsync(mean_out + (size_t)b * lc * L * L, mom_nchw + (size_t)b * 2 * lc * L * L, (size_t)lc * L * L * 4, hipMemcpyDeviceToDevice, st);
+    hipMemcpyAsync(logvar_out + (size_t)b * lc * L * L, mom_nchw + ((size_t)b * 2 + 1) * lc * L * L, (size_t)lc * L * L * 4, hipMemcpyDeviceToDevice, st);
+  }
+  hipStreamSynchronize(st);
   return 0;
 }

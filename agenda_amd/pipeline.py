@@ -156,6 +156,16 @@ class Engine:
                  "agd_vae_decode")
         return (u8, f32) if want_f32 else u8
 
+    def vae_encode(self, image: torch.Tensor):
+        """`vae.encode(image).latent_dist` moments: image [B,3,S,S] in [-1,1] -> (mean, logvar) fp32 [B,4,S/8,S/8]."""
+        image = image.to(device=f"cuda:{self.device}", dtype=torch.float32).contiguous()
+        b, _, S, _ = image.shape
+        L = S // (2 ** (len(self.cfg.vae.block_out_channels) - 1))
+        mean = torch.empty(b, self.cfg.vae.latent_channels, L, L, device=image.device, dtype=torch.float32)
+        logvar = torch.empty_like(mean)
+        self._ck(self.lib.agd_vae_encode(self.ctx, _lib.ptr(image), b, S, _lib.ptr(mean), _lib.ptr(logvar), self._stream()), "agd_vae_encode")
+        return mean, logvar.clamp_(-30.0, 20.0)
+
     # recorder
     def record_config(self, mode: int, is_train: bool = False, rec_tokens: int = 0):
         self._ck(self.lib.agd_record_config(self.ctx, mode, int(is_train), rec_tokens), "agd_record_config")
@@ -448,6 +458,9 @@ class StableDiffusionPipeline:
         self.engine.denoise(lat, ts, a_t, a_p, guidance_scale)
         if output_type == "latent":
             return PipelineOutput(images=[], latents=lat)
+        return self._finish(lat, B, output_type)
+
+    def _finish(self, lat, B, output_type):
         u8 = self.engine.vae_decode(lat)
         if output_type == "pt":
             return PipelineOutput(images=u8, latents=lat)
@@ -456,3 +469,44 @@ class StableDiffusionPipeline:
             return PipelineOutput(images=arr, latents=lat, nsfw_content_detected=[False] * B)
         from PIL import Image
         return PipelineOutput(images=[Image.fromarray(a) for a in arr], latents=lat, nsfw_content_detected=[False] * B)
+
+    # ---- img2img (diffusers StableDiffusionImg2ImgPipeline semantics, parity-unpinned) ------
+    @torch.no_grad()
+    def img2img(self, prompt=None, image: torch.Tensor = None, strength: float = 0.8, num_inference_steps: int = 50,
+                guidance_scale: float = 7.5, generator: Optional[torch.Generator] = None, prompt_embeds: Optional[torch.Tensor] = None,
+                noise_enc: Optional[torch.Tensor] = None, noise: Optional[torch.Tensor] = None, output_type: str = "pil"):
+        """image: float [B,3,S,S] in [-1,1] (or uint8 [B,S,S,3]).  Noise draws come from a CPU generator (or are passed
+        explicitly) for the same host-reproducibility reason as the txt2img latents."""
+        if image.dtype == torch.uint8:
+            image = image.permute(0, 3, 1, 2).float() / 127.5 - 1.0
+        B, _, S, _ = image.shape
+        if prompt_embeds is None:
+            prompts = [prompt] * B if isinstance(prompt, str) else list(prompt)
+            prompt_embeds = self.encode_prompt(prompts)
+        L = S // self.vae_scale_factor
+        shape = (B, self.cfg.unet.in_channels, L, L)
+        if generator is not None and generator.device.type != "cpu":
+            raise ValueError("use a CPU torch.Generator")
+        noise_enc = noise_enc if noise_enc is not None else torch.randn(shape, generator=generator)
+        noise = noise if noise is not None else torch.randn(shape, generator=generator)
+        ts = self.scheduler.set_timesteps(num_inference_steps)
+        a_t, a_p = self.scheduler.step_coeffs()
+        init = min(int(num_inference_steps * strength), num_inference_steps)
+        t0 = max(num_inference_steps - init, 0)
+        ts, a_t, a_p = ts[t0:], a_t[t0:], a_p[t0:]
+        mean, logvar = self.engine.vae_encode(image)
+        x0 = (mean + torch.exp(0.5 * logvar) * noise_enc.to(mean.device)) * self.cfg.vae.scaling_factor
+        a = float(self.scheduler.alphas_cumprod[int(ts[0])])
+        lat = (a ** 0.5 * x0 + (1 - a) ** 0.5 * noise.to(mean.device)).contiguous()
+        self.engine.set_context(prompt_embeds)
+        self._apply_record_mode()
+        if self._trace is not None or self._hooker is not None:
+            self.engine.record_reset(B, L)
+            if self._trace is not None:
+                self._trace._on_generate(B, L, self._last_prompt)
+            if self._hooker is not None:
+                self._hooker._on_generate(B, L, prompt_embeds.shape[1])
+        self.engine.denoise(lat, ts, a_t, a_p, guidance_scale)
+        if output_type == "latent":
+            return PipelineOutput(images=[], latents=lat)
+        return self._finish(lat, B, output_type)

@@ -12,7 +12,7 @@ from typing import Dict
 
 import torch
 
-from .config import SDConfig, unet_param_shapes, vae_decoder_param_shapes, text_param_shapes
+from .config import SDConfig, unet_param_shapes, vae_decoder_param_shapes, vae_encoder_param_shapes, text_param_shapes
 
 
 def _bf16_round(t: torch.Tensor) -> torch.Tensor:
@@ -51,9 +51,12 @@ def make_unet_weights(cfg: SDConfig, seed: int = 1234, gain: float = 1.0, bias_s
 
 
 def make_vae_weights(cfg: SDConfig, seed: int = 4321, gain: float = 1.0, bias_std: float = 0.0,
-                     perturb_norm: float = 0.0, device: str = "cpu") -> Dict[str, torch.Tensor]:
+                     perturb_norm: float = 0.0, device: str = "cpu", with_encoder: bool = False) -> Dict[str, torch.Tensor]:
     g = torch.Generator(device).manual_seed(seed)
-    return _fill(vae_decoder_param_shapes(cfg.vae), g, gain, bias_std, perturb_norm)
+    sd = _fill(vae_decoder_param_shapes(cfg.vae), g, gain, bias_std, perturb_norm)
+    if with_encoder:            # drawn after the decoder so decoder weights do not depend on the flag
+        sd.update(_fill(vae_encoder_param_shapes(cfg.vae), g, gain, bias_std, perturb_norm))
+    return sd
 
 
 def make_context(cfg: SDConfig, batch: int, seed: int = 7) -> torch.Tensor:

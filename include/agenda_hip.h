@@ -88,6 +88,10 @@ int agd_denoise(agd_ctx* ctx, float* latents, int batch, int latent_side, int n_
 int agd_vae_decode(agd_ctx* ctx, const float* latents, int batch, int latent_side, unsigned char* out_u8,
                    float* out_f32, void* stream);
 
+/* ---- `vae.encode(image).latent_dist` (img2img front end; anchors: finetune_sd.py:764-765):
+ * image fp32 NCHW [B,3,S,S] in [-1,1] -> mean and logvar fp32 NCHW [B,4,S/8,S/8].  Syncs. */
+int agd_vae_encode(agd_ctx* ctx, const float* image, int batch, int side, float* mean_out, float* logvar_out, void* stream);
+
 /* ---- heat-map recording (daam.trace / hook.py UNetCrossAttentionHooker state)
  * mode 0 off; 1 DAAM (per-layer/head time sums, mid block excluded, conditional half);
  * 2 HOOK (hook.py: head-mean per call, every attn2 incl. mid; is_train=1 keeps all batch rows).

@@ -508,3 +508,51 @@ def pil_resize_u8(img: np.ndarray, out_hw: Tuple[int, int]) -> np.ndarray:
     y = one_pass(x, W, ow, 1)           # horizontal first
     y = one_pass(y, H, oh, 0)           # then vertical
     return y[..., 0] if squeeze else y
+
+
+# ==========================================================================================
+# 9. img2img front end -- PARITY UNPINNED: the reference has no img2img call site
+#    (data_generation.py:59 is txt2img); semantics follow diffusers' StableDiffusionImg2ImgPipeline /
+#    AutoencoderKL.encode [upstream-knowledge]; the only reference anchor is the training-time
+#    `vae.encode(...).latent_dist.sample() * scaling_factor` (finetune_sd.py:764-765).
+# ==========================================================================================
+def vae_encode_moments(sd: Dict[str, Tensor], vcfg, x: Tensor):
+    """`vae.encode(x).latent_dist` -> (mean, logvar); x [B,3,S,S] in [-1,1]."""
+    g = vcfg.norm_num_groups
+    h = F.conv2d(x, sd["encoder.conv_in.weight"], sd["encoder.conv_in.bias"], padding=1)
+    n = len(vcfg.block_out_channels)
+    for i in range(n):
+        for j in range(vcfg.layers_per_block):
+            h = resnet_block(h, None, sd, f"encoder.down_blocks.{i}.resnets.{j}.", g, 1e-6)
+        if i != n - 1:      # Downsample2D(padding=0): F.pad (0,1,0,1) then stride-2 conv
+            h = F.conv2d(F.pad(h, (0, 1, 0, 1)), sd[f"encoder.down_blocks.{i}.downsamplers.0.conv.weight"],
+                         sd[f"encoder.down_blocks.{i}.downsamplers.0.conv.bias"], stride=2)
+    h = resnet_block(h, None, sd, "encoder.mid_block.resnets.0.", g, 1e-6)
+    h = vae_attention(h, sd, "encoder.mid_block.attentions.0.", g)
+    h = resnet_block(h, None, sd, "encoder.mid_block.resnets.1.", g, 1e-6)
+    h = F.silu(_gn(h, sd, "encoder.conv_norm_out", g, 1e-6))
+    h = F.conv2d(h, sd["encoder.conv_out.weight"], sd["encoder.conv_out.bias"], padding=1)
+    m = F.conv2d(h, sd["quant_conv.weight"], sd["quant_conv.bias"])
+    mean, logvar = m.chunk(2, dim=1)
+    return mean, logvar.clamp(-30.0, 20.0)
+
+
+def img2img(unet_sd, vae_sd, cfg, ctx: Tensor, image: Tensor, noise_enc: Tensor, noise: Tensor, num_inference_steps: int,
+            strength: float = 0.8, guidance_scale: float = 7.5, recorder=None, decode: bool = True):
+    """image [B,3,S,S] in [-1,1]; noise_enc / noise: explicit N(0,1) draws for the posterior sample and add_noise."""
+    sch = DDIM(cfg.sched.num_train_timesteps, cfg.sched.beta_start, cfg.sched.beta_end, cfg.sched.steps_offset,
+               cfg.sched.set_alpha_to_one, cfg.sched.prediction_type)
+    ts = sch.set_timesteps(num_inference_steps)
+    init = min(int(num_inference_steps * strength), num_inference_steps)
+    ts = ts[max(num_inference_steps - init, 0):]
+    with torch.no_grad():
+        mean, logvar = vae_encode_moments(vae_sd, cfg.vae, image)
+        x0 = (mean + torch.exp(0.5 * logvar) * noise_enc) * cfg.vae.scaling_factor
+        a = float(sch.alphas_cumprod[int(ts[0])])
+        x = a ** 0.5 * x0 + (1 - a) ** 0.5 * noise
+        for t in ts:
+            eps = unet_forward(unet_sd, cfg.unet, torch.cat([x, x], 0), torch.tensor(int(t)), ctx, recorder)
+            eu, ec = eps.chunk(2)
+            x = sch.step(eu + guidance_scale * (ec - eu), int(t), x)
+        img = postprocess_image(vae_decode(vae_sd, cfg.vae, x / cfg.vae.scaling_factor)) if decode else None
+    return img, x, (mean, logvar)

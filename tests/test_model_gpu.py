@@ -244,3 +244,31 @@ def test_generation_driver_cli_layout_and_device_export(tmp_path):
         for n in ("0.png", "1.png"):
             np.testing.assert_array_equal(np.asarray(Image.open(tmp_path / "dev" / sub / n)), np.asarray(Image.open(tmp_path / "host" / sub / n)))
     pipe.engine.close()
+
+
+def test_vae_encode_and_img2img_match_oracle():
+    """img2img front end: encoder moments (asymmetric-pad stride-2 convs) and the strength-truncated
+    schedule vs the oracle's restatement of diffusers' semantics (parity-unpinned: no reference call site)."""
+    from agenda_amd import StableDiffusionPipeline, config, synthetic, trace
+    from oracle import sd_oracle as O
+    cfg = config.tiny()
+    u = synthetic.make_unet_weights(cfg, 11, bias_std=0.05, perturb_norm=0.1)
+    v = synthetic.make_vae_weights(cfg, 12, bias_std=0.05, perturb_norm=0.1, with_encoder=True)
+    pipe = StableDiffusionPipeline(cfg, u, v, workspace_bytes=2 << 30)
+    g = torch.Generator().manual_seed(4)
+    B, S, steps, strength = 2, 128, 5, 0.6
+    image = (torch.rand(B, 3, S, S, generator=g) * 2 - 1).to(torch.bfloat16).float()
+    ctx = synthetic.make_context(cfg, B, seed=2)
+    ne, nz = torch.randn(B, 4, 16, 16, generator=g), torch.randn(B, 4, 16, 16, generator=g)
+    want_img, want_lat, (wm, wl) = O.img2img(u, v, cfg, ctx, image, ne, nz, steps, strength)
+    mean, logvar = pipe.engine.vae_encode(image)
+    assert _rms_rel(mean, wm) < 2.0 ** -6 and _rms_rel(logvar, wl) < 2.0 ** -6
+    with trace(pipe) as trc:
+        out = pipe.img2img(prompt_embeds=ctx, image=image, strength=strength, num_inference_steps=steps, noise_enc=ne, noise=nz,
+                           output_type="np")
+        hm = trc.compute_global_heat_map(image_index=1).heat_maps
+    assert out.images.shape == want_img.shape
+    assert _rms_rel(out.latents, want_lat) < 0.06
+    assert _psnr(out.images, want_img) > 30.0
+    assert float(hm.sum(0).mean()) == pytest.approx(int(steps * strength), rel=0.02)     # 3 of the 5 steps ran
+    pipe.engine.close()
