@@ -162,3 +162,54 @@ def test_bicubic_clamp_mean_matches_torch(ops):
         want = torch.stack([F.interpolate(x[None], size=(64, 64), mode="bicubic")[0].clamp_(min=0) for x in m]).mean(0)
         got = ops.bicubic_clamp_mean(m.cuda(), 64)
         assert float((got.cpu() - want).abs().max()) < 2e-5
+
+
+def test_igemm_random_shape_sweep(ops):
+    """Randomised conv / linear shapes: tails in M and N, every (ksize, stride, upsample) combination the path uses,
+    channel counts that are / are not multiples of 64, and sizes on both sides of the tile and split-K thresholds."""
+    import random
+    rnd = random.Random(1234)
+    g = torch.Generator().manual_seed(99)
+    n_conv = n_lin = 0
+    for _ in range(28):
+        k = rnd.choice([1, 3, 3])
+        stride, up = rnd.choice([(1, False), (1, False), (2, False), (1, True)]) if k == 3 else (1, False)
+        B = rnd.choice([1, 2, 3, 8])
+        H = rnd.choice([5, 8, 12, 16, 24, 32]) if not up else rnd.choice([4, 8, 16])
+        if stride == 2 and H % 2:
+            H += 1
+        Cin = rnd.choice([4, 64, 128, 192, 320, 640, 1280])
+        Cout = rnd.choice([3, 4, 64, 100, 128, 160, 320, 640])
+        if B * H * H * Cin * 9 > 6e7:
+            Cin = 64
+        x = bfr(torch.randn(B, Cin, H, H, generator=g))
+        w = bfr(torch.randn(Cout, Cin, k, k, generator=g) / math.sqrt(Cin * k * k))
+        b = torch.randn(Cout, generator=g) * 0.1
+        xi = F.interpolate(x, scale_factor=2.0, mode="nearest") if up else x
+        want = F.conv2d(xi, w, b, stride=stride, padding=1 if k == 3 else 0)
+        got = ops.conv2d(x.cuda(), w.cuda(), b.cuda(), stride=stride, upsample=up)
+        assert got.shape == want.shape, (B, Cin, H, Cout, k, stride, up)
+        assert rel_err(got, want) < 1e-4, (B, Cin, H, Cout, k, stride, up, rel_err(got, want))
+        n_conv += 1
+    for _ in range(16):
+        M = rnd.choice([1, 7, 77, 128, 200, 616, 1000, 2048, 4100])
+        K = rnd.choice([64, 320, 768, 1280, 4096, 5120])
+        N = rnd.choice([8, 64, 160, 320, 960, 1280])
+        geglu = rnd.random() < 0.25
+        if geglu:
+            N = rnd.choice([128, 256, 2560])
+        res = rnd.random() < 0.5
+        x = bfr(torch.randn(M, K, generator=g))
+        w = bfr(torch.randn(N, K, generator=g) / math.sqrt(K))
+        b = torch.randn(N, generator=g) * 0.1
+        y = F.linear(x, w, b)
+        if geglu:
+            val, gate = y.chunk(2, dim=-1)
+            y = val * F.gelu(gate)
+        r = bfr(torch.randn(M, y.shape[1], generator=g)) if res else None
+        if res:
+            y = y + r
+        got = ops.linear(x.cuda(), w.cuda(), b.cuda(), r.cuda() if res else None, geglu=geglu)
+        assert rel_err(got, y) < 1e-4, (M, K, N, geglu, res, rel_err(got, y))
+        n_lin += 1
+    assert n_conv == 28 and n_lin == 16
