@@ -30,16 +30,21 @@ template <int D> struct AttnCfg {
   // A spare (padded) V column exists when D is not a multiple of 32: column D is set to 1.0 so the
   // PV MFMA also produces the softmax row sum (row D of O^T) -- no VALU adds for the denominator.
   static constexpr bool ONES = (DBLK * 32 > D);
+  // A spare (padded) QK^T k-column exists when D is not a multiple of 16: K's pad column D is set to 1.0 and Q's
+  // to -m (the running reference max), so the MFMA itself subtracts the max -- no VALU op and no C-operand tuple.
+  static constexpr bool QPAD = (KSTEPS * 16 > D);
 };
 
 #define DEFER_THR 8.0f   // log2 units: rescale O only when a row max grows by more than 2^8
 
 template <int D, int KB, int QB, int RECORD>
-__global__ __launch_bounds__(256, ((QB == 1 && D <= 40 && !RECORD) ? 4 : (QB == 1 && D <= 80) ? 2 : 1)) void attn_kernel(const AttnP p) {
+__global__ __launch_bounds__(256, ((QB == 1 && D <= 40 && !RECORD) ? 4 : (QB == 1 && D <= 64 && !RECORD) ? 3 : (QB == 1 && D <= 80) ? 2 : 1)) void attn_kernel(const AttnP p) {
   using C = AttnCfg<D>;
   constexpr int KEYS = KB * 32;
   constexpr int KSTEPS = C::KSTEPS, DBLK = C::DBLK, KPITCH = C::KPITCH, VPITCH = C::VPITCH, CH = C::CH;
   constexpr bool ONES = C::ONES && !RECORD;
+  constexpr bool QPAD = C::QPAD && !RECORD;              // -m through the K-dim pad column
+  constexpr bool CNEG = !QPAD && !RECORD;                // -m through the MFMA C operand
   constexpr int NCHUNK = KEYS * CH;                      // 16-B chunks per K (or V) tile
   constexpr int LD_IT = (NCHUNK + 255) / 256;
   constexpr int STAGE = KEYS * (KPITCH + VPITCH);
@@ -74,7 +79,7 @@ __global__ __launch_bounds__(256, ((QB == 1 && D <= 40 && !RECORD) ? 4 : (QB == 
     if constexpr (C::KCH > CH) {
       for (int i = tid; i < KEYS * (C::KCH - CH); i += 256) {
         const int r = i / (C::KCH - CH), cc = CH + i % (C::KCH - CH);
-        *(u32x4*)(sK + r * KPITCH + cc * 16) = u32x4{0, 0, 0, 0};
+        *(u32x4*)(sK + r * KPITCH + cc * 16) = u32x4{(QPAD && cc == CH) ? 0x3F80u : 0u, 0, 0, 0};
       }
     }
     if constexpr (DBLK * 4 > CH) {
@@ -85,6 +90,7 @@ __global__ __launch_bounds__(256, ((QB == 1 && D <= 40 && !RECORD) ? 4 : (QB == 
     }
   }
 
+  const float qscale = p.scale * 1.44269504088896340736f;   // exp(x) = exp2(x*log2e)
   // Q fragments: lane (c, hh) holds Q[q0 + 32*qb + c][16s + 8hh .. +8]
   bf16x8 qf[QB][KSTEPS];
 #pragma unroll
@@ -97,6 +103,12 @@ __global__ __launch_bounds__(256, ((QB == 1 && D <= 40 && !RECORD) ? 4 : (QB == 
       u32x4 v = u32x4{0, 0, 0, 0};
       if (qok && d0 < D) v = *(const u32x4*)(qp + (long long)qrow * p.ldq + d0);
       qf[qb][s] = __builtin_bit_cast(bf16x8, v);
+      if constexpr (!RECORD) {
+        // fold scale*log2(e) into Q once (fp32 multiply, RNE back to bf16): the QK^T accumulator then holds
+        // log2-domain logits and the per-score v_fma in the softmax disappears (that kernel is VALU-bound).
+#pragma unroll
+        for (int j = 0; j < 8; ++j) qf[qb][s][j] = (__bf16)((float)qf[qb][s][j] * qscale);
+      }
     }
   }
 
@@ -145,9 +157,18 @@ __global__ __launch_bounds__(256, ((QB == 1 && D <= 40 && !RECORD) ? 4 : (QB == 
 #pragma unroll
       for (int j = 0; j < 16; ++j) oacc[qb][i][j] = 0.f;
   float m_run[QB], l_run[QB];
+  // non-RECORD: -m_run replicated over a 16-register tuple = the C operand of the first QK^T MFMA, so the
+  // accumulator comes out as (logit - m) and exp2 applies to it directly.  Rewritten only on a (rare) rescale.
+  f32x16 negm[CNEG ? QB : 1];
 #pragma unroll
-  for (int qb = 0; qb < QB; ++qb) { m_run[qb] = -INFINITY; l_run[qb] = 0.f; }
-  const float sc = p.scale * 1.44269504088896340736f;   // exp(x) = exp2(x*log2e)
+  for (int qb = 0; qb < QB; ++qb) {
+    m_run[qb] = RECORD ? -INFINITY : 0.f; l_run[qb] = 0.f;
+    if constexpr (CNEG) {
+#pragma unroll
+      for (int j = 0; j < 16; ++j) negm[qb][j] = 0.f;
+    }
+  }
+  const float sc = qscale;
 
   const int ntiles = RECORD ? 1 : (p.Nk + KEYS - 1) / KEYS;   // RECORD: host guarantees Nk <= KEYS
   const bool ragged = (p.Nk % KEYS) != 0 || p.causal;   // causal: every tile takes the masked path
@@ -176,7 +197,7 @@ __global__ __launch_bounds__(256, ((QB == 1 && D <= 40 && !RECORD) ? 4 : (QB == 
 #pragma unroll
         for (int qb = 0; qb < QB; ++qb) {
           if (s == 0) { const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                        sacc[qb][kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[qb][s], z, 0, 0, 0); }
+                        sacc[qb][kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[qb][s], CNEG ? negm[qb] : z, 0, 0, 0); }
           else sacc[qb][kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[qb][s], sacc[qb][kb], 0, 0, 0);
         }
       }
@@ -200,26 +221,10 @@ __global__ __launch_bounds__(256, ((QB == 1 && D <= 40 && !RECORD) ? 4 : (QB == 
       for (int kb = 0; kb < KB; ++kb)
 #pragma unroll
         for (int i = 0; i < 16; ++i) mx = fmaxf(mx, sacc[qb][kb][i]);
-      mx = xhalf_max(mx) * sc;
       if constexpr (RECORD) {
+        mx = xhalf_max(mx) * sc;
         m_run[qb] = mx;                                   // single tile: no running state to rescale
-      } else if (!__all(mx <= m_run[qb] + DEFER_THR)) {
-        const float m_new = fmaxf(m_run[qb], mx);
-        const float alpha = __builtin_amdgcn_exp2f(m_run[qb] - m_new);
-        m_run[qb] = m_new;
-        l_run[qb] *= alpha;
-#pragma unroll
-        for (int db = 0; db < DBLK; ++db)
-#pragma unroll
-          for (int j = 0; j < 16; ++j) oacc[qb][db][j] *= alpha;
-      }
-      const float nm = -m_run[qb];
-      if constexpr (ONES) {
-#pragma unroll
-        for (int kb = 0; kb < KB; ++kb)
-#pragma unroll
-          for (int i = 0; i < 16; ++i) sacc[qb][kb][i] = __builtin_amdgcn_exp2f(fmaf(sacc[qb][kb][i], sc, nm));
-      } else {
+        const float nm = -mx;
         float rs = 0.f;
 #pragma unroll
         for (int kb = 0; kb < KB; ++kb)
@@ -230,6 +235,54 @@ __global__ __launch_bounds__(256, ((QB == 1 && D <= 40 && !RECORD) ? 4 : (QB == 
             rs += pv;
           }
         l_run[qb] += rs;
+      } else {
+        // sacc already holds (logit - m_run) in log2 units.  Deferred rescale: only when some score of this
+        // tile exceeds the reference by 2^DEFER_THR (or on the first tile, which fixes the reference).
+        if (t == 0 || !__all(mx <= DEFER_THR)) {
+          const float mxf = xhalf_max(mx);
+          float delta = (t == 0) ? mxf : fmaxf(mxf, 0.f);
+          if (!(delta > -INFINITY)) delta = 0.f;
+          if constexpr (QPAD) {                             // the reference lives in a bf16 Q slot: round it
+            const float mb = (float)(__bf16)(m_run[qb] + delta);
+            delta = mb - m_run[qb];
+            constexpr int pc = D - 16 * (KSTEPS - 1);       // pad column within the last k-step
+            if (hh == pc / 8) qf[qb][KSTEPS - 1][pc % 8] = (__bf16)(-mb);
+          }
+          const float alpha = __builtin_amdgcn_exp2f(-delta);
+          m_run[qb] += delta;
+          l_run[qb] *= alpha;
+#pragma unroll
+          for (int db = 0; db < DBLK; ++db)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) oacc[qb][db][j] *= alpha;
+#pragma unroll
+          for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) sacc[qb][kb][i] -= delta;
+          if constexpr (CNEG) {
+            const float nm = -m_run[qb];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) negm[qb][j] = nm;
+          }
+        }
+        if constexpr (CNEG) asm volatile("" : "+v"(negm[qb]));   // keep the tuple resident (no per-tile re-splat)
+        if constexpr (ONES) {
+#pragma unroll
+          for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) sacc[qb][kb][i] = __builtin_amdgcn_exp2f(sacc[qb][kb][i]);
+        } else {
+          float rs = 0.f;
+#pragma unroll
+          for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+              const float pv = __builtin_amdgcn_exp2f(sacc[qb][kb][i]);
+              sacc[qb][kb][i] = pv;
+              rs += pv;
+            }
+          l_run[qb] += rs;
+        }
       }
     }
 
@@ -344,6 +397,7 @@ __global__ __launch_bounds__(256, ((QB == 1 && D <= 40 && !RECORD) ? 4 : (QB == 
     }
   }
 }
+
 
 template <int D, int KB, int QB, int RECORD>
 static int launch_attn_t(const AttnP& p, hipStream_t st) {

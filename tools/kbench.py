@@ -80,7 +80,8 @@ if what in ("attn", "all"):
     for qb in (2, 1):
         lib.agd_set_attn_qb(qb)
         print(f" [qb={qb}]")
-        attn(B, 8, 40, 4096, 4096); attn(B, 8, 80, 1024, 1024)
+        attn(B, 8, 40, 4096, 4096); attn(B, 8, 80, 1024, 1024); attn(B, 8, 160, 256, 256)
+        attn(B, 5, 64, 9216, 9216, iters=5); attn(B, 10, 64, 2304, 2304); attn(B, 20, 64, 576, 576)   # SD-2.1 768 px
     t = 0
     t += attn(B, 8, 40, 4096, 4096, cnt=5); t += attn(B, 8, 80, 1024, 1024, cnt=5); t += attn(B, 8, 160, 256, 256, cnt=5)
     t += attn(B, 8, 160, 64, 64, cnt=1)
