@@ -444,6 +444,9 @@ class StableDiffusionPipeline:
                     raise ValueError("use a CPU torch.Generator (initial latents are an explicit, host-reproducible input)")
                 parts.append(torch.randn(1, self.cfg.unet.in_channels, L, L, generator=g))
             latents = torch.cat(parts, 0)
+        expect = (B, self.cfg.unet.in_channels, L, L)
+        if tuple(latents.shape) != expect:                 # diffusers prepare_latents raises the same way
+            raise ValueError(f"Unexpected latents shape, got {tuple(latents.shape)}, expected {expect}")
         lat = (latents.to(torch.float32) * self.scheduler.init_noise_sigma).to(self.device).contiguous().clone()
         self.engine.set_context(prompt_embeds)
         self._apply_record_mode()
