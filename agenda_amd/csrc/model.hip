@@ -61,6 +61,8 @@ struct agd_ctx {
   bool finalized = false;
   // time embedding
   WMat tproj_all; float* tproj_bias = nullptr; float* tproj_out = nullptr; int tproj_total = 0;
+  const float* tproj_cur = nullptr;                 // time_emb_proj outputs of the forward being walked
+  float* tsteps_buf = nullptr; int tsteps_cap = 0;   // agd_denoise: embeddings of ALL steps, computed up front
   std::unordered_map<std::string, int> tproj_off;
   float* temb_buf = nullptr;   // [dim | 4dim | 4dim] fp32 scratch
   float* t_dev = nullptr;
@@ -178,7 +180,7 @@ static int resnet(agd_ctx* c, hipStream_t st, const std::string& pre, const Act&
   if (has_temb) {
     auto it = c->tproj_off.find(pre);
     if (it == c->tproj_off.end()) FAIL("no time_emb_proj for %s", pre.c_str());
-    o1.rowadd = c->tproj_out + it->second; o1.rowadd_ld = 0;
+    o1.rowadd = c->tproj_cur + it->second; o1.rowadd_ld = 0;
   }
   CK(run_conv(c, st, n1.p, Cin, nullptr, 0, B, H, Wd, *w1, 3, h.p, o1, c->zero_page));
   Act n2 = alloc_act(c, B, H, Wd, Cout); if (!n2.p) return -1;
@@ -296,28 +298,31 @@ static int transformer(agd_ctx* c, hipStream_t st, const std::string& pre, const
   return 0;
 }
 
-// time embedding for a single timestep (inference: identical for every batch row)
-static int time_embed(agd_ctx* c, hipStream_t st, float t) {
+// time embeddings of n <= 8 timesteps (inference: one timestep serves every batch row); scratch = n * 9 * dim floats,
+// out = [n][tproj_total]: every resnet's time_emb_proj(silu(temb)) from one stacked matrix
+static int time_embed(agd_ctx* c, hipStream_t st, const float* ts, int n, float* scratch, float* out) {
   const int dim = c->cfg.block_out_channels[0], td = dim * 4;
   ProfScope ps(c, st, PC_ELEM, 0);
-  float* e0 = c->temb_buf; float* e1 = e0 + dim; float* e2 = e1 + td;
-  CK(launch_timestep_embed(t, e0, dim, st));
+  float* e0 = scratch; float* e1 = e0 + (size_t)n * dim; float* e2 = e1 + (size_t)n * td;
+  for (int i = 0; i < n; ++i) CK(launch_timestep_embed(ts[i], e0 + (size_t)i * dim, dim, st));
   GETW(w1, "unet.time_embedding.linear_1.weight"); GETV(b1, "unet.time_embedding.linear_1.bias");
   GETW(w2, "unet.time_embedding.linear_2.weight"); GETV(b2, "unet.time_embedding.linear_2.bias");
-  CK(launch_small_linear(e0, w1->w, b1, e1, 1, td, w1->Cpad, 0, 1, st));     // linear_1 + SiLU
-  CK(launch_small_linear(e1, w2->w, b2, e2, 1, td, w2->Cpad, 0, 0, st));     // linear_2 -> temb
-  // every resnet's time_emb_proj(silu(temb)) in one launch
-  CK(launch_small_linear(e2, c->tproj_all.w, c->tproj_bias, c->tproj_out, 1, c->tproj_total, td, 1, 0, st));
+  CK(launch_small_linear(e0, w1->w, b1, e1, n, td, w1->Cpad, 0, 1, st));     // linear_1 + SiLU
+  CK(launch_small_linear(e1, w2->w, b2, e2, n, td, w2->Cpad, 0, 0, st));     // linear_2 -> temb
+  CK(launch_small_linear(e2, c->tproj_all.w, c->tproj_bias, out, n, c->tproj_total, td, 1, 0, st));
   return 0;
 }
 
 // x: [B2][L*L][64] bf16 (latent channels zero-padded) -> eps [B2][L*L][out_channels] fp32 NHWC
-static int unet_walk(agd_ctx* c, hipStream_t st, const bf16_t* xin, int B2, int L, float t, float* eps_out) {
+// tproj_row: this timestep's time_emb_proj outputs when the caller computed them up front (agd_denoise), else nullptr
+static int unet_walk(agd_ctx* c, hipStream_t st, const bf16_t* xin, int B2, int L, float t, float* eps_out,
+                     const float* tproj_row = nullptr) {
   const agd_config& g = c->cfg;
   const int nl = g.n_levels, G = g.norm_num_groups;
   const std::string u = "unet.";
   c->arena.release(0);
-  CK(time_embed(c, st, t));
+  if (tproj_row) c->tproj_cur = tproj_row;
+  else { CK(time_embed(c, st, &t, 1, c->temb_buf, c->tproj_out)); c->tproj_cur = c->tproj_out; }
   std::vector<Act> skips;
   Act h = alloc_act(c, B2, L, L, g.block_out_channels[0]); if (!h.p) return -1;
   { GETW(w, u + "conv_in.weight"); GETV(b, u + "conv_in.bias"); GemmOpt o; o.bias = b;
@@ -531,6 +536,7 @@ extern "C" void agd_destroy(agd_ctx* c) {
   for (void* p : c->owned) hipFree(p);
   if (c->arena.base) hipFree(c->arena.base);
   if (c->stage) hipFree(c->stage);
+  if (c->tsteps_buf) hipFree(c->tsteps_buf);
   for (auto e : c->ev_pool) hipEventDestroy(e);
   delete c;
 }
@@ -701,9 +707,25 @@ extern "C" int agd_denoise(agd_ctx* c, float* latents, int batch, int L, int n_s
   const int B2 = 2 * batch, Cl = c->cfg.in_channels, HW = L * L;
   API_CK(c, ensure_lat(c, B2, L));
   if (c->ctx_B2 != B2) { agd_set_error("denoise: context batch %d != 2*batch %d", c->ctx_B2, B2); return fail_ctx(c); }
+  // the timesteps are known up front: embed all of them now, 8 per launch (the stacked time_emb_proj matrix is
+  // ~50 MB of weights -- streamed ceil(n/8) times here instead of once per step)
+  const int dim0 = c->cfg.block_out_channels[0];
+  const size_t per_step = (size_t)c->tproj_total + (size_t)9 * dim0;
+  if (c->tsteps_cap < n_steps) {
+    if (c->tsteps_buf) hipFree(c->tsteps_buf);
+    c->tsteps_buf = nullptr; c->tsteps_cap = 0;
+    if (hipMalloc((void**)&c->tsteps_buf, per_step * n_steps * sizeof(float)) != hipSuccess) { agd_set_error("denoise: time-embedding buffer alloc failed"); return fail_ctx(c); }
+    c->tsteps_cap = n_steps;
+  }
+  float* tp_all = c->tsteps_buf;                                  // [n_steps][tproj_total]
+  float* tscratch = c->tsteps_buf + (size_t)c->tproj_total * n_steps;
+  for (int s0 = 0; s0 < n_steps; s0 += 8) {
+    const int n = n_steps - s0 < 8 ? n_steps - s0 : 8;
+    API_CK(c, time_embed(c, st, timesteps + s0, n, tscratch, tp_all + (size_t)s0 * c->tproj_total));
+  }
   for (int s = 0; s < n_steps; ++s) {
     { ProfScope ps(c, st, PC_ELEM, 0); API_CK(c, launch_prep_latents(latents, c->lat_bf16, batch, Cl, HW, 64, 2, 1.0f, st)); }
-    API_CK(c, unet_walk(c, st, c->lat_bf16, B2, L, timesteps[s], c->eps_nhwc));
+    API_CK(c, unet_walk(c, st, c->lat_bf16, B2, L, timesteps[s], c->eps_nhwc, tp_all + (size_t)s * c->tproj_total));
     { ProfScope ps(c, st, PC_ELEM, 0);
       API_CK(c, launch_cfg_ddim(c->eps_nhwc, c->cfg.out_channels, latents, batch, Cl, HW, guidance, alpha_t[s], alpha_prev[s], c->cfg.prediction_type, st)); }
   }

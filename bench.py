@@ -141,6 +141,14 @@ def main():
                 "frac": round(ach / MFMA_PEAK_TF, 4), "traffic": pmc_traffic_mb(),
                 "launches": conv["launches"], "avg_launch_us": round(conv["ms"] * 1e3 / max(conv["launches"], 1), 1),
                 "end_to_end_frac": round(value / world * TFLOP_PER_IMAGE.get(args.ddim_steps, (2 * args.ddim_steps * UNET_GF + VAE_GF) / 1e3) / MFMA_PEAK_TF, 4)}
+    daam = None
+    if classes and classes.get("attn_cross_daam", {}).get("ms"):
+        # accumulator read+write = 132.5 MB per image per denoise step (15 layers x 8 heads x 77 rows, fp32);
+        # the accumulation is fused into the cross-attention kernels, so their class time is the time spent on it
+        gb = 132.5e-3 * args.ddim_steps * B
+        gbs = gb / (classes["attn_cross_daam"]["ms"] * 1e-3)
+        daam = {"bound": "hbm", "achieved": round(gbs, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(gbs / 8000.0, 4),
+                "algorithmic_GB_per_batch": round(gb, 2), "kernel": "attn_kernel<RECORD> (cross-attention + fused accumulate)"}
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         usd, vsd = pipe.synthetic_weights
@@ -158,6 +166,8 @@ def main():
                 "config": {"workload": f"SD-1.5 512x512 batch={B}/GPU, {args.ddim_steps} DDIM steps (eta 0, CFG 7.5), DAAM heat maps on (77 rows recorded, 2 word maps), VAE decode",
                            "global_batch": world * B, "ddim_steps": args.ddim_steps, "parallelism": f"seed-sharded x{world} + all_gather"},
                 "roofline": roof, "cpu_baseline": cpu}
+        if daam:
+            line["daam_accumulate"] = daam
         if classes:
             line["kernel_classes_ms"] = {k: round(v["ms"], 2) for k, v in classes.items() if v["launches"]}
         print(json.dumps(line))
