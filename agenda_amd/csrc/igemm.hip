@@ -21,6 +21,8 @@
 //    time-embedding row add / residual / GEGLU / SiLU fused, one rounding to bf16;
 //  * block->tile map is XCD-aware (tiles sharing an A panel share an L2).
 #include "kernels.h"
+#include <cstdio>
+#include <cstdlib>
 #include "igemm_epilogue.h"
 #include <cstdlib>
 #define CK0(expr) do { if ((expr) != 0) return -1; } while (0)
@@ -327,6 +329,9 @@ static int launch_one(const IgemmP& p, int splits, hipStream_t st) {
 
 template <int BM, int BN, int WM, int WN, int STAGES = 2>
 static int launch_cfg(const IgemmP& p, int splits, hipStream_t st) {
+  static const bool logit = getenv("AGD_IGEMM_LOG") != nullptr;      // tools/layer_report.py joins this with a kernel trace
+  if (logit) fprintf(stderr, "IGEMM M=%d N=%d K=%d ks=%d stride=%d up=%d geglu=%d res=%d tile=%dx%d splits=%d batch=%d\n", p.M, p.N, p.K, p.ksize,
+                     p.stride, p.up, p.geglu, p.residual ? 1 : 0, BM, BN, splits, p.batch > 0 ? p.batch : 1);
   if (splits > 1) {
     int rc = (p.ksize == 3) ? launch_one<BM, BN, WM, WN, 3, STAGES, 0, 1>(p, splits, st) : launch_one<BM, BN, WM, WN, 1, STAGES, 0, 1>(p, splits, st);
     if (rc) return rc;
@@ -381,7 +386,17 @@ int launch_igemm(const IgemmP& p_in, hipStream_t st) {
     }
   }
   if (t128 >= ((g_igemm_cfg & 15) == 3 ? 128 : 192)) {
-    const bool n160 = (p.N % 160) == 0 && (p.N % 128) != 0;
+    // 128x128 or 128x160: both hold 2 workgroups per CU.  Wave quantisation decides: a launch of T tiles keeps
+    // every CU busy for ceil(T/256) tile-times (x1.33 when T <= 256: a lone workgroup per CU has nothing to overlap
+    // its loads/epilogue with), and a 160-wide tile is 1.25 tile-times.  E.g. M=8192, N=640: 320 tiles of 128x128
+    // leave 192 CUs idle for the second half; 256 tiles of 128x160 do not.
+    bool n160 = (p.N % 160) == 0 && (p.N % 128) != 0;
+    if (p.ksize == 3 && (p.N % 160) == 0 && (p.N % 128) == 0 && (g_igemm_cfg & 15) != 4) {   // measured: helps 3x3, hurts 1x1
+      const long long mt = (p.M + 127) / 128;
+      const long long T8 = mt * (p.N / 128) * batch, T0 = mt * (p.N / 160) * batch;
+      auto cost = [](long long T, double w) { return w * (T <= 256 ? 1.33 : (double)((T + 255) / 256)); };
+      n160 = cost(T0, 1.25) < cost(T8, 1.0) - 1e-9;
+    }
     if (n160) return launch_cfg<128, 160, 2, 2>(p, 1, st);
     return launch_cfg<128, 128, 2, 2>(p, 1, st);
   }
