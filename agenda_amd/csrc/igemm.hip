@@ -32,7 +32,7 @@ template <int N> AGD_DEV void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" 
 #define OOB_OFF 0x80000000u      // >= num_records (0x7FFFFFF0): buffer range check returns zeros
 
 template <int BM, int BN, int WM, int WN, int KS, int STAGES, int GEGLU, int SPLITK>
-__global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(const IgemmP p) {
+__global__ __launch_bounds__(WM * WN * 64, 2) void igemm_kernel(const IgemmP p) {
   constexpr int NT = WM * WN * 64;
   constexpr int NW = WM * WN;
   constexpr int WTM = BM / WM, WTN = BN / WN;
@@ -125,27 +125,29 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(const IgemmP p) {
     bsoff = (unsigned)ks0 * 128u;
   }
 
-  auto issue = [&](int slot) {
+  // prologue stage fill; live == false issues the same instructions through a zero-record descriptor (dropped):
+  // keeps the per-wave vmcnt arithmetic of the deeper rings uniform when the K range is shorter than the ring
+  auto issue = [&](int slot, bool live) {
     if (p.dbg & 4) return;                      // timing experiment: no DMA instructions at all
-    if (seg_left == 0) new_segment();
+    if (live && seg_left == 0) new_segment();
     char* sA = smem + slot * STAGE;
     char* sB = sA + A_BYTES;
     // make the scalar operands provably wave-uniform (else hipcc wraps every load in a waterfall loop)
     const unsigned aso = __builtin_amdgcn_readfirstlane(asoff), bso = __builtin_amdgcn_readfirstlane(bsoff);
+    const unsigned nrA = live ? nrecA : 0u, nrB = live ? nrecB : 0u;
     if (__builtin_amdgcn_readfirstlane(cursrc)) {
 #pragma unroll
       for (int i = 0; i < A_IT; ++i)
-        if (i * NW + wid < A_Q) bufdma16(base1, sA + (i * NW + wid) * 1024, avoff[i], aso, nrecA);
+        if (i * NW + wid < A_Q) bufdma16(base1, sA + (i * NW + wid) * 1024, avoff[i], aso, nrA);
     } else {
 #pragma unroll
       for (int i = 0; i < A_IT; ++i)
-        if (i * NW + wid < A_Q) bufdma16(base0, sA + (i * NW + wid) * 1024, avoff[i], aso, nrecA);
+        if (i * NW + wid < A_Q) bufdma16(base0, sA + (i * NW + wid) * 1024, avoff[i], aso, nrA);
     }
 #pragma unroll
     for (int i = 0; i < B_IT; ++i)
-      if (i * NW + wid < B_Q) bufdma16(baseW, sB + (i * NW + wid) * 1024, bvoff[i], bso, nrecB);
-    asoff += 128u; bsoff += 128u;
-    --seg_left;
+      if (i * NW + wid < B_Q) bufdma16(baseW, sB + (i * NW + wid) * 1024, bvoff[i], bso, nrB);
+    if (live) { asoff += 128u; bsoff += 128u; --seg_left; }
   };
 
   f32x4 acc[MI][NI];
@@ -166,13 +168,12 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(const IgemmP p) {
   // Memory ops keep source order (the compiler cannot prove DMA stores and fragment loads disjoint);
   // sched_group_barrier pins the register-only MFMAs in between.  The last step issues its DMAs
   // through a zero-record descriptor (dropped) so there is no branch in the loop body.
-  static_assert(STAGES == 2, "hand-interleaved loop is written for the 2-stage ring");
   static_assert((BM * 8) % NT == 0 && (BN * 8) % NT == 0, "tile rows must split evenly over the DMA lanes");
   constexpr int NF = MI + NI, ND = A_IT + B_IT, NG = NF > ND ? NF : ND;
 
   // one K step: barrier, then {kk0 fragment reads | (2 MFMA, 1 DMA, 1 kk1 read) x n | remaining MFMAs}
-  auto kstep = [&](int cur, const bf16_t* baseA, const unsigned (&av)[A_IT], unsigned aso, unsigned bso, unsigned nrA, unsigned nrB) {
-    char* dA = smem + (cur ^ 1) * STAGE;
+  auto kstep = [&](int cur, int dst, const bf16_t* baseA, const unsigned (&av)[A_IT], unsigned aso, unsigned bso, unsigned nrA, unsigned nrB) {
+    char* dA = smem + dst * STAGE;
     char* dB = dA + A_BYTES;
     const char* sA = smem + cur * STAGE + wm * WTM * 128;
     const char* sB = smem + cur * STAGE + A_BYTES + wn * WTN * 128;
@@ -209,7 +210,7 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(const IgemmP p) {
     __builtin_amdgcn_sched_group_barrier(0x8, 2 * MI * NI - 2 * NG, 0);
   };
 
-  if (KS == 3 && p.up == 1 && (p.dbg & 8)) {     // opt-in (AGD_IGEMM_CFG=128): measured slower, see DESIGN.md §4
+  if (STAGES == 2 && KS == 3 && p.up == 1 && (p.dbg & 8)) {     // opt-in (AGD_IGEMM_CFG=128): measured slower, see DESIGN.md §4
     // K order = channel-chunk major, tap minor: the 9 taps of one 64-channel chunk run back to back, so the
     // shifted re-reads of the same pixels hit in L2 (tap-major order sweeps every chunk between two uses of a
     // pixel: ~9x the algorithmic fetch, measured with FETCH_SIZE).  Gather offset of tap (kh,kw) =
@@ -270,19 +271,27 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_kernel(const IgemmP p) {
         const unsigned aso = __builtin_amdgcn_readfirstlane((unsigned)ichunk * 128u);
         const unsigned bso = __builtin_amdgcn_readfirstlane((unsigned)((nt * Ctot + (isrc ? p.C0 : 0) + ichunk * 64) * 2));
         const bf16_t* baseA = __builtin_amdgcn_readfirstlane(isrc) ? base1 : base0;
-        kstep(gs & 1, baseA, av, aso, bso, more ? nrecA : 0u, more ? nrecB : 0u);
+        kstep(gs & 1, (gs & 1) ^ 1, baseA, av, aso, bso, more ? nrecA : 0u, more ? nrecB : 0u);
         ++gs;
       }
     }
   } else {
-    if (nk > 0) issue(0);
+    // STAGES-deep ring: stages ks+1 .. ks+STAGES-2 stay in flight across the barrier (counted vmcnt), the stage
+    // for step ks+STAGES-1 is issued inside step ks into the slot step ks-1 just released.  A deeper ring is what
+    // covers the L2/HBM latency when few workgroups share a CU (small feature maps).
+    if (nk > 0) {
+#pragma unroll
+      for (int s_ = 0; s_ < STAGES - 1; ++s_) issue(s_, s_ < nk);
+    }
     for (int ks = 0; ks < nk; ++ks) {
-      asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-      const bool more = ks + 1 < nk;
+      wait_vmcnt<(STAGES - 2) * LPS>();
+      asm volatile("s_barrier" ::: "memory");
+      const int nxt = ks + STAGES - 1;
+      const bool more = nxt < nk;
       if (more && seg_left == 0) new_segment();
       const bf16_t* baseA = __builtin_amdgcn_readfirstlane(cursrc) ? base1 : base0;
       const unsigned aso = __builtin_amdgcn_readfirstlane(asoff), bso = __builtin_amdgcn_readfirstlane(bsoff);
-      kstep(ks & 1, baseA, avoff, aso, bso, more ? nrecA : 0u, more ? nrecB : 0u);
+      kstep(ks % STAGES, nxt % STAGES, baseA, avoff, aso, bso, more ? nrecA : 0u, more ? nrecB : 0u);
       if (more) { asoff += 128u; bsoff += 128u; --seg_left; }
     }
   }
@@ -400,5 +409,6 @@ int launch_igemm(const IgemmP& p_in, hipStream_t st) {
     if (n160) return launch_cfg<128, 160, 2, 2>(p, 1, st);
     return launch_cfg<128, 128, 2, 2>(p, 1, st);
   }
-  return launch_cfg<64, 64, 2, 2>(p, 1, st);
+  if ((g_igemm_cfg & 15) == 5) return launch_cfg<64, 64, 2, 2>(p, 1, st);      // A/B: the 2-stage ring
+  return launch_cfg<64, 64, 2, 2, 4>(p, 1, st);
 }
