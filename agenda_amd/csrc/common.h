@@ -60,6 +60,16 @@ AGD_DEV void bufdma16(const void* base, void* lds_wave_base, unsigned voff, unsi
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voff, soff, 0, 0);
 }
 
+// x / d for 0 <= x < 2^24 and d >= 1 without the ~40-instruction integer-division sequence: float estimate + one
+// correction step each way (the estimate is off by at most 1).  Used for the im2col row -> (image, y, x) split.
+AGD_DEV int fast_udiv(int x, int d, float inv_d) {
+  int q = (int)((float)x * inv_d);
+  int r = x - q * d;
+  if (r < 0) { --q; r += d; }
+  if (r >= d) ++q;
+  return q;
+}
+
 // XCD-aware bijective block remap: consecutive logical ids land on the same XCD (8 XCDs,
 // round-robin dispatch), so tiles that share an operand panel share an L2.  Speed only.
 AGD_DEV int xcd_remap(int bid, int nwg) {

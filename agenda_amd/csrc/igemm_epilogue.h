@@ -10,6 +10,7 @@ AGD_DEV void igemm_epilogue(const IgemmP& p, f32x4 (&acc)[BM / WM / 16][BN / WN 
   constexpr int WTM = BM / WM, WTN = BN / WN;
   constexpr int MI = WTM / 16, NI = WTN / 16;
   const int HWo = p.Hout * p.Wout;
+  const float inv_hwo_e = 1.0f / (float)HWo;        // rowadd image index (M < 2^24 is checked by the launcher)
   // ---- epilogue: acc -> LDS fp32 [BM][BN] -> coalesced 16-B row chunks -----------------------
   // Residual chunks are prefetched into registers before the LDS round trip so their HBM latency
   // overlaps the staging; all trip counts are compile-time.
@@ -113,7 +114,7 @@ AGD_DEV void igemm_epilogue(const IgemmP& p, f32x4 (&acc)[BM / WM / 16][BN / WN 
           for (int e = 0; e < 8; ++e) v[e] += bm;
         }
         if (p.rowadd) {
-          const float* ra = p.rowadd + (long long)(m / HWo) * p.rowadd_ld + no;
+          const float* ra = p.rowadd + (long long)fast_udiv(m, HWo, inv_hwo_e) * p.rowadd_ld + no;
           if (nvalid == 8) {
             float rv[8];
             *(f32x4*)&rv[0] = *(const f32x4*)ra; *(f32x4*)&rv[4] = *(const f32x4*)(ra + 4);
