@@ -243,20 +243,36 @@ static int cross_attention(agd_ctx* c, hipStream_t st, XLayer& xl, const bf16_t*
 }
 
 // Transformer2DModel with one BasicTransformerBlock
-static int transformer(agd_ctx* c, hipStream_t st, const std::string& pre, const Act& x, int heads, int groups, Act& out) {
-  const int B = x.B, HW = x.H * x.W, C = x.C, M = B * HW;
+// the second half of a [2B'] activation := its first half (CFG: both halves saw identical inputs so far)
+static int dup_half(agd_ctx* c, hipStream_t st, bf16_t* p, long long half_elems) {
+  ProfScope ps(c, st, PC_ELEM, 0);
+  if (hipMemcpyAsync(p + half_elems, p, (size_t)half_elems * 2, hipMemcpyDeviceToDevice, st) != hipSuccess) FAIL("dup_half copy failed");
+  return 0;
+}
+
+// dup != 0 (first transformer of a CFG forward, agd_denoise only): x holds B' = batch/2 images whose unconditional and
+// conditional rows are still IDENTICAL (same latents, same timestep; the text context enters at attn2).  GroupNorm,
+// proj_in, norm1 and the self-attention run once on B' rows; the result is duplicated right before the first
+// cross-attention and the block returns 2B' rows.  Bit-identical to running both halves (every op here is
+// row- or image-local), at half the cost for the most expensive attention call of the forward.
+static int transformer(agd_ctx* c, hipStream_t st, const std::string& pre, const Act& x, int heads, int groups, Act& out, int dup = 0) {
+  const int Bs = x.B;                                  // batch of the shared part
+  int B = dup ? 2 * x.B : x.B;
+  const int HW = x.H * x.W, C = x.C;
+  int M = Bs * HW;                                     // rows until the duplication point, B*HW after it
   out = alloc_act(c, B, x.H, x.W, C); if (!out.p) return -1;
   const size_t mk = c->arena.mark();
   const std::string t = pre + "transformer_blocks.0.";
   Act n = alloc_act(c, B, x.H, x.W, C); if (!n.p) return -1;
   GETV(gg, pre + "norm.weight"); GETV(gb, pre + "norm.bias");
-  CK(run_gn(c, st, x.p, C, nullptr, 0, B, HW, gg, gb, groups, 1e-6f, 0, n.p));
+  CK(run_gn(c, st, x.p, C, nullptr, 0, Bs, HW, gg, gb, groups, 1e-6f, 0, n.p));
   Act h = alloc_act(c, B, x.H, x.W, C); if (!h.p) return -1;
   { GETW(w, pre + "proj_in.weight"); GETV(b, pre + "proj_in.bias"); GemmOpt o; o.bias = b;
     CK(run_conv(c, st, n.p, C, nullptr, 0, 1, 1, M, *w, 1, h.p, o, c->zero_page)); }
   Act ln = n;  // reuse
-  bf16_t* qkv = (bf16_t*)c->arena.alloc((size_t)M * 3 * C * 2); if (!qkv) return -1;
-  bf16_t* att = (bf16_t*)c->arena.alloc((size_t)M * C * 2); if (!att) return -1;
+  bf16_t* qkv = (bf16_t*)c->arena.alloc((size_t)B * HW * 3 * C * 2); if (!qkv) return -1;
+  bf16_t* att = (bf16_t*)c->arena.alloc((size_t)B * HW * C * 2); if (!att) return -1;
+  const bf16_t* xres = x.p;                            // residual of proj_out
   // --- self attention ---
   { GETV(g, t + "norm1.weight"); GETV(b, t + "norm1.bias");
     { ProfScope ps(c, st, PC_LN, 0); CK(launch_layernorm(h.p, ln.p, g, b, M, C, 1e-5f, st)); }
@@ -264,11 +280,20 @@ static int transformer(agd_ctx* c, hipStream_t st, const std::string& pre, const
     CK(run_conv(c, st, ln.p, C, nullptr, 0, 1, 1, M, *w, 1, qkv, o, c->zero_page));
     AttnP a{}; a.q = qkv; a.k = qkv + C; a.v = qkv + 2 * C; a.o = att;
     a.ldq = a.ldk = a.ldv = 3 * C; a.ldo = C; a.sq = a.sk = a.sv = (long long)HW * 3 * C; a.so = (long long)HW * C;
-    a.B = B; a.H = heads; a.D = C / heads; a.Nq = HW; a.Nk = HW; a.scale = 1.0f / sqrtf((float)(C / heads));
+    a.B = Bs; a.H = heads; a.D = C / heads; a.Nq = HW; a.Nk = HW; a.scale = 1.0f / sqrtf((float)(C / heads));
     CK(run_attention(c, st, PC_ATTN_SELF, a));
     GETW(wo, t + "attn1.to_out.0.weight"); GETV(bo, t + "attn1.to_out.0.bias");
     GemmOpt oo; oo.bias = bo; oo.residual = h.p;
     CK(run_conv(c, st, att, C, nullptr, 0, 1, 1, M, *wo, 1, h.p, oo, c->zero_page)); }
+  if (dup) {                                           // the halves diverge from here on (text context)
+    CK(dup_half(c, st, h.p, (long long)M * C));
+    Act x2 = alloc_act(c, B, x.H, x.W, C); if (!x2.p) return -1;
+    { ProfScope ps(c, st, PC_ELEM, 0);
+      if (hipMemcpyAsync(x2.p, x.p, (size_t)M * C * 2, hipMemcpyDeviceToDevice, st) != hipSuccess) FAIL("dup copy failed"); }
+    CK(dup_half(c, st, x2.p, (long long)M * C));
+    xres = x2.p;
+    M = B * HW;
+  }
   // --- cross attention (the processor seam) ---
   { GETV(g, t + "norm2.weight"); GETV(b, t + "norm2.bias");
     { ProfScope ps(c, st, PC_LN, 0); CK(launch_layernorm(h.p, ln.p, g, b, M, C, 1e-5f, st)); }
@@ -292,7 +317,7 @@ static int transformer(agd_ctx* c, hipStream_t st, const std::string& pre, const
     GETW(w2, t + "ff.net.2.weight"); GETV(b2, t + "ff.net.2.bias");
     GemmOpt o2; o2.bias = b2; o2.residual = h.p;
     CK(run_conv(c, st, ff, 4 * C, nullptr, 0, 1, 1, M, *w2, 1, h.p, o2, c->zero_page)); }
-  { GETW(w, pre + "proj_out.weight"); GETV(b, pre + "proj_out.bias"); GemmOpt o; o.bias = b; o.residual = x.p;
+  { GETW(w, pre + "proj_out.weight"); GETV(b, pre + "proj_out.bias"); GemmOpt o; o.bias = b; o.residual = xres;
     CK(run_conv(c, st, h.p, C, nullptr, 0, 1, 1, M, *w, 1, out.p, o, c->zero_page)); }
   c->arena.release(mk);
   return 0;
@@ -315,8 +340,9 @@ static int time_embed(agd_ctx* c, hipStream_t st, const float* ts, int n, float*
 
 // x: [B2][L*L][64] bf16 (latent channels zero-padded) -> eps [B2][L*L][out_channels] fp32 NHWC
 // tproj_row: this timestep's time_emb_proj outputs when the caller computed them up front (agd_denoise), else nullptr
+// cfg_shared: rows [0,B2/2) and [B2/2,B2) of xin are identical (agd_denoise): share everything ahead of the first attn2
 static int unet_walk(agd_ctx* c, hipStream_t st, const bf16_t* xin, int B2, int L, float t, float* eps_out,
-                     const float* tproj_row = nullptr) {
+                     const float* tproj_row = nullptr, bool cfg_shared = false) {
   const agd_config& g = c->cfg;
   const int nl = g.n_levels, G = g.norm_num_groups;
   const std::string u = "unet.";
@@ -324,17 +350,22 @@ static int unet_walk(agd_ctx* c, hipStream_t st, const bf16_t* xin, int B2, int 
   if (tproj_row) c->tproj_cur = tproj_row;
   else { CK(time_embed(c, st, &t, 1, c->temb_buf, c->tproj_out)); c->tproj_cur = c->tproj_out; }
   std::vector<Act> skips;
+  const bool shared = cfg_shared && (B2 % 2) == 0 && g.down_cross[0] && !getenv("AGD_NO_CFG_SHARE");
+  const int Bh = shared ? B2 / 2 : B2;
   Act h = alloc_act(c, B2, L, L, g.block_out_channels[0]); if (!h.p) return -1;
   { GETW(w, u + "conv_in.weight"); GETV(b, u + "conv_in.bias"); GemmOpt o; o.bias = b;
-    CK(run_conv(c, st, xin, 64, nullptr, 0, B2, L, L, *w, 3, h.p, o, c->zero_page)); }
+    CK(run_conv(c, st, xin, 64, nullptr, 0, Bh, L, L, *w, 3, h.p, o, c->zero_page)); }
+  if (shared) CK(dup_half(c, st, h.p, (long long)Bh * L * L * h.C));       // the skip connection needs all B2 rows
   skips.push_back(h);
   for (int i = 0; i < nl; ++i) {
     const int co = g.block_out_channels[i];
     for (int j = 0; j < g.layers_per_block; ++j) {
-      Act r; CK(resnet(c, st, u + "down_blocks." + std::to_string(i) + ".resnets." + std::to_string(j) + ".", h, nullptr, co, 1e-5f, true, G, r));
+      const bool first = shared && i == 0 && j == 0;
+      Act hin = h; if (first) hin.B = Bh;
+      Act r; CK(resnet(c, st, u + "down_blocks." + std::to_string(i) + ".resnets." + std::to_string(j) + ".", hin, nullptr, co, 1e-5f, true, G, r));
       h = r;
       if (g.down_cross[i]) {
-        Act a; CK(transformer(c, st, u + "down_blocks." + std::to_string(i) + ".attentions." + std::to_string(j) + ".", h, g.num_heads[i], G, a));
+        Act a; CK(transformer(c, st, u + "down_blocks." + std::to_string(i) + ".attentions." + std::to_string(j) + ".", h, g.num_heads[i], G, a, first ? 1 : 0));
         h = a;
       }
       skips.push_back(h);
@@ -725,7 +756,7 @@ extern "C" int agd_denoise(agd_ctx* c, float* latents, int batch, int L, int n_s
   }
   for (int s = 0; s < n_steps; ++s) {
     { ProfScope ps(c, st, PC_ELEM, 0); API_CK(c, launch_prep_latents(latents, c->lat_bf16, batch, Cl, HW, 64, 2, 1.0f, st)); }
-    API_CK(c, unet_walk(c, st, c->lat_bf16, B2, L, timesteps[s], c->eps_nhwc, tp_all + (size_t)s * c->tproj_total));
+    API_CK(c, unet_walk(c, st, c->lat_bf16, B2, L, timesteps[s], c->eps_nhwc, tp_all + (size_t)s * c->tproj_total, true));
     { ProfScope ps(c, st, PC_ELEM, 0);
       API_CK(c, launch_cfg_ddim(c->eps_nhwc, c->cfg.out_channels, latents, batch, Cl, HW, guidance, alpha_t[s], alpha_prev[s], c->cfg.prediction_type, st)); }
   }

@@ -272,3 +272,26 @@ def test_vae_encode_and_img2img_match_oracle():
     assert _psnr(out.images, want_img) > 30.0
     assert float(hm.sum(0).mean()) == pytest.approx(int(steps * strength), rel=0.02)     # 3 of the 5 steps ran
     pipe.engine.close()
+
+
+def test_cfg_shared_prefix_is_bit_identical(tiny_pipe, monkeypatch):
+    """agd_denoise shares the layers ahead of the first cross-attention between the (identical) unconditional and
+    conditional halves; the result must equal running both halves, bit for bit (every shared op is row/image-local)."""
+    from agenda_amd import synthetic, trace
+    pipe, cfg = tiny_pipe[0], tiny_pipe[1]
+    B, L = 2, 16
+    ctx = synthetic.make_context(cfg, B, seed=21)
+    lat = synthetic.make_latents(cfg, [5, 6], L)
+
+    def run():
+        with trace(pipe) as trc:
+            out = pipe(prompt_embeds=ctx, latents=lat, num_inference_steps=3, output_type="pt")
+            maps = torch.stack([trc.compute_global_heat_map(image_index=i).heat_maps for i in range(B)])
+        return out.images.clone(), out.latents.clone(), maps.clone()
+
+    a = run()
+    monkeypatch.setenv("AGD_NO_CFG_SHARE", "1")
+    b = run()
+    monkeypatch.delenv("AGD_NO_CFG_SHARE")
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
