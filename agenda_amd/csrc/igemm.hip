@@ -395,6 +395,26 @@ int launch_igemm(const IgemmP& p_in, hipStream_t st) {
   const long long t128 = (long long)((p.M + 127) / 128) * ((p.N + 127) / 128) * batch;
   const int nk = p.K >> 6;
   if (p.geglu) return launch_cfg<128, 128, 2, 2>(p, 1, st);
+  // tiny-M launches (8x8 feature maps, <= 64 tiles): ONE workgroup per CU on the 4-stage ring (128 KB LDS), K split only
+  // up to 256 workgroups -- these launches are a load-latency chain, and a second co-resident workgroup per CU (the
+  // 2-stage path below) hides less of it than two more stages in flight do (35 -> 30 us for 8x8 1280->1280).  The same
+  // rule for the 160-tile 16x16 maps measured SLOWER (70 -> 81 us): they stay on the 2-stage, 2-per-CU path.
+  if ((g_igemm_cfg & 15) != 6 && batch == 1 && t128 <= ((g_igemm_cfg & 15) == 7 ? 160 : 64) && nk >= 64 && p.M >= 128 && (p.N & 3) == 0) {
+    int S = (int)(256 / t128);
+    if (S > 8) S = 8;
+    if (S > nk / 8) S = nk / 8;
+    if (S >= 2) {
+      const size_t need = (size_t)S * p.M * p.N * 4;
+      if (need > g_splitk_cap) {
+        if (g_splitk_ws) hipFree(g_splitk_ws);
+        const size_t cap = need > ((size_t)64 << 20) ? need : ((size_t)64 << 20);
+        if (hipMalloc((void**)&g_splitk_ws, cap) != hipSuccess) { g_splitk_ws = nullptr; g_splitk_cap = 0; agd_set_error("split-K workspace alloc failed"); return -1; }
+        g_splitk_cap = cap;
+      }
+      p.splitk_ws = g_splitk_ws;
+    }
+    return launch_cfg<128, 128, 2, 2, 4>(p, S < 1 ? 1 : S, st);
+  }
   // split-K for small-M problems (8x8 / 16x16 feature maps): fill the 256 CUs with K slices
   if (batch == 1 && t128 <= 160 && nk >= 64 && (p.N & 3) == 0 && p.M >= 128) {
     const int target = (g_igemm_cfg & 15) == 7 ? 256 : (g_igemm_cfg & 15) == 8 ? 512 : 384;
