@@ -439,14 +439,17 @@ int launch_igemm(const IgemmP& p_in, hipStream_t st) {
     // its loads/epilogue with), and a 160-wide tile is 1.25 tile-times.  E.g. M=8192, N=640: 320 tiles of 128x128
     // leave 192 CUs idle for the second half; 256 tiles of 128x160 do not.
     bool n160 = (p.N % 160) == 0 && (p.N % 128) != 0;
-    if (p.ksize == 3 && (p.N % 160) == 0 && (p.N % 128) == 0 && (g_igemm_cfg & 15) != 4) {   // measured: helps 3x3, hurts 1x1
+    if ((p.ksize == 3 || (g_igemm_cfg & 15) == 10) && (p.N % 160) == 0 && (p.N % 128) == 0 && (g_igemm_cfg & 15) != 4) {   // measured: helps 3x3, hurts 1x1
       const long long mt = (p.M + 127) / 128;
       const long long T8 = mt * (p.N / 128) * batch, T0 = mt * (p.N / 160) * batch;
       auto cost = [](long long T, double w) { return w * (T <= 256 ? 1.33 : (double)((T + 255) / 256)); };
       n160 = cost(T0, 1.25) < cost(T8, 1.0) - 1e-9;
     }
-    if (n160) return launch_cfg<128, 160, 2, 2>(p, 1, st);
-    return launch_cfg<128, 128, 2, 2>(p, 1, st);
+    // <= 256 tiles: one workgroup per CU whatever the ring -> take the 4-stage ring (147 / 128 KB LDS)
+    const long long Tsel = (long long)((p.M + 127) / 128) * ((p.N + (n160 ? 159 : 127)) / (n160 ? 160 : 128)) * batch;
+    const bool deep = Tsel <= 256 && nk >= 8 && (g_igemm_cfg & 15) != 9;
+    if (n160) return deep ? launch_cfg<128, 160, 2, 2, 4>(p, 1, st) : launch_cfg<128, 160, 2, 2>(p, 1, st);
+    return deep ? launch_cfg<128, 128, 2, 2, 4>(p, 1, st) : launch_cfg<128, 128, 2, 2>(p, 1, st);
   }
   if ((g_igemm_cfg & 15) == 5) return launch_cfg<64, 64, 2, 2>(p, 1, st);      // A/B: the 2-stage ring
   return launch_cfg<64, 64, 2, 2, 4>(p, 1, st);
