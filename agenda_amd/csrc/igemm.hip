@@ -395,25 +395,35 @@ int launch_igemm(const IgemmP& p_in, hipStream_t st) {
   const long long t128 = (long long)((p.M + 127) / 128) * ((p.N + 127) / 128) * batch;
   const int nk = p.K >> 6;
   if (p.geglu) return launch_cfg<128, 128, 2, 2>(p, 1, st);
-  // tiny-M launches (8x8 feature maps, <= 64 tiles): ONE workgroup per CU on the 4-stage ring (128 KB LDS), K split only
-  // up to 256 workgroups -- these launches are a load-latency chain, and a second co-resident workgroup per CU (the
-  // 2-stage path below) hides less of it than two more stages in flight do (35 -> 30 us for 8x8 1280->1280).  The same
-  // rule for the 160-tile 16x16 maps measured SLOWER (70 -> 81 us): they stay on the 2-stage, 2-per-CU path.
-  if ((g_igemm_cfg & 15) != 6 && batch == 1 && t128 <= ((g_igemm_cfg & 15) == 7 ? 160 : 64) && nk >= 64 && p.M >= 128 && (p.N & 3) == 0) {
-    int S = (int)(256 / t128);
-    if (S > 8) S = 8;
-    if (S > nk / 8) S = nk / 8;
-    if (S >= 2) {
-      const size_t need = (size_t)S * p.M * p.N * 4;
-      if (need > g_splitk_cap) {
-        if (g_splitk_ws) hipFree(g_splitk_ws);
-        const size_t cap = need > ((size_t)64 << 20) ? need : ((size_t)64 << 20);
-        if (hipMalloc((void**)&g_splitk_ws, cap) != hipSuccess) { g_splitk_ws = nullptr; g_splitk_cap = 0; agd_set_error("split-K workspace alloc failed"); return -1; }
-        g_splitk_cap = cap;
-      }
-      p.splitk_ws = g_splitk_ws;
+  // Small-M launches (8x8 / 16x16 feature maps): ONE workgroup per CU on the 4-stage ring, tile width and K split
+  // chosen so that the launch has as close to 256 workgroups as possible.  These launches are a load-latency chain:
+  // two more stages in flight hide more of it than a second co-resident workgroup on a 2-stage ring does
+  // (8x8 1280->1280: 35 -> 30 us).  16x16 maps (M = 2048, N = 1280) get 128 tiles of 128x160 x 2 K slices = 256.
+  auto ensure_ws = [&](int S) -> int {
+    const size_t need = (size_t)S * p.M * p.N * 4;
+    if (need > g_splitk_cap) {
+      if (g_splitk_ws) (void)hipFree(g_splitk_ws);
+      const size_t cap = need > ((size_t)64 << 20) ? need : ((size_t)64 << 20);
+      if (hipMalloc((void**)&g_splitk_ws, cap) != hipSuccess) { g_splitk_ws = nullptr; g_splitk_cap = 0; agd_set_error("split-K workspace alloc failed"); return -1; }
+      g_splitk_cap = cap;
     }
-    return launch_cfg<128, 128, 2, 2, 4>(p, S < 1 ? 1 : S, st);
+    p.splitk_ws = g_splitk_ws;
+    return 0;
+  };
+  const int nkmin = (g_igemm_cfg & 15) == 11 ? 16 : 64;
+  if ((g_igemm_cfg & 15) != 6 && batch == 1 && t128 <= 160 && nk >= nkmin && p.M >= 128 && (p.N & 3) == 0) {
+    auto splits = [&](long long tt) { int S = (int)(256 / tt); if (S > 8) S = 8; if (S > nk / 8) S = nk / 8; return S < 1 ? 1 : S; };
+    const long long mt = (p.M + 127) / 128;
+    const int S8 = splits(t128);
+    long long T8 = t128 * S8, T0 = 0; int S0 = 1;
+    if ((p.N % 160) == 0) { const long long t160 = mt * (p.N / 160); if (t160 <= 256) { S0 = splits(t160); T0 = t160 * S0; } }
+    const bool use160 = T0 > T8 && (g_igemm_cfg & 15) != 7;
+    const int S = use160 ? S0 : S8;
+    const long long T = use160 ? T0 : T8;
+    if (T >= 192 || t128 <= 64) {                                   // else: too few workgroups -> 2-stage path below
+      if (S >= 2) CK0(ensure_ws(S));
+      return use160 ? launch_cfg<128, 160, 2, 2, 4>(p, S, st) : launch_cfg<128, 128, 2, 2, 4>(p, S, st);
+    }
   }
   // split-K for small-M problems (8x8 / 16x16 feature maps): fill the 256 CUs with K slices
   if (batch == 1 && t128 <= 160 && nk >= 64 && (p.N & 3) == 0 && p.M >= 128) {
