@@ -394,6 +394,21 @@ int launch_igemm(const IgemmP& p_in, hipStream_t st) {
   const int batch = p.batch > 0 ? p.batch : 1;
   const long long t128 = (long long)((p.M + 127) / 128) * ((p.N + 127) / 128) * batch;
   const int nk = p.K >> 6;
+  {  // exploration only: AGD_IGEMM_FORCE="<bn>:<splits>:<stages>" forces one configuration for every non-GEGLU launch
+    static int f_bn = -1, f_s = 1, f_st = 2;
+    if (f_bn < 0) { const char* e = getenv("AGD_IGEMM_FORCE"); f_bn = 0; if (e) sscanf(e, "%d:%d:%d", &f_bn, &f_s, &f_st); }
+    if (f_bn > 0 && !p.geglu && batch == 1) {
+      int S = f_s; if (S > nk / 2) S = nk / 2; if (S < 1) S = 1;
+      if (S >= 2) {
+        const size_t need = (size_t)S * p.M * p.N * 4;
+        if (need > g_splitk_cap) { if (g_splitk_ws) (void)hipFree(g_splitk_ws); if (hipMalloc((void**)&g_splitk_ws, need) != hipSuccess) return -1; g_splitk_cap = need; }
+        p.splitk_ws = g_splitk_ws;
+      }
+      if (f_bn == 64) return f_st == 4 ? launch_cfg<64, 64, 2, 2, 4>(p, S, st) : launch_cfg<64, 64, 2, 2>(p, S, st);
+      if (f_bn == 160) return f_st == 4 ? launch_cfg<128, 160, 2, 2, 4>(p, S, st) : launch_cfg<128, 160, 2, 2>(p, S, st);
+      return f_st == 4 ? launch_cfg<128, 128, 2, 2, 4>(p, S, st) : launch_cfg<128, 128, 2, 2>(p, S, st);
+    }
+  }
   if (p.geglu) return launch_cfg<128, 128, 2, 2>(p, 1, st);
   // Small-M launches (8x8 / 16x16 feature maps): ONE workgroup per CU on the 4-stage ring, tile width and K split
   // chosen so that the launch has as close to 256 workgroups as possible.  These launches are a load-latency chain:
@@ -449,11 +464,11 @@ int launch_igemm(const IgemmP& p_in, hipStream_t st) {
     // its loads/epilogue with), and a 160-wide tile is 1.25 tile-times.  E.g. M=8192, N=640: 320 tiles of 128x128
     // leave 192 CUs idle for the second half; 256 tiles of 128x160 do not.
     bool n160 = (p.N % 160) == 0 && (p.N % 128) != 0;
-    if ((p.ksize == 3 || (g_igemm_cfg & 15) == 10) && (p.N % 160) == 0 && (p.N % 128) == 0 && (g_igemm_cfg & 15) != 4) {   // measured: helps 3x3, hurts 1x1
+    if ((p.N % 160) == 0 && (p.N % 128) == 0 && (g_igemm_cfg & 15) != 4) {
       const long long mt = (p.M + 127) / 128;
       const long long T8 = mt * (p.N / 128) * batch, T0 = mt * (p.N / 160) * batch;
       auto cost = [](long long T, double w) { return w * (T <= 256 ? 1.33 : (double)((T + 255) / 256)); };
-      n160 = cost(T0, 1.25) < cost(T8, 1.0) - 1e-9;
+      if (p.ksize == 3 || (g_igemm_cfg & 15) == 10) n160 = cost(T0, 1.25) < cost(T8, 1.0) - 1e-9;   // measured: helps 3x3, hurts / neutral for 1x1
     }
     // <= 256 tiles: one workgroup per CU whatever the ring -> take the 4-stage ring (147 / 128 KB LDS)
     const long long Tsel = (long long)((p.M + 127) / 128) * ((p.N + (n160 ? 159 : 127)) / (n160 ? 160 : 128)) * batch;
