@@ -305,6 +305,10 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_kernel(const IgemmP p) 
     }
   }
 
+  // The tail K steps issued their LDS-DMAs through a zero-record descriptor: nothing is fetched, but the hardware still
+  // WRITES ZEROS to the LDS destination.  Those writes must have landed before the epilogue reuses the ring as its
+  // staging buffer (__syncthreads() does not wait on vmcnt at workgroup scope).
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if (p.dbg & 64) {                                // timing experiment (AGD_IGEMM_CFG=1024): no epilogue (keeps acc live)
     float sacc = 0.f;
 #pragma unroll
