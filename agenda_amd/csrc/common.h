@@ -34,7 +34,20 @@ AGD_DEV float erf_fast(float x) {
   const float r = 1.0f - p * t * e;
   return x < 0.f ? -r : r;
 }
-AGD_DEV float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erf_fast(x * 0.70710678118654752440f)); }
+// gelu(x) = x * Phi(x) with the same A&S 7.1.26 erf, rearranged to 13 VALU + 2 transcendental ops per element:
+// q = 1 - Phi(|x|) = (0.5 * poly(t)) * t * exp(-x^2 / 2),  t = 1 / (1 + (p / sqrt 2) |x|);  gelu = max(x, 0) - |x| * q
+// (x >= 0: x - x q = x Phi(x);  x < 0: -|x| q = x (1 - Phi(|x|)) = x Phi(x)).  The GEGLU epilogue runs it 32x per thread.
+AGD_DEV float gelu_erf_f(float x) {
+  const float ax = fabsf(x);
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.2316418878f, ax, 1.0f));
+  float p = fmaf(0.5307027145f, t, -0.7265760135f);
+  p = fmaf(p, t, 0.7107068705f);
+  p = fmaf(p, t, -0.142248368f);
+  p = fmaf(p, t, 0.127414796f);
+  const float e = __builtin_amdgcn_exp2f(ax * ax * -0.72134752044448170368f);
+  const float q = p * t * e;
+  return fmaxf(x, 0.f) - ax * q;
+}
 
 // value held by lane (l ^ 32) combined with own: one VALU v_permlane32_swap instead of a ds_bpermute round trip
 AGD_DEV float xhalf_max(float x) {
