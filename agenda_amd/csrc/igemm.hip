@@ -409,6 +409,7 @@ int launch_igemm(const IgemmP& p_in, hipStream_t st) {
         p.splitk_ws = g_splitk_ws;
       }
       if (f_bn == 64) return f_st == 4 ? launch_cfg<64, 64, 2, 2, 4>(p, S, st) : launch_cfg<64, 64, 2, 2>(p, S, st);
+      if (f_bn == 1264) return f_st == 3 ? launch_cfg<128, 64, 2, 2, 3>(p, S, st) : launch_cfg<128, 64, 2, 2>(p, S, st);
       if (f_bn == 160) return f_st == 4 ? launch_cfg<128, 160, 2, 2, 4>(p, S, st) : launch_cfg<128, 160, 2, 2>(p, S, st);
       return f_st == 4 ? launch_cfg<128, 128, 2, 2, 4>(p, S, st) : launch_cfg<128, 128, 2, 2>(p, S, st);
     }

@@ -13,7 +13,7 @@ else:
     shapes = [(16, 1280, 1280, 1, 1), (32, 640, 640, 1, 1), (64, 320, 320, 1, 1), (16, 5120, 1280, 1, 1), (32, 2560, 640, 1, 1), (16, 1280, 3840, 1, 0), (64, 320, 960, 1, 0)]
     for sh in shapes:
         print("shape H=%d Cin=%d Cout=%d k=%d res=%d" % sh, flush=True)
-        for force in ("", "128:1:2", "128:1:4", "160:1:2", "160:1:4", "64:1:2", "64:1:4", "128:2:4", "160:2:4", "128:2:2", "64:2:4"):
+        for force in (sys.argv[1:] or ("", "128:1:2", "128:1:4", "160:1:2", "160:1:4", "64:1:2", "64:1:4", "128:2:4", "160:2:4", "128:2:2", "64:2:4", "1264:1:2", "1264:1:3")):
             env = dict(os.environ); 
             if force: env["AGD_IGEMM_FORCE"] = force
             r = subprocess.run([sys.executable, __file__, "--one"] + [str(x) for x in sh], env=env, capture_output=True, text=True)
