@@ -78,7 +78,7 @@ def _norm_maps(m):
 
 @pytest.mark.parametrize("cfgname,steps,tol_rel,tol_norm", [
     # tolerances are the measured bf16-vs-fp32 levels on synthetic weights with ~2x headroom
-    # (tools/diag_parity.py: 1 step 0.9% / 5.9 per 255; 4 steps 2.0% / 11.6 per 255); DESIGN.md §parity
+    # (tests/diag_parity.py: 1 step 0.9% / 5.9 per 255; 4 steps 2.0% / 11.6 per 255); DESIGN.md §parity
     ("tiny", 1, 0.02, 12 / 255), ("tiny", 4, 0.05, 24 / 255), ("tiny40", 2, 0.05, 24 / 255),
 ])
 def test_generate_with_daam_matches_oracle(cfgname, steps, tol_rel, tol_norm):
