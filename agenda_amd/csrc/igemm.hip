@@ -463,6 +463,8 @@ int launch_igemm(const IgemmP& p_in, hipStream_t st) {
       return launch_cfg<128, 128, 2, 2>(p, S, st);
     }
   }
+  // N <= 64 (conv_out: 4 / 3 output channels): a 128-wide tile would be > 95 % padding -> 64x64 tiles
+  if (p.N <= 64 && (g_igemm_cfg & 15) != 12) return launch_cfg<64, 64, 2, 2, 4>(p, 1, st);
   if (t128 >= ((g_igemm_cfg & 15) == 3 ? 128 : 192)) {
     // 128x128 or 128x160: both hold 2 workgroups per CU.  Wave quantisation decides: a launch of T tiles keeps
     // every CU busy for ceil(T/256) tile-times (x1.33 when T <= 256: a lone workgroup per CU has nothing to overlap
