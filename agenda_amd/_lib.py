@@ -62,6 +62,7 @@ _SIGS = {
     "agd_hook_count": (C.c_int, [_P]),
     "agd_hook_last_map": (C.c_int, [_P, _P, C.c_int, _P]),
     "agd_cross_attn": (C.c_int, [_P, C.c_char_p, _P, _P, C.c_int, C.c_int, C.c_int, _P, C.c_int, _P]),
+    "agd_attn_processor": (C.c_int, [_P, C.c_char_p, _P, _P, _P, C.c_int, C.c_int, C.c_int, _P, C.c_int, _P]),
     "agd_op_conv2d": (C.c_int, [_P, _P, _P, _P] + [C.c_int] * 9 + [_P]),
     "agd_op_linear": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "agd_op_groupnorm": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, _P]),
@@ -73,7 +74,11 @@ _SIGS = {
     "agd_op_stack_heatmaps": (C.c_int, [_P, _P, _P, C.c_longlong, _P, _P, _P]),
     "agd_profile_begin": (C.c_int, [_P]),
     "agd_profile_end": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_longlong)]),
+    "agd_profile_end_ex": (C.c_int, [_P, C.c_double, C.c_double] + [C.POINTER(C.c_double)] * 5 + [C.POINTER(C.c_longlong)]),
     "agd_profile_class_name": (C.c_char_p, [C.c_int]),
+    "agd_bench_conv": (C.c_int, [C.c_int] * 12 + [C.POINTER(C.c_double)]),
+    "agd_bench_attention": (C.c_int, [C.c_int] * 7 + [C.POINTER(C.c_double)]),
+    "agd_bench_groupnorm": (C.c_int, [C.c_int] * 4 + [C.POINTER(C.c_double)]),
     "agd_version": (C.c_char_p, []),
 }
 

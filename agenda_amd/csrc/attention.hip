@@ -17,8 +17,12 @@
 #include "kernels.h"
 #include <type_traits>
 
-int g_attn_qb = 1;   // queries per wave / 32 for the long self-attention shapes (tunable)
-extern "C" void agd_set_attn_qb(int v) { g_attn_qb = v; }
+#ifdef AGD_EXPERIMENTS
+int g_attn_qb = 1;   // queries per wave / 32 for the long self-attention shapes (tools/ only)
+extern "C" __attribute__((visibility("default"))) void agd_set_attn_qb(int v) { g_attn_qb = v; }
+#else
+constexpr int g_attn_qb = 1;
+#endif
 
 template <int D> struct AttnCfg {
   static constexpr int KSTEPS = (D + 15) / 16;           // QK^T k-steps (d padded to 16)
@@ -37,8 +41,10 @@ template <int D> struct AttnCfg {
 
 #define DEFER_THR 8.0f   // log2 units: rescale O only when a row max grows by more than 2^8
 
-template <int D, int KB, int QB, int RECORD>
-__global__ __launch_bounds__(256, ((QB == 1 && D <= 40 && !RECORD) ? 4 : (QB == 1 && D <= 64 && !RECORD) ? 3 : (QB == 1 && D <= 80) ? 2 : 1)) void attn_kernel(const AttnP p) {
+// AMASK: additive attention mask [B][Nk] (diffusers `attention_mask` after prepare_attention_mask, hook.py:92,108:
+// broadcast over heads and queries) -- a separate instantiation so the production kernels carry none of it.
+template <int D, int KB, int QB, int RECORD, int AMASK = 0>
+__global__ __launch_bounds__(256, (AMASK ? 1 : (QB == 1 && D <= 40 && !RECORD) ? 4 : (QB == 1 && D <= 64 && !RECORD) ? 3 : (QB == 1 && D <= 80) ? 2 : 1)) void attn_kernel(const AttnP p) {
   using C = AttnCfg<D>;
   constexpr int KEYS = KB * 32;
   constexpr int KSTEPS = C::KSTEPS, DBLK = C::DBLK, KPITCH = C::KPITCH, VPITCH = C::VPITCH, CH = C::CH;
@@ -171,7 +177,7 @@ __global__ __launch_bounds__(256, ((QB == 1 && D <= 40 && !RECORD) ? 4 : (QB == 
   const float sc = qscale;
 
   const int ntiles = RECORD ? 1 : (p.Nk + KEYS - 1) / KEYS;   // RECORD: host guarantees Nk <= KEYS
-  const bool ragged = (p.Nk % KEYS) != 0 || p.causal;   // causal: every tile takes the masked path
+  const bool ragged = (p.Nk % KEYS) != 0 || p.causal || AMASK;   // causal / additive mask: every tile takes the masked path
   gload(0);
   lstore(0);
   __syncthreads();
@@ -212,6 +218,11 @@ __global__ __launch_bounds__(256, ((QB == 1 && D <= 40 && !RECORD) ? 4 : (QB == 
           for (int i = 0; i < 16; ++i) {
             const int key = t * KEYS + kb * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
             if (key >= p.Nk || (p.causal && key > q0 + qb * 32 + c)) sacc[qb][kb][i] = -INFINITY;
+            else if constexpr (AMASK) {
+              // RECORD keeps raw logits (scaled below): pre-divide so that (s + a/scale)*scale = s*scale + a
+              const float a = p.mask[(long long)b * p.Nk + key];
+              sacc[qb][kb][i] += RECORD ? a / p.scale : a * 1.44269504088896340736f;
+            }
           }
     }
 #pragma unroll
@@ -361,7 +372,7 @@ __global__ __launch_bounds__(256, ((QB == 1 && D <= 40 && !RECORD) ? 4 : (QB == 
     if constexpr (RECORD) {
       tile_body(0, T_{});                              // single (always key-masked) tile
     } else {
-      if (p.causal) { for (int t = 0; t < ntiles - 1; ++t) tile_body(t, T_{}); }
+      if (p.causal || AMASK) { for (int t = 0; t < ntiles - 1; ++t) tile_body(t, T_{}); }
       else { for (int t = 0; t < ntiles - 1; ++t) tile_body(t, F_{}); }
       if (ragged) tile_body(ntiles - 1, T_{}); else tile_body(ntiles - 1, F_{});
     }
@@ -399,7 +410,7 @@ __global__ __launch_bounds__(256, ((QB == 1 && D <= 40 && !RECORD) ? 4 : (QB == 
 }
 
 
-template <int D, int KB, int QB, int RECORD>
+template <int D, int KB, int QB, int RECORD, int AMASK = 0>
 static int launch_attn_t(const AttnP& p, hipStream_t st) {
   using C = AttnCfg<D>;
   constexpr int lds = (RECORD ? 1 : 2) * KB * 32 * (C::KPITCH + C::VPITCH);
@@ -407,9 +418,13 @@ static int launch_attn_t(const AttnP& p, hipStream_t st) {
   pp.nqt = (p.Nq + 128 * QB - 1) / (128 * QB);
   const int per = (p.B * p.H + 7) / 8;
   dim3 grid(8 * per * pp.nqt);
-  auto kfn = attn_kernel<D, KB, QB, RECORD>;
-  static bool attr = false;
-  if (!attr && lds > 65536) { HIP_CHECK_RET(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); attr = true; }
+  auto kfn = attn_kernel<D, KB, QB, RECORD, AMASK>;
+  if (lds > 65536) {                                   // per (instantiation, device) latch
+    static bool attr[AGD_MAX_DEVICES] = {};
+    int dev = 0; HIP_CHECK_RET(hipGetDevice(&dev));
+    if (dev < 0 || dev >= AGD_MAX_DEVICES) { agd_set_error("attention: device ordinal %d out of range", dev); return -1; }
+    if (!attr[dev]) { HIP_CHECK_RET(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); attr[dev] = true; }
+  }
   hipLaunchKernelGGL(kfn, grid, dim3(256), lds, st, pp);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
@@ -419,7 +434,11 @@ template <int D>
 static int launch_attn_d(const AttnP& p, hipStream_t st) {
   if (p.record_mode != 0) {
     if (p.Nk > 96) { agd_set_error("attention: recording needs Nk <= 96 (got %d)", p.Nk); return -1; }
-    return launch_attn_t<D, 3, 1, 1>(p, st);
+    return p.mask ? launch_attn_t<D, 3, 1, 1, 1>(p, st) : launch_attn_t<D, 3, 1, 1>(p, st);
+  }
+  if (p.mask) {                                  // processor-seam calls with an attention_mask (never on the SD hot path)
+    if (p.causal) { agd_set_error("attention: additive mask + causal unsupported"); return -1; }
+    return (p.Nk <= 96 && p.Nk > 64) ? launch_attn_t<D, 3, 1, 0, 1>(p, st) : launch_attn_t<D, 2, 1, 0, 1>(p, st);
   }
   if (p.Nk <= 96 && p.Nk > 64) return launch_attn_t<D, 3, 1, 0>(p, st);
   if constexpr (D <= 80) { if (p.Nq >= 1024 && g_attn_qb == 2) return launch_attn_t<D, 2, 2, 0>(p, st); }

@@ -46,7 +46,9 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_kernel(const IgemmP p) 
   static_assert(STAGES >= 2 && STAGES <= 4 && (STAGES - 2) * LPS < 64, "vmcnt field");
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
+#ifdef AGD_EXPERIMENTS
   if (p.dbg & 32) return;                          // timing experiment (AGD_IGEMM_CFG=512): dispatch cost of this grid only
+#endif
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wid / WN, wn = wid % WN;
@@ -60,8 +62,11 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_kernel(const IgemmP p) 
   const bf16_t* base0 = p.src0 + bz * p.sA0;
   const bf16_t* base1 = p.src1 ? p.src1 + bz * p.sA1 : p.src0;
   const bf16_t* baseW = p.W + bz * p.sW;
-  // timing experiments only (p.dbg): zero-record descriptors drop the loads but keep the instruction stream
+#ifdef AGD_EXPERIMENTS   // timing experiments only (p.dbg): zero-record descriptors drop the loads but keep the instruction stream
   const unsigned nrecA = (p.dbg & 1) ? 0u : 0x7FFFFFF0u, nrecB = (p.dbg & 2) ? 0u : 0x7FFFFFF0u;
+#else
+  constexpr unsigned nrecA = 0x7FFFFFF0u, nrecB = 0x7FFFFFF0u;
+#endif
 
   // ---- per-thread gather state ---------------------------------------------------------
   const int lrow = lane >> 3;                       // row within the 8-row DMA group
@@ -137,7 +142,9 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_kernel(const IgemmP p) 
   // prologue stage fill; live == false issues the same instructions through a zero-record descriptor (dropped):
   // keeps the per-wave vmcnt arithmetic of the deeper rings uniform when the K range is shorter than the ring
   auto issue = [&](int slot, bool live) {
+#ifdef AGD_EXPERIMENTS
     if (p.dbg & 4) return;                      // timing experiment: no DMA instructions at all
+#endif
     if (live && seg_left == 0) new_segment();
     char* sA = smem + slot * STAGE;
     char* sB = sA + A_BYTES;
@@ -219,72 +226,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_kernel(const IgemmP p) 
     __builtin_amdgcn_sched_group_barrier(0x8, 2 * MI * NI - 2 * NG, 0);
   };
 
-  if (STAGES == 2 && KS == 3 && p.up == 1 && (p.dbg & 8)) {     // opt-in (AGD_IGEMM_CFG=128): measured slower, see DESIGN.md §4
-    // K order = channel-chunk major, tap minor: the 9 taps of one 64-channel chunk run back to back, so the
-    // shifted re-reads of the same pixels hit in L2 (tap-major order sweeps every chunk between two uses of a
-    // pixel: ~9x the algorithmic fetch, measured with FETCH_SIZE).  Gather offset of tap (kh,kw) =
-    // per-row base (pixel (oy*s-1, ox*s-1), may wrap) + scalar delta (kh*Win + kw)*Cs*2; a 9-bit mask per row
-    // marks the taps that fall inside the image (the others get the out-of-range offset -> zeros).
-    unsigned abase[A_IT], amask[A_IT];
-    auto fill_base = [&](int src) {
-      const int Cs = src ? p.C1 : p.C0;
-#pragma unroll
-      for (int i = 0; i < A_IT; ++i) {
-        const int pix = (a_b[i] * p.Hin + a_y[i]) * p.Win + a_x[i];
-        abase[i] = (unsigned)(pix * Cs * 2 + lchunk * 16);
-      }
-    };
-#pragma unroll
-    for (int i = 0; i < A_IT; ++i) {
-      unsigned mk = 0;
-#pragma unroll
-      for (int t = 0; t < 9; ++t) {
-        const int iy = a_y[i] + t / 3, ix = a_x[i] + t % 3;
-        const bool ok = ((a_rowok >> i) & 1) && (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win;
-        mk |= (ok ? 1u : 0u) << t;
-      }
-      amask[i] = mk;
-    }
-    const int Ctot = p.C0 + p.C1, nch0 = p.C0 >> 6;
-    int isrc, ichunk;                                   // coordinates of the NEXT stage to issue
-    { const int c0 = ks0 / 9; if (c0 < nch0) { isrc = 0; ichunk = c0; } else { isrc = 1; ichunk = c0 - nch0; } }
-    fill_base(isrc);
-    auto tap_offsets = [&](int t, unsigned (&av)[A_IT]) {
-      const int Cs = isrc ? p.C1 : p.C0;
-      const unsigned delta = __builtin_amdgcn_readfirstlane((unsigned)(((t / 3) * p.Win + (t % 3)) * Cs * 2));
-#pragma unroll
-      for (int i = 0; i < A_IT; ++i) av[i] = ((amask[i] >> t) & 1u) ? abase[i] + delta : OOB_OFF;
-    };
-    if (nk > 0) {   // prologue: stage 0 = (isrc, ichunk, tap 0)
-      const unsigned aso = (unsigned)ichunk * 128u, bso = (unsigned)(((isrc ? p.C0 : 0) + ichunk * 64) * 2);
-      unsigned av[A_IT]; tap_offsets(0, av);
-      char* dA = smem; char* dB = dA + A_BYTES;
-#pragma unroll
-      for (int i = 0; i < A_IT; ++i) bufdma16(isrc ? base1 : base0, dA + (i * NW + wid) * 1024, av[i], aso, nrecA);
-#pragma unroll
-      for (int i = 0; i < B_IT; ++i) bufdma16(baseW, dB + (i * NW + wid) * 1024, bvoff[i], bso, nrecB);
-    }
-    const int niter = nk / 9;
-    int gs = 0;                                         // k-step counter within this block
-    for (int it = 0; it < niter; ++it) {
-#pragma unroll
-      for (int t = 0; t < 9; ++t) {
-        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-        const bool more = gs + 1 < nk;
-        if (t == 8 && more) {                           // next stage starts a new chunk (maybe the second source)
-          ++ichunk;
-          if (isrc == 0 && ichunk == nch0) { isrc = 1; ichunk = 0; fill_base(1); }
-        }
-        const int nt = (t + 1) % 9;
-        unsigned av[A_IT]; tap_offsets(nt, av);
-        const unsigned aso = __builtin_amdgcn_readfirstlane((unsigned)ichunk * 128u);
-        const unsigned bso = __builtin_amdgcn_readfirstlane((unsigned)((nt * Ctot + (isrc ? p.C0 : 0) + ichunk * 64) * 2));
-        const bf16_t* baseA = __builtin_amdgcn_readfirstlane(isrc) ? base1 : base0;
-        kstep(gs & 1, (gs & 1) ^ 1, baseA, av, aso, bso, more ? nrecA : 0u, more ? nrecB : 0u);
-        ++gs;
-      }
-    }
-  } else {
+  {
     // STAGES-deep ring: stages ks+1 .. ks+STAGES-2 stay in flight across the barrier (counted vmcnt), the stage
     // for step ks+STAGES-1 is issued inside step ks into the slot step ks-1 just released.  A deeper ring is what
     // covers the L2/HBM latency when few workgroups share a CU (small feature maps).
@@ -309,6 +251,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_kernel(const IgemmP p) 
   // WRITES ZEROS to the LDS destination.  Those writes must have landed before the epilogue reuses the ring as its
   // staging buffer (__syncthreads() does not wait on vmcnt at workgroup scope).
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef AGD_EXPERIMENTS
   if (p.dbg & 64) {                                // timing experiment (AGD_IGEMM_CFG=1024): no epilogue (keeps acc live)
     float sacc = 0.f;
 #pragma unroll
@@ -318,6 +261,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_kernel(const IgemmP p) 
     if (sacc == 1.2345e-30f) ((float*)p.out)[0] = sacc;
     return;
   }
+#endif
   igemm_epilogue<BM, BN, WM, WN, GEGLU, SPLITK>(p, acc, smem, tid, lane, wm, wn, m0, n0, tn, bz);
 }
 
@@ -351,8 +295,11 @@ static int launch_one(const IgemmP& p, int splits, hipStream_t st) {
   const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
   dim3 grid(tiles, p.batch > 0 ? p.batch : 1, splits);
   auto kfn = igemm_kernel<BM, BN, WM, WN, KS, STAGES, GEGLU, SPLITK>;
-  static bool attr = false;
-  if (!attr) { HIP_CHECK_RET(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); attr = true; }
+  // the dynamic-LDS attribute is per device: latch it per (instantiation, device)
+  static bool attr[AGD_MAX_DEVICES] = {};
+  int dev = 0; HIP_CHECK_RET(hipGetDevice(&dev));
+  if (dev < 0 || dev >= AGD_MAX_DEVICES) { agd_set_error("igemm: device ordinal %d out of range", dev); return -1; }
+  if (!attr[dev]) { HIP_CHECK_RET(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); attr[dev] = true; }
   hipLaunchKernelGGL(kfn, grid, dim3(NT), lds, st, p);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
@@ -380,109 +327,113 @@ static int launch_cfg(const IgemmP& p, int splits, hipStream_t st) {
   return launch_one<BM, BN, WM, WN, 1, STAGES, 0, 0>(p, 1, st);
 }
 
-int g_igemm_cfg = 0;   // experiment knob
-extern "C" void agd_set_igemm_cfg(int v) { g_igemm_cfg = v; }
+// split-K partial slabs: the caller's (per-ctx) workspace when it supplies one, else one per device for the ctx-less
+// single-op entry points.  Reuse is stream-ordered: every launch that writes the slabs is followed, on the same stream,
+// by the reduce that reads them.
+static SplitKWs g_splitk_dev[AGD_MAX_DEVICES];
+static int ensure_splitk(IgemmP& p, int S) {
+  SplitKWs* ws = p.ws;
+  if (!ws) {
+    int dev = 0; HIP_CHECK_RET(hipGetDevice(&dev));
+    if (dev < 0 || dev >= AGD_MAX_DEVICES) { agd_set_error("igemm: device ordinal %d out of range", dev); return -1; }
+    ws = &g_splitk_dev[dev];
+  }
+  const size_t need = (size_t)S * p.M * p.N * 4;
+  if (need > ws->cap) {
+    if (ws->p) { (void)hipDeviceSynchronize(); (void)hipFree(ws->p); }
+    const size_t cap = need > ((size_t)64 << 20) ? need : ((size_t)64 << 20);
+    if (hipMalloc((void**)&ws->p, cap) != hipSuccess) { ws->p = nullptr; ws->cap = 0; agd_set_error("split-K workspace alloc failed"); return -1; }
+    ws->cap = cap;
+  }
+  p.splitk_ws = ws->p;
+  return 0;
+}
 
-static float* g_splitk_ws = nullptr; static size_t g_splitk_cap = 0;
+#ifdef AGD_EXPERIMENTS
+int g_igemm_cfg = 0;   // experiment knob (tools/ only; production builds have no run-time dispatch knobs)
+extern "C" __attribute__((visibility("default"))) void agd_set_igemm_cfg(int v) { g_igemm_cfg = v; }
+#define KNOB(n) ((g_igemm_cfg & 15) == (n))
+#else
+#define KNOB(n) false
+#endif
 
 int launch_igemm(const IgemmP& p_in, hipStream_t st) {
   IgemmP p = p_in;
+#ifdef AGD_EXPERIMENTS
   static bool env_read = false;
   if (!env_read) { env_read = true; const char* e = getenv("AGD_IGEMM_CFG"); if (e) g_igemm_cfg = atoi(e); }
   p.dbg = g_igemm_cfg >> 4;
+#endif
   if (p.K & 63 || p.C0 & 63 || p.C1 & 63) { agd_set_error("igemm: K/C0/C1 must be multiples of 64 (K=%d C0=%d C1=%d)", p.K, p.C0, p.C1); return -1; }
   if (p.K != p.ksize * p.ksize * (p.C0 + p.C1)) { agd_set_error("igemm: K=%d != ks^2*(C0+C1)=%d", p.K, p.ksize * p.ksize * (p.C0 + p.C1)); return -1; }
   if (p.ksize != 1 && p.ksize != 3) { agd_set_error("igemm: ksize %d", p.ksize); return -1; }
+  if (p.M < 1 || p.N < 1) { agd_set_error("igemm: empty problem M=%d N=%d", p.M, p.N); return -1; }
   if (p.rowadd && p.M >= (1 << 24)) { agd_set_error("igemm: rowadd needs M < 2^24"); return -1; }
   if (p.geglu && (p.N % 128)) { agd_set_error("igemm: geglu needs N %% 128 == 0"); return -1; }
   const int batch = p.batch > 0 ? p.batch : 1;
   const long long t128 = (long long)((p.M + 127) / 128) * ((p.N + 127) / 128) * batch;
   const int nk = p.K >> 6;
+#ifdef AGD_EXPERIMENTS
   {  // exploration only: AGD_IGEMM_FORCE="<bn>:<splits>:<stages>" forces one configuration for every non-GEGLU launch
     static int f_bn = -1, f_s = 1, f_st = 2;
     if (f_bn < 0) { const char* e = getenv("AGD_IGEMM_FORCE"); f_bn = 0; if (e) sscanf(e, "%d:%d:%d", &f_bn, &f_s, &f_st); }
     if (f_bn > 0 && !p.geglu && batch == 1) {
       int S = f_s; if (S > nk / 2) S = nk / 2; if (S < 1) S = 1;
-      if (S >= 2) {
-        const size_t need = (size_t)S * p.M * p.N * 4;
-        if (need > g_splitk_cap) { if (g_splitk_ws) (void)hipFree(g_splitk_ws); if (hipMalloc((void**)&g_splitk_ws, need) != hipSuccess) return -1; g_splitk_cap = need; }
-        p.splitk_ws = g_splitk_ws;
-      }
+      if (S >= 2) CK0(ensure_splitk(p, S));
       if (f_bn == 64) return f_st == 4 ? launch_cfg<64, 64, 2, 2, 4>(p, S, st) : launch_cfg<64, 64, 2, 2>(p, S, st);
-      if (f_bn == 1264) return f_st == 3 ? launch_cfg<128, 64, 2, 2, 3>(p, S, st) : launch_cfg<128, 64, 2, 2>(p, S, st);
       if (f_bn == 160) return f_st == 4 ? launch_cfg<128, 160, 2, 2, 4>(p, S, st) : launch_cfg<128, 160, 2, 2>(p, S, st);
       return f_st == 4 ? launch_cfg<128, 128, 2, 2, 4>(p, S, st) : launch_cfg<128, 128, 2, 2>(p, S, st);
     }
   }
+#endif
   if (p.geglu) return launch_cfg<128, 128, 2, 2>(p, 1, st);
   // Small-M launches (8x8 / 16x16 feature maps): ONE workgroup per CU on the 4-stage ring, tile width and K split
   // chosen so that the launch has as close to 256 workgroups as possible.  These launches are a load-latency chain:
   // two more stages in flight hide more of it than a second co-resident workgroup on a 2-stage ring does
   // (8x8 1280->1280: 35 -> 30 us).  16x16 maps (M = 2048, N = 1280) get 128 tiles of 128x160 x 2 K slices = 256.
-  auto ensure_ws = [&](int S) -> int {
-    const size_t need = (size_t)S * p.M * p.N * 4;
-    if (need > g_splitk_cap) {
-      if (g_splitk_ws) (void)hipFree(g_splitk_ws);
-      const size_t cap = need > ((size_t)64 << 20) ? need : ((size_t)64 << 20);
-      if (hipMalloc((void**)&g_splitk_ws, cap) != hipSuccess) { g_splitk_ws = nullptr; g_splitk_cap = 0; agd_set_error("split-K workspace alloc failed"); return -1; }
-      g_splitk_cap = cap;
-    }
-    p.splitk_ws = g_splitk_ws;
-    return 0;
-  };
-  const int nkmin = (g_igemm_cfg & 15) == 11 ? 16 : 64;
-  if ((g_igemm_cfg & 15) != 6 && batch == 1 && t128 <= 160 && nk >= nkmin && p.M >= 128 && (p.N & 3) == 0) {
+  if (!KNOB(6) && batch == 1 && t128 <= 160 && nk >= 64 && p.M >= 128 && (p.N & 3) == 0) {
     auto splits = [&](long long tt) { int S = (int)(256 / tt); if (S > 8) S = 8; if (S > nk / 8) S = nk / 8; return S < 1 ? 1 : S; };
     const long long mt = (p.M + 127) / 128;
     const int S8 = splits(t128);
     long long T8 = t128 * S8, T0 = 0; int S0 = 1;
     if ((p.N % 160) == 0) { const long long t160 = mt * (p.N / 160); if (t160 <= 256) { S0 = splits(t160); T0 = t160 * S0; } }
-    const bool use160 = T0 > T8 && (g_igemm_cfg & 15) != 7;
+    const bool use160 = T0 > T8 && !KNOB(7);
     const int S = use160 ? S0 : S8;
     const long long T = use160 ? T0 : T8;
     if (T >= 192 || t128 <= 64) {                                   // else: too few workgroups -> 2-stage path below
-      if (S >= 2) CK0(ensure_ws(S));
+      if (S >= 2) CK0(ensure_splitk(p, S));
       return use160 ? launch_cfg<128, 160, 2, 2, 4>(p, S, st) : launch_cfg<128, 128, 2, 2, 4>(p, S, st);
     }
   }
   // split-K for small-M problems (8x8 / 16x16 feature maps): fill the 256 CUs with K slices
   if (batch == 1 && t128 <= 160 && nk >= 64 && (p.N & 3) == 0 && p.M >= 128) {
-    const int target = (g_igemm_cfg & 15) == 7 ? 256 : (g_igemm_cfg & 15) == 8 ? 512 : 384;
-    int S = (int)((target + t128 - 1) / t128);
+    int S = (int)((384 + t128 - 1) / t128);
     if (S > 8) S = 8;
     if (S > nk / 8) S = nk / 8;
     if (S >= 2) {
-      const size_t need = (size_t)S * p.M * p.N * 4;
-      if (need > g_splitk_cap) {
-        if (g_splitk_ws) hipFree(g_splitk_ws);
-        const size_t cap = need > ((size_t)64 << 20) ? need : ((size_t)64 << 20);
-        if (hipMalloc((void**)&g_splitk_ws, cap) != hipSuccess) { g_splitk_ws = nullptr; g_splitk_cap = 0; agd_set_error("split-K workspace alloc failed"); return -1; }
-        g_splitk_cap = cap;
-      }
-      p.splitk_ws = g_splitk_ws;
+      CK0(ensure_splitk(p, S));
       return launch_cfg<128, 128, 2, 2>(p, S, st);
     }
   }
   // N <= 64 (conv_out: 4 / 3 output channels): a 128-wide tile would be > 95 % padding -> 64x64 tiles
-  if (p.N <= 64 && (g_igemm_cfg & 15) != 12) return launch_cfg<64, 64, 2, 2, 4>(p, 1, st);
-  if (t128 >= ((g_igemm_cfg & 15) == 3 ? 128 : 192)) {
+  if (p.N <= 64) return launch_cfg<64, 64, 2, 2, 4>(p, 1, st);
+  if (t128 >= 192) {
     // 128x128 or 128x160: both hold 2 workgroups per CU.  Wave quantisation decides: a launch of T tiles keeps
     // every CU busy for ceil(T/256) tile-times (x1.33 when T <= 256: a lone workgroup per CU has nothing to overlap
     // its loads/epilogue with), and a 160-wide tile is 1.25 tile-times.  E.g. M=8192, N=640: 320 tiles of 128x128
     // leave 192 CUs idle for the second half; 256 tiles of 128x160 do not.
     bool n160 = (p.N % 160) == 0 && (p.N % 128) != 0;
-    if ((p.N % 160) == 0 && (p.N % 128) == 0 && (g_igemm_cfg & 15) != 4) {
+    if ((p.N % 160) == 0 && (p.N % 128) == 0) {
       const long long mt = (p.M + 127) / 128;
       const long long T8 = mt * (p.N / 128) * batch, T0 = mt * (p.N / 160) * batch;
       auto cost = [](long long T, double w) { return w * (T <= 256 ? 1.33 : (double)((T + 255) / 256)); };
-      if (p.ksize == 3 || (g_igemm_cfg & 15) == 10) n160 = cost(T0, 1.25) < cost(T8, 1.0) - 1e-9;   // measured: helps 3x3, hurts / neutral for 1x1
+      if (p.ksize == 3 || KNOB(10)) n160 = cost(T0, 1.25) < cost(T8, 1.0) - 1e-9;   // measured: helps 3x3, hurts / neutral for 1x1
     }
     // <= 256 tiles: one workgroup per CU whatever the ring -> take the 4-stage ring (147 / 128 KB LDS)
     const long long Tsel = (long long)((p.M + 127) / 128) * ((p.N + (n160 ? 159 : 127)) / (n160 ? 160 : 128)) * batch;
-    const bool deep = Tsel <= 256 && nk >= 8 && (g_igemm_cfg & 15) != 9;
+    const bool deep = Tsel <= 256 && nk >= 8 && !KNOB(9);
     if (n160) return deep ? launch_cfg<128, 160, 2, 2, 4>(p, 1, st) : launch_cfg<128, 160, 2, 2>(p, 1, st);
     return deep ? launch_cfg<128, 128, 2, 2, 4>(p, 1, st) : launch_cfg<128, 128, 2, 2>(p, 1, st);
   }
-  if ((g_igemm_cfg & 15) == 5) return launch_cfg<64, 64, 2, 2>(p, 1, st);      // A/B: the 2-stage ring
   return launch_cfg<64, 64, 2, 2, 4>(p, 1, st);
 }

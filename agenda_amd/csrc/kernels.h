@@ -8,6 +8,9 @@
 //   nearest-2x upsample of the input and stride/pad (3x3 or 1x1 taps).  k = tap*(C0+C1) + c.
 //   Linear layers are the KS=1, stride=1 case with Hin*Win = tokens.
 // ---------------------------------------------------------------------------------------
+#define AGD_MAX_DEVICES 16
+struct SplitKWs { float* p = nullptr; size_t cap = 0; };   // split-K fp32 partial slabs, owned by the caller (one per ctx)
+
 struct IgemmP {
   const bf16_t* src0; const bf16_t* src1;
   int C0, C1;
@@ -25,8 +28,9 @@ struct IgemmP {
   int batch;                        // grid.y
   long long sA0, sA1, sW, sO, sR;   // per-batch element strides
   const bf16_t* zero_page;          // >= 256 B of zeros
+  SplitKWs* ws;                     // caller's split-K workspace (grown on demand); NULL: a per-device default
   float* splitk_ws;                 // set by the launcher: fp32 partial slabs [S][M][N]
-  int dbg;                          // timing experiments only
+  int dbg;                          // timing experiments only (builds with -DAGD_EXPERIMENTS)
 };
 int launch_igemm(const IgemmP& p, hipStream_t st);
 
@@ -46,6 +50,7 @@ struct AttnP {
   int rec_T;                        // number of token rows to record (<= Nk)
   int nqt;                          // set by the launcher: query tiles per (batch, head)
   int causal;                       // 1: key j attends only to queries i >= j (CLIP text encoder)
+  const float* mask;                // additive fp32 [B][Nk] (broadcast over heads and queries) or NULL
 };
 int launch_attention(const AttnP& p, hipStream_t st);
 
@@ -60,6 +65,7 @@ struct GroupNormP {
   float* ws;                                         // workspace: B*C*2 (sums) + B*C*2 (scale/shift)
 };
 int launch_groupnorm(const GroupNormP& p, hipStream_t st);
+long long groupnorm_ws_floats(int B, int C, int HW, int groups);   // workspace floats a launch_groupnorm call needs
 int launch_layernorm(const bf16_t* x, bf16_t* y, const float* g, const float* b, int rows, int C, float eps, hipStream_t st);
 
 // ---------------------------------------------------------------------------------------

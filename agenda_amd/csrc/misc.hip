@@ -306,6 +306,7 @@ __global__ __launch_bounds__(256) void heatmap_u8_kernel(const float* __restrict
   }
 }
 int launch_heatmap_u8(const float* hm, int n, int npix, unsigned char* out, hipStream_t st) {
+  if (n <= 0 || npix <= 0) return 0;                           // images-only runs request no word maps: nothing to launch
   hipLaunchKernelGGL(heatmap_u8_kernel, dim3(n), dim3(256), 0, st, hm, npix, out);
   HIP_CHECK_RET(hipGetLastError()); return 0;
 }
@@ -332,6 +333,7 @@ __global__ void pil_resample_kernel(const unsigned char* __restrict__ in, unsign
 int launch_pil_resample(const unsigned char* in, unsigned char* out, const int* bounds, const int* kk, int ksize,
                         long long n_outer, int in_len, int out_len, int inner, hipStream_t st) {
   const long long total = n_outer * out_len * inner;
+  if (total <= 0) return 0;
   hipLaunchKernelGGL(pil_resample_kernel, dim3(grid_for(total)), dim3(256), 0, st, in, out, bounds, kk, ksize, n_outer, in_len, out_len, inner);
   HIP_CHECK_RET(hipGetLastError()); return 0;
 }
@@ -347,6 +349,7 @@ __global__ void stack_heatmaps_kernel(const unsigned char* __restrict__ obj, con
 }
 int launch_stack_heatmaps(const unsigned char* obj, const unsigned char* fg, const unsigned char* bg, long long npix,
                           unsigned char* rgb, unsigned char* inv, hipStream_t st) {
+  if (npix <= 0) return 0;
   hipLaunchKernelGGL(stack_heatmaps_kernel, dim3(grid_for(npix)), dim3(256), 0, st, obj, fg, bg, npix, rgb, inv);
   HIP_CHECK_RET(hipGetLastError()); return 0;
 }

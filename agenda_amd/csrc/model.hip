@@ -17,10 +17,11 @@
 // errors
 // ---------------------------------------------------------------------------------------
 static thread_local char g_err[2048] = "";
+// C ABI entry points are the only default-visibility symbols of the library (built with -fvisibility=hidden)
+#define AGD_API extern "C" __attribute__((visibility("default")))
 extern "C" void agd_set_error(const char* fmt, ...) {
   va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof(g_err), fmt, ap); va_end(ap);
 }
-extern "C" long long agd_groupnorm_ws_floats(int B, int C, int HW, int groups);
 #define CK(expr) do { if ((expr) != 0) return -1; } while (0)
 #define FAIL(...) do { agd_set_error(__VA_ARGS__); return -1; } while (0)
 
@@ -43,12 +44,27 @@ enum { PC_CONV3 = 0, PC_GEMM, PC_ATTN_SELF, PC_ATTN_CROSS, PC_GN, PC_LN, PC_ELEM
 static const char* kClassNames[AGD_N_CLASSES] = {"igemm_conv3x3", "igemm_linear_1x1", "attn_self_flash", "attn_cross_daam",
                                                  "groupnorm", "layernorm", "elementwise", "heatmap", "vae_attn_softmax", "other"};
 
-struct XLayer {
-  std::string name; int C = 0, heads = 0, level = 0; bool mid = false;
-  WMat wkv; bf16_t* kv = nullptr; float* acc = nullptr; int acc_side = 0;
+// device buffer that only grows (capacity in bytes); the old block is freed when a larger one is needed
+struct DBuf {
+  void* p = nullptr; size_t cap = 0;
+  template <typename T> T* as() const { return (T*)p; }
+  int ensure(size_t bytes) {
+    if (p && bytes <= cap) return 0;
+    if (p) { (void)hipDeviceSynchronize(); (void)hipFree(p); p = nullptr; cap = 0; }
+    const size_t want = bytes ? bytes : 256;
+    if (hipMalloc(&p, want) != hipSuccess) { p = nullptr; agd_set_error("hipMalloc(%zu) failed", want); return -1; }
+    cap = want;
+    return 0;
+  }
+  void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
 };
 
-struct ProfEv { int cls; double flops; hipEvent_t a, b; };
+struct XLayer {
+  std::string name; int C = 0, heads = 0, level = 0; bool mid = false;
+  WMat wkv; DBuf kvb; bf16_t* kv = nullptr; DBuf accb; float* acc = nullptr; int acc_side = 0;
+};
+
+struct ProfEv { int cls; double flops, bytes; hipEvent_t a, b; };   // algorithmic flop / HBM bytes of the launch
 
 struct agd_ctx {
   int device = 0; agd_config cfg{}; std::string err;
@@ -68,12 +84,15 @@ struct agd_ctx {
   float* t_dev = nullptr;
   // cross attention
   std::vector<XLayer> xl; std::unordered_map<std::string, int> xl_idx;
-  bf16_t* ctx_bf16 = nullptr; int ctx_B2 = 0, ctx_T = 0;
+  DBuf ctxb; bf16_t* ctx_bf16 = nullptr; int ctx_B2 = 0, ctx_T = 0;
   // recorder
-  int rec_mode = 0, rec_is_train = 0, rec_T = 0, rec_B = 0, rec_L = 0;
-  float* hook_sum = nullptr; float* hook_scratch = nullptr; int hook_count = 0, hook_Bp = 0;
+  int rec_mode = 0, rec_is_train = 0, rec_T_cfg = 0, rec_T = 0, rec_B = 0, rec_L = 0;   // rec_T: rows the accumulators were sized for (set by record_reset)
+  DBuf hook_sumb, hook_scratchb;
+  float* hook_sum = nullptr; float* hook_scratch = nullptr; int hook_count = 0, hook_Bp = 0, hook_T = 0;
   // denoise scratch
-  bf16_t* lat_bf16 = nullptr; float* eps_nhwc = nullptr; size_t lat_cap = 0;
+  DBuf latb, epsb, vae_imgb;
+  bf16_t* lat_bf16 = nullptr; float* eps_nhwc = nullptr;
+  SplitKWs splitk;                                    // split-K partial slabs of this ctx (stream-ordered reuse)
   // profiling
   bool prof_on = false; std::vector<ProfEv> prof; std::vector<hipEvent_t> ev_pool; size_t ev_used = 0;
   long long launches[AGD_N_CLASSES] = {0};
@@ -84,11 +103,11 @@ static int fail_ctx(agd_ctx* c) { if (c) c->err = g_err; return -1; }
 
 struct ProfScope {
   agd_ctx* c; hipStream_t st; bool on; size_t idx;
-  ProfScope(agd_ctx* c_, hipStream_t st_, int cls, double flops) : c(c_), st(st_), on(c_ && c_->prof_on), idx(0) {
+  ProfScope(agd_ctx* c_, hipStream_t st_, int cls, double flops, double bytes = 0) : c(c_), st(st_), on(c_ && c_->prof_on), idx(0) {
     if (c) c->launches[cls]++;
     if (!on) return;
     auto get = [&]() { if (c->ev_used == c->ev_pool.size()) { hipEvent_t e; hipEventCreate(&e); c->ev_pool.push_back(e); } return c->ev_pool[c->ev_used++]; };
-    ProfEv pe; pe.cls = cls; pe.flops = flops; pe.a = get(); pe.b = get();
+    ProfEv pe; pe.cls = cls; pe.flops = flops; pe.bytes = bytes; pe.a = get(); pe.b = get();
     hipEventRecord(pe.a, st);
     idx = c->prof.size(); c->prof.push_back(pe);
   }
@@ -131,9 +150,12 @@ static int run_conv(agd_ctx* c, hipStream_t st, const bf16_t* s0, int C0, const 
   p.residual = o.residual; p.N = w.N; p.K = w.taps * w.Cpad; p.M = B * p.Hout * p.Wout;
   const int nout = o.geglu ? w.N / 2 : w.N;
   p.ldr = o.ldr ? o.ldr : nout; p.out = out; p.out_f32 = o.out_f32; p.ldo = o.ldo ? o.ldo : nout;
-  p.alpha = o.alpha; p.geglu = o.geglu; p.act = o.act; p.batch = 1; p.zero_page = zero_page;
+  p.alpha = o.alpha; p.geglu = o.geglu; p.act = o.act; p.batch = 1; p.zero_page = zero_page; p.ws = c ? &c->splitk : nullptr;
   if (w.taps != ksize * ksize || w.Cpad != C0 + C1) FAIL("conv: weight [N=%d taps=%d Cpad=%d] does not match input C=%d+%d ksize=%d", w.N, w.taps, w.Cpad, C0, C1, ksize);
-  ProfScope ps(c, st, ksize == 3 ? PC_CONV3 : PC_GEMM, 2.0 * p.M * (double)p.N * p.K);
+  // algorithmic HBM bytes: every input pixel / weight read once, the output written once (+ the residual read)
+  const double in_b = 2.0 * B * Hin * Win * (double)(C0 + C1), w_b = 2.0 * p.N * (double)p.K;
+  const double out_b = (double)p.M * nout * (o.out_f32 ? 4.0 : 2.0) + (o.residual ? 2.0 * p.M * nout : 0.0);
+  ProfScope ps(c, st, ksize == 3 ? PC_CONV3 : PC_GEMM, 2.0 * p.M * (double)p.N * p.K, in_b + w_b + out_b);
   return launch_igemm(p, st);
 }
 
@@ -141,11 +163,11 @@ static int run_gn(agd_ctx* c, hipStream_t st, const bf16_t* x0, int C0, const bf
                   const float* gamma, const float* beta, int groups, float eps, int silu, bf16_t* y) {
   GroupNormP g{}; g.x0 = x0; g.x1 = x1; g.C0 = C0; g.C1 = C1; g.y = y; g.gamma = gamma; g.beta = beta;
   g.B = B; g.HW = HW; g.groups = groups; g.eps = eps; g.silu = silu;
-  const long long wsf = agd_groupnorm_ws_floats(B, C0 + C1, HW, groups);
+  const long long wsf = groupnorm_ws_floats(B, C0 + C1, HW, groups);
   const size_t mk = c->arena.mark();
   g.ws = (float*)c->arena.alloc((size_t)wsf * 4);
   if (!g.ws) return -1;
-  ProfScope ps(c, st, PC_GN, 0);
+  ProfScope ps(c, st, PC_GN, 0, 4.0 * B * HW * (double)(C0 + C1));       // one read + one write of the activation
   const int rc = launch_groupnorm(g, st);
   c->arena.release(mk);   // stream-ordered: later kernels that reuse this memory run after the norm
   return rc;
@@ -204,18 +226,23 @@ static int resnet(agd_ctx* c, hipStream_t st, const std::string& pre, const Act&
 
 static int run_attention(agd_ctx* c, hipStream_t st, int cls, AttnP& a) {
   const double fl = 4.0 * a.B * a.H * (double)a.Nq * a.Nk * a.D;
-  ProfScope ps(c, st, cls, fl);
+  // q read + o written + k/v read once per (batch, head); the recorder's read-modify-write of its fp32 rows on top
+  double by = 2.0 * a.B * a.H * (double)a.D * (2.0 * a.Nq + 2.0 * a.Nk);
+  if (a.record_mode == 1) by += 8.0 * (a.B - a.rec_b0) * a.H * (double)a.rec_T * a.Nq;
+  else if (a.record_mode == 2) by += 8.0 * (a.B - a.rec_b0) * (double)a.rec_T * a.Nq;
+  ProfScope ps(c, st, cls, fl, by);
   return launch_attention(a, st);
 }
 
 // cross-attention attn2 body shared by the UNet walk and the agd_cross_attn seam
-static int cross_attention(agd_ctx* c, hipStream_t st, XLayer& xl, const bf16_t* q, int B2, int N, bf16_t* out, bool record) {
+static int cross_attention(agd_ctx* c, hipStream_t st, XLayer& xl, const bf16_t* q, int B2, int N, bf16_t* out, bool record,
+                           const float* mask = nullptr) {
   const int C = xl.C, D = C / xl.heads, T = c->ctx_T;
   AttnP a{}; a.q = q; a.k = xl.kv; a.v = xl.kv + C; a.o = out;
   a.ldq = C; a.ldk = 2 * C; a.ldv = 2 * C; a.ldo = C;
   a.sq = (long long)N * C; a.sk = (long long)T * 2 * C; a.sv = a.sk; a.so = a.sq;
   a.B = B2; a.H = xl.heads; a.D = D; a.Nq = N; a.Nk = T; a.scale = 1.0f / sqrtf((float)D);
-  a.record_mode = 0;
+  a.record_mode = 0; a.mask = mask;
   const int side = (int)lrintf(sqrtf((float)N));
   bool hook_call = false;
   if (record && c->rec_mode == 1 && !xl.mid && xl.acc) {
@@ -227,6 +254,7 @@ static int cross_attention(agd_ctx* c, hipStream_t st, XLayer& xl, const bf16_t*
   } else if (record && c->rec_mode == 2 && c->hook_scratch) {
     const int b0 = c->rec_is_train ? 0 : B2 / 2;
     if (B2 - b0 == c->hook_Bp) {
+      if (T != c->hook_T || side > c->rec_L) FAIL("hook recorder was reset for %d tokens / latent side %d but this call has %d tokens / side %d: call clear() (agd_record_reset) after changing the context", c->hook_T, c->rec_L, T, side);
       a.record_mode = 2; a.rec_b0 = b0; a.rec = c->hook_scratch; a.rec_T = T;
       a.rec_img_stride = (long long)T * N; a.rec_head_stride = 0;
       if (hipMemsetAsync(c->hook_scratch, 0, (size_t)c->hook_Bp * T * N * 4, st) != hipSuccess) FAIL("memset hook scratch");
@@ -275,7 +303,7 @@ static int transformer(agd_ctx* c, hipStream_t st, const std::string& pre, const
   const bf16_t* xres = x.p;                            // residual of proj_out
   // --- self attention ---
   { GETV(g, t + "norm1.weight"); GETV(b, t + "norm1.bias");
-    { ProfScope ps(c, st, PC_LN, 0); CK(launch_layernorm(h.p, ln.p, g, b, M, C, 1e-5f, st)); }
+    { ProfScope ps(c, st, PC_LN, 0, 4.0 * M * (double)C); CK(launch_layernorm(h.p, ln.p, g, b, M, C, 1e-5f, st)); }
     GETW(w, t + "attn1.qkv"); GemmOpt o;
     CK(run_conv(c, st, ln.p, C, nullptr, 0, 1, 1, M, *w, 1, qkv, o, c->zero_page));
     AttnP a{}; a.q = qkv; a.k = qkv + C; a.v = qkv + 2 * C; a.o = att;
@@ -296,7 +324,7 @@ static int transformer(agd_ctx* c, hipStream_t st, const std::string& pre, const
   }
   // --- cross attention (the processor seam) ---
   { GETV(g, t + "norm2.weight"); GETV(b, t + "norm2.bias");
-    { ProfScope ps(c, st, PC_LN, 0); CK(launch_layernorm(h.p, ln.p, g, b, M, C, 1e-5f, st)); }
+    { ProfScope ps(c, st, PC_LN, 0, 4.0 * M * (double)C); CK(launch_layernorm(h.p, ln.p, g, b, M, C, 1e-5f, st)); }
     GETW(wq, t + "attn2.to_q.weight"); GemmOpt o;
     bf16_t* q = qkv;
     CK(run_conv(c, st, ln.p, C, nullptr, 0, 1, 1, M, *wq, 1, q, o, c->zero_page));
@@ -309,7 +337,7 @@ static int transformer(agd_ctx* c, hipStream_t st, const std::string& pre, const
     CK(run_conv(c, st, att, C, nullptr, 0, 1, 1, M, *wo, 1, h.p, oo, c->zero_page)); }
   // --- GEGLU feed-forward ---
   { GETV(g, t + "norm3.weight"); GETV(b, t + "norm3.bias");
-    { ProfScope ps(c, st, PC_LN, 0); CK(launch_layernorm(h.p, ln.p, g, b, M, C, 1e-5f, st)); }
+    { ProfScope ps(c, st, PC_LN, 0, 4.0 * M * (double)C); CK(launch_layernorm(h.p, ln.p, g, b, M, C, 1e-5f, st)); }
     bf16_t* ff = (bf16_t*)c->arena.alloc((size_t)M * 4 * C * 2); if (!ff) return -1;
     GETW(w1, t + "ff.net.0.proj.weight"); GETV(b1, t + "ff.net.0.proj.bias");
     GemmOpt o1; o1.bias = b1; o1.geglu = 1;
@@ -536,11 +564,11 @@ static int vae_encode_walk(agd_ctx* c, hipStream_t st, const bf16_t* xin, int B,
 // ---------------------------------------------------------------------------------------
 // C ABI
 // ---------------------------------------------------------------------------------------
-extern "C" const char* agd_version(void) { return "agenda_hip 0.1 (gfx950)"; }
-extern "C" const char* agd_last_error(agd_ctx* c) { return (c && !c->err.empty()) ? c->err.c_str() : g_err; }
-extern "C" const char* agd_profile_class_name(int cls) { return (cls >= 0 && cls < AGD_N_CLASSES) ? kClassNames[cls] : ""; }
+AGD_API const char* agd_version(void) { return "agenda_hip 0.1 (gfx950)"; }
+AGD_API const char* agd_last_error(agd_ctx* c) { return (c && !c->err.empty()) ? c->err.c_str() : g_err; }
+AGD_API const char* agd_profile_class_name(int cls) { return (cls >= 0 && cls < AGD_N_CLASSES) ? kClassNames[cls] : ""; }
 
-extern "C" agd_ctx* agd_create(int device_id, const agd_config* cfg) {
+AGD_API agd_ctx* agd_create(int device_id, const agd_config* cfg) {
   if (!cfg || cfg->struct_size != (int)sizeof(agd_config)) { agd_set_error("agd_create: bad config (struct_size %d != %zu)", cfg ? cfg->struct_size : -1, sizeof(agd_config)); return nullptr; }
   if (cfg->n_levels < 1 || cfg->n_levels > AGD_MAX_LEVELS || cfg->vae_n_levels < 1 || cfg->vae_n_levels > AGD_MAX_LEVELS) { agd_set_error("agd_create: bad level count"); return nullptr; }
   for (int i = 0; i < cfg->n_levels; ++i)
@@ -560,11 +588,15 @@ extern "C" agd_ctx* agd_create(int device_id, const agd_config* cfg) {
   return c;
 }
 
-extern "C" void agd_destroy(agd_ctx* c) {
+AGD_API void agd_destroy(agd_ctx* c) {
   if (!c) return;
   hipSetDevice(c->device);
   hipDeviceSynchronize();
   for (void* p : c->owned) hipFree(p);
+  for (auto& xl : c->xl) { xl.kvb.release(); xl.accb.release(); }
+  c->ctxb.release(); c->hook_sumb.release(); c->hook_scratchb.release();
+  c->latb.release(); c->epsb.release(); c->vae_imgb.release();
+  if (c->splitk.p) hipFree(c->splitk.p);
   if (c->arena.base) hipFree(c->arena.base);
   if (c->stage) hipFree(c->stage);
   if (c->tsteps_buf) hipFree(c->tsteps_buf);
@@ -574,7 +606,7 @@ extern "C" void agd_destroy(agd_ctx* c) {
 
 static bool ends_with(const std::string& s, const char* suf) { const size_t n = strlen(suf); return s.size() >= n && s.compare(s.size() - n, n, suf) == 0; }
 
-extern "C" int agd_load_tensor(agd_ctx* c, const char* name, const void* ptr, int dtype, int ndim, const long long* shape) {
+AGD_API int agd_load_tensor(agd_ctx* c, const char* name, const void* ptr, int dtype, int ndim, const long long* shape) {
   if (!c || !name || !ptr || !shape) { agd_set_error("agd_load_tensor: null argument"); return fail_ctx(c); }
   if (dtype != 0) { agd_set_error("agd_load_tensor: only float32 (dtype 0) supported"); return fail_ctx(c); }
   hipSetDevice(c->device);
@@ -616,7 +648,7 @@ static int concat_rows(agd_ctx* c, const std::vector<const WMat*>& parts, WMat& 
   return 0;
 }
 
-extern "C" int agd_finalize(agd_ctx* c) {
+AGD_API int agd_finalize(agd_ctx* c) {
   if (!c) return -1;
   hipSetDevice(c->device);
   const agd_config& g = c->cfg;
@@ -675,16 +707,16 @@ extern "C" int agd_finalize(agd_ctx* c) {
 static hipStream_t S(void* s) { return (hipStream_t)s; }
 static int need_final(agd_ctx* c) { if (!c) { agd_set_error("null ctx"); return -1; } if (!c->finalized) { agd_set_error("agd_finalize not called"); return -1; } hipSetDevice(c->device); return 0; }
 
-extern "C" int agd_set_context(agd_ctx* c, const float* ctx_emb, int batch2, int tokens, void* stream) {
+AGD_API int agd_set_context(agd_ctx* c, const float* ctx_emb, int batch2, int tokens, void* stream) {
   API_CK(c, need_final(c));
   hipStream_t st = S(stream);
   const int Dc = c->cfg.cross_attention_dim;
   if (tokens > 96) { agd_set_error("set_context: tokens %d > 96 unsupported", tokens); return fail_ctx(c); }
-  if (batch2 != c->ctx_B2 || tokens != c->ctx_T) {
-    c->ctx_bf16 = dmalloc<bf16_t>(c, (size_t)batch2 * tokens * Dc); if (!c->ctx_bf16) return fail_ctx(c);
-    for (auto& xl : c->xl) { xl.kv = dmalloc<bf16_t>(c, (size_t)batch2 * tokens * 2 * xl.C); if (!xl.kv) return fail_ctx(c); }
-    c->ctx_B2 = batch2; c->ctx_T = tokens;
-  }
+  if (batch2 < 1 || tokens < 1) { agd_set_error("set_context: batch2 %d tokens %d", batch2, tokens); return fail_ctx(c); }
+  // buffers only ever grow (capacity-tracked); a shorter/smaller context reuses the same blocks
+  API_CK(c, c->ctxb.ensure((size_t)batch2 * tokens * Dc * 2)); c->ctx_bf16 = c->ctxb.as<bf16_t>();
+  for (auto& xl : c->xl) { API_CK(c, xl.kvb.ensure((size_t)batch2 * tokens * 2 * xl.C * 2)); xl.kv = xl.kvb.as<bf16_t>(); }
+  c->ctx_B2 = batch2; c->ctx_T = tokens;
   API_CK(c, launch_f32_to_bf16(ctx_emb, c->ctx_bf16, (long long)batch2 * tokens * Dc, st));
   for (auto& xl : c->xl) {
     GemmOpt o;
@@ -695,15 +727,13 @@ extern "C" int agd_set_context(agd_ctx* c, const float* ctx_emb, int batch2, int
 
 static int ensure_lat(agd_ctx* c, int B2, int L) {
   const size_t need = (size_t)B2 * L * L * 64;
-  if (need > c->lat_cap) {
-    c->lat_bf16 = dmalloc<bf16_t>(c, need); c->eps_nhwc = dmalloc<float>(c, (size_t)B2 * L * L * 4 * 4);
-    if (!c->lat_bf16 || !c->eps_nhwc) return -1;
-    c->lat_cap = need;
-  }
+  const int oc = c->cfg.out_channels > 4 ? c->cfg.out_channels : 4;
+  CK(c->latb.ensure(need * 2)); CK(c->epsb.ensure((size_t)B2 * L * L * oc * 4));
+  c->lat_bf16 = c->latb.as<bf16_t>(); c->eps_nhwc = c->epsb.as<float>();
   return 0;
 }
 
-extern "C" int agd_unet_forward(agd_ctx* c, const float* sample, int batch2, int L, float timestep, float* out, void* stream) {
+AGD_API int agd_unet_forward(agd_ctx* c, const float* sample, int batch2, int L, float timestep, float* out, void* stream) {
   API_CK(c, need_final(c));
   hipStream_t st = S(stream);
   API_CK(c, ensure_lat(c, batch2, L));
@@ -715,7 +745,7 @@ extern "C" int agd_unet_forward(agd_ctx* c, const float* sample, int batch2, int
 }
 
 // eps strides for cfg_ddim: NCHW eps handled by transposing through the NHWC kernel's stride form
-extern "C" int agd_cfg_ddim_step(agd_ctx* c, const float* eps, float* latents, int batch, int L, float guidance, float alpha_t,
+AGD_API int agd_cfg_ddim_step(agd_ctx* c, const float* eps, float* latents, int batch, int L, float guidance, float alpha_t,
                                  float alpha_prev, void* stream) {
   API_CK(c, need_final(c));
   hipStream_t st = S(stream);
@@ -731,7 +761,7 @@ extern "C" int agd_cfg_ddim_step(agd_ctx* c, const float* eps, float* latents, i
   return 0;
 }
 
-extern "C" int agd_denoise(agd_ctx* c, float* latents, int batch, int L, int n_steps, const float* timesteps, const float* alpha_t,
+AGD_API int agd_denoise(agd_ctx* c, float* latents, int batch, int L, int n_steps, const float* timesteps, const float* alpha_t,
                            const float* alpha_prev, float guidance, void* stream) {
   API_CK(c, need_final(c));
   hipStream_t st = S(stream);
@@ -763,7 +793,7 @@ extern "C" int agd_denoise(agd_ctx* c, float* latents, int batch, int L, int n_s
   return 0;
 }
 
-extern "C" int agd_vae_decode(agd_ctx* c, const float* latents, int batch, int L, unsigned char* out_u8, float* out_f32, void* stream) {
+AGD_API int agd_vae_decode(agd_ctx* c, const float* latents, int batch, int L, unsigned char* out_u8, float* out_f32, void* stream) {
   API_CK(c, need_final(c));
   hipStream_t st = S(stream);
   API_CK(c, ensure_lat(c, batch, L));
@@ -771,57 +801,56 @@ extern "C" int agd_vae_decode(agd_ctx* c, const float* latents, int batch, int L
   const long long npix = (long long)batch * S8 * S8;
   { ProfScope ps(c, st, PC_ELEM, 0);
     API_CK(c, launch_prep_latents(latents, c->lat_bf16, batch, c->cfg.vae_latent_channels, L * L, 64, 1, 1.0f / c->cfg.vae_scaling_factor, st)); }
-  float* img = nullptr;
-  if (hipMalloc((void**)&img, (size_t)npix * 4 * 4) != hipSuccess) { agd_set_error("vae image alloc failed"); return fail_ctx(c); }
+  API_CK(c, c->vae_imgb.ensure((size_t)npix * 4 * 4));     // grows once per (batch, side); stream-ordered reuse, no sync
+  float* img = c->vae_imgb.as<float>();
   int rc = vae_walk(c, st, c->lat_bf16, batch, L, img);
   if (rc == 0 && out_u8) { ProfScope ps(c, st, PC_ELEM, 0); rc = launch_image_u8(img, 4, out_u8, npix, c->cfg.vae_out_channels, st); }
   if (rc == 0 && out_f32) {
     // [npix][4] -> [npix][3] : "NCHW from NHWC" with HW=1 does exactly that per pixel
     rc = launch_nchw_from_nhwc_f32(img, 4, out_f32, (int)npix, c->cfg.vae_out_channels, 1, st);
   }
-  hipStreamSynchronize(st);
-  hipFree(img);
   return rc ? fail_ctx(c) : 0;
 }
 
 // ---- recorder -------------------------------------------------------------------------
-extern "C" int agd_record_config(agd_ctx* c, int mode, int is_train, int rec_tokens) {
+AGD_API int agd_record_config(agd_ctx* c, int mode, int is_train, int rec_tokens) {
   if (!c) return -1;
   if (mode < 0 || mode > 2) { agd_set_error("record_config: mode %d", mode); return fail_ctx(c); }
-  c->rec_mode = mode; c->rec_is_train = is_train; c->rec_T = rec_tokens;
+  c->rec_mode = mode; c->rec_is_train = is_train; c->rec_T_cfg = rec_tokens;   // takes effect at the next agd_record_reset
   return 0;
 }
 
-extern "C" int agd_record_reset(agd_ctx* c, int batch, int L, void* stream) {
+AGD_API int agd_record_reset(agd_ctx* c, int batch, int L, void* stream) {
   API_CK(c, need_final(c));
   hipStream_t st = S(stream);
-  const int T = c->rec_T > 0 ? c->rec_T : c->cfg.max_tokens;
+  if (batch < 1 || L < 1) { agd_set_error("record_reset: batch %d latent side %d", batch, L); return fail_ctx(c); }
+  const int T = c->rec_T_cfg > 0 ? c->rec_T_cfg : c->cfg.max_tokens;
   c->rec_T = T;
   if (c->rec_mode == 1) {
     for (auto& xl : c->xl) {
       if (xl.mid) continue;
       const int side = L >> xl.level;
-      if (side < 1 || (L / side) == 8) continue;
+      if (side < 1 || (L / side) == 8) { xl.acc = nullptr; xl.acc_side = 0; continue; }
+      // capacity-tracked: a larger batch / token count / side than the block was allocated for reallocates it
       const size_t n = (size_t)batch * xl.heads * T * side * side;
-      if (!xl.acc || xl.acc_side != side || c->rec_B != batch) { xl.acc = dmalloc<float>(c, n); if (!xl.acc) return fail_ctx(c); xl.acc_side = side; }
+      API_CK(c, xl.accb.ensure(n * 4)); xl.acc = xl.accb.as<float>(); xl.acc_side = side;
       if (hipMemsetAsync(xl.acc, 0, n * 4, st) != hipSuccess) { agd_set_error("memset acc"); return fail_ctx(c); }
     }
   } else if (c->rec_mode == 2) {
     const int Bp = c->rec_is_train ? 2 * batch : batch;   // `batch` = images; UNet batch is 2*batch under CFG
     const int Tc = c->ctx_T > 0 ? c->ctx_T : c->cfg.max_tokens;
-    if (!c->hook_sum || c->hook_Bp != Bp || c->rec_L != L) {
-      c->hook_sum = dmalloc<float>(c, (size_t)Bp * Tc * L * L); c->hook_scratch = dmalloc<float>(c, (size_t)Bp * Tc * L * L);
-      if (!c->hook_sum || !c->hook_scratch) return fail_ctx(c);
-      c->hook_Bp = Bp;
-    }
-    if (hipMemsetAsync(c->hook_sum, 0, (size_t)Bp * Tc * L * L * 4, st) != hipSuccess) { agd_set_error("memset hook"); return fail_ctx(c); }
+    const size_t n = (size_t)Bp * Tc * L * L;
+    API_CK(c, c->hook_sumb.ensure(n * 4)); API_CK(c, c->hook_scratchb.ensure(n * 4));
+    c->hook_sum = c->hook_sumb.as<float>(); c->hook_scratch = c->hook_scratchb.as<float>();
+    c->hook_Bp = Bp; c->hook_T = Tc;
+    if (hipMemsetAsync(c->hook_sum, 0, n * 4, st) != hipSuccess) { agd_set_error("memset hook"); return fail_ctx(c); }
     c->hook_count = 0;
   }
   c->rec_B = batch; c->rec_L = L;
   return 0;
 }
 
-extern "C" int agd_daam_global(agd_ctx* c, int img, int rows, float* out, void* stream) {
+AGD_API int agd_daam_global(agd_ctx* c, int img, int rows, float* out, void* stream) {
   API_CK(c, need_final(c));
   hipStream_t st = S(stream);
   std::vector<HeatLayer> hl; int total = 0;
@@ -834,73 +863,116 @@ extern "C" int agd_daam_global(agd_ctx* c, int img, int rows, float* out, void* 
   if (hl.empty() || c->rec_mode != 1) { agd_set_error("No heat maps found. Did you forget to call `with trace(...)`?"); c->err = g_err; return -2; }
   if (rows > c->rec_T || img >= c->rec_B) { agd_set_error("daam_global: rows %d > recorded %d or img %d >= %d", rows, c->rec_T, img, c->rec_B); return fail_ctx(c); }
   { ProfScope ps(c, st, PC_HEAT, 0); API_CK(c, launch_daam_global(hl.data(), (int)hl.size(), total, rows, c->rec_L, img, out, st)); }
-  hipStreamSynchronize(st);
   return 0;
 }
 
-extern "C" int agd_hook_count(agd_ctx* c) { return c ? c->hook_count : 0; }
+AGD_API int agd_hook_count(agd_ctx* c) { return c ? c->hook_count : 0; }
 
-extern "C" int agd_hook_last_map(agd_ctx* c, float* out, int n_query, void* stream) {
+AGD_API int agd_hook_last_map(agd_ctx* c, float* out, int n_query, void* stream) {
   API_CK(c, need_final(c));
   hipStream_t st = S(stream);
   if (c->hook_count == 0 || !c->hook_scratch) { agd_set_error("No heat maps found."); c->err = g_err; return -2; }
-  const size_t n = (size_t)c->hook_Bp * c->ctx_T * n_query;
+  const size_t n = (size_t)c->hook_Bp * c->hook_T * n_query;
   if (hipMemcpyAsync(out, c->hook_scratch, n * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) { agd_set_error("hook_last_map copy"); return fail_ctx(c); }
-  hipStreamSynchronize(st);
   return 0;
 }
 
-extern "C" int agd_hook_global(agd_ctx* c, float* out, void* stream) {
+AGD_API int agd_hook_global(agd_ctx* c, float* out, void* stream) {
   API_CK(c, need_final(c));
   hipStream_t st = S(stream);
   if (c->hook_count == 0 || !c->hook_sum) { agd_set_error("No heat maps found."); c->err = g_err; return -2; }
-  const long long n = (long long)c->hook_Bp * c->ctx_T * c->rec_L * c->rec_L;
+  const long long n = (long long)c->hook_Bp * c->hook_T * c->rec_L * c->rec_L;
   hipMemcpyAsync(out, c->hook_sum, (size_t)n * 4, hipMemcpyDeviceToDevice, st);
   API_CK(c, launch_scale(out, n, 1.0f / (float)c->hook_count, st));
-  hipStreamSynchronize(st);
   return 0;
 }
 
-extern "C" int agd_cross_attn(agd_ctx* c, const char* layer, const float* hidden, const float* ctx_emb, int batch2, int n_query,
-                              int tokens, float* out, int record, void* stream) {
+// The processor seam: one `Attention` module call of the UNet, hook.py:83-122 in full.
+//   layer "...attn2" + ctx_emb        -> cross-attention (is_cross, hook.py:95-99), feeds the recorder when record != 0
+//   layer "...attn1" + ctx_emb NULL   -> self-attention (encoder_hidden_states = hidden_states), records nothing
+//   attn_mask: additive fp32 [batch2][keys] or NULL (hook.py:92 prepare_attention_mask -> hook.py:108 get_attention_scores)
+// Output is to_out[0](attention) + bias (to_out[1] is Dropout(0)); the residual is the caller's (BasicTransformerBlock).
+AGD_API int agd_attn_processor(agd_ctx* c, const char* layer, const float* hidden, const float* ctx_emb, const float* attn_mask,
+                               int batch2, int n_query, int tokens, float* out, int record, void* stream) {
   API_CK(c, need_final(c));
   hipStream_t st = S(stream);
-  auto it = c->xl_idx.find(std::string("unet.") + layer);
-  if (it == c->xl_idx.end()) it = c->xl_idx.find(layer);
-  if (it == c->xl_idx.end()) { agd_set_error("cross_attn: unknown layer '%s'", layer); return fail_ctx(c); }
+  if (!layer || !hidden || !out || batch2 < 1 || n_query < 1) { agd_set_error("attn_processor: bad argument"); return fail_ctx(c); }
+  std::string name(layer);
+  if (name.compare(0, 5, "unet.") != 0) name = "unet." + name;
+  const bool is_attn2 = ends_with(name, "attn2"), is_attn1 = ends_with(name, "attn1");
+  if (!is_attn1 && !is_attn2) { agd_set_error("attn_processor: layer '%s' is neither an attn1 nor an attn2 module", layer); return fail_ctx(c); }
+  const std::string t = name.substr(0, name.size() - 5);
+  auto it = c->xl_idx.find(t + "attn2");
+  if (it == c->xl_idx.end()) { agd_set_error("attn_processor: unknown layer '%s'", layer); return fail_ctx(c); }
   XLayer& xl = c->xl[it->second];
-  if (ctx_emb) API_CK(c, agd_set_context(c, ctx_emb, batch2, tokens, stream));
-  if (c->ctx_B2 != batch2) { agd_set_error("cross_attn: context batch mismatch"); return fail_ctx(c); }
   const int C = xl.C, M = batch2 * n_query;
+  if (is_attn2) {
+    // cross-attention needs the text context (a self-attention call on attn2 would feed C-wide rows to a ctx_dim-wide to_k)
+    if (ctx_emb) API_CK(c, agd_set_context(c, ctx_emb, batch2, tokens, stream));
+    else if (c->ctx_T <= 0) { agd_set_error("attn_processor: attn2 called without encoder_hidden_states and no context set"); return fail_ctx(c); }
+    if (c->ctx_B2 != batch2) { agd_set_error("attn_processor: context batch %d != %d", c->ctx_B2, batch2); return fail_ctx(c); }
+  } else if (ctx_emb) {
+    agd_set_error("attn_processor: attn1 is the self-attention module (encoder_hidden_states must be NULL)"); return fail_ctx(c);
+  }
   c->arena.release(0);
-  bf16_t* x = (bf16_t*)c->arena.alloc((size_t)M * C * 2); bf16_t* q = (bf16_t*)c->arena.alloc((size_t)M * C * 2);
-  bf16_t* att = (bf16_t*)c->arena.alloc((size_t)M * C * 2); float* o32 = out;
+  bf16_t* x = (bf16_t*)c->arena.alloc((size_t)M * C * 2);
+  bf16_t* q = (bf16_t*)c->arena.alloc((size_t)M * (is_attn2 ? 1 : 3) * C * 2);
+  bf16_t* att = (bf16_t*)c->arena.alloc((size_t)M * C * 2);
   if (!x || !q || !att) return fail_ctx(c);
   API_CK(c, launch_f32_to_bf16(hidden, x, (long long)M * C, st));
-  const std::string t = xl.name.substr(0, xl.name.size() - 5);   // strip "attn2"
-  const WMat* wq = getW(c, t + "attn2.to_q.weight"); const WMat* wo = getW(c, t + "attn2.to_out.0.weight"); const float* bo = getV(c, t + "attn2.to_out.0.bias");
-  if (!wq || !wo || !bo) return fail_ctx(c);
-  { GemmOpt o; API_CK(c, run_conv(c, st, x, C, nullptr, 0, 1, 1, M, *wq, 1, q, o, c->zero_page)); }
-  API_CK(c, cross_attention(c, st, xl, q, batch2, n_query, att, record != 0));
-  { GemmOpt o; o.bias = bo; o.out_f32 = 1; API_CK(c, run_conv(c, st, att, C, nullptr, 0, 1, 1, M, *wo, 1, o32, o, c->zero_page)); }
+  const std::string an = t + (is_attn2 ? "attn2." : "attn1.");
+  const WMat* wo = getW(c, an + "to_out.0.weight"); const float* bo = getV(c, an + "to_out.0.bias");
+  if (!wo || !bo) return fail_ctx(c);
+  if (is_attn2) {
+    const WMat* wq = getW(c, an + "to_q.weight"); if (!wq) return fail_ctx(c);
+    { GemmOpt o; API_CK(c, run_conv(c, st, x, C, nullptr, 0, 1, 1, M, *wq, 1, q, o, c->zero_page)); }
+    API_CK(c, cross_attention(c, st, xl, q, batch2, n_query, att, record != 0, attn_mask));
+  } else {
+    const WMat* wqkv = getW(c, t + "attn1.qkv"); if (!wqkv) return fail_ctx(c);
+    { GemmOpt o; API_CK(c, run_conv(c, st, x, C, nullptr, 0, 1, 1, M, *wqkv, 1, q, o, c->zero_page)); }
+    AttnP a{}; a.q = q; a.k = q + C; a.v = q + 2 * C; a.o = att;
+    a.ldq = a.ldk = a.ldv = 3 * C; a.ldo = C; a.sq = a.sk = a.sv = (long long)n_query * 3 * C; a.so = (long long)n_query * C;
+    a.B = batch2; a.H = xl.heads; a.D = C / xl.heads; a.Nq = n_query; a.Nk = n_query; a.scale = 1.0f / sqrtf((float)(C / xl.heads));
+    a.mask = attn_mask;
+    API_CK(c, run_attention(c, st, PC_ATTN_SELF, a));
+  }
+  { GemmOpt o; o.bias = bo; o.out_f32 = 1; API_CK(c, run_conv(c, st, att, C, nullptr, 0, 1, 1, M, *wo, 1, out, o, c->zero_page)); }
   return 0;
+}
+
+AGD_API int agd_cross_attn(agd_ctx* c, const char* layer, const float* hidden, const float* ctx_emb, int batch2, int n_query,
+                           int tokens, float* out, int record, void* stream) {
+  return agd_attn_processor(c, layer, hidden, ctx_emb, nullptr, batch2, n_query, tokens, out, record, stream);
 }
 
 // ---- profiling ------------------------------------------------------------------------
-extern "C" int agd_profile_begin(agd_ctx* c) {
+AGD_API int agd_profile_begin(agd_ctx* c) {
   if (!c) return -1;
   c->prof.clear(); c->ev_used = 0; c->prof_on = true;
   for (int i = 0; i < AGD_N_CLASSES; ++i) c->launches[i] = 0;
   return 0;
 }
-extern "C" int agd_profile_end(agd_ctx* c, double* ms, double* flops, long long* launches) {
-  if (!c) return -1;
+// per class: Sum of HIP-event ms, algorithmic flop and HBM bytes, launches, and roof_ms = Sum over launches of
+// max(flop / mfma_peak, bytes / hbm_peak) -- the time the launch's BINDING roof allows (short-K GEMMs are HBM-bound)
+AGD_API int agd_profile_end_ex(agd_ctx* c, double mfma_peak_flops, double hbm_peak_bytes, double* ms, double* flops, double* bytes,
+                               double* roof_ms, double* roof_ms_hbm_bound, long long* launches) {
+  if (!c || !ms || !flops || !bytes || !roof_ms || !launches) return -1;
   hipSetDevice(c->device);
   hipDeviceSynchronize();
-  for (int i = 0; i < AGD_N_CLASSES; ++i) { ms[i] = 0; flops[i] = 0; launches[i] = c->launches[i]; }
-  for (auto& pe : c->prof) { float t = 0; hipEventElapsedTime(&t, pe.a, pe.b); ms[pe.cls] += t; flops[pe.cls] += pe.flops; }
+  for (int i = 0; i < AGD_N_CLASSES; ++i) { ms[i] = 0; flops[i] = 0; bytes[i] = 0; roof_ms[i] = 0; launches[i] = c->launches[i]; if (roof_ms_hbm_bound) roof_ms_hbm_bound[i] = 0; }
+  for (auto& pe : c->prof) {
+    float t = 0; hipEventElapsedTime(&t, pe.a, pe.b);
+    ms[pe.cls] += t; flops[pe.cls] += pe.flops; bytes[pe.cls] += pe.bytes;
+    const double tm = mfma_peak_flops > 0 ? pe.flops / mfma_peak_flops * 1e3 : 0, th = hbm_peak_bytes > 0 ? pe.bytes / hbm_peak_bytes * 1e3 : 0;
+    roof_ms[pe.cls] += tm > th ? tm : th;
+    if (roof_ms_hbm_bound && th > tm) roof_ms_hbm_bound[pe.cls] += th;
+  }
   c->prof_on = false; c->prof.clear(); c->ev_used = 0;
   return 0;
+}
+AGD_API int agd_profile_end(agd_ctx* c, double* ms, double* flops, long long* launches) {
+  double by[AGD_N_CLASSES], rf[AGD_N_CLASSES];
+  return agd_profile_end_ex(c, 0, 0, ms, flops, by, rf, nullptr, launches);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -920,7 +992,7 @@ static bf16_t* op_zero_page() {
 // NCHW fp32 <-> NHWC bf16 (padded) helpers built from the library kernels
 static int to_nhwc_bf16(const float* x, bf16_t* y, int B, int C, int HW, int Cpad, hipStream_t st) { return launch_prep_latents(x, y, B, C, HW, Cpad, 1, 1.0f, st); }
 
-extern "C" int agd_op_conv2d(const float* x, const float* w, const float* bias, float* y, int B, int Cin, int H, int W, int Cout,
+AGD_API int agd_op_conv2d(const float* x, const float* w, const float* bias, float* y, int B, int Cin, int H, int W, int Cout,
                              int ksize, int stride, int pad, int upsample, void* stream) {
   hipStream_t st = S(stream); Tmp tmp;
   if (pad != (ksize == 3 ? 1 : 0)) { agd_set_error("op_conv2d: pad must be 1 for 3x3, 0 for 1x1"); return -1; }
@@ -939,7 +1011,7 @@ extern "C" int agd_op_conv2d(const float* x, const float* w, const float* bias, 
   return 0;
 }
 
-extern "C" int agd_op_linear(const float* x, const float* w, const float* bias, const float* residual, float* y, int M, int K, int N,
+AGD_API int agd_op_linear(const float* x, const float* w, const float* bias, const float* residual, float* y, int M, int K, int N,
                              int geglu, void* stream) {
   hipStream_t st = S(stream); Tmp tmp;
   if (K % 64) { agd_set_error("op_linear: K must be a multiple of 64"); return -1; }
@@ -957,11 +1029,11 @@ extern "C" int agd_op_linear(const float* x, const float* w, const float* bias, 
   return 0;
 }
 
-extern "C" int agd_op_groupnorm(const float* x, const float* gamma, const float* beta, float* y, int B, int C, int HW, int groups,
+AGD_API int agd_op_groupnorm(const float* x, const float* gamma, const float* beta, float* y, int B, int C, int HW, int groups,
                                 float eps, int silu, void* stream) {
   hipStream_t st = S(stream); Tmp tmp;
   bf16_t* xb = tmp.get<bf16_t>((size_t)B * HW * C); bf16_t* yb = tmp.get<bf16_t>((size_t)B * HW * C);
-  float* ws = tmp.get<float>((size_t)agd_groupnorm_ws_floats(B, C, HW, groups)); float* yf = tmp.get<float>((size_t)B * HW * C);
+  float* ws = tmp.get<float>((size_t)groupnorm_ws_floats(B, C, HW, groups)); float* yf = tmp.get<float>((size_t)B * HW * C);
   if (!xb || !yb || !ws || !yf) return -1;
   CK(to_nhwc_bf16(x, xb, B, C, HW, C, st));
   GroupNormP g{}; g.x0 = xb; g.C0 = C; g.y = yb; g.gamma = gamma; g.beta = beta; g.B = B; g.HW = HW; g.groups = groups; g.eps = eps; g.silu = silu; g.ws = ws;
@@ -972,7 +1044,7 @@ extern "C" int agd_op_groupnorm(const float* x, const float* gamma, const float*
   return 0;
 }
 
-extern "C" int agd_op_layernorm(const float* x, const float* gamma, const float* beta, float* y, int rows, int C, float eps, void* stream) {
+AGD_API int agd_op_layernorm(const float* x, const float* gamma, const float* beta, float* y, int rows, int C, float eps, void* stream) {
   hipStream_t st = S(stream); Tmp tmp;
   bf16_t* xb = tmp.get<bf16_t>((size_t)rows * C); bf16_t* yb = tmp.get<bf16_t>((size_t)rows * C);
   if (!xb || !yb) return -1;
@@ -983,7 +1055,7 @@ extern "C" int agd_op_layernorm(const float* x, const float* gamma, const float*
   return 0;
 }
 
-extern "C" int agd_op_attention(const float* q, const float* k, const float* v, float* o, int B, int H, int D, int Nq, int Nk,
+AGD_API int agd_op_attention(const float* q, const float* k, const float* v, float* o, int B, int H, int D, int Nq, int Nk,
                                 float scale, float* probs_out, void* stream) {
   hipStream_t st = S(stream); Tmp tmp;
   const int C = H * D;
@@ -1007,7 +1079,7 @@ extern "C" int agd_op_attention(const float* q, const float* k, const float* v, 
   return 0;
 }
 
-extern "C" int agd_op_bicubic_clamp_mean(const float* maps, int n_maps, int T, int side, int S_, float* out, void* stream) {
+AGD_API int agd_op_bicubic_clamp_mean(const float* maps, int n_maps, int T, int side, int S_, float* out, void* stream) {
   hipStream_t st = S(stream);
   // n_maps accumulators of [T][side][side]: treat as one layer with n_maps "heads"
   HeatLayer h; h.acc = maps; h.side = side; h.heads = n_maps; h.head_stride = (long long)T * side * side; h.img_stride = 0;
@@ -1029,7 +1101,7 @@ static void fill_rand(bf16_t* p, long long n, unsigned seed, float scale) {
   hipLaunchKernelGGL(fill_random_bf16, dim3(4096), dim3(256), 0, 0, p, n, seed, scale);
 }
 
-extern "C" int agd_bench_conv(int B, int H, int W, int C0, int C1, int Cout, int ksize, int stride, int up, int geglu,
+AGD_API int agd_bench_conv(int B, int H, int W, int C0, int C1, int Cout, int ksize, int stride, int up, int geglu,
                               int with_residual, int iters, double* ms_out) {
   Tmp tmp;
   const int Ctot = C0 + C1, taps = ksize * ksize, pad = ksize == 3 ? 1 : 0;
@@ -1057,7 +1129,7 @@ extern "C" int agd_bench_conv(int B, int H, int W, int C0, int C1, int Cout, int
   return 0;
 }
 
-extern "C" int agd_bench_attention(int B, int H, int D, int Nq, int Nk, int record, int iters, double* ms_out) {
+AGD_API int agd_bench_attention(int B, int H, int D, int Nq, int Nk, int record, int iters, double* ms_out) {
   Tmp tmp;
   const int C = H * D;
   const bool self = (Nq == Nk);
@@ -1084,10 +1156,10 @@ extern "C" int agd_bench_attention(int B, int H, int D, int Nq, int Nk, int reco
   return 0;
 }
 
-extern "C" int agd_bench_groupnorm(int B, int HW, int C, int iters, double* ms_out) {
+AGD_API int agd_bench_groupnorm(int B, int HW, int C, int iters, double* ms_out) {
   Tmp tmp;
   bf16_t* x = tmp.get<bf16_t>((size_t)B * HW * C); bf16_t* y = tmp.get<bf16_t>((size_t)B * HW * C);
-  float* ws = tmp.get<float>((size_t)agd_groupnorm_ws_floats(B, C, HW, 32)); float* g = tmp.get<float>(2 * C);
+  float* ws = tmp.get<float>((size_t)groupnorm_ws_floats(B, C, HW, 32)); float* g = tmp.get<float>(2 * C);
   if (!x || !y || !ws || !g) return -1;
   fill_rand(x, (long long)B * HW * C, 7, 1.0f); hipMemset(g, 0, 2 * C * 4);
   GroupNormP p{}; p.x0 = x; p.C0 = C; p.y = y; p.gamma = g; p.beta = g + C; p.B = B; p.HW = HW; p.groups = 32; p.eps = 1e-5f; p.silu = 1; p.ws = ws;
@@ -1148,13 +1220,13 @@ const PilCoeffs* pil_coeffs(int in_size, int out_size) {
 }
 }  // namespace
 
-extern "C" int agd_op_heatmap_u8(const float* hm, int n, int npix, unsigned char* out, void* stream) {
+AGD_API int agd_op_heatmap_u8(const float* hm, int n, int npix, unsigned char* out, void* stream) {
   CK(launch_heatmap_u8(hm, n, npix, out, S(stream)));
   return 0;
 }
 
 // in [n][H][W][C] uint8 -> out [n][oh][ow][C], == PIL Image.resize((ow, oh)) per image (default BICUBIC)
-extern "C" int agd_op_resize_u8_pil(const unsigned char* in, int n, int H, int W, int C, int oh, int ow, unsigned char* out, void* stream) {
+AGD_API int agd_op_resize_u8_pil(const unsigned char* in, int n, int H, int W, int C, int oh, int ow, unsigned char* out, void* stream) {
   hipStream_t st = S(stream);
   const unsigned char* src = in;
   unsigned char* tmp = nullptr;
@@ -1176,7 +1248,7 @@ extern "C" int agd_op_resize_u8_pil(const unsigned char* in, int n, int H, int W
   return 0;
 }
 
-extern "C" int agd_op_stack_heatmaps(const unsigned char* obj, const unsigned char* fg, const unsigned char* bg, long long npix,
+AGD_API int agd_op_stack_heatmaps(const unsigned char* obj, const unsigned char* fg, const unsigned char* bg, long long npix,
                                      unsigned char* rgb, unsigned char* inv, void* stream) {
   CK(launch_stack_heatmaps(obj, fg, bg, npix, rgb, inv, S(stream)));
   return 0;
@@ -1186,7 +1258,7 @@ extern "C" int agd_op_stack_heatmaps(const unsigned char* obj, const unsigned ch
 // ---------------------------------------------------------------------------------------
 // CLIP text encoder: `pipeline.text_encoder(input_ids)[0]`
 // ---------------------------------------------------------------------------------------
-extern "C" int agd_text_set_embedding_row(agd_ctx* c, int token_id, const float* row) {
+AGD_API int agd_text_set_embedding_row(agd_ctx* c, int token_id, const float* row) {
   API_CK(c, need_final(c));
   const WMat* te = getW(c, "text.embeddings.token_embedding.weight"); if (!te) return fail_ctx(c);
   if (token_id < 0 || token_id >= te->N + kTextExtraRows) { agd_set_error("text: token id %d out of range (vocab %d + %d)", token_id, te->N, kTextExtraRows); return fail_ctx(c); }
@@ -1197,7 +1269,7 @@ extern "C" int agd_text_set_embedding_row(agd_ctx* c, int token_id, const float*
   return 0;
 }
 
-extern "C" int agd_text_encode(agd_ctx* c, const int* input_ids, int B, int T, float* out, void* stream) {
+AGD_API int agd_text_encode(agd_ctx* c, const int* input_ids, int B, int T, float* out, void* stream) {
   API_CK(c, need_final(c));
   hipStream_t st = S(stream);
   const agd_config& g = c->cfg;
@@ -1244,7 +1316,7 @@ extern "C" int agd_text_encode(agd_ctx* c, const int* input_ids, int B, int T, f
 
 
 // `vae.encode(image).latent_dist` moments: image fp32 NCHW [B,3,S,S] in [-1,1] -> mean, logvar fp32 NCHW [B,lc,L,L]
-extern "C" int agd_vae_encode(agd_ctx* c, const float* image, int batch, int side, float* mean_out, float* logvar_out, void* stream) {
+AGD_API int agd_vae_encode(agd_ctx* c, const float* image, int batch, int side, float* mean_out, float* logvar_out, void* stream) {
   API_CK(c, need_final(c));
   hipStream_t st = S(stream);
   const int lc = c->cfg.vae_latent_channels, L = side >> (c->cfg.vae_n_levels - 1);

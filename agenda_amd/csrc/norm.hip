@@ -161,7 +161,7 @@ int launch_groupnorm(const GroupNormP& p, hipStream_t st) {
 }
 
 // required workspace floats for a groupnorm call (host helper)
-extern "C" long long agd_groupnorm_ws_floats(int B, int C, int HW, int groups) {
+long long groupnorm_ws_floats(int B, int C, int HW, int groups) {
   const GnGeom g = gn_geom(B, C, HW);
   return (long long)B * g.nchunk * groups * 2 + 2LL * B * C;
 }

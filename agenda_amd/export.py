@@ -17,6 +17,8 @@ def heatmaps_to_u8(hm: torch.Tensor) -> torch.Tensor:
     npix = x.shape[-1] * x.shape[-2]
     n = x.numel() // npix
     out = torch.empty(x.shape, device=x.device, dtype=torch.uint8)
+    if x.numel() == 0:                      # images-only runs (no --word_token_heatmaps): nothing to convert
+        return out
     _lib.check(lib.agd_op_heatmap_u8(_lib.ptr(x), n, npix, _lib.ptr(out), _lib.current_stream_ptr()), None, "agd_op_heatmap_u8")
     return out
 
@@ -30,6 +32,8 @@ def resize_u8(img: torch.Tensor, out_hw) -> torch.Tensor:
     n, H, W, Cc = x.shape
     oh, ow = out_hw
     out = torch.empty(n, oh, ow, Cc, device=x.device, dtype=torch.uint8)
+    if n == 0:
+        return out[..., 0] if squeeze else out
     _lib.check(lib.agd_op_resize_u8_pil(_lib.ptr(x), n, H, W, Cc, oh, ow, _lib.ptr(out), _lib.current_stream_ptr()), None,
                "agd_op_resize_u8_pil")
     return out[..., 0] if squeeze else out

@@ -89,21 +89,55 @@ def generate_batch(pipe, seeds: Sequence[int], words: Sequence[str], prompt: Opt
     return out.images, torch.stack(hms)
 
 
-def gather_outputs(images: torch.Tensor, heatmaps: torch.Tensor):
-    """The final exchange step: all_gather images + heat maps across ranks (no-op for world 1)."""
+def gather_outputs(images: torch.Tensor, heatmaps: torch.Tensor, seeds: Optional[Sequence[int]] = None, max_batch: Optional[int] = None):
+    """The final exchange step: ONE all_gather of images + heat maps (+ their seeds) across ranks.
+
+    Ranks may hold different batch sizes (the last, ragged round of `shard_seeds`; even zero images): every rank pads its
+    tensors to `max_batch` rows, the padding is dropped after the collective, and rows come back ordered by seed.
+    `max_batch` must be the same on every rank (defaults to the local batch: the equal-batch case of bench.py).
+    Returns (images, heatmaps) when `seeds` is None (equal batches, rank-interleaved = global seed order of
+    `shard_seeds`), else (seeds, images, heatmaps).  No-op for world size 1."""
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
-        return images, heatmaps
+        return (images, heatmaps) if seeds is None else (list(seeds), images, heatmaps)
     w = dist.get_world_size()
-    il = [torch.empty_like(images) for _ in range(w)]
-    hl = [torch.empty_like(heatmaps) for _ in range(w)]
-    dist.all_gather(il, images.contiguous())
-    dist.all_gather(hl, heatmaps.contiguous())
-    # interleave back to global seed order: seed = rank + world * local_index
-    return torch.stack(il, 1).flatten(0, 1), torch.stack(hl, 1).flatten(0, 1)
+    b = images.shape[0]
+    mb = int(max_batch) if max_batch is not None else b
+    if b > mb:
+        raise ValueError(f"local batch {b} > max_batch {mb}")
+
+    def pad(t):
+        t = t.contiguous()
+        if t.shape[0] == mb:
+            return t
+        return torch.cat([t, t.new_zeros((mb - t.shape[0],) + tuple(t.shape[1:]))])
+
+    def gather(t):
+        """one collective per tensor into a single [world * mb, ...] buffer (no per-rank list copies)"""
+        t = pad(t)
+        out = t.new_empty((w * mb,) + tuple(t.shape[1:]))
+        try:
+            dist.all_gather_into_tensor(out, t)
+        except (RuntimeError, NotImplementedError):           # a backend without the flat form
+            parts = [torch.empty_like(t) for _ in range(w)]
+            dist.all_gather(parts, t)
+            out = torch.cat(parts)
+        return out
+
+    ids = torch.full((mb,), -1, dtype=torch.int64, device=images.device)
+    if seeds is not None and b:
+        ids[:b] = torch.as_tensor(list(seeds), dtype=torch.int64, device=images.device)
+    elif b:
+        ids[:b] = torch.arange(b, device=images.device) * w + dist.get_rank()     # seed = rank + world * local_index
+    gi, gh, gs = gather(images), gather(heatmaps), gather(ids)
+    keep = torch.nonzero(gs >= 0).flatten()
+    order = keep[torch.argsort(gs[keep])]
+    if seeds is None:
+        return gi[order], gh[order]
+    return gs[order].tolist(), gi[order], gh[order]
 
 
-def save_outputs(save_dir: str, seeds, images_u8, heatmaps, words, image_size: int, stack_words=None):
+def save_outputs(save_dir: str, seeds, images_u8, heatmaps, words, image_size: int, stack_words=None, exported: bool = False):
     """data_generation.py:60-62,66-86: resize, skip all-black, images/ + daam_<word>_heatmaps/ PNGs.
     CUDA tensors take the device export path (agenda_amd/export.py: min-max -> uint8 -> PIL-exact bicubic resize on
     the GPU, one D2H copy of the finished buffers); numpy inputs take the reference's literal host code.  Both
@@ -111,7 +145,9 @@ def save_outputs(save_dir: str, seeds, images_u8, heatmaps, words, image_size: i
     daam_stack_heatmaps/ + daam_inv_heatmaps/ as postprocess_heatmap.py:44-50 would."""
     from PIL import Image
     os.makedirs(os.path.join(save_dir, "images"), exist_ok=True)
-    if torch.is_tensor(images_u8) and images_u8.is_cuda:
+    if exported:                                # already the final payloads (export_batch ran before the gather)
+        small, hm = (t.cpu().numpy() if torch.is_tensor(t) else np.asarray(t) for t in (images_u8, heatmaps))
+    elif torch.is_tensor(images_u8) and images_u8.is_cuda:
         from . import export
         small, hm = export.export_batch(images_u8, heatmaps, image_size)
         small, hm = small.cpu().numpy(), hm.cpu().numpy()
@@ -152,6 +188,8 @@ def parse_args(argv=None):
     p.add_argument("--synthetic-config", type=str, default="sd15", help="architecture for synthetic weights when no checkpoint is given")
     p.add_argument("--stack", type=str, default=None, nargs=3, metavar=("OBJ", "FG", "BG"),
                    help="also write daam_stack_heatmaps/ + daam_inv_heatmaps/ for these three words (postprocess_heatmap.py)")
+    p.add_argument("--no-gather", action="store_true",
+                   help="multi-GPU: every rank writes its own files instead of the final all_gather to rank 0")
     return p.parse_args(argv)
 
 
@@ -161,9 +199,14 @@ def main(argv=None):
     args = parse_args(argv)
     rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
+    if "AGD_FORCE_DEVICE" in os.environ:          # rehearsal of the multi-rank path on a 1-GPU box (ranks share one card)
+        local = int(os.environ["AGD_FORCE_DEVICE"])
     torch.cuda.set_device(local)
-    if world > 1:
-        dist.init_process_group("nccl")
+    own_group = False
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(os.environ.get("AGD_DIST_BACKEND", "nccl"))          # "nccl" = RCCL on ROCm
+        own_group = True
     pipe = (StableDiffusionPipeline.from_pretrained(args.pretrained_model_path, device=local)
             if args.pretrained_model_path else StableDiffusionPipeline.from_synthetic(args.synthetic_config, device=local))
     embeds = torch.load(args.learnable_tokens_embedding_path) if args.learnable_tokens_embedding_path else {}
@@ -175,13 +218,36 @@ def main(argv=None):
         words = args.word_token_heatmaps if args.word_token_heatmaps is not None else []
         prompt = " ".join(args.prompt.replace("{}", " ").split())
     seeds = shard_seeds(args.num_images, rank, world)
-    for i in range(0, len(seeds), args.batch_size):
-        chunk = seeds[i:i + args.batch_size]
-        imgs, hms = generate_batch(pipe, chunk, words, prompt=prompt, num_inference_steps=args.num_inference_steps)
-        save_outputs(args.save_dir, chunk, imgs, hms, words, args.image_size, stack_words=args.stack)
+    gather = world > 1 and not args.no_gather
+    # every rank joins every round (the collective count must match): ranks whose shard ran out contribute zero rows
+    per_rank = (args.num_images + world - 1) // world
+    rounds = (per_rank + args.batch_size - 1) // args.batch_size if gather else (len(seeds) + args.batch_size - 1) // args.batch_size
+    S = args.image_size
+    for r in range(rounds):
+        chunk = seeds[r * args.batch_size:(r + 1) * args.batch_size]
+        if chunk:
+            imgs, hms = generate_batch(pipe, chunk, words, prompt=prompt, num_inference_steps=args.num_inference_steps)
+        if not gather:
+            save_outputs(args.save_dir, chunk, imgs, hms, words, S, stack_words=args.stack)
+            continue
+        # export on the producing GPU (resize 512 -> S, min-max -> uint8 -> resize), then ONE gather of the finished
+        # payloads (S*S*3 + S*S per word bytes per image instead of the full-size tensors); rank 0 writes the files
+        from . import export
+        dev = torch.device("cuda", local)
+        if chunk:
+            small, hm8 = export.export_batch(imgs, hms, S)
+        else:
+            small = torch.zeros(0, S, S, 3, dtype=torch.uint8, device=dev)
+            hm8 = torch.zeros(0, len(words), S, S, dtype=torch.uint8, device=dev)
+        if dist.get_backend() == "gloo":
+            small, hm8 = small.cpu(), hm8.cpu()
+        all_seeds, small, hm8 = gather_outputs(small, hm8, seeds=chunk, max_batch=args.batch_size)
+        if rank == 0:
+            save_outputs(args.save_dir, all_seeds, small, hm8, words, S, stack_words=args.stack, exported=True)
     if world > 1:
         dist.barrier()
-        dist.destroy_process_group()
+        if own_group:
+            dist.destroy_process_group()
 
 
 if __name__ == "__main__":

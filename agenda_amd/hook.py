@@ -7,9 +7,12 @@ finetune_sd_token.py:755-757) it switches the fused HIP cross-attention kernel i
 recording: per call, head-mean probability maps (hook.py:55) of the kept batch rows
 (hook.py:48-49) are bicubic-upsampled, clamped and summed on the GPU as they are produced, so the
 [B*H, N, 77] tensor of hook.py:108 and the python list of hook.py:112 never exist.
-Called directly as a processor it routes one layer through the C-ABI seam `agd_cross_attn`.
+Called directly as a processor it routes one `Attention` module (attn1 or attn2, with or without an
+attention mask) through the C-ABI seam `agd_attn_processor`.
 """
 from __future__ import annotations
+
+import math
 
 import torch
 
@@ -58,20 +61,34 @@ class UNetCrossAttentionHooker:
         return self._pipe.engine.hook_global(self._bp, self._tokens, self._side)
 
     def __call__(self, attn, hidden_states, encoder_hidden_states=None, attention_mask=None):
-        """hook.py:83-122 for one cross-attention layer through the C-ABI seam."""
+        """hook.py:83-122 for one `Attention` module through the C-ABI seam (`agd_attn_processor`):
+        cross-attention (`encoder_hidden_states` given; the head-mean map is appended, hook.py:110-112) or
+        self-attention (`encoder_hidden_states is None`, hook.py:95-99; records nothing).  `attention_mask` is the
+        additive float mask of diffusers' `prepare_attention_mask` (hook.py:92): [B, keys] or [B, 1, keys]."""
         self._need_pipe()
-        if attention_mask is not None:
-            raise NotImplementedError("attention_mask is None on the SD path (hook.py:92)")
-        if encoder_hidden_states is None:
-            raise NotImplementedError("self-attention runs inside the fused UNet walk; the seam covers attn2")
         b2, n, _ = hidden_states.shape
-        side = int(round(n ** 0.5))
+        mask = None
+        if attention_mask is not None:
+            mask = attention_mask.to(torch.float32)
+            if mask.ndim == 3 and mask.shape[1] == 1:
+                mask = mask[:, 0]
+            n_keys = n if encoder_hidden_states is None else encoder_hidden_states.shape[1]
+            if mask.ndim != 2 or tuple(mask.shape) != (b2, n_keys):
+                raise ValueError(f"attention_mask must be [B, keys] or [B, 1, keys] = ({b2}, {n_keys}), got {tuple(attention_mask.shape)}")
+        if encoder_hidden_states is None:                          # is_cross_attn False: nothing is recorded
+            if getattr(attn, "is_cross", False):
+                raise ValueError(f"{attn.name} is a cross-attention module: encoder_hidden_states is required "
+                                 "(its to_k/to_v take the text width)")
+            return self._pipe.engine.attn_processor(attn.name, hidden_states, None, mask, record=False)
+        side = int(math.sqrt(n))
+        if side * side != n:                                       # hook.py:43-46: map_.view(.., h, w) fails the same way
+            raise RuntimeError(f"shape '[-1, {side}, {side}]' is invalid for input of size {n} per map")
         bp = b2 if self.is_train else b2 // 2
         if self._bp != bp or self._side != self.latent_hw or self._tokens != encoder_hidden_states.shape[1]:
             self._bp, self._side, self._tokens = bp, self.latent_hw, encoder_hidden_states.shape[1]
             self._pipe._apply_record_mode()
             self._pipe.engine.set_context(encoder_hidden_states)
             self._pipe.engine.record_reset(bp // 2 if self.is_train else bp, self.latent_hw)
-        out = self._pipe.engine.cross_attn(attn.name, hidden_states, encoder_hidden_states, record=True)
+        out = self._pipe.engine.attn_processor(attn.name, hidden_states, encoder_hidden_states, mask, record=True)
         self.cross_attn_maps.append(self._pipe.engine.hook_last_map(bp, self._tokens, n))     # hook.py:110-112
         return out

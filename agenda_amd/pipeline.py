@@ -146,6 +146,18 @@ class Engine:
                  "agd_denoise")
         return latents
 
+    def cfg_ddim_step(self, eps: torch.Tensor, latents: torch.Tensor, guidance: float, alpha_t: float, alpha_prev: float):
+        """`scheduler.step` of the call-by-call loop: CFG combine of eps [2B,4,L,L] (rows [0,B) unconditional) + one DDIM
+        (eta 0) update of `latents` [B,4,L,L] in place (`agd_cfg_ddim_step`; the fused loop is `denoise`)."""
+        assert latents.is_cuda and latents.dtype == torch.float32 and latents.is_contiguous()
+        eps = eps.to(device=latents.device, dtype=torch.float32).contiguous()
+        b, _, L, _ = latents.shape
+        if eps.shape[0] != 2 * b:
+            raise ValueError(f"eps batch {eps.shape[0]} != 2 x latents batch {b}")
+        self._ck(self.lib.agd_cfg_ddim_step(self.ctx, _lib.ptr(eps), _lib.ptr(latents), b, L, float(guidance), float(alpha_t),
+                                            float(alpha_prev), self._stream()), "agd_cfg_ddim_step")
+        return latents
+
     def vae_decode(self, latents: torch.Tensor, want_f32: bool = False):
         latents = latents.to(device=f"cuda:{self.device}", dtype=torch.float32).contiguous()
         b, _, L, _ = latents.shape
@@ -210,14 +222,36 @@ class Engine:
                                          _lib.ptr(out), int(record), self._stream()), "agd_cross_attn")
         return out
 
+    def attn_processor(self, layer: str, hidden: torch.Tensor, ctx_emb: Optional[torch.Tensor], mask: Optional[torch.Tensor],
+                       record: bool) -> torch.Tensor:
+        """One `Attention` module call (hook.py:83-122): attn2 with `ctx_emb`, attn1 with `ctx_emb=None`; additive mask [B2, keys]."""
+        dev = f"cuda:{self.device}"
+        hidden = hidden.to(device=dev, dtype=torch.float32).contiguous()
+        b2, n, _ = hidden.shape
+        t = 0
+        if ctx_emb is not None:
+            ctx_emb = ctx_emb.to(device=dev, dtype=torch.float32).contiguous()
+            t = ctx_emb.shape[1]
+        if mask is not None:
+            mask = mask.to(device=dev, dtype=torch.float32).contiguous()
+        out = torch.empty_like(hidden)
+        self._ck(self.lib.agd_attn_processor(self.ctx, layer.encode(), _lib.ptr(hidden), _lib.ptr(ctx_emb), _lib.ptr(mask), b2, n, t,
+                                             _lib.ptr(out), int(record), self._stream()), "agd_attn_processor")
+        self._keep = (hidden, ctx_emb, mask)
+        return out
+
     def profile_begin(self):
         self._ck(self.lib.agd_profile_begin(self.ctx), "agd_profile_begin")
 
-    def profile_end(self):
+    def profile_end(self, mfma_peak_flops: float = 2.5e15, hbm_peak_bytes: float = 8.0e12):
+        """Per kernel class: HIP-event ms, algorithmic flop / HBM bytes, launches, and `roof_ms` = the time the binding roof
+        (max of flop / MFMA peak and bytes / HBM peak, per launch) allows."""
         n = _lib.AGD_N_CLASSES
-        ms, fl, ln = (C.c_double * n)(), (C.c_double * n)(), (C.c_longlong * n)()
-        self._ck(self.lib.agd_profile_end(self.ctx, ms, fl, ln), "agd_profile_end")
-        return {self.lib.agd_profile_class_name(i).decode(): {"ms": ms[i], "flops": fl[i], "launches": ln[i]} for i in range(n)}
+        ms, fl, by, rf, rh = ((C.c_double * n)() for _ in range(5))
+        ln = (C.c_longlong * n)()
+        self._ck(self.lib.agd_profile_end_ex(self.ctx, mfma_peak_flops, hbm_peak_bytes, ms, fl, by, rf, rh, ln), "agd_profile_end_ex")
+        return {self.lib.agd_profile_class_name(i).decode(): {"ms": ms[i], "flops": fl[i], "bytes": by[i], "roof_ms": rf[i],
+                                                              "roof_ms_hbm_bound": rh[i], "launches": ln[i]} for i in range(n)}
 
 
 class AttnHandle:
@@ -238,6 +272,7 @@ class UNetHandle:
         self._default = "AttnProcessor(fused-hip)"
         names = cross_attn_layer_names(pipe.cfg.unet, include_mid=True)
         self._attn2 = {n: AttnHandle(self, n, 0, True) for n in names}
+        self._attn1 = {n.replace("attn2", "attn1"): AttnHandle(self, n.replace("attn2", "attn1"), 0, False) for n in names}
         self._procs = {}
         for n in names:
             self._procs[n + ".processor"] = self._default
@@ -262,6 +297,13 @@ class UNetHandle:
 
     def attn2(self, name: str) -> AttnHandle:
         return self._attn2[name]
+
+    def attn1(self, name: str) -> AttnHandle:
+        return self._attn1[name]
+
+    def attn(self, name: str) -> AttnHandle:
+        """The `Attention` module handle (attn1 = self-, attn2 = cross-attention) the processor is called with."""
+        return self._attn2[name] if name in self._attn2 else self._attn1[name]
 
     def __call__(self, sample, timestep, encoder_hidden_states=None):
         if encoder_hidden_states is not None:
@@ -364,7 +406,9 @@ class StableDiffusionPipeline:
             raise FileNotFoundError(f"no safetensors weights under {path}/{sub}")
 
         usd = wload("unet")
-        vsd = {k: v for k, v in wload("vae").items() if k.startswith(("decoder.", "post_quant_conv."))}
+        # decoder side for txt2img, encoder side (`vae.encode`, img2img front end) as well
+        vsd = {k: v for k, v in wload("vae").items()
+               if k.startswith(("decoder.", "post_quant_conv.", "encoder.", "quant_conv."))}
         # pre-0.18 VAE attention naming
         ren = {"query": "to_q", "key": "to_k", "value": "to_v", "proj_attn": "to_out.0"}
         vsd = {(".".join(ren.get(p, p) for p in k.split(".")) if ".attentions." in k else k): v for k, v in vsd.items()}
@@ -384,8 +428,14 @@ class StableDiffusionPipeline:
             try:
                 from transformers import CLIPTokenizer
                 tok = CLIPTokenizer.from_pretrained(os.path.join(path, "tokenizer"))
-            except Exception:
+            except Exception as e:
+                if tsd is not None:        # real CLIP weights + a word-level stand-in tokenizer = garbage embeddings: refuse
+                    raise _lib.AgendaHipError(f"text_encoder/ weights found but tokenizer/ could not be loaded ({e}); "
+                                              "no silent fallback to the synthetic tokenizer") from e
                 tok = None
+        elif tsd is not None:
+            raise _lib.AgendaHipError(f"{path}: text_encoder/ weights found but no tokenizer/ directory; "
+                                      "no silent fallback to the synthetic tokenizer")
         return cls(cfg, usd, vsd, tokenizer=tok, device=device, workspace_bytes=workspace_bytes, text_sd=tsd)
 
 

@@ -5,10 +5,16 @@ bf16 compute, synthetic weights/context (BASELINE.json metric; workload = config
 A "step" = one pass of the hot path over one batch on every rank: 50 x (CFG-batched UNet forward
 + fused DAAM accumulation + DDIM update), VAE decode, heat-map aggregation, and (N>1) the RCCL
 all_gather of images + heat maps.  One process per GPU; rank 0 prints ONE JSON line.
+
+`python bench.py --gpus N` with N > 1 and no launcher environment starts the N ranks itself
+(`python -m torch.distributed.run ...` as a child process, before this process touches the GPU);
+under a launcher (RANK / WORLD_SIZE set, as the driver runs it) it is one rank of the job.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -18,20 +24,44 @@ sys.path.insert(0, ROOT)
 TFLOP_PER_IMAGE = {50: 82.84}          # 2*50*803.3 GF + 2514.5 GF
 UNET_GF, VAE_GF = 803.3, 2514.5
 MFMA_PEAK_TF = 2500.0                  # bf16 dense, MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0                  # HBM3E spec, MI355X_MICROARCH.md (6.3 TB/s is what a copy achieves)
+PMC_CSV = os.path.join("profiles", "r02_pmc_traffic_summary.csv")
+
+# the igemm template instantiations behind each class, as rocprofv3 names them: <BM, BN, WM, WN, KS, ...>
+CLASS_KERNEL = {"igemm_conv3x3": ("igemm_kernel", ", 3, "), "igemm_linear_1x1": ("igemm_kernel", ", 1, "),
+                "attn_self_flash": ("attn_kernel", ", 0, 0>"), "attn_cross_daam": ("attn_kernel", ", 1, 0>"),
+                "groupnorm": ("gn_", ""), "layernorm": ("layernorm_kernel", "")}
 
 
-def pmc_traffic_mb():
-    """HBM-side MB per launch of the dominant kernel class (3x3 igemm), from the committed rocprofv3 --pmc
-    passes (profiles/r01_pmc_traffic_summary.csv: FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE);
-    PMC counters cannot be sampled from inside this process, so this is the offline figure or None."""
-    p = os.path.join(ROOT, "profiles", "r01_pmc_traffic_summary.csv")
+def self_launch_command(gpus, argv, n_devices):
+    """None = run in this process (single rank, or already one rank of a launcher's job); else the child command that
+    starts `gpus` ranks.  Raises SystemExit on an impossible request.  Never touches the GPU."""
+    world_env = os.environ.get("WORLD_SIZE")
+    if world_env is not None:                                  # under torchrun / the driver's launcher
+        if int(world_env) != gpus:
+            raise SystemExit(f"WORLD_SIZE {world_env} != --gpus {gpus}")
+        return None
+    if gpus <= 1:
+        return None
+    if n_devices < gpus:
+        raise SystemExit(f"--gpus {gpus} requested but only {n_devices} visible GPU(s): refusing to report a {gpus}-GPU number")
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus),
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def pmc_traffic(cls):
+    """HBM-side bytes per launch of a kernel class from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 per the gfx950
+    correction + WRITE_SIZE; tools/pmc_traffic.py writes the CSV).  PMC counters cannot be sampled from inside this
+    process, so this is the offline figure of the same command, or None."""
     try:
+        pat = CLASS_KERNEL[cls]
         n = mb = 0.0
-        for line in open(p).read().splitlines()[1:]:
-            f = line.rsplit(",", 5)
-            if "igemm_kernel" in f[0] and ", 3, 2, 0," in f[0]:
-                n += float(f[1]); mb += float(f[1]) * (float(f[3]) + float(f[4]))
-        return {"MB_per_launch": round(mb / n, 1), "source": "profiles/r01_pmc_traffic_summary.csv"} if n else None
+        for line in open(os.path.join(ROOT, PMC_CSV)).read().splitlines()[1:]:
+            f = line.rsplit(",", 5)                            # kernel, launches, avg_us, fetch_MB, write_MB, total_MB
+            if pat[0] in f[0] and pat[1] in f[0]:
+                n += float(f[1]); mb += float(f[1]) * float(f[5])
+        return {"MB_per_launch": round(mb / n, 2), "launches_profiled": int(n), "source": PMC_CSV} if n else None
     except Exception:
         return None
 
@@ -61,6 +91,22 @@ def cpu_baseline(cfg, usd, vsd, ctx, threads):
                       f"extrapolated x50 steps; fp32 PyTorch restatement of the reference path (diffusers absent)"}
 
 
+def class_table(classes):
+    """Per kernel class: time, achieved TFLOP/s and GB/s (algorithmic work / HIP-event time), the fraction of each roof, and
+    `frac` against the BINDING roof of each launch (max(flop / 2.5 PF, bytes / 8 TB/s) summed over the class's launches)."""
+    out = {}
+    for k, v in classes.items():
+        if not v["launches"] or v["ms"] <= 0:
+            continue
+        s = v["ms"] * 1e-3
+        tf, gbs = v["flops"] / s / 1e12, v["bytes"] / s / 1e9
+        out[k] = {"ms": round(v["ms"], 2), "launches": v["launches"], "TFLOPs": round(tf, 1), "GBs": round(gbs, 1),
+                  "frac_mfma": round(tf / MFMA_PEAK_TF, 4), "frac_hbm": round(gbs / HBM_PEAK_GBS, 4),
+                  "frac": round(v["roof_ms"] / v["ms"], 4),
+                  "hbm_bound_share": round(v["roof_ms_hbm_bound"] / v["roof_ms"], 3) if v["roof_ms"] > 0 else None}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -72,18 +118,23 @@ def main():
     ap.add_argument("--no-profile", action="store_true")
     args = ap.parse_args()
 
-    import torch
+    import torch                                             # device_count() does not initialise the GPU on this image
+    cmd = self_launch_command(args.gpus, sys.argv[1:], torch.cuda.device_count())
+    if cmd is not None:                                      # start the N ranks as a CHILD job and hand its exit code on
+        raise SystemExit(subprocess.run(cmd).returncode)
+
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"WORLD_SIZE {world} != --gpus {args.gpus}")
     # AGD_FORCE_DEVICE / AGD_DIST_BACKEND exist only to rehearse the multi-rank path on a 1-GPU box
     # (ranks share cuda:0, gloo instead of RCCL); the driver's real runs use one GPU per rank + nccl.
     if "AGD_FORCE_DEVICE" in os.environ:
         local = int(os.environ["AGD_FORCE_DEVICE"])
+    elif world > 1 and torch.cuda.device_count() <= local:
+        raise SystemExit(f"rank {rank}: local rank {local} has no GPU ({torch.cuda.device_count()} visible)")
     torch.cuda.set_device(local)
+    backend = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = os.environ.get("AGD_DIST_BACKEND", "nccl")
@@ -91,6 +142,7 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
         else:
             dist.init_process_group(backend)
+        assert dist.get_world_size() == world == args.gpus
 
     from agenda_amd import StableDiffusionPipeline, synthetic
     from agenda_amd.generation import generate_batch, gather_outputs
@@ -99,13 +151,14 @@ def main():
                                                   workspace_bytes=12 << 30)
     cfg = pipe.cfg
     ctx = synthetic.make_context(cfg, B, seed=7)
-    n_rows = 14                                    # T' = len(tokens)+2 rows that daam reads
     word_rows = [[5], [8, 9]]                      # two "words" (one single-token, one two-token)
 
     def one_step(step_idx, gather=True):
         seeds = [(step_idx * world + rank) * B + i for i in range(B)]
         imgs, hms = generate_batch(pipe, seeds, [], prompt_embeds=ctx, num_inference_steps=args.ddim_steps,
                                    word_rows=word_rows)
+        if gather and backend == "gloo":           # rehearsal only: gloo moves host tensors
+            imgs, hms = imgs.cpu(), hms.cpu()
         return gather_outputs(imgs, hms) if gather else (imgs, hms)
 
     def sync():
@@ -122,33 +175,43 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        assert imgs.shape[0] == world * B and hms.shape[0] == world * B      # the gather really delivered every rank's rows
+        tt = torch.tensor([dt], device="cuda" if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     n_img = world * B * args.steps
     value = n_img / dt
 
     roof = None
-    classes = None
+    table = None
     if rank == 0 and not args.no_profile:
-        # dominant kernel = implicit-GEMM conv3x3: live HIP-event timing on the launch stream
+        # live HIP-event timing of every launch on the launch stream, one more batch on rank 0 (no collective in here)
         pipe.engine.profile_begin()
-        one_step(10 ** 6, gather=False)              # rank 0 only: no collective in here
-        classes = pipe.engine.profile_end()
-        conv = classes["igemm_conv3x3"]
-        ach = conv["flops"] / (conv["ms"] * 1e-3) / 1e12
-        roof = {"bound": "mfma", "kernel": "igemm_kernel<3x3>", "achieved": round(ach, 1), "peak": MFMA_PEAK_TF, "unit": "TFLOP/s",
-                "frac": round(ach / MFMA_PEAK_TF, 4), "traffic": pmc_traffic_mb(),
-                "launches": conv["launches"], "avg_launch_us": round(conv["ms"] * 1e3 / max(conv["launches"], 1), 1),
+        one_step(10 ** 6, gather=False)
+        classes = pipe.engine.profile_end(MFMA_PEAK_TF * 1e12, HBM_PEAK_GBS * 1e9)
+        table = class_table(classes)
+        dom = max(table, key=lambda k: table[k]["ms"])                         # dominant = the class with the most time
+        d, raw = table[dom], classes[dom]
+        mfma_bound = d["frac_mfma"] >= d["frac_hbm"]
+        ig_ms = sum(table[k]["ms"] for k in table if k.startswith("igemm"))
+        ig_fl = sum(classes[k]["flops"] for k in table if k.startswith("igemm"))
+        roof = {"bound": "mfma" if mfma_bound else "hbm", "kernel": f"{CLASS_KERNEL.get(dom, (dom,))[0]} [{dom}]",
+                "achieved": d["TFLOPs"] if mfma_bound else d["GBs"], "peak": MFMA_PEAK_TF if mfma_bound else HBM_PEAK_GBS,
+                "unit": "TFLOP/s" if mfma_bound else "GB/s", "frac": d["frac_mfma"] if mfma_bound else d["frac_hbm"],
+                "frac_binding_roof": d["frac"], "traffic": pmc_traffic(dom),
+                "launches": d["launches"], "avg_launch_us": round(raw["ms"] * 1e3 / max(raw["launches"], 1), 1),
+                "algorithmic_per_launch": {"GFLOP": round(raw["flops"] / raw["launches"] / 1e9, 2), "MB": round(raw["bytes"] / raw["launches"] / 1e6, 2)},
+                "igemm_all_frac_mfma": round(ig_fl / (ig_ms * 1e-3) / 1e12 / MFMA_PEAK_TF, 4) if ig_ms else None,
                 "end_to_end_frac": round(value / world * TFLOP_PER_IMAGE.get(args.ddim_steps, (2 * args.ddim_steps * UNET_GF + VAE_GF) / 1e3) / MFMA_PEAK_TF, 4)}
     daam = None
-    if classes and classes.get("attn_cross_daam", {}).get("ms"):
+    if table and "attn_cross_daam" in table:
         # accumulator read+write = 132.5 MB per image per denoise step (15 layers x 8 heads x 77 rows, fp32);
         # the accumulation is fused into the cross-attention kernels, so their class time is the time spent on it
         gb = 132.5e-3 * args.ddim_steps * B
-        gbs = gb / (classes["attn_cross_daam"]["ms"] * 1e-3)
-        daam = {"bound": "hbm", "achieved": round(gbs, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(gbs / 8000.0, 4),
-                "algorithmic_GB_per_batch": round(gb, 2), "kernel": "attn_kernel<RECORD> (cross-attention + fused accumulate)"}
+        gbs = gb / (table["attn_cross_daam"]["ms"] * 1e-3)
+        daam = {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+                "algorithmic_GB_per_batch": round(gb, 2), "kernel": "attn_kernel<RECORD> (cross-attention + fused accumulate)",
+                "traffic": pmc_traffic("attn_cross_daam")}
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         usd, vsd = pipe.synthetic_weights
@@ -164,12 +227,13 @@ def main():
                 "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2),
                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
                 "config": {"workload": f"SD-1.5 512x512 batch={B}/GPU, {args.ddim_steps} DDIM steps (eta 0, CFG 7.5), DAAM heat maps on (77 rows recorded, 2 word maps), VAE decode",
-                           "global_batch": world * B, "ddim_steps": args.ddim_steps, "parallelism": f"seed-sharded x{world} + all_gather"},
+                           "global_batch": world * B, "ddim_steps": args.ddim_steps, "parallelism": f"seed-sharded x{world} + all_gather",
+                           "collective_backend": backend},
                 "roofline": roof, "cpu_baseline": cpu}
         if daam:
             line["daam_accumulate"] = daam
-        if classes:
-            line["kernel_classes_ms"] = {k: round(v["ms"], 2) for k, v in classes.items() if v["launches"]}
+        if table:
+            line["kernel_classes"] = table
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()

@@ -95,20 +95,28 @@ int agd_vae_encode(agd_ctx* ctx, const float* image, int batch, int side, float*
 /* ---- heat-map recording (daam.trace / hook.py UNetCrossAttentionHooker state)
  * mode 0 off; 1 DAAM (per-layer/head time sums, mid block excluded, conditional half);
  * 2 HOOK (hook.py: head-mean per call, every attn2 incl. mid; is_train=1 keeps all batch rows).
- * rec_tokens: token rows recorded (<= tokens; rows beyond len(prompt)+2 are never read by daam). */
+ * rec_tokens: token rows recorded (<= tokens; rows beyond len(prompt)+2 are never read by daam); takes effect at the
+ * next agd_record_reset, which (re)sizes the accumulators for it. */
 int agd_record_config(agd_ctx* ctx, int mode, int is_train, int rec_tokens);
 int agd_record_reset(agd_ctx* ctx, int batch, int latent_side, void* stream);   /* hooker.clear() / new trace */
-/* daam `compute_global_heat_map()` for image `img`: out [rows, S, S] fp32 (rows <= rec_tokens). Syncs. */
+/* daam `compute_global_heat_map()` for image `img`: out [rows, S, S] fp32 (rows <= rec_tokens). Stream-ordered. */
 int agd_daam_global(agd_ctx* ctx, int img, int rows, float* out, void* stream);
-/* hook.py `compute_global_heat_map()`: out [B', T, S, S]; returns -2 if nothing was recorded. Syncs. */
+/* hook.py `compute_global_heat_map()`: out [B', T, S, S]; returns -2 if nothing was recorded. Stream-ordered. */
 int agd_hook_global(agd_ctx* ctx, float* out, void* stream);
 int agd_hook_count(agd_ctx* ctx);
-/* the map hook.py:110-112 appends for the most recent recorded call: out [B', T, h, w] (h*w = n_query). Syncs. */
+/* the map hook.py:110-112 appends for the most recent recorded call: out [B', T, h, w] (h*w = n_query). Stream-ordered. */
 int agd_hook_last_map(agd_ctx* ctx, float* out, int n_query, void* stream);
 
-/* ---- the processor seam: one attn2 call (hook.py:91-120) for UNet cross-attention layer
- * `layer` (module path, e.g. "down_blocks.0.attentions.0.transformer_blocks.0.attn2").
- * hidden/out fp32 [B2, N, C]; ctx_emb fp32 [B2, T, ctx_dim]; record != 0 feeds the recorder. */
+/* ---- the processor seam, hook.py:83-122 in full: one call of the diffusers attention-processor protocol
+ * `proc(attn, hidden_states, encoder_hidden_states=None, attention_mask=None)` for the UNet `Attention` module
+ * `layer` (module path, e.g. "down_blocks.0.attentions.0.transformer_blocks.0.attn2" or "...attn1").
+ *   ctx_emb != NULL on an attn2 module: cross-attention (is_cross_attn, hook.py:94-99); record != 0 feeds the recorder
+ *   ctx_emb == NULL on an attn1 module: self-attention (encoder_hidden_states = hidden_states); records nothing
+ *   attn_mask: additive fp32 [B2, keys] (hook.py:92 `prepare_attention_mask`, broadcast over heads and queries) or NULL
+ * hidden/out fp32 [B2, N, C]; ctx_emb fp32 [B2, T, ctx_dim].  Returns to_out[0](softmax(scale QK^T + mask) V) + bias. */
+int agd_attn_processor(agd_ctx* ctx, const char* layer, const float* hidden, const float* ctx_emb, const float* attn_mask,
+                       int batch2, int n_query, int tokens, float* out, int record, void* stream);
+/* the same for an attn2 module without a mask (kept for callers of the round-1 ABI) */
 int agd_cross_attn(agd_ctx* ctx, const char* layer, const float* hidden, const float* ctx_emb, int batch2,
                    int n_query, int tokens, float* out, int record, void* stream);
 
@@ -141,7 +149,18 @@ int agd_op_stack_heatmaps(const unsigned char* obj, const unsigned char* fg, con
 #define AGD_N_CLASSES 10
 int agd_profile_begin(agd_ctx* ctx);
 int agd_profile_end(agd_ctx* ctx, double* ms, double* flops, long long* launches);  /* arrays of AGD_N_CLASSES; syncs */
+/* the same plus, per class, the algorithmic HBM bytes and roof_ms = Sum over launches of max(flop / mfma_peak_flops,
+ * bytes / hbm_peak_bytes) [ms]: the time each launch's BINDING roof allows (bench.py's per-class roofline fractions);
+ * roof_ms_hbm_bound (may be NULL): the part of roof_ms that came from launches whose binding roof is HBM. */
+int agd_profile_end_ex(agd_ctx* ctx, double mfma_peak_flops, double hbm_peak_bytes, double* ms, double* flops, double* bytes,
+                       double* roof_ms, double* roof_ms_hbm_bound, long long* launches);
 const char* agd_profile_class_name(int cls);
+
+/* ---- kernel micro-benchmarks (tools/kbench.py): random bf16 operands, HIP-event timing of `iters` launches -> ms per launch */
+int agd_bench_conv(int B, int H, int W, int C0, int C1, int Cout, int ksize, int stride, int up, int geglu, int with_residual,
+                   int iters, double* ms_out);
+int agd_bench_attention(int B, int H, int D, int Nq, int Nk, int record, int iters, double* ms_out);
+int agd_bench_groupnorm(int B, int HW, int C, int iters, double* ms_out);
 
 const char* agd_version(void);
 

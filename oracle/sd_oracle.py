@@ -46,15 +46,19 @@ def batch_to_head_dim(t: Tensor, heads: int) -> Tensor:
     return t.reshape(bh // heads, heads, n, d).permute(0, 2, 1, 3).reshape(bh // heads, n, d * heads)
 
 
-def attention_scores(q: Tensor, k: Tensor, scale: float) -> Tensor:
-    """`attn.get_attention_scores` (hook.py:108): softmax(scale * q k^T) over keys, fp32."""
-    return torch.softmax(scale * torch.bmm(q, k.transpose(1, 2)), dim=-1)
+def attention_scores(q: Tensor, k: Tensor, scale: float, mask: Optional[Tensor] = None) -> Tensor:
+    """`attn.get_attention_scores` (hook.py:108): softmax(scale * q k^T [+ mask]) over keys, fp32.
+    `mask`: the additive mask `prepare_attention_mask` returns (hook.py:92), [B*H, 1, keys] [upstream-knowledge]."""
+    s = scale * torch.bmm(q, k.transpose(1, 2))
+    if mask is not None:
+        s = s + mask
+    return torch.softmax(s, dim=-1)
 
 
 def explicit_attention_processor(x: Tensor, ctx: Optional[Tensor], wq: Tensor, wk: Tensor, wv: Tensor,
                                  wo: Tensor, bo: Optional[Tensor], heads: int,
                                  recorder: Optional[Callable[[Tensor, int], None]] = None,
-                                 bq=None, bk=None, bv=None) -> Tensor:
+                                 bq=None, bk=None, bv=None, attention_mask: Optional[Tensor] = None) -> Tensor:
     """Body of `UNetCrossAttentionHooker.__call__` (hook.py:91-120): explicit-softmax attention,
     probabilities handed to `recorder` only for cross-attention (hook.py:110-112)."""
     is_cross = ctx is not None                                   # hook.py:95
@@ -64,7 +68,9 @@ def explicit_attention_processor(x: Tensor, ctx: Optional[Tensor], wq: Tensor, w
     v = F.linear(kv_src, wv, bv)                                 # hook.py:102
     d = q.shape[-1] // heads
     q, k, v = (head_to_batch_dim(t, heads) for t in (q, k, v))   # hook.py:104-106
-    p = attention_scores(q, k, d ** -0.5)                        # hook.py:108
+    if attention_mask is not None:                               # hook.py:92: [B, 1, keys] repeated per head (head-minor)
+        attention_mask = attention_mask.reshape(attention_mask.shape[0], 1, -1).repeat_interleave(heads, dim=0)
+    p = attention_scores(q, k, d ** -0.5, attention_mask)        # hook.py:108
     if is_cross and recorder is not None:
         recorder(p, heads)                                       # hook.py:110-112
     o = batch_to_head_dim(torch.bmm(p, v), heads)                # hook.py:114-115

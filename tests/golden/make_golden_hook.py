@@ -55,7 +55,10 @@ class DuckAttn:
             self.to_out[0].bias.copy_(torch.randn(C, generator=gen) * 0.1)
 
     def prepare_attention_mask(self, mask, n, b):
-        return mask
+        # diffusers 0.21.2: a [B, 1, keys] additive mask is repeated per head -> [B*H, 1, keys] (head-minor batch axis)
+        if mask is None:
+            return None
+        return mask.repeat_interleave(self.heads, dim=0)
 
     def head_to_batch_dim(self, t):
         b, n, c = t.shape
@@ -68,8 +71,12 @@ class DuckAttn:
         return t.reshape(bh // h, h, n, d).permute(0, 2, 1, 3).reshape(bh // h, n, d * h)
 
     def get_attention_scores(self, q, k, mask=None):
-        s = torch.baddbmm(torch.empty(q.shape[0], q.shape[1], k.shape[1], dtype=q.dtype),
-                          q, k.transpose(-1, -2), beta=0, alpha=self.scale)
+        if mask is None:
+            s = torch.baddbmm(torch.empty(q.shape[0], q.shape[1], k.shape[1], dtype=q.dtype),
+                              q, k.transpose(-1, -2), beta=0, alpha=self.scale)
+        else:       # diffusers: baddbmm(attention_mask, q, k^T, beta=1, alpha=scale)
+            s = torch.baddbmm(mask.expand(q.shape[0], q.shape[1], k.shape[1]).contiguous(), q, k.transpose(-1, -2),
+                              beta=1, alpha=self.scale)
         return s.softmax(dim=-1)
 
 
@@ -142,8 +149,35 @@ def main():
             out[f"{name}_self_y_train{int(is_train)}"] = ys.numpy()
             out[f"{name}_map_train{int(is_train)}"] = hk.cross_attn_maps[0].numpy()
             out[f"{name}_nmaps_train{int(is_train)}"] = np.array([n_after_cross, n_after_self])
+    # (4) the same __call__ at the shapes of an agenda_amd `tiny` UNet layer (C=64, 2 heads, ctx 64, 16x16 tokens) so the
+    #     fixture can be driven through the C-ABI seam (agd_attn_processor) with these weights loaded into the layer;
+    #     with and without an additive attention mask (hook.py:92,108)
+    C, H, T, ctxd, N = 64, 2, 77, 64, 256
+    gw = torch.Generator().manual_seed(4242)
+    cross = DuckAttn(C, ctxd, H, gw, cross=True)
+    selfa = DuckAttn(C, ctxd, H, gw, cross=False)
+    x = torch.randn(2, N, C, generator=gw)
+    ctx = torch.randn(2, T, ctxd, generator=gw)
+    mask_c = torch.where(torch.rand(2, 1, T, generator=gw) < 0.3, -10000.0, 0.0) + 0.5 * torch.randn(2, 1, T, generator=gw)
+    mask_s = torch.where(torch.rand(2, 1, N, generator=gw) < 0.3, -10000.0, 0.0) + 0.5 * torch.randn(2, 1, N, generator=gw)
+    for key, a in (("cross", cross), ("self", selfa)):
+        for wn, lin in (("wq", a.to_q), ("wk", a.to_k), ("wv", a.to_v), ("wo", a.to_out[0])):
+            out[f"seam_{key}_{wn}"] = lin.weight.detach().numpy()
+        out[f"seam_{key}_bo"] = a.to_out[0].bias.detach().numpy()
+    out["seam_x"], out["seam_ctx"] = x.numpy(), ctx.numpy()
+    out["seam_mask_cross"], out["seam_mask_self"] = mask_c.numpy(), mask_s.numpy()
+    for is_train in (True, False):
+        for tag, mc, ms in (("nomask", None, None), ("mask", mask_c, mask_s)):
+            hk = ref_hook.UNetCrossAttentionHooker(is_train=is_train, latent_hw=16)
+            with torch.no_grad():
+                yc = hk(cross, x, encoder_hidden_states=ctx, attention_mask=mc)
+                ys = hk(selfa, x, attention_mask=ms)
+            assert len(hk.cross_attn_maps) == 1
+            out[f"seam_{tag}_cross_y_train{int(is_train)}"] = yc.numpy()
+            out[f"seam_{tag}_self_y_train{int(is_train)}"] = ys.numpy()
+            out[f"seam_{tag}_map_train{int(is_train)}"] = hk.cross_attn_maps[0].numpy()
     # split to keep each fixture small
-    groups = {"hook_unravel": "unravel", "hook_global": "global", "hook_call": "call"}
+    groups = {"hook_unravel": "unravel", "hook_global": "global", "hook_call": "call", "hook_seam": "seam"}
     for fn, pref in groups.items():
         sub = {k: (v.astype(np.float32) if v.dtype == np.float64 else v) for k, v in out.items() if k.startswith(pref)}
         np.savez_compressed(os.path.join(OUT, fn + ".npz"), **sub)

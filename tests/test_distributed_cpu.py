@@ -36,3 +36,61 @@ def test_gather_restores_global_seed_order(tmp_path):
         assert gi.shape == (6, 4, 4, 3) and gh.shape == (6, 2, 8, 8)
         assert [int(x[0, 0, 0]) for x in gi] == [0, 1, 2, 3, 4, 5]       # interleaved back to seed order
         assert [float(x[0, 0, 0]) for x in gh] == [0, 1, 2, 3, 4, 5]
+
+
+def _ragged_worker(rank, world, port, out_dir, num_images, batch):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from agenda_amd.generation import shard_seeds, gather_outputs
+    seeds = shard_seeds(num_images, rank, world)
+    per_rank = (num_images + world - 1) // world
+    rounds = (per_rank + batch - 1) // batch                  # every rank joins every round (generation.main)
+    got_s, got_i, got_h = [], [], []
+    for r in range(rounds):
+        chunk = seeds[r * batch:(r + 1) * batch]              # may be shorter than `batch`, or empty
+        imgs = torch.stack([torch.full((4, 4, 3), s, dtype=torch.uint8) for s in chunk]) if chunk else torch.zeros(0, 4, 4, 3, dtype=torch.uint8)
+        hms = torch.stack([torch.full((2, 8, 8), float(s)) for s in chunk]) if chunk else torch.zeros(0, 2, 8, 8)
+        s_, i_, h_ = gather_outputs(imgs, hms, seeds=chunk, max_batch=batch)
+        got_s += s_; got_i.append(i_); got_h.append(h_)
+    np.save(os.path.join(out_dir, f"s{rank}.npy"), np.array(got_s))
+    np.save(os.path.join(out_dir, f"i{rank}.npy"), torch.cat(got_i).numpy())
+    np.save(os.path.join(out_dir, f"h{rank}.npy"), torch.cat(got_h).numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,num_images,batch", [(2, 7, 2), (3, 4, 2), (2, 1, 4)])
+def test_gather_handles_ragged_and_empty_last_batches(tmp_path, world, num_images, batch):
+    """The last round of `shard_seeds` leaves ranks with fewer (or zero) images: the collective count and the tensor
+    shapes must still match on every rank, and every seed must come back exactly once with its own payload."""
+    port = _free_port()
+    mp.start_processes(_ragged_worker, args=(world, port, str(tmp_path), num_images, batch), nprocs=world, join=True, start_method="spawn")
+    for r in range(world):
+        s = np.load(tmp_path / f"s{r}.npy"); gi = np.load(tmp_path / f"i{r}.npy"); gh = np.load(tmp_path / f"h{r}.npy")
+        assert sorted(s.tolist()) == list(range(num_images))
+        assert gi.shape == (num_images, 4, 4, 3) and gh.shape == (num_images, 2, 8, 8)
+        assert [int(x[0, 0, 0]) for x in gi] == s.tolist() and [float(x[0, 0, 0]) for x in gh] == [float(v) for v in s]
+
+
+def test_bench_launcher_plans_n_ranks_before_touching_the_gpu(monkeypatch):
+    """`python bench.py --gpus N` without a launcher environment must start N ranks itself (torch.distributed.run as a
+    CHILD process, before any GPU call) and must refuse when fewer than N devices are visible."""
+    import importlib.util
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    cmd = bench.self_launch_command(4, ["--gpus", "4", "--steps", "2"], n_devices=8)
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nproc-per-node" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "4"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-4:] == ["--gpus", "4", "--steps", "2"]
+    with pytest.raises(SystemExit, match="only 1 visible"):
+        bench.self_launch_command(4, ["--gpus", "4"], n_devices=1)
+    assert bench.self_launch_command(1, ["--gpus", "1"], n_devices=1) is None       # single rank: run in-process
+    monkeypatch.setenv("WORLD_SIZE", "4"); monkeypatch.setenv("RANK", "0")
+    assert bench.self_launch_command(4, ["--gpus", "4"], n_devices=8) is None       # already under a launcher
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    with pytest.raises(SystemExit, match="WORLD_SIZE 2 != --gpus 4"):
+        bench.self_launch_command(4, ["--gpus", "4"], n_devices=8)

@@ -81,21 +81,108 @@ def test_sd15_512px_batch4_properties(sd15_cuda):
     assert float((maps1[0] - maps[2]).abs().max() / maps[2].abs().max()) < 0.05
 
 
-def test_sd15_vae_decode_512_ranges(sd15_cuda):
-    from agenda_amd import synthetic
-    pipe = sd15_cuda
-    z = synthetic.make_latents(pipe.cfg, [1, 2], 64) * 0.18215
-    u8, f32 = pipe.engine.vae_decode(z, want_f32=True)
-    assert u8.shape == (2, 512, 512, 3) and torch.isfinite(f32).all()
-    want_u8 = ((f32 / 2 + 0.5).clamp(0, 1) * 255).round().to(torch.uint8)
-    assert torch.equal(u8, want_u8)                                # post-process = round-half-even(255 x)
-
-
 def _psnr_u8(a, b):
     a = np.asarray(a, dtype=np.float64)
     b = np.asarray(b, dtype=np.float64)
     mse = ((a - b) ** 2).mean()
     return float("inf") if mse == 0 else float(10 * np.log10(255.0 ** 2 / mse))
+
+
+@pytest.fixture(scope="module")
+def sd15_host_weights():
+    """The same seeded SD-1.5-shaped weights on the host (for the CPU oracle) -- incl. the VAE encoder (config 3)."""
+    from agenda_amd import config, synthetic
+    cfg = config.sd15()
+    return cfg, synthetic.make_unet_weights(cfg, 1234), synthetic.make_vae_weights(cfg, 1235, with_encoder=True)
+
+
+@pytest.fixture(scope="module")
+def sd15_pipe(sd15_host_weights):
+    from agenda_amd import StableDiffusionPipeline
+    cfg, u, v = sd15_host_weights
+    pipe = StableDiffusionPipeline(cfg, u, v, workspace_bytes=12 << 30)
+    yield pipe
+    pipe.engine.close()
+
+
+def test_sd15_unet_forward_512px_matches_oracle(sd15_host_weights, sd15_pipe):
+    """BASELINE config 2 at ITS OWN size: SD-1.5, 512 px (latent 64, 4096 tokens), CFG batch 2, one UNet forward with the
+    DAAM recorder on -- the forward bench.py times -- against the fp32 CPU oracle (data_generation.py:57-64 semantics)."""
+    from agenda_amd import synthetic
+    from oracle import sd_oracle as O
+    cfg, u, v = sd15_host_weights
+    pipe, L = sd15_pipe, 64
+    ctx = synthetic.make_context(cfg, 1, seed=7)
+    lat = synthetic.make_latents(cfg, [0], L)
+    x = torch.cat([lat, lat]).to(torch.bfloat16).float()
+    rec = O.DaamRecorder(L * L, 77)
+    with torch.no_grad():
+        want = O.unet_forward(u, cfg.unet, x, torch.tensor(981), ctx, rec)
+    pipe.engine.set_context(ctx)
+    pipe.engine.record_config(1, False, 77)
+    pipe.engine.record_reset(1, L)
+    got = pipe.engine.unet_forward(x, 981.0)
+    err = _rms_rel(got, want)
+    hm = pipe.engine.daam_global(0, 77, L).cpu()
+    whm = rec.compute_global_heat_map()[0]
+    hm_err = float((hm - whm).abs().max() / whm.abs().max())
+    print(f"config2 forward (512 px): rms rel {err:.5f}, heat map rel {hm_err:.4f}")
+    assert len(rec.acc) == 15 * 8                                  # 15 recorded attn2 layers x 8 heads
+    assert err < 2.0 ** -6, err                                    # bf16 storage / fp32 accumulate vs the fp32 oracle
+    assert hm_err < 0.02, hm_err
+    pipe.engine.record_config(0)
+
+
+def test_sd15_vae_decode_512_matches_oracle(sd15_host_weights, sd15_pipe):
+    """`vae.decode` at 512 px (the decode bench.py times) against the CPU oracle, plus the uint8 post-process rule."""
+    from agenda_amd import synthetic
+    from oracle import sd_oracle as O
+    cfg, u, v = sd15_host_weights
+    z = (synthetic.make_latents(cfg, [1], 64) * 0.18215).to(torch.bfloat16).float()
+    with torch.no_grad():
+        want = O.vae_decode(v, cfg.vae, z / cfg.vae.scaling_factor)
+    u8, f32 = sd15_pipe.engine.vae_decode(z, want_f32=True)
+    assert u8.shape == (1, 512, 512, 3) and torch.isfinite(f32).all()
+    got = f32.permute(0, 3, 1, 2)
+    err = _rms_rel(got, want)
+    psnr = _psnr_u8(u8.cpu().numpy(), O.postprocess_image(want))
+    print(f"vae decode 512 px: rms rel {err:.5f}, PSNR {psnr:.1f} dB")
+    assert err < 2.0 ** -6, err
+    assert psnr > 40.0, psnr
+    want_u8 = ((f32 / 2 + 0.5).clamp(0, 1) * 255).round().to(torch.uint8)
+    assert torch.equal(u8, want_u8)                                # post-process = round-half-even(255 x)
+
+
+def test_config3_sd15_vae_encode_512_and_img2img_match_oracle(sd15_host_weights, sd15_pipe):
+    """BASELINE config 3 at SD-1.5 shapes on one GPU's shard: `vae.encode` at 512 px (128..512-channel stride-2 convs with
+    the asymmetric (0,1,0,1) padding, 4096-token mid attention) and a 3-step img2img tail, against the oracle's
+    restatement of diffusers' img2img semantics (parity-unpinned: the reference has no img2img call site)."""
+    from agenda_amd import synthetic, trace
+    from oracle import sd_oracle as O
+    cfg, u, v = sd15_host_weights
+    pipe = sd15_pipe
+    g = torch.Generator().manual_seed(40)
+    S, steps, strength = 512, 5, 0.6                                   # int(5 * 0.6) = 3 denoise steps run
+    image = (torch.rand(1, 3, S, S, generator=g) * 2 - 1).to(torch.bfloat16).float()
+    ctx = synthetic.make_context(cfg, 1, seed=7)
+    ne, nz = torch.randn(1, 4, 64, 64, generator=g), torch.randn(1, 4, 64, 64, generator=g)
+    rec = O.DaamRecorder(64 * 64, 77)
+    want_img, want_lat, (wm, wl) = O.img2img(u, v, cfg, ctx, image, ne, nz, steps, strength, recorder=rec)
+    mean, logvar = pipe.engine.vae_encode(image)
+    e_m, e_l = _rms_rel(mean, wm), _rms_rel(logvar, wl)
+    with trace(pipe) as trc:
+        out = pipe.img2img(prompt_embeds=ctx, image=image, strength=strength, num_inference_steps=steps, noise_enc=ne, noise=nz,
+                           output_type="np")
+        hm = trc.compute_global_heat_map(image_index=0).heat_maps.cpu()
+    whm = rec.compute_global_heat_map()[0]
+    lat_err, psnr = _rms_rel(out.latents, want_lat), _psnr_u8(out.images, want_img)
+    hm_err = float((hm - whm).abs().max() / whm.abs().max())
+    print(f"config3 (512 px): moments rms rel {e_m:.5f}/{e_l:.5f}, latents rms rel {lat_err:.4f}, PSNR {psnr:.1f} dB, heat map rel {hm_err:.4f}")
+    assert e_m < 2.0 ** -6 and e_l < 2.0 ** -6, (e_m, e_l)
+    assert lat_err < 0.05, lat_err
+    assert psnr > 30.0, psnr
+    assert hm_err < 0.03, hm_err
+    assert float(hm.sum(0).mean()) == pytest.approx(3, rel=0.02)       # 3 of the 5 steps ran
 
 
 def test_config1_sd15_256px_10_steps_end_to_end_vs_oracle():

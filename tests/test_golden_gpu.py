@@ -84,3 +84,44 @@ def test_hooker_seam_records_per_call_maps():
     hk.clear()
     assert hk.cross_attn_maps == []
     pipe.engine.close()
+
+
+@pytest.mark.parametrize("tag", ["nomask", "mask"])
+@pytest.mark.parametrize("is_train", [True, False])
+def test_processor_seam_through_c_abi_matches_reference_fixture(golden_dir, tag, is_train):
+    """hook.py:83-122 end to end THROUGH THE C ABI (`agd_attn_processor`): the reference's own outputs for one cross- and
+    one self-attention call (with / without an additive attention mask) vs the HIP seam, the fixture's weights loaded
+    into a `tiny` UNet layer.  Covers hook.py:92 (mask), :95-99 (self path records nothing), :110-112 (map)."""
+    from agenda_amd import StableDiffusionPipeline, UNetCrossAttentionHooker, config, synthetic
+    z = np.load(os.path.join(golden_dir, "hook_seam.npz"))
+    cfg = config.tiny()
+    u, v = synthetic.make_unet_weights(cfg, 11), synthetic.make_vae_weights(cfg, 12)
+    t = "down_blocks.0.attentions.0.transformer_blocks.0."
+    for mod, key in (("attn2", "cross"), ("attn1", "self")):
+        for wn, dst in (("wq", "to_q.weight"), ("wk", "to_k.weight"), ("wv", "to_v.weight"), ("wo", "to_out.0.weight"), ("bo", "to_out.0.bias")):
+            src = torch.from_numpy(z[f"seam_{key}_{wn}"])
+            assert u[t + mod + "." + dst].shape == src.shape
+            u[t + mod + "." + dst] = src
+    pipe = StableDiffusionPipeline(cfg, u, v, workspace_bytes=1 << 30)
+    x, ctx = torch.from_numpy(z["seam_x"]), torch.from_numpy(z["seam_ctx"])
+    mc = torch.from_numpy(z["seam_mask_cross"]) if tag == "mask" else None
+    ms = torch.from_numpy(z["seam_mask_self"]) if tag == "mask" else None
+    hk = UNetCrossAttentionHooker(is_train=is_train, latent_hw=16)
+    pipe.unet.set_attn_processor(hk)
+    assert len(pipe.unet.attn_processors) == 32 and all(p is hk for p in pipe.unet.attn_processors.values())
+    yc = hk(pipe.unet.attn(t + "attn2"), x, encoder_hidden_states=ctx, attention_mask=mc)
+    ys = hk(pipe.unet.attn(t + "attn1"), x, attention_mask=ms)
+    assert len(hk.cross_attn_maps) == 1                                     # the self call recorded nothing
+    want_c, want_s = (torch.from_numpy(z[f"seam_{tag}_{k}_y_train{int(is_train)}"]) for k in ("cross", "self"))
+    # bf16 operands / fp32 accumulate vs the reference's fp32: 2^-6 of the output scale
+    assert float((yc.cpu() - want_c).abs().max() / want_c.abs().max()) < 2.0 ** -6
+    assert float((ys.cpu() - want_s).abs().max() / want_s.abs().max()) < 2.0 ** -6
+    want_m = torch.from_numpy(z[f"seam_{tag}_map_train{int(is_train)}"])
+    assert hk.cross_attn_maps[0].shape == want_m.shape
+    assert float((hk.cross_attn_maps[0].cpu() - want_m).abs().max()) < 2e-3
+    # a cross-attention module cannot serve a self-attention call, a non-square token count cannot be unravelled
+    with pytest.raises(ValueError):
+        hk(pipe.unet.attn(t + "attn2"), x)
+    with pytest.raises(RuntimeError):
+        hk(pipe.unet.attn(t + "attn2"), x[:, :250], encoder_hidden_states=ctx)
+    pipe.engine.close()

@@ -38,6 +38,16 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert b"gfx950" in lib.agd_version()
 
 
+def test_library_exports_nothing_the_header_does_not_declare():
+    """The C ABI is exactly include/agenda_hip.h: the library is built with -fvisibility=hidden, so no helper, experiment
+    knob or internal launcher leaks out as an `agd_*` symbol."""
+    import subprocess
+    so = os.path.join(ROOT, "agenda_amd", "libagenda_hip.so")
+    out = subprocess.run(["nm", "-D", "--defined-only", so], capture_output=True, text=True, check=True).stdout
+    exported = {l.split()[-1] for l in out.splitlines() if l.split() and l.split()[-1].startswith("agd_")}
+    assert exported == set(_declared_symbols()), exported ^ set(_declared_symbols())
+
+
 def test_python_binding_covers_the_header():
     from agenda_amd import _lib
     assert set(_declared_symbols()) == set(_lib.EXPORTS)

@@ -170,8 +170,13 @@ def test_from_pretrained_roundtrip(tmp_path, tiny_pipe):
     import json
     from safetensors.torch import save_file
     from agenda_amd import StableDiffusionPipeline, synthetic
+    from _util import write_tiny_clip_tokenizer
     pipe, cfg, u, v = tiny_pipe
+    v = dict(v)
+    v.update({k: t for k, t in synthetic.make_vae_weights(cfg, 12, bias_std=0.05, perturb_norm=0.1, with_encoder=True).items()
+              if k.startswith(("encoder.", "quant_conv."))})          # save_pretrained writes the whole AutoencoderKL
     (tmp_path / "unet").mkdir(); (tmp_path / "vae").mkdir(); (tmp_path / "scheduler").mkdir()
+    n_vocab = write_tiny_clip_tokenizer(str(tmp_path / "tokenizer"))
     uc = {"in_channels": 4, "out_channels": 4, "block_out_channels": list(cfg.unet.block_out_channels),
           "down_block_types": ["CrossAttnDownBlock2D" if c else "DownBlock2D" for c in cfg.unet.down_cross],
           "layers_per_block": cfg.unet.layers_per_block, "attention_head_dim": list(cfg.unet.num_heads),
@@ -184,7 +189,7 @@ def test_from_pretrained_roundtrip(tmp_path, tiny_pipe):
     json.dump({"num_train_timesteps": 1000, "beta_start": 0.00085, "beta_end": 0.012, "steps_offset": 1,
                "set_alpha_to_one": False, "prediction_type": "epsilon"}, open(tmp_path / "scheduler" / "scheduler_config.json", "w"))
     save_file({k: t.contiguous() for k, t in u.items()}, str(tmp_path / "unet" / "diffusion_pytorch_model.safetensors"))
-    # store the VAE attention with the pre-0.18 names to exercise the renaming, plus an encoder key that must be ignored
+    # store the VAE attention with the pre-0.18 names to exercise the renaming (decoder AND encoder mid blocks)
     old = {"to_q": "query", "to_k": "key", "to_v": "value", "to_out.0": "proj_attn"}
     vsd = {}
     for k, t in v.items():
@@ -192,14 +197,13 @@ def test_from_pretrained_roundtrip(tmp_path, tiny_pipe):
             for new, o in old.items():
                 k = k.replace("." + new + ".", "." + o + ".")
         vsd[k] = t.contiguous()
-    vsd["encoder.conv_in.weight"] = torch.zeros(8, 3, 3, 3)
     save_file(vsd, str(tmp_path / "vae" / "diffusion_pytorch_model.safetensors"))
     # text_encoder/ in transformers-4.x naming (text_model. prefix + position_ids buffer) -> device CLIP encoder
     from agenda_amd import config as _config
     from agenda_amd.text import HipCLIPTextEncoder
-    tcfg = _config.tiny(); tcfg.text = _config.TextConfig(hidden_size=64, num_hidden_layers=1, num_attention_heads=1, intermediate_size=128, vocab_size=300)
+    tcfg = _config.tiny(); tcfg.text = _config.TextConfig(hidden_size=64, num_hidden_layers=1, num_attention_heads=1, intermediate_size=128, vocab_size=n_vocab)
     (tmp_path / "text_encoder").mkdir()
-    json.dump({"hidden_size": 64, "num_hidden_layers": 1, "num_attention_heads": 1, "intermediate_size": 128, "vocab_size": 300,
+    json.dump({"hidden_size": 64, "num_hidden_layers": 1, "num_attention_heads": 1, "intermediate_size": 128, "vocab_size": n_vocab,
                "max_position_embeddings": 77, "hidden_act": "quick_gelu", "layer_norm_eps": 1e-5}, open(tmp_path / "text_encoder" / "config.json", "w"))
     tsd = {"text_model." + k: t.contiguous() for k, t in synthetic.make_text_weights(tcfg, 3).items()}
     tsd["text_model.embeddings.position_ids"] = torch.arange(77)[None].float()
@@ -213,7 +217,28 @@ def test_from_pretrained_roundtrip(tmp_path, tiny_pipe):
     a = pipe(prompt_embeds=ctx, latents=lat, num_inference_steps=2, output_type="pt")
     b = p2(prompt_embeds=ctx, latents=lat, num_inference_steps=2, output_type="pt")
     assert torch.equal(a.images, b.images)
+    # the prompt side runs on the real tokenizer class: learned-token injection (data_generation.py:45-52) reaches the device
+    from agenda_amd.generation import inject_learned_tokens
+    base = p2.text_encoder(["an aerial view image with cars"])
+    ids = inject_learned_tokens(p2, {"new_token_v0": torch.randn(64)}, ["new_token_v0"])
+    assert ids == [n_vocab]
+    e2 = p2.text_encoder(["an aerial view image with new_token_v0 cars"])
+    assert not torch.allclose(e2, base)
+    # from_pretrained -> img2img: the encoder half of the VAE was loaded too (vae.encode, finetune_sd.py:764-765)
+    img = (torch.rand(1, 3, 128, 128, generator=torch.Generator().manual_seed(0)) * 2 - 1)
+    ne, nz = torch.randn(1, 4, 16, 16), torch.randn(1, 4, 16, 16)
+    pw = StableDiffusionPipeline(cfg, u, v, workspace_bytes=1 << 30)
+    o1 = pw.img2img(prompt_embeds=ctx, image=img, strength=0.5, num_inference_steps=4, noise_enc=ne, noise=nz, output_type="pt")
+    o2 = p2.img2img(prompt_embeds=ctx, image=img, strength=0.5, num_inference_steps=4, noise_enc=ne, noise=nz, output_type="pt")
+    assert torch.equal(o1.images, o2.images)
+    pw.engine.close()
     p2.engine.close()
+    # real CLIP weights without a loadable tokenizer must NOT fall back to the word-level stand-in
+    import shutil
+    from agenda_amd import _lib
+    shutil.rmtree(tmp_path / "tokenizer")
+    with pytest.raises(_lib.AgendaHipError, match="tokenizer"):
+        StableDiffusionPipeline.from_pretrained(str(tmp_path), workspace_bytes=1 << 30)
 
 
 def test_generation_driver_cli_layout_and_device_export(tmp_path):
@@ -295,3 +320,125 @@ def test_cfg_shared_prefix_is_bit_identical(tiny_pipe, monkeypatch):
     monkeypatch.delenv("AGD_NO_CFG_SHARE")
     for x, y in zip(a, b):
         assert torch.equal(x, y)
+
+
+def test_generation_cli_images_only(tmp_path):
+    """The reference's images-only mode (no --word_token_heatmaps, no learned tokens): zero word maps per image must not
+    launch zero-sized grids on the device export path."""
+    import os
+    from agenda_amd import generation
+    out = tmp_path / "run"
+    generation.main(["--save-dir", str(out), "--num-images", "3", "--batch-size", "2", "--num-inference-steps", "1",
+                     "--synthetic-config", "tiny", "--image-size", "56"])
+    assert sorted(os.listdir(out)) == ["images"]
+    assert sorted(os.listdir(out / "images")) == ["0.png", "1.png", "2.png"]
+
+
+@pytest.mark.parametrize("cfgname", ["tiny", "tiny21"])
+def test_cfg_ddim_step_matches_oracle(cfgname):
+    """`agd_cfg_ddim_step` (the call-by-call `scheduler.step`): CFG combine + DDIM eta-0 update vs the oracle's DDIM.step,
+    epsilon- and v-prediction, NCHW eps in / in-place NCHW latents out."""
+    from agenda_amd import StableDiffusionPipeline, config
+    from oracle import sd_oracle as O
+    cfg = config.CONFIGS[cfgname]()
+    pipe = StableDiffusionPipeline.from_synthetic(cfg, workspace_bytes=1 << 28)
+    sc = cfg.sched
+    sch = O.DDIM(sc.num_train_timesteps, sc.beta_start, sc.beta_end, sc.steps_offset, sc.set_alpha_to_one, sc.prediction_type)
+    ts = sch.set_timesteps(10)
+    g = torch.Generator().manual_seed(5)
+    B, L, s = 3, 24, 7.5
+    x = torch.randn(B, 4, L, L, generator=g)
+    eps = torch.randn(2 * B, 4, L, L, generator=g)
+    for t in (int(ts[0]), int(ts[4]), int(ts[-1])):
+        eu, ec = eps.chunk(2)
+        want = sch.step(eu + s * (ec - eu), t, x)
+        a_t, a_p = sch.coeffs(t)
+        lat = x.clone().cuda()
+        pipe.engine.cfg_ddim_step(eps, lat, s, a_t, a_p)
+        assert float((lat.cpu() - want).abs().max()) < 2e-5 * float(want.abs().max()), (cfgname, t)
+    with pytest.raises(ValueError):
+        pipe.engine.cfg_ddim_step(eps[:3], x.clone().cuda(), s, 0.5, 0.6)
+    pipe.engine.close()
+
+
+def test_manual_loop_matches_fused_denoise(tiny_pipe):
+    """`unet(...)` + `agd_cfg_ddim_step` call by call == the fused `agd_denoise` loop (same kernels, same order)."""
+    from agenda_amd import synthetic
+    pipe, cfg = tiny_pipe[0], tiny_pipe[1]
+    B, L, steps = 2, 16, 3
+    ctx = synthetic.make_context(cfg, B, seed=31)
+    lat0 = synthetic.make_latents(cfg, [7, 8], L)
+    fused = pipe(prompt_embeds=ctx, latents=lat0, num_inference_steps=steps, output_type="latent").latents
+    ts = pipe.scheduler.set_timesteps(steps)
+    a_t, a_p = pipe.scheduler.step_coeffs()
+    lat = lat0.clone().cuda()
+    pipe.engine.set_context(ctx)
+    for i, t in enumerate(ts):
+        eps = pipe.engine.unet_forward(torch.cat([lat, lat]), float(t))
+        pipe.engine.cfg_ddim_step(eps, lat, 7.5, a_t[i], a_p[i])
+    assert _rms_rel(lat, fused.cpu()) < 1e-5
+
+
+def test_recorder_buffers_follow_token_count_and_batch(tiny_pipe):
+    """accumulators are capacity-tracked.  trace(rec_tokens=14) then trace() with all 77 rows (5.5x larger),
+    then a larger batch, on ONE pipeline: results must equal a fresh pipeline's and nothing may be corrupted."""
+    from agenda_amd import StableDiffusionPipeline, synthetic, trace
+    pipe, cfg, u, v = tiny_pipe
+    L, steps = 16, 2
+    ctx1, lat1 = synthetic.make_context(cfg, 1, seed=41), synthetic.make_latents(cfg, [3], L)
+    ctx3, lat3 = synthetic.make_context(cfg, 3, seed=42), synthetic.make_latents(cfg, [4, 5, 6], L)
+
+    def run(p, ctx, lat, rec_tokens):
+        with trace(p, rec_tokens=rec_tokens) as trc:
+            out = p(prompt_embeds=ctx, latents=lat, num_inference_steps=steps, output_type="pt")
+            maps = torch.stack([trc.compute_global_heat_map(image_index=i).heat_maps for i in range(lat.shape[0])])
+        return out.images.clone(), maps.clone()
+
+    a14 = run(pipe, ctx1, lat1, 14)
+    a77 = run(pipe, ctx1, lat1, None)
+    a3 = run(pipe, ctx3, lat3, None)
+    b14 = run(pipe, ctx1, lat1, 14)                                  # shrinking again reuses the larger blocks
+    fresh = StableDiffusionPipeline(cfg, u, v, workspace_bytes=1 << 30)
+    f77, f3 = run(fresh, ctx1, lat1, None), run(fresh, ctx3, lat3, None)
+    fresh.engine.close()
+    assert a14[1].shape == (1, 14, L, L) and a77[1].shape == (1, 77, L, L) and a3[1].shape == (3, 77, L, L)
+    assert torch.equal(a77[0], f77[0]) and torch.equal(a77[1], f77[1])
+    assert torch.equal(a3[0], f3[0]) and torch.equal(a3[1], f3[1])
+    assert torch.equal(a14[1], a77[1][:, :14]) and torch.equal(a14[1], b14[1]) and torch.equal(a14[0], b14[0])
+    # weights next to the accumulators in device memory are intact: the UNet still answers as before
+    x = torch.cat([lat1, lat1])
+    pipe.engine.set_context(ctx1)
+    e1 = pipe.engine.unet_forward(x, 500.0)
+    fresh = StableDiffusionPipeline(cfg, u, v, workspace_bytes=1 << 30)
+    fresh.engine.set_context(ctx1)
+    assert torch.equal(e1, fresh.engine.unet_forward(x, 500.0))
+    fresh.engine.close()
+
+
+def test_hooker_context_length_change_resizes_the_recorder():
+    """the hooker sees the token count change between direct seam calls (20 -> 77 tokens): the recorder is reset
+    and re-sized, maps come out right for both lengths."""
+    from agenda_amd import StableDiffusionPipeline, UNetCrossAttentionHooker, config, synthetic
+    from oracle import sd_oracle as O
+    cfg = config.tiny()
+    u, v = synthetic.make_unet_weights(cfg, 11), synthetic.make_vae_weights(cfg, 12)
+    pipe = StableDiffusionPipeline(cfg, u, v, workspace_bytes=1 << 30)
+    name = "up_blocks.1.attentions.0.transformer_blocks.0.attn2"
+    t = name.rsplit("attn2", 1)[0]
+    C = u[t + "attn2.to_q.weight"].shape[0]
+    hk = UNetCrossAttentionHooker(is_train=True, latent_hw=16)
+    pipe.unet.set_attn_processor(hk)
+    g = torch.Generator().manual_seed(3)
+    for T in (20, 77, 20):
+        hidden = torch.randn(2, 64, C, generator=g).to(torch.bfloat16).float()
+        ctx = torch.randn(2, T, cfg.unet.cross_attention_dim, generator=g).to(torch.bfloat16).float()
+        hk.clear()
+        y = hk(pipe.unet.attn2(name), hidden, ctx)
+        rec = O.HookRecorder(is_train=True, latent_hw=16)
+        want = O.explicit_attention_processor(hidden, ctx, u[t + "attn2.to_q.weight"], u[t + "attn2.to_k.weight"], u[t + "attn2.to_v.weight"],
+                                              u[t + "attn2.to_out.0.weight"], u[t + "attn2.to_out.0.bias"], 2, recorder=rec)
+        assert float((y.cpu() - want).abs().max() / want.abs().max()) < 2.0 ** -6
+        assert hk.cross_attn_maps[-1].shape == (2, T, 8, 8)
+        assert float((hk.cross_attn_maps[-1].cpu() - rec.cross_attn_maps[0]).abs().max()) < 2e-3
+        assert float((hk.compute_global_heat_map().cpu() - rec.compute_global_heat_map()).abs().max()) < 2e-3
+    pipe.engine.close()

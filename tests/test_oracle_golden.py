@@ -60,3 +60,23 @@ def test_processor_call_matches_reference(golden_dir, name, is_train):
     # self-attention records nothing (hook.py:110)
     assert len(rec.cross_attn_maps) == 1
     assert list(z[f"{name}_nmaps_train{int(is_train)}"]) == [1, 1]
+
+
+@pytest.mark.parametrize("tag", ["nomask", "mask"])
+@pytest.mark.parametrize("is_train", [True, False])
+def test_processor_seam_fixture_matches_reference(golden_dir, tag, is_train):
+    """The reference's `__call__` at the shapes of a `tiny` UNet layer, with and without an additive attention mask
+    (hook.py:92,108) -- the fixture tests/test_golden_gpu.py drives through the C-ABI seam."""
+    z = _load(golden_dir, "hook_seam.npz")
+    x, ctx = torch.from_numpy(z["seam_x"]), torch.from_numpy(z["seam_ctx"])
+    mc = torch.from_numpy(z["seam_mask_cross"]) if tag == "mask" else None
+    ms = torch.from_numpy(z["seam_mask_self"]) if tag == "mask" else None
+    rec = O.HookRecorder(is_train=is_train, latent_hw=16)
+    w = {k: torch.from_numpy(z[f"seam_cross_{k}"]) for k in ("wq", "wk", "wv", "wo", "bo")}
+    y = O.explicit_attention_processor(x, ctx, w["wq"], w["wk"], w["wv"], w["wo"], w["bo"], 2, recorder=rec, attention_mask=mc)
+    np.testing.assert_allclose(y.numpy(), z[f"seam_{tag}_cross_y_train{int(is_train)}"], rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(rec.cross_attn_maps[0].numpy(), z[f"seam_{tag}_map_train{int(is_train)}"], rtol=1e-5, atol=1e-7)
+    w = {k: torch.from_numpy(z[f"seam_self_{k}"]) for k in ("wq", "wk", "wv", "wo", "bo")}
+    ys = O.explicit_attention_processor(x, None, w["wq"], w["wk"], w["wv"], w["wo"], w["bo"], 2, recorder=rec, attention_mask=ms)
+    np.testing.assert_allclose(ys.numpy(), z[f"seam_{tag}_self_y_train{int(is_train)}"], rtol=1e-5, atol=2e-6)
+    assert len(rec.cross_attn_maps) == 1
