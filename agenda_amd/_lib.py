@@ -55,6 +55,7 @@ _SIGS = {
                               C.POINTER(C.c_float), C.c_float, _P]),
     "agd_vae_decode": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P, _P]),
     "agd_vae_encode": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P, _P]),
+    "agd_set_option": (C.c_int, [_P, C.c_char_p, C.c_int]),
     "agd_record_config": (C.c_int, [_P, C.c_int, C.c_int, C.c_int]),
     "agd_record_reset": (C.c_int, [_P, C.c_int, C.c_int, _P]),
     "agd_daam_global": (C.c_int, [_P, C.c_int, C.c_int, _P, _P]),

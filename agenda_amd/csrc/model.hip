@@ -93,6 +93,7 @@ struct agd_ctx {
   DBuf latb, epsb, vae_imgb;
   bf16_t* lat_bf16 = nullptr; float* eps_nhwc = nullptr;
   SplitKWs splitk;                                    // split-K partial slabs of this ctx (stream-ordered reuse)
+  int opt_cfg_share = 1;                              // agd_set_option("cfg_shared_prefix")
   // profiling
   bool prof_on = false; std::vector<ProfEv> prof; std::vector<hipEvent_t> ev_pool; size_t ev_used = 0;
   long long launches[AGD_N_CLASSES] = {0};
@@ -378,7 +379,7 @@ static int unet_walk(agd_ctx* c, hipStream_t st, const bf16_t* xin, int B2, int 
   if (tproj_row) c->tproj_cur = tproj_row;
   else { CK(time_embed(c, st, &t, 1, c->temb_buf, c->tproj_out)); c->tproj_cur = c->tproj_out; }
   std::vector<Act> skips;
-  const bool shared = cfg_shared && (B2 % 2) == 0 && g.down_cross[0] && !getenv("AGD_NO_CFG_SHARE");
+  const bool shared = cfg_shared && (B2 % 2) == 0 && g.down_cross[0] && c->opt_cfg_share;
   const int Bh = shared ? B2 / 2 : B2;
   Act h = alloc_act(c, B2, L, L, g.block_out_channels[0]); if (!h.p) return -1;
   { GETW(w, u + "conv_in.weight"); GETV(b, u + "conv_in.bias"); GemmOpt o; o.bias = b;
@@ -810,6 +811,14 @@ AGD_API int agd_vae_decode(agd_ctx* c, const float* latents, int batch, int L, u
     rc = launch_nchw_from_nhwc_f32(img, 4, out_f32, (int)npix, c->cfg.vae_out_channels, 1, st);
   }
   return rc ? fail_ctx(c) : 0;
+}
+
+// ---- options --------------------------------------------------------------------------
+AGD_API int agd_set_option(agd_ctx* c, const char* name, int value) {
+  if (!c || !name) { agd_set_error("set_option: null argument"); return fail_ctx(c); }
+  if (!strcmp(name, "cfg_shared_prefix")) { c->opt_cfg_share = value != 0; return 0; }
+  agd_set_error("set_option: unknown option '%s'", name);
+  return fail_ctx(c);
 }
 
 // ---- recorder -------------------------------------------------------------------------

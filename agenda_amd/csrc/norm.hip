@@ -12,7 +12,7 @@
 struct GnGeom { int nvec, PR, ppb, nchunk; };
 static GnGeom gn_geom(int B, int C, int HW) {
   GnGeom g; g.nvec = C / 8; g.PR = 512 / g.nvec;
-  static const int nblk = getenv("AGD_GN_BLOCKS") ? atoi(getenv("AGD_GN_BLOCKS")) : 256;   // one 512-thread block per CU measured best (kbench gn: 0.96 -> 0.88 ms per forward vs 512)
+  constexpr int nblk = 256;   // one 512-thread block per CU measured best (kbench gn: 0.96 -> 0.88 ms per forward vs 512)
   const long long target = ((long long)HW * B + nblk - 1) / nblk;    // pixels per block for ~nblk blocks
   int it = (int)((target + g.PR - 1) / g.PR); if (it < 1) it = 1; if (it > 16) it = 16;
   g.ppb = it * g.PR; g.nchunk = (HW + g.ppb - 1) / g.ppb;

@@ -178,6 +178,9 @@ class Engine:
         self._ck(self.lib.agd_vae_encode(self.ctx, _lib.ptr(image), b, S, _lib.ptr(mean), _lib.ptr(logvar), self._stream()), "agd_vae_encode")
         return mean, logvar.clamp_(-30.0, 20.0)
 
+    def set_option(self, name: str, value: int):
+        self._ck(self.lib.agd_set_option(self.ctx, name.encode(), int(value)), f"agd_set_option({name})")
+
     # recorder
     def record_config(self, mode: int, is_train: bool = False, rec_tokens: int = 0):
         self._ck(self.lib.agd_record_config(self.ctx, mode, int(is_train), rec_tokens), "agd_record_config")

@@ -92,6 +92,10 @@ int agd_vae_decode(agd_ctx* ctx, const float* latents, int batch, int latent_sid
  * image fp32 NCHW [B,3,S,S] in [-1,1] -> mean and logvar fp32 NCHW [B,4,S/8,S/8].  Syncs. */
 int agd_vae_encode(agd_ctx* ctx, const float* image, int batch, int side, float* mean_out, float* logvar_out, void* stream);
 
+/* ---- per-ctx options (no environment variables steer the library).  "cfg_shared_prefix" (default 1): agd_denoise runs the
+ * layers ahead of the first cross-attention once for the identical unconditional / conditional halves (bit-identical to 0). */
+int agd_set_option(agd_ctx* ctx, const char* name, int value);
+
 /* ---- heat-map recording (daam.trace / hook.py UNetCrossAttentionHooker state)
  * mode 0 off; 1 DAAM (per-layer/head time sums, mid block excluded, conditional half);
  * 2 HOOK (hook.py: head-mean per call, every attn2 incl. mid; is_train=1 keeps all batch rows).

@@ -299,7 +299,7 @@ def test_vae_encode_and_img2img_match_oracle():
     pipe.engine.close()
 
 
-def test_cfg_shared_prefix_is_bit_identical(tiny_pipe, monkeypatch):
+def test_cfg_shared_prefix_is_bit_identical(tiny_pipe):
     """agd_denoise shares the layers ahead of the first cross-attention between the (identical) unconditional and
     conditional halves; the result must equal running both halves, bit for bit (every shared op is row/image-local)."""
     from agenda_amd import synthetic, trace
@@ -315,9 +315,11 @@ def test_cfg_shared_prefix_is_bit_identical(tiny_pipe, monkeypatch):
         return out.images.clone(), out.latents.clone(), maps.clone()
 
     a = run()
-    monkeypatch.setenv("AGD_NO_CFG_SHARE", "1")
+    pipe.engine.set_option("cfg_shared_prefix", 0)
     b = run()
-    monkeypatch.delenv("AGD_NO_CFG_SHARE")
+    pipe.engine.set_option("cfg_shared_prefix", 1)
+    with pytest.raises(Exception, match="unknown option"):
+        pipe.engine.set_option("no_such_option", 1)
     for x, y in zip(a, b):
         assert torch.equal(x, y)
 

@@ -1,4 +1,5 @@
-"""Explore igemm configurations for one shape: python tools/kb_force.py M_side Cin Cout ksize [res]   (B=8)"""
+"""Explore igemm configurations for one shape: python tools/kb_force.py M_side Cin Cout ksize [res]   (B=8)
+Needs an experiments build of the library: make -C agenda_amd/csrc clean all EXTRA=-DAGD_EXPERIMENTS (AGD_IGEMM_FORCE)."""
 import ctypes as C, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if len(sys.argv) > 1 and sys.argv[1] == "--one":

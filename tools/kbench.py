@@ -45,7 +45,7 @@ def gn(B, HW, Cc, iters=20, cnt=1):
 
 
 what = sys.argv[1] if len(sys.argv) > 1 else "all"
-if len(sys.argv) > 2:
+if len(sys.argv) > 2:            # experiment knob: only in builds made with `make EXTRA=-DAGD_EXPERIMENTS`
     lib.agd_set_igemm_cfg(int(sys.argv[2]))
     print("igemm cfg", sys.argv[2])
 B = 8
@@ -77,8 +77,9 @@ if what in ("lin", "all"):
     print(f"  -> linear total per UNet forward: {t:.3f} ms"); tot += t
 if what in ("attn", "all"):
     print("== attention")
-    for qb in (2, 1):
-        lib.agd_set_attn_qb(qb)
+    for qb in ((2, 1) if hasattr(lib, "agd_set_attn_qb") else (1,)):
+        if hasattr(lib, "agd_set_attn_qb"):
+            lib.agd_set_attn_qb(qb)
         print(f" [qb={qb}]")
         attn(B, 8, 40, 4096, 4096); attn(B, 8, 80, 1024, 1024); attn(B, 8, 160, 256, 256)
         attn(B, 5, 64, 9216, 9216, iters=5); attn(B, 10, 64, 2304, 2304); attn(B, 20, 64, 576, 576)   # SD-2.1 768 px
