@@ -17,8 +17,10 @@
 //    16x16x32 MFMA operand fetch; the XOR is applied on the SOURCE address (LDS-DMA writes
 //    lane-linear);
 //  * skip-connection concat, nearest-2x upsample and stride-2 are folded into the gather;
-//  * epilogue goes through LDS as fp32 and is written as whole 16-B row chunks with bias /
-//    time-embedding row add / residual / GEGLU / SiLU fused, one rounding to bf16;
+//  * MFMA operand roles are swapped (D = W_tile . X_tile^T) and the weight rows permuted inside a wave's N range, so a
+//    lane's accumulators are consecutive output channels of one pixel: the epilogue (bias / time-embedding row add /
+//    residual / GEGLU / SiLU, one rounding to bf16) runs straight from registers and stores whole 16-B row chunks --
+//    no LDS staging, no barrier (igemm_epilogue.h);
 //  * block->tile map is XCD-aware (tiles sharing an A panel share an L2).
 #include "kernels.h"
 #include <cstdio>
@@ -52,6 +54,13 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_kernel(const IgemmP p) 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wid / WN, wn = wid % WN;
+  // Phase stagger (short-K launches with several tiles per CU slot): the two workgroups that share a CU start in
+  // lockstep and stay there -- both in the LDS/MFMA-bound main loop, then both in the store/VALU-bound epilogue.  The
+  // second occupant of each CU (blocks 256..511 of the first dispatch wave) starts `stagger` x 1024 cycles late, so one
+  // workgroup's epilogue runs beside the other's main loop for the rest of the launch.  Speed only: any placement is correct.
+  if (p.stagger > 0 && blockIdx.y == 0 && blockIdx.z == 0 && (blockIdx.x >> 8) == 1) {
+    for (int i = 0; i < p.stagger; ++i) __builtin_amdgcn_s_sleep(16);
+  }
   const int tiles_n = (p.N + BN - 1) / BN;
   const int bid = xcd_remap(blockIdx.x, gridDim.x);
   const int tn = bid % tiles_n, tm = bid / tiles_n;
@@ -94,11 +103,16 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_kernel(const IgemmP p) 
     }
     a_rowok |= (ok ? 1u : 0u) << i;
   }
+  // B rows are read by the MFMA in permuted order (tile j, fragment row rho = 4q' + r' <-> wave-local row q'*4NI + 4j + r',
+  // see igemm_epilogue.h), so the conflict-free swizzle key of a row is rho & 7 = (row & 3) | ((q' & 1) << 2)
   unsigned bvoff[B_IT];                              // fixed for the whole kernel
 #pragma unroll
   for (int i = 0; i < B_IT; ++i) {
-    const int n = n0 + (i * NW + wid) * 8 + lrow;
-    bvoff[i] = (n < p.N) ? (unsigned)(((long long)n * p.K + lchunk * 8) * 2) : OOB_OFF;
+    const int row = (i * NW + wid) * 8 + lrow;       // tile-local weight row this lane fetches
+    const int n = n0 + row;
+    const int qp = (row % WTN) / (4 * NI);
+    const int key = (row & 3) | ((qp & 1) << 2);
+    bvoff[i] = (n < p.N) ? (unsigned)(((long long)n * p.K + ((lane & 7) ^ key) * 8) * 2) : OOB_OFF;
   }
   unsigned avoff[A_IT];                              // fixed within a (tap, source) segment
   unsigned asoff = 0, bsoff = 0;                     // SGPR byte offsets: K advance
@@ -174,9 +188,13 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_kernel(const IgemmP p) 
 
   // fragment read offsets (row&7 == lane&7 because every row base is a multiple of 16)
   const int frow = lane & 15;
-  int foff[2];
+  int foff[2], foffB[2];                             // A: row = 16i + rho ; B: row = q'*4NI + 4j + r' (rho = 4q' + r')
 #pragma unroll
-  for (int kk = 0; kk < 2; ++kk) foff[kk] = frow * 128 + ((((kk << 2) + (lane >> 4)) ^ (lane & 7)) << 4);
+  for (int kk = 0; kk < 2; ++kk) {
+    const int sw = (((kk << 2) + (lane >> 4)) ^ (lane & 7)) << 4;
+    foff[kk] = frow * 128 + sw;
+    foffB[kk] = (frow >> 2) * (4 * NI * 128) + (frow & 3) * 128 + sw;
+  }
 
   // ---- main loop (2-stage ring): ONE basic block per K step, hand-interleaved so the LDS-DMA issue of
   // the next stage hides under this stage's MFMAs inside the same wave:
@@ -197,24 +215,24 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_kernel(const IgemmP p) 
 #pragma unroll
     for (int i = 0; i < MI; ++i) a0[i] = *(const bf16x8*)(sA + i * 2048 + foff[0]);
 #pragma unroll
-    for (int j = 0; j < NI; ++j) b0[j] = *(const bf16x8*)(sB + j * 2048 + foff[0]);
+    for (int j = 0; j < NI; ++j) b0[j] = *(const bf16x8*)(sB + j * 512 + foffB[0]);
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
       if (g < A_IT) bufdma16(baseA, dA + (g * NW + wid) * 1024, av[g < A_IT ? g : 0], aso, nrA);
       else if (g < ND) bufdma16(baseW, dB + ((g - A_IT) * NW + wid) * 1024, bvoff[(g >= A_IT && g < ND) ? g - A_IT : 0], bso, nrB);
       if (g < MI) a1[g] = *(const bf16x8*)(sA + g * 2048 + foff[1]);
-      else if (g < NF) b1[g - MI] = *(const bf16x8*)(sB + (g - MI) * 2048 + foff[1]);
+      else if (g < NF) b1[g - MI] = *(const bf16x8*)(sB + (g - MI) * 512 + foffB[1]);
     }
 #pragma unroll
     for (int i = 0; i < MI; ++i)
 #pragma unroll
       for (int j = 0; j < NI; ++j)
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0[i], b0[j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0[j], a0[i], acc[i][j], 0, 0, 0);   // D = W . X^T
 #pragma unroll
     for (int i = 0; i < MI; ++i)
 #pragma unroll
       for (int j = 0; j < NI; ++j)
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[i], b1[j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1[j], a1[i], acc[i][j], 0, 0, 0);
     // pin the interleave (masks: MFMA 0x8, VMEM_READ 0x20, DS_READ 0x100)
     __builtin_amdgcn_sched_group_barrier(0x100, NF, 0);
 #pragma unroll
@@ -248,8 +266,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_kernel(const IgemmP p) 
   }
 
   // The tail K steps issued their LDS-DMAs through a zero-record descriptor: nothing is fetched, but the hardware still
-  // WRITES ZEROS to the LDS destination.  Those writes must have landed before the epilogue reuses the ring as its
-  // staging buffer (__syncthreads() does not wait on vmcnt at workgroup scope).
+  // WRITES ZEROS to the LDS destination.  Let those land before the wave retires (the epilogue itself no longer touches LDS).
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #ifdef AGD_EXPERIMENTS
   if (p.dbg & 64) {                                // timing experiment (AGD_IGEMM_CFG=1024): no epilogue (keeps acc live)
@@ -262,7 +279,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_kernel(const IgemmP p) 
     return;
   }
 #endif
-  igemm_epilogue<BM, BN, WM, WN, GEGLU, SPLITK>(p, acc, smem, tid, lane, wm, wn, m0, n0, tn, bz);
+  igemm_epilogue<BM, BN, WM, WN, GEGLU, SPLITK>(p, acc, lane, wm, wn, m0, n0, bz);
 }
 
 // split-K second pass: out = epilogue(sum_s partial[s])   (deterministic slab sum, no atomics)
@@ -291,7 +308,7 @@ template <int BM, int BN, int WM, int WN, int KS, int STAGES, int GEGLU, int SPL
 static int launch_one(const IgemmP& p, int splits, hipStream_t st) {
   constexpr int NT = WM * WN * 64;
   constexpr int stage = (BM + BN) * 128;
-  constexpr int lds = (STAGES * stage > BM * BN * 4) ? STAGES * stage : BM * BN * 4;
+  constexpr int lds = STAGES * stage;
   const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
   dim3 grid(tiles, p.batch > 0 ? p.batch : 1, splits);
   auto kfn = igemm_kernel<BM, BN, WM, WN, KS, STAGES, GEGLU, SPLITK>;
@@ -320,7 +337,7 @@ static int launch_cfg(const IgemmP& p, int splits, hipStream_t st) {
     return 0;
   }
   if (p.geglu) {
-    if constexpr (BN == 128) { if (p.ksize == 1) return launch_one<BM, BN, WM, WN, 1, STAGES, 1, 0>(p, 1, st); }
+    if constexpr (BN / WN == 64) { if (p.ksize == 1) return launch_one<BM, BN, WM, WN, 1, STAGES, 1, 0>(p, 1, st); }
     agd_set_error("igemm: geglu only on 1x1 with the 128-wide tile"); return -1;
   }
   if (p.ksize == 3) return launch_one<BM, BN, WM, WN, 3, STAGES, 0, 0>(p, 1, st);
@@ -363,6 +380,7 @@ int launch_igemm(const IgemmP& p_in, hipStream_t st) {
   static bool env_read = false;
   if (!env_read) { env_read = true; const char* e = getenv("AGD_IGEMM_CFG"); if (e) g_igemm_cfg = atoi(e); }
   p.dbg = g_igemm_cfg >> 4;
+  { static int stg = -1; if (stg < 0) { const char* e = getenv("AGD_IGEMM_STAGGER"); stg = e ? atoi(e) : 0; } p.stagger = stg; }
 #endif
   if (p.K & 63 || p.C0 & 63 || p.C1 & 63) { agd_set_error("igemm: K/C0/C1 must be multiples of 64 (K=%d C0=%d C1=%d)", p.K, p.C0, p.C1); return -1; }
   if (p.K != p.ksize * p.ksize * (p.C0 + p.C1)) { agd_set_error("igemm: K=%d != ks^2*(C0+C1)=%d", p.K, p.ksize * p.ksize * (p.C0 + p.C1)); return -1; }
@@ -377,6 +395,7 @@ int launch_igemm(const IgemmP& p_in, hipStream_t st) {
   {  // exploration only: AGD_IGEMM_FORCE="<bn>:<splits>:<stages>" forces one configuration for every non-GEGLU launch
     static int f_bn = -1, f_s = 1, f_st = 2;
     if (f_bn < 0) { const char* e = getenv("AGD_IGEMM_FORCE"); f_bn = 0; if (e) sscanf(e, "%d:%d:%d", &f_bn, &f_s, &f_st); }
+    if (f_bn == 256 && batch == 1) return f_st == 2 ? launch_cfg<256, 128, 4, 2, 2>(p, 1, st) : launch_cfg<256, 128, 4, 2, 3>(p, 1, st);
     if (f_bn > 0 && !p.geglu && batch == 1) {
       int S = f_s; if (S > nk / 2) S = nk / 2; if (S < 1) S = 1;
       if (S >= 2) CK0(ensure_splitk(p, S));

@@ -1,167 +1,164 @@
-// Shared igemm epilogue: accumulators -> LDS (fp32) -> whole 16-B row chunks with bias / time-embedding
-// row add / residual (prefetched) / GEGLU / SiLU fused, one rounding to bf16; split-K writes fp32 slabs.
+// igemm epilogue, straight from the accumulator registers (no LDS round trip, no barrier).
+//
+// The main loop issues its MFMAs with the operand roles swapped -- D = W_tile . X_tile^T -- so a lane's accumulator
+// registers hold CONSECUTIVE OUTPUT CHANNELS of ONE pixel (16x16x32 C/D map: col = lane & 15 = pixel, row =
+// 4 * (lane >> 4) + reg = weight row), and the weight rows of the wave's N range are assigned to the 16-row MFMA tiles
+// as   tile j, row 4q + r  <->  wave-local column q * 4NI + 4j + r   (a free permutation: the fragment read address is
+// per lane).  Lane (q, pixel) therefore owns the 4*NI consecutive channels  q*4NI .. q*4NI + 4NI-1  of its pixel in
+// every pixel tile i: bias / time-embedding row / residual / GEGLU / activation are lane-local and the result leaves as
+// 16-byte (8-byte for the 160-wide tile) row chunks -- the same store instructions the LDS-staged epilogue issued, minus
+// 64 KB of LDS writes + reads and two barriers per tile (the epilogue was a third of a K = 320 tile's LDS time).
+// Split-K writes its fp32 slab rows the same way.
 #pragma once
 #include "kernels.h"
 
 template <int BM, int BN, int WM, int WN, int GEGLU, int SPLITK>
-AGD_DEV void igemm_epilogue(const IgemmP& p, f32x4 (&acc)[BM / WM / 16][BN / WN / 16], char* smem, int tid, int lane,
-                            int wm, int wn, int m0, int n0, int tn, int bz) {
-  constexpr int NT = WM * WN * 64;
+AGD_DEV void igemm_epilogue(const IgemmP& p, f32x4 (&acc)[BM / WM / 16][BN / WN / 16], int lane, int wm, int wn, int m0, int n0,
+                            int bz) {
   constexpr int WTM = BM / WM, WTN = BN / WN;
   constexpr int MI = WTM / 16, NI = WTN / 16;
+  static_assert(!GEGLU || NI == 4, "GEGLU epilogue: a lane's 16 columns must be one [8 values | 8 gates] group");
+  constexpr int CA = 4 * NI;                        // accumulator columns per lane and pixel
+  constexpr int CW = GEGLU ? CA / 2 : CA;           // output channels per lane and pixel
+  constexpr int SV = (CW % 8 == 0) ? 8 : 4;         // elements per vector access (16 B of bf16, else 8 B)
+  const int q = lane >> 4, px = lane & 15;
   const int HWo = p.Hout * p.Wout;
-  const float inv_hwo_e = 1.0f / (float)HWo;        // rowadd image index (M < 2^24 is checked by the launcher)
-  // ---- epilogue: acc -> LDS fp32 [BM][BN] -> coalesced 16-B row chunks -----------------------
-  // Residual chunks are prefetched into registers before the LDS round trip so their HBM latency
-  // overlaps the staging; all trip counts are compile-time.
-  constexpr int OW = GEGLU ? BN / 2 : BN;           // output columns produced by this tile
-  constexpr int CPR = OW / 8;                       // 8-column chunks per output row
-  constexpr int EP_IT = (BM * CPR + NT - 1) / NT;
+  const float inv_hwo = 1.0f / (float)HWo;          // rowadd image index (M < 2^24 is checked by the launcher)
   const int Nout = GEGLU ? p.N / 2 : p.N;
-  const int no0 = GEGLU ? tn * (BN / 2) : n0;
-
-  auto stage_acc = [&]() {
-    __syncthreads();
-    float* stg_ = (float*)smem;
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-      for (int j = 0; j < NI; ++j)
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          stg_[(wm * WTM + i * 16 + (lane >> 4) * 4 + r) * BN + wn * WTN + j * 16 + (lane & 15)] = acc[i][j][r] * p.alpha;
-    __syncthreads();
-  };
-  const float* stg = (const float*)smem;
+  const int ncol = n0 + wn * WTN + q * CA;          // first accumulator column of this lane (global)
+  const int no = GEGLU ? ncol / 2 : ncol;           // first output channel ([8 values | 8 gates] per 16 columns)
+  const int mrow0 = m0 + wm * WTM + px;
 
   if constexpr (SPLITK) {
-    stage_acc();
     float* part = p.splitk_ws + ((long long)blockIdx.z * p.M) * p.N;
 #pragma unroll
-    for (int it = 0; it < EP_IT; ++it) {
-      const int idx = tid + it * NT;
-      const int r = idx / CPR, cc = idx - r * CPR;
-      const int m = m0 + r, no = no0 + cc * 8;
-      const int nvalid = (Nout - no) < 8 ? (Nout - no) : 8;
-      if (idx < BM * CPR && m < p.M && nvalid > 0) {
-        const float* sp = stg + r * BN + cc * 8;
-        float* op = part + (long long)m * p.N + no;
-        if (nvalid == 8) { *(f32x4*)op = *(const f32x4*)sp; *(f32x4*)(op + 4) = *(const f32x4*)(sp + 4); }
-        else for (int e = 0; e < nvalid; ++e) op[e] = sp[e];
+    for (int i = 0; i < MI; ++i) {
+      const int m = mrow0 + i * 16;
+      if (m >= p.M) continue;
+      float* op = part + (long long)m * p.N + no;
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        const int n = no + 4 * j;
+        if (n + 4 <= p.N) *(f32x4*)(op + 4 * j) = acc[i][j] * p.alpha;          // N % 4 == 0 (launcher)
+        else for (int r = 0; r < 4; ++r) if (n + r < p.N) op[4 * j + r] = acc[i][j][r] * p.alpha;
       }
     }
     return;
   } else {
-    const bool vec_all = ((p.ldo & 7) == 0) && (!p.residual || (p.ldr & 7) == 0);
-    s16x8 rres[EP_IT];
-    if (p.residual && vec_all) {
-#pragma unroll
-      for (int it = 0; it < EP_IT; ++it) {
-        const int idx = tid + it * NT;
-        const int r = idx / CPR, cc = idx - r * CPR;
-        const int m = m0 + r, no = no0 + cc * 8;
-        if (idx < BM * CPR && m < p.M && no + 8 <= Nout) rres[it] = *(const s16x8*)(p.residual + bz * p.sR + (long long)m * p.ldr + no);
-      }
-    }
-    // when the thread count is a multiple of the chunks per row, each thread keeps ONE column chunk for all its
-    // rows: per-column epilogue operands (bias vectors) are loaded once, before the staging barriers
-    constexpr bool FIXED_CC = (NT % CPR) == 0;
-    float hb[8], hg[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) { hb[e] = 0.f; hg[e] = 0.f; }
-    if constexpr (FIXED_CC) {
-      const int no_ = no0 + (tid % CPR) * 8;
-      if (p.bias && p.bias_mode != 2 && no_ + 8 <= Nout) {
-        *(f32x4*)&hb[0] = *(const f32x4*)(p.bias + no_); *(f32x4*)&hb[4] = *(const f32x4*)(p.bias + no_ + 4);
-        if constexpr (GEGLU) { *(f32x4*)&hg[0] = *(const f32x4*)(p.bias + Nout + no_); *(f32x4*)&hg[4] = *(const f32x4*)(p.bias + Nout + no_ + 4); }
-      }
-    }
-    stage_acc();
-#pragma unroll
-    for (int it = 0; it < EP_IT; ++it) {
-      const int idx = tid + it * NT;
-      const int r = idx / CPR, cc = idx - r * CPR;
-      const int m = m0 + r, no = no0 + cc * 8;
-      const int nvalid = (Nout - no) < 8 ? (Nout - no) : 8;
-      if (idx >= BM * CPR || m >= p.M || nvalid <= 0) continue;
-      const bool vec_ok = vec_all && nvalid == 8;
-      float v[8];
-      const float* sp = stg + r * BN + cc * 8;
-      *(f32x4*)&v[0] = *(const f32x4*)sp;
-      *(f32x4*)&v[4] = *(const f32x4*)(sp + 4);
-      if constexpr (GEGLU) {
-        float g[8];
-        *(f32x4*)&g[0] = *(const f32x4*)(sp + BN / 2);
-        *(f32x4*)&g[4] = *(const f32x4*)(sp + BN / 2 + 4);
-        if constexpr (!FIXED_CC) {
-          *(f32x4*)&hb[0] = *(const f32x4*)(p.bias + no); *(f32x4*)&hb[4] = *(const f32x4*)(p.bias + no + 4);
-          *(f32x4*)&hg[0] = *(const f32x4*)(p.bias + Nout + no); *(f32x4*)&hg[4] = *(const f32x4*)(p.bias + Nout + no + 4);
-        }
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = (v[e] + hb[e]) * gelu_erf_f(g[e] + hg[e]);
-      } else {
-        if (p.bias_mode == 1) {
-          if (nvalid == 8) {
-            if constexpr (!FIXED_CC) { *(f32x4*)&hb[0] = *(const f32x4*)(p.bias + no); *(f32x4*)&hb[4] = *(const f32x4*)(p.bias + no + 4); }
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] += hb[e];
-          } else {
-            for (int e = 0; e < nvalid; ++e) v[e] += p.bias[no + e];
-          }
-        } else if (p.bias_mode == 2) {
-          const float bm = p.bias[m];
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] += bm;
-        }
-        if (p.rowadd) {
-          const float* ra = p.rowadd + (long long)fast_udiv(m, HWo, inv_hwo_e) * p.rowadd_ld + no;
-          if (nvalid == 8) {
-            float rv[8];
-            *(f32x4*)&rv[0] = *(const f32x4*)ra; *(f32x4*)&rv[4] = *(const f32x4*)(ra + 4);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] += rv[e];
-          } else {
-            for (int e = 0; e < nvalid; ++e) v[e] += ra[e];
-          }
-        }
-      }
+    const bool full = no + CW <= Nout;
+    const bool fast = full && (no % SV) == 0 && (p.ldo % (p.out_f32 ? 4 : SV)) == 0 && (!p.residual || (p.ldr % SV) == 0);
+    if (fast) {
+      // residual chunks first: their latency overlaps the bias loads and the arithmetic
+      unsigned rres[MI][CW / 2];
       if (p.residual) {
-        if (vec_ok) {
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] += bf2f((bf16_t)rres[it][e]);
-        } else {
-          const bf16_t* rp = p.residual + bz * p.sR + (long long)m * p.ldr + no;
-          for (int e = 0; e < nvalid; ++e) v[e] += bf2f(rp[e]);
+        for (int i = 0; i < MI; ++i) {
+          const int m = mrow0 + i * 16;
+          if (m < p.M) {
+            const bf16_t* rp = p.residual + bz * p.sR + (long long)m * p.ldr + no;
+#pragma unroll
+            for (int c = 0; c < CW / SV; ++c) {
+              if constexpr (SV == 8) { const u32x4 t = *(const u32x4*)(rp + 8 * c); rres[i][4 * c] = t[0]; rres[i][4 * c + 1] = t[1]; rres[i][4 * c + 2] = t[2]; rres[i][4 * c + 3] = t[3]; }
+              else { const u32x2 t = *(const u32x2*)(rp + 4 * c); rres[i][2 * c] = t[0]; rres[i][2 * c + 1] = t[1]; }
+            }
+          }
         }
       }
-      if (p.act == 1) {
+      float hb[CW], hg[GEGLU ? CW : 1];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = silu_f(v[e]);
-      } else if (p.act == 2) {
+      for (int e = 0; e < CW; ++e) hb[e] = 0.f;
+      if (p.bias && p.bias_mode == 1) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = v[e] / (1.0f + __expf(-1.702f * v[e]));
-      } else if (p.act == 3) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = gelu_erf_f(v[e]);
+        for (int c = 0; c < CW / 4; ++c) *(f32x4*)&hb[4 * c] = *(const f32x4*)(p.bias + no + 4 * c);
       }
-      if (p.out_f32) {
-        float* op = (float*)p.out + bz * p.sO + (long long)m * p.ldo + no;
-        if (((p.ldo & 3) == 0) && nvalid == 8) {
-          *(f32x4*)op = *(f32x4*)&v[0];
-          *(f32x4*)(op + 4) = *(f32x4*)&v[4];
+      if constexpr (GEGLU) {
+#pragma unroll
+        for (int c = 0; c < CW / 4; ++c) *(f32x4*)&hg[4 * c] = *(const f32x4*)(p.bias + Nout + no + 4 * c);
+      }
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        const int m = mrow0 + i * 16;
+        if (m >= p.M) continue;
+        float v[CW];
+        if constexpr (GEGLU) {
+#pragma unroll
+          for (int e = 0; e < CW; ++e)
+            v[e] = (acc[i][e >> 2][e & 3] * p.alpha + hb[e]) * gelu_erf_f(acc[i][NI / 2 + (e >> 2)][e & 3] * p.alpha + hg[e]);
         } else {
-          for (int e = 0; e < nvalid; ++e) op[e] = v[e];
+          const float bm = p.bias_mode == 2 ? p.bias[m] : 0.f;
+#pragma unroll
+          for (int e = 0; e < CW; ++e) v[e] = acc[i][e >> 2][e & 3] * p.alpha + hb[e] + bm;
+          if (p.rowadd) {
+            const float* ra = p.rowadd + (long long)fast_udiv(m, HWo, inv_hwo) * p.rowadd_ld + no;
+#pragma unroll
+            for (int c = 0; c < CW / 4; ++c) {
+              const f32x4 t = *(const f32x4*)(ra + 4 * c);
+              v[4 * c] += t[0]; v[4 * c + 1] += t[1]; v[4 * c + 2] += t[2]; v[4 * c + 3] += t[3];
+            }
+          }
         }
-      } else {
-        bf16_t* op = (bf16_t*)p.out + bz * p.sO + (long long)m * p.ldo + no;
-        if (vec_ok) {
-          u32x4 pk;
-          pk[0] = pack_bf2(v[0], v[1]); pk[1] = pack_bf2(v[2], v[3]);
-          pk[2] = pack_bf2(v[4], v[5]); pk[3] = pack_bf2(v[6], v[7]);
-          *(u32x4*)op = pk;
+        if (p.residual) {
+#pragma unroll
+          for (int e = 0; e < CW; e += 2) {
+            v[e] += __uint_as_float(rres[i][e >> 1] << 16);
+            v[e + 1] += __uint_as_float(rres[i][e >> 1] & 0xFFFF0000u);
+          }
+        }
+        if (p.act == 1) {
+#pragma unroll
+          for (int e = 0; e < CW; ++e) v[e] = silu_f(v[e]);
+        } else if (p.act == 2) {
+#pragma unroll
+          for (int e = 0; e < CW; ++e) v[e] = v[e] / (1.0f + __expf(-1.702f * v[e]));
+        } else if (p.act == 3) {
+#pragma unroll
+          for (int e = 0; e < CW; ++e) v[e] = gelu_erf_f(v[e]);
+        }
+        if (p.out_f32) {
+          float* op = (float*)p.out + bz * p.sO + (long long)m * p.ldo + no;
+#pragma unroll
+          for (int c = 0; c < CW / 4; ++c) *(f32x4*)(op + 4 * c) = f32x4{v[4 * c], v[4 * c + 1], v[4 * c + 2], v[4 * c + 3]};
         } else {
-          for (int e = 0; e < nvalid; ++e) op[e] = f2bf(v[e]);
+          bf16_t* op = (bf16_t*)p.out + bz * p.sO + (long long)m * p.ldo + no;
+#pragma unroll
+          for (int c = 0; c < CW / SV; ++c) {
+            if constexpr (SV == 8) {
+              u32x4 pk;
+              pk[0] = pack_bf2(v[8 * c], v[8 * c + 1]); pk[1] = pack_bf2(v[8 * c + 2], v[8 * c + 3]);
+              pk[2] = pack_bf2(v[8 * c + 4], v[8 * c + 5]); pk[3] = pack_bf2(v[8 * c + 6], v[8 * c + 7]);
+              *(u32x4*)(op + 8 * c) = pk;
+            } else {
+              u32x2 pk;
+              pk[0] = pack_bf2(v[4 * c], v[4 * c + 1]); pk[1] = pack_bf2(v[4 * c + 2], v[4 * c + 3]);
+              *(u32x2*)(op + 4 * c) = pk;
+            }
+          }
         }
+      }
+      return;
+    }
+    // ragged / unaligned tiles (conv_out's 4 channels, N tails): element by element
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      const int m = mrow0 + i * 16;
+      if (m >= p.M) continue;
+      const int img = p.rowadd ? fast_udiv(m, HWo, inv_hwo) : 0;
+#pragma unroll
+      for (int e = 0; e < CW; ++e) {
+        const int n = no + e;
+        if (n >= Nout) continue;
+        float x;
+        if constexpr (GEGLU) {
+          x = (acc[i][e >> 2][e & 3] * p.alpha + p.bias[n]) * gelu_erf_f(acc[i][NI / 2 + (e >> 2)][e & 3] * p.alpha + p.bias[Nout + n]);
+        } else {
+          x = acc[i][e >> 2][e & 3] * p.alpha;
+          if (p.bias_mode == 1) x += p.bias[n]; else if (p.bias_mode == 2) x += p.bias[m];
+          if (p.rowadd) x += p.rowadd[(long long)img * p.rowadd_ld + n];
+        }
+        if (p.residual) x += bf2f(p.residual[bz * p.sR + (long long)m * p.ldr + n]);
+        if (p.act == 1) x = silu_f(x); else if (p.act == 2) x = x / (1.0f + __expf(-1.702f * x)); else if (p.act == 3) x = gelu_erf_f(x);
+        if (p.out_f32) ((float*)p.out)[bz * p.sO + (long long)m * p.ldo + n] = x;
+        else ((bf16_t*)p.out)[bz * p.sO + (long long)m * p.ldo + n] = f2bf(x);
       }
     }
   }

@@ -3,8 +3,9 @@
 
 // ---------------------------------------------------------------------------------------
 // Weight re-layout: torch [N][Cin][taps] fp32 -> [N][tap][Cpad] bf16 (K = tap-major, channel
-// minor, zero-padded to Cpad).  geglu_bn>0: permute rows so every geglu_bn-wide tile holds
-// [val half | gate half] (ff.net.0.proj: first N/2 rows are values, last N/2 are gates).
+// minor, zero-padded to Cpad).  geglu_bn>0: permute rows so every group of geglu_bn (= 16) rows holds
+// [8 values | 8 gates] (ff.net.0.proj: first N/2 rows are values, last N/2 are gates): a lane of the igemm
+// epilogue owns 16 consecutive rows of one pixel = 8 output channels with their gates.
 // ---------------------------------------------------------------------------------------
 __global__ void convert_weight_kernel(const float* __restrict__ w, bf16_t* __restrict__ out, int N, int Cin, int taps,
                                       int Cpad, int geglu_bn) {

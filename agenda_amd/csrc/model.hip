@@ -631,8 +631,8 @@ AGD_API int agd_load_tensor(agd_ctx* c, const char* name, const void* ptr, int d
     const bool is_tok_emb = ends_with(k, "token_embedding.weight");
     w.w = dmalloc<bf16_t>(c, (size_t)(w.N + (is_tok_emb ? kTextExtraRows : 0)) * w.taps * w.Cpad); if (!w.w) return fail_ctx(c);
     if (is_tok_emb) hipMemset(w.w + (size_t)w.N * w.Cpad, 0, (size_t)kTextExtraRows * w.Cpad * 2);
-    const int geglu_bn = ends_with(k, "ff.net.0.proj.weight") ? 128 : 0;
-    if (geglu_bn && (w.N % 128)) { agd_set_error("'%s': GEGLU projection rows %d not a multiple of 128", name, w.N); return fail_ctx(c); }
+    const int geglu_bn = ends_with(k, "ff.net.0.proj.weight") ? 16 : 0;   // [8 values | 8 gates] per 16 rows (igemm_epilogue.h)
+    if (geglu_bn && (w.N % 256)) { agd_set_error("'%s': GEGLU projection rows %d not a multiple of 256", name, w.N); return fail_ctx(c); }
     API_CK(c, launch_convert_weight(c->stage, w.w, w.N, w.Cin, w.taps, w.Cpad, geglu_bn, 0));
     hipDeviceSynchronize();
     c->W[k] = w;
@@ -909,7 +909,7 @@ AGD_API int agd_attn_processor(agd_ctx* c, const char* layer, const float* hidde
   std::string name(layer);
   if (name.compare(0, 5, "unet.") != 0) name = "unet." + name;
   const bool is_attn2 = ends_with(name, "attn2"), is_attn1 = ends_with(name, "attn1");
-  if (!is_attn1 && !is_attn2) { agd_set_error("attn_processor: layer '%s' is neither an attn1 nor an attn2 module", layer); return fail_ctx(c); }
+  if (!is_attn1 && !is_attn2) { agd_set_error("attn_processor: unknown layer '%s' (neither an attn1 nor an attn2 module)", layer); return fail_ctx(c); }
   const std::string t = name.substr(0, name.size() - 5);
   auto it = c->xl_idx.find(t + "attn2");
   if (it == c->xl_idx.end()) { agd_set_error("attn_processor: unknown layer '%s'", layer); return fail_ctx(c); }
@@ -1029,7 +1029,7 @@ AGD_API int agd_op_linear(const float* x, const float* w, const float* bias, con
   bf16_t* rb = residual ? tmp.get<bf16_t>((size_t)M * Nout) : nullptr;
   if (!xb || !wb || (residual && !rb)) return -1;
   CK(launch_f32_to_bf16(x, xb, (long long)M * K, st));
-  CK(launch_convert_weight(w, wb, N, K, 1, K, geglu ? 128 : 0, st));
+  CK(launch_convert_weight(w, wb, N, K, 1, K, geglu ? 16 : 0, st));
   if (residual) CK(launch_f32_to_bf16(residual, rb, (long long)M * Nout, st));
   WMat wm; wm.w = wb; wm.N = N; wm.Cin = K; wm.Cpad = K; wm.taps = 1;
   GemmOpt o; o.bias = bias; o.residual = rb; o.geglu = geglu; o.out_f32 = 1;
