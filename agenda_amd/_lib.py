@@ -53,6 +53,8 @@ _SIGS = {
     "agd_cfg_ddim_step": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, _P]),
     "agd_denoise": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float),
                               C.POINTER(C.c_float), C.c_float, _P]),
+    "agd_denoise_plms": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float),
+                                   C.POINTER(C.c_float), C.c_float, _P]),
     "agd_vae_decode": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P, _P]),
     "agd_vae_encode": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P, _P]),
     "agd_set_option": (C.c_int, [_P, C.c_char_p, C.c_int]),

@@ -81,6 +81,8 @@ int launch_small_linear(const float* x, const bf16_t* W, const float* bias, floa
                         int silu_out, hipStream_t st);
 int launch_cfg_ddim(const float* eps_nhwc, int ldc, float* lat_nchw, int B, int C, int HW, float guidance,
                     float a_t, float a_p, int vpred, hipStream_t st);
+int launch_cfg_plms(const float* eps_nhwc, int ldc, float* lat, const float* src, const float* h1, const float* h2, const float* h3,
+                    float* store, int B, int C, int HW, float guidance, const float* w4, float a, float b, hipStream_t st);
 int launch_image_u8(const float* x_nhwc, int ldc, unsigned char* out, long long npix, int C, hipStream_t st);
 int launch_nchw_from_nhwc_f32(const float* x, int ldc, float* out, int B, int C, int HW, hipStream_t st);
 int launch_softmax_rows(const float* s, bf16_t* p, int rows, int cols, hipStream_t st);

@@ -151,6 +151,38 @@ int launch_cfg_ddim(const float* eps, int ldc, float* lat, int B, int C, int HW,
   HIP_CHECK_RET(hipGetLastError()); return 0;
 }
 
+// CFG combine + one linear-multistep (PNDM / PLMS) update on fp32 NCHW latents:
+//   e0 = eps_u + g (eps_c - eps_u);  e = w0 e0 + w1 h1 + w2 h2 + w3 h3;  lat = a * src + b * e;  store (if given) = e0
+// h1..h3: CFG-combined eps of earlier model evaluations (NCHW); src: the sample the step starts from (lat itself, or the
+// sample saved at the first evaluation for PLMS's second call).
+__global__ void cfg_plms_kernel(const float* __restrict__ eps, int ldc, float* __restrict__ lat, const float* __restrict__ src,
+                                const float* __restrict__ h1, const float* __restrict__ h2, const float* __restrict__ h3,
+                                float* __restrict__ store, int B, int C, int HW, float guidance, float w0, float w1, float w2, float w3,
+                                float a, float b) {
+  const long long total = (long long)B * C * HW;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int p = (int)(i % HW);
+    const int c = (int)((i / HW) % C);
+    const int bb = (int)(i / ((long long)HW * C));
+    const float eu = eps[((long long)bb * HW + p) * ldc + c];
+    const float ec = eps[((long long)(bb + B) * HW + p) * ldc + c];
+    const float e0 = eu + guidance * (ec - eu);
+    float e = w0 * e0;
+    if (h1) e += w1 * h1[i];
+    if (h2) e += w2 * h2[i];
+    if (h3) e += w3 * h3[i];
+    const float x = src[i];
+    if (store) store[i] = e0;
+    lat[i] = a * x + b * e;
+  }
+}
+int launch_cfg_plms(const float* eps, int ldc, float* lat, const float* src, const float* h1, const float* h2, const float* h3, float* store,
+                    int B, int C, int HW, float guidance, const float* w, float a, float b, hipStream_t st) {
+  hipLaunchKernelGGL(cfg_plms_kernel, dim3(grid_for((long long)B * C * HW)), dim3(256), 0, st, eps, ldc, lat, src, h1, h2, h3, store, B, C, HW,
+                     guidance, w[0], w[1], w[2], w[3], a, b);
+  HIP_CHECK_RET(hipGetLastError()); return 0;
+}
+
 // diffusers post-process: (x/2+0.5).clamp(0,1) -> round-half-even(255 x) -> uint8, NHWC
 __global__ void image_u8_kernel(const float* __restrict__ x, int ldc, unsigned char* __restrict__ out, long long npix, int C) {
   const long long total = npix * C;

@@ -90,7 +90,7 @@ struct agd_ctx {
   DBuf hook_sumb, hook_scratchb;
   float* hook_sum = nullptr; float* hook_scratch = nullptr; int hook_count = 0, hook_Bp = 0, hook_T = 0;
   // denoise scratch
-  DBuf latb, epsb, vae_imgb;
+  DBuf latb, epsb, vae_imgb, plmsb;
   bf16_t* lat_bf16 = nullptr; float* eps_nhwc = nullptr;
   SplitKWs splitk;                                    // split-K partial slabs of this ctx (stream-ordered reuse)
   int opt_cfg_share = 1;                              // agd_set_option("cfg_shared_prefix")
@@ -596,7 +596,7 @@ AGD_API void agd_destroy(agd_ctx* c) {
   for (void* p : c->owned) hipFree(p);
   for (auto& xl : c->xl) { xl.kvb.release(); xl.accb.release(); }
   c->ctxb.release(); c->hook_sumb.release(); c->hook_scratchb.release();
-  c->latb.release(); c->epsb.release(); c->vae_imgb.release();
+  c->latb.release(); c->epsb.release(); c->vae_imgb.release(); c->plmsb.release();
   if (c->splitk.p) hipFree(c->splitk.p);
   if (c->arena.base) hipFree(c->arena.base);
   if (c->stage) hipFree(c->stage);
@@ -762,6 +762,27 @@ AGD_API int agd_cfg_ddim_step(agd_ctx* c, const float* eps, float* latents, int 
   return 0;
 }
 
+// time embeddings of every model evaluation of a denoise loop, 8 timesteps per launch (the stacked time_emb_proj matrix is
+// ~50 MB of weights: streamed ceil(n/8) times instead of once per step); returns [n][tproj_total] in *out
+static int embed_all_timesteps(agd_ctx* c, hipStream_t st, const float* timesteps, int n, const float** out) {
+  const int dim0 = c->cfg.block_out_channels[0];
+  const size_t per_step = (size_t)c->tproj_total + (size_t)9 * dim0;
+  if (c->tsteps_cap < n) {
+    if (c->tsteps_buf) { hipDeviceSynchronize(); hipFree(c->tsteps_buf); }
+    c->tsteps_buf = nullptr; c->tsteps_cap = 0;
+    if (hipMalloc((void**)&c->tsteps_buf, per_step * n * sizeof(float)) != hipSuccess) FAIL("denoise: time-embedding buffer alloc failed");
+    c->tsteps_cap = n;
+  }
+  float* tp_all = c->tsteps_buf;                                  // [n][tproj_total]
+  float* tscratch = c->tsteps_buf + (size_t)c->tproj_total * n;
+  for (int s0 = 0; s0 < n; s0 += 8) {
+    const int m = n - s0 < 8 ? n - s0 : 8;
+    CK(time_embed(c, st, timesteps + s0, m, tscratch, tp_all + (size_t)s0 * c->tproj_total));
+  }
+  *out = tp_all;
+  return 0;
+}
+
 AGD_API int agd_denoise(agd_ctx* c, float* latents, int batch, int L, int n_steps, const float* timesteps, const float* alpha_t,
                            const float* alpha_prev, float guidance, void* stream) {
   API_CK(c, need_final(c));
@@ -769,27 +790,61 @@ AGD_API int agd_denoise(agd_ctx* c, float* latents, int batch, int L, int n_step
   const int B2 = 2 * batch, Cl = c->cfg.in_channels, HW = L * L;
   API_CK(c, ensure_lat(c, B2, L));
   if (c->ctx_B2 != B2) { agd_set_error("denoise: context batch %d != 2*batch %d", c->ctx_B2, B2); return fail_ctx(c); }
-  // the timesteps are known up front: embed all of them now, 8 per launch (the stacked time_emb_proj matrix is
-  // ~50 MB of weights -- streamed ceil(n/8) times here instead of once per step)
-  const int dim0 = c->cfg.block_out_channels[0];
-  const size_t per_step = (size_t)c->tproj_total + (size_t)9 * dim0;
-  if (c->tsteps_cap < n_steps) {
-    if (c->tsteps_buf) hipFree(c->tsteps_buf);
-    c->tsteps_buf = nullptr; c->tsteps_cap = 0;
-    if (hipMalloc((void**)&c->tsteps_buf, per_step * n_steps * sizeof(float)) != hipSuccess) { agd_set_error("denoise: time-embedding buffer alloc failed"); return fail_ctx(c); }
-    c->tsteps_cap = n_steps;
-  }
-  float* tp_all = c->tsteps_buf;                                  // [n_steps][tproj_total]
-  float* tscratch = c->tsteps_buf + (size_t)c->tproj_total * n_steps;
-  for (int s0 = 0; s0 < n_steps; s0 += 8) {
-    const int n = n_steps - s0 < 8 ? n_steps - s0 : 8;
-    API_CK(c, time_embed(c, st, timesteps + s0, n, tscratch, tp_all + (size_t)s0 * c->tproj_total));
-  }
+  const float* tp_all = nullptr;                                   // all timesteps are known up front: embed them now
+  API_CK(c, embed_all_timesteps(c, st, timesteps, n_steps, &tp_all));
   for (int s = 0; s < n_steps; ++s) {
     { ProfScope ps(c, st, PC_ELEM, 0); API_CK(c, launch_prep_latents(latents, c->lat_bf16, batch, Cl, HW, 64, 2, 1.0f, st)); }
     API_CK(c, unet_walk(c, st, c->lat_bf16, B2, L, timesteps[s], c->eps_nhwc, tp_all + (size_t)s * c->tproj_total, true));
     { ProfScope ps(c, st, PC_ELEM, 0);
       API_CK(c, launch_cfg_ddim(c->eps_nhwc, c->cfg.out_channels, latents, batch, Cl, HW, guidance, alpha_t[s], alpha_prev[s], c->cfg.prediction_type, st)); }
+  }
+  return 0;
+}
+
+// The denoise loop under the reference's ACTUAL scheduler: `pipeline(prompt, num_inference_steps=20)` at
+// data_generation.py:59 runs the checkpoint's PNDMScheduler (skip_prk_steps, i.e. PLMS) -- n_evals = steps + 1 model
+// evaluations, the second timestep evaluated twice [upstream-knowledge: diffusers 0.21.2 PNDMScheduler.step_plms].
+// Per evaluation i the host passes the UNet timestep and the two coefficients of `_get_prev_sample`
+// (prev = sample_coeff[i] * sample + eps_coeff[i] * model_output); the linear-multistep weights are applied here:
+//   i = 0: e0                       (the sample is kept: evaluation 1 restarts from it)
+//   i = 1: (e1 + e0) / 2 from the KEPT sample (e1 is not added to the history)
+//   then : (3 e - h1) / 2 ; (23 e - 16 h1 + 5 h2) / 12 ; (55 e - 59 h1 + 37 h2 - 9 h3) / 24
+AGD_API int agd_denoise_plms(agd_ctx* c, float* latents, int batch, int L, int n_evals, const float* timesteps, const float* sample_coeff,
+                             const float* eps_coeff, float guidance, void* stream) {
+  API_CK(c, need_final(c));
+  hipStream_t st = S(stream);
+  if (c->cfg.prediction_type != 0) { agd_set_error("denoise_plms: epsilon prediction only"); return fail_ctx(c); }
+  if (n_evals < 2) { agd_set_error("denoise_plms: needs >= 2 model evaluations (got %d)", n_evals); return fail_ctx(c); }
+  const int B2 = 2 * batch, Cl = c->cfg.in_channels, HW = L * L;
+  API_CK(c, ensure_lat(c, B2, L));
+  if (c->ctx_B2 != B2) { agd_set_error("denoise: context batch %d != 2*batch %d", c->ctx_B2, B2); return fail_ctx(c); }
+  const size_t n1 = (size_t)batch * Cl * HW;
+  API_CK(c, c->plmsb.ensure(n1 * 5 * sizeof(float)));            // 4 history slots + the kept sample
+  float* hist[4]; for (int k = 0; k < 4; ++k) hist[k] = c->plmsb.as<float>() + n1 * k;
+  float* kept = c->plmsb.as<float>() + n1 * 4;
+  const float* tp_all = nullptr;
+  API_CK(c, embed_all_timesteps(c, st, timesteps, n_evals, &tp_all));
+  int n_hist = 0, head = 0;                                       // hist[(head - 1 - k) & 3] = k-th newest stored eps
+  for (int i = 0; i < n_evals; ++i) {
+    { ProfScope ps(c, st, PC_ELEM, 0); API_CK(c, launch_prep_latents(latents, c->lat_bf16, batch, Cl, HW, 64, 2, 1.0f, st)); }
+    API_CK(c, unet_walk(c, st, c->lat_bf16, B2, L, timesteps[i], c->eps_nhwc, tp_all + (size_t)i * c->tproj_total, true));
+    float w[4] = {1.f, 0.f, 0.f, 0.f};
+    const float* h[3] = {nullptr, nullptr, nullptr};
+    const float* src = latents; float* store = nullptr;
+    if (i == 1) {                                                 // PLMS second call: average with e0, restart from the kept sample
+      w[0] = 0.5f; w[1] = 0.5f; h[0] = hist[(head - 1) & 3]; src = kept;
+    } else {
+      if (i == 0 && hipMemcpyAsync(kept, latents, n1 * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) { agd_set_error("plms: keep sample"); return fail_ctx(c); }
+      store = hist[head & 3];
+      for (int k = 0; k < 3 && k < n_hist; ++k) h[k] = hist[(head - 1 - k) & 3];
+      if (n_hist == 1) { w[0] = 1.5f; w[1] = -0.5f; }
+      else if (n_hist == 2) { w[0] = 23.f / 12.f; w[1] = -16.f / 12.f; w[2] = 5.f / 12.f; }
+      else if (n_hist >= 3) { w[0] = 55.f / 24.f; w[1] = -59.f / 24.f; w[2] = 37.f / 24.f; w[3] = -9.f / 24.f; }
+    }
+    { ProfScope ps(c, st, PC_ELEM, 0);
+      API_CK(c, launch_cfg_plms(c->eps_nhwc, c->cfg.out_channels, latents, src, h[0], h[1], h[2], store, batch, Cl, HW, guidance, w,
+                                sample_coeff[i], eps_coeff[i], st)); }
+    if (store) { ++head; if (n_hist < 3) ++n_hist; }
   }
   return 0;
 }

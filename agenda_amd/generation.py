@@ -188,6 +188,9 @@ def parse_args(argv=None):
     p.add_argument("--synthetic-config", type=str, default="sd15", help="architecture for synthetic weights when no checkpoint is given")
     p.add_argument("--stack", type=str, default=None, nargs=3, metavar=("OBJ", "FG", "BG"),
                    help="also write daam_stack_heatmaps/ + daam_inv_heatmaps/ for these three words (postprocess_heatmap.py)")
+    p.add_argument("--scheduler", type=str, default=None, choices=["DDIMScheduler", "PNDMScheduler"],
+                   help="default: the checkpoint's scheduler/scheduler_config.json (PNDM for SD-1.4, as the reference runs it); "
+                        "DDIMScheduler for synthetic weights")
     p.add_argument("--no-gather", action="store_true",
                    help="multi-GPU: every rank writes its own files instead of the final all_gather to rank 0")
     return p.parse_args(argv)
@@ -207,8 +210,9 @@ def main(argv=None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(os.environ.get("AGD_DIST_BACKEND", "nccl"))          # "nccl" = RCCL on ROCm
         own_group = True
-    pipe = (StableDiffusionPipeline.from_pretrained(args.pretrained_model_path, device=local)
-            if args.pretrained_model_path else StableDiffusionPipeline.from_synthetic(args.synthetic_config, device=local))
+    pipe = (StableDiffusionPipeline.from_pretrained(args.pretrained_model_path, device=local, scheduler=args.scheduler)
+            if args.pretrained_model_path else
+            StableDiffusionPipeline.from_synthetic(args.synthetic_config, device=local, scheduler=args.scheduler or "DDIMScheduler"))
     embeds = torch.load(args.learnable_tokens_embedding_path) if args.learnable_tokens_embedding_path else {}
     if embeds:
         new_tokens, words, prompt = select_learned_tokens(args.prompt, args.initialize_token, list(embeds.keys()),

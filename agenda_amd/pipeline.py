@@ -25,7 +25,7 @@ import torch
 
 from . import _lib
 from .config import SDConfig, CONFIGS, UNetConfig, VAEConfig, SchedulerConfig, cross_attn_layer_names
-from .scheduler import DDIMScheduler
+from .scheduler import DDIMScheduler, PNDMScheduler, SCHEDULERS
 from .text import SimpleTokenizer, SyntheticTextEncoder
 
 
@@ -156,6 +156,18 @@ class Engine:
             raise ValueError(f"eps batch {eps.shape[0]} != 2 x latents batch {b}")
         self._ck(self.lib.agd_cfg_ddim_step(self.ctx, _lib.ptr(eps), _lib.ptr(latents), b, L, float(guidance), float(alpha_t),
                                             float(alpha_prev), self._stream()), "agd_cfg_ddim_step")
+        return latents
+
+    def denoise_plms(self, latents: torch.Tensor, timesteps, sample_coeff, eps_coeff, guidance: float):
+        """The fused loop under PNDM/PLMS (`agd_denoise_plms`): len(timesteps) = num_inference_steps + 1 model evaluations."""
+        assert latents.is_cuda and latents.dtype == torch.float32 and latents.is_contiguous()
+        n = len(timesteps)
+        ts = (C.c_float * n)(*[float(t) for t in timesteps])
+        ca = (C.c_float * n)(*[float(x) for x in sample_coeff])
+        cb = (C.c_float * n)(*[float(x) for x in eps_coeff])
+        b, _, L, _ = latents.shape
+        self._ck(self.lib.agd_denoise_plms(self.ctx, _lib.ptr(latents), b, L, n, ts, ca, cb, float(guidance), self._stream()),
+                 "agd_denoise_plms")
         return latents
 
     def vae_decode(self, latents: torch.Tensor, want_f32: bool = False):
@@ -328,7 +340,7 @@ class VAEHandle:
 class StableDiffusionPipeline:
     def __init__(self, cfg: SDConfig, unet_sd: Dict[str, torch.Tensor], vae_sd: Dict[str, torch.Tensor],
                  tokenizer=None, text_encoder=None, device: Union[int, str] = 0, workspace_bytes: int = 0,
-                 text_sd: Optional[Dict[str, torch.Tensor]] = None):
+                 text_sd: Optional[Dict[str, torch.Tensor]] = None, scheduler: str = "DDIMScheduler"):
         self.cfg = cfg
         dev = int(str(device).split(":")[-1]) if not isinstance(device, int) and ":" in str(device) else (device if isinstance(device, int) else 0)
         self.engine = Engine(cfg, dev, workspace_bytes)
@@ -346,7 +358,9 @@ class StableDiffusionPipeline:
             from .text import HipCLIPTextEncoder
             text_encoder = HipCLIPTextEncoder(self.engine, self.tokenizer, text_sd)
         self.text_encoder = text_encoder or SyntheticTextEncoder(self.tokenizer, cfg.unet.cross_attention_dim)
-        self.scheduler = DDIMScheduler.from_config(cfg.sched)
+        if scheduler not in SCHEDULERS:
+            raise ValueError(f"scheduler '{scheduler}' is not implemented (have: {sorted(SCHEDULERS)})")
+        self.scheduler = SCHEDULERS[scheduler].from_config(cfg.sched)
         self.unet = UNetHandle(self)
         self.vae = VAEHandle(self)
         self.vae_scale_factor = cfg.vae_scale_factor
@@ -358,18 +372,18 @@ class StableDiffusionPipeline:
     # ---- construction -------------------------------------------------------------------
     @classmethod
     def from_synthetic(cls, cfg: Union[str, SDConfig] = "sd15", seed: int = 1234, device=0, workspace_bytes: int = 0,
-                       weights_device: str = "cpu", keep_weights: bool = False, **kw):
+                       weights_device: str = "cpu", keep_weights: bool = False, scheduler: str = "DDIMScheduler", **kw):
         from . import synthetic
         cfg = CONFIGS[cfg]() if isinstance(cfg, str) else cfg
         usd = synthetic.make_unet_weights(cfg, seed, device=weights_device, **kw)
         vsd = synthetic.make_vae_weights(cfg, seed + 1, device=weights_device, **kw)
-        pipe = cls(cfg, usd, vsd, device=device, workspace_bytes=workspace_bytes)
+        pipe = cls(cfg, usd, vsd, device=device, workspace_bytes=workspace_bytes, scheduler=scheduler)
         if keep_weights:
             pipe.synthetic_weights = (usd, vsd)
         return pipe
 
     @classmethod
-    def from_pretrained(cls, path: str, device=0, workspace_bytes: int = 0):
+    def from_pretrained(cls, path: str, device=0, workspace_bytes: int = 0, scheduler: Optional[str] = None):
         """Reads the diffusers on-disk layout (`unet/config.json`, `unet/diffusion_pytorch_model.safetensors`,
         `vae/...`) that `save_pretrained` writes (reference finetune_sd_token.py:164-187)."""
         from safetensors.torch import load_file
@@ -393,9 +407,15 @@ class StableDiffusionPipeline:
                          block_out_channels=tuple(vc["block_out_channels"]), layers_per_block=vc.get("layers_per_block", 2),
                          norm_num_groups=vc.get("norm_num_groups", 32), scaling_factor=vc.get("scaling_factor", 0.18215))
         sc = SchedulerConfig()
+        sched_name = scheduler or "DDIMScheduler"
         sp = os.path.join(path, "scheduler", "scheduler_config.json")
         if os.path.exists(sp):
             sj = jload(sp)
+            if scheduler is None:           # the checkpoint's own scheduler, as `from_pretrained` of the reference gives it
+                sched_name = sj.get("_class_name", "DDIMScheduler")
+                if sched_name not in SCHEDULERS:
+                    raise _lib.AgendaHipError(f"{sp}: scheduler '{sched_name}' is not implemented (have: {sorted(SCHEDULERS)}); "
+                                              "pass from_pretrained(..., scheduler='DDIMScheduler') to override")
             sc = SchedulerConfig(sj.get("num_train_timesteps", 1000), sj.get("beta_start", 0.00085), sj.get("beta_end", 0.012),
                                  sj.get("steps_offset", 1), sj.get("set_alpha_to_one", False), sj.get("prediction_type", "epsilon"))
         cfg = SDConfig(name=os.path.basename(path.rstrip("/")), unet=ucfg, vae=vcfg, sched=sc,
@@ -439,7 +459,7 @@ class StableDiffusionPipeline:
         elif tsd is not None:
             raise _lib.AgendaHipError(f"{path}: text_encoder/ weights found but no tokenizer/ directory; "
                                       "no silent fallback to the synthetic tokenizer")
-        return cls(cfg, usd, vsd, tokenizer=tok, device=device, workspace_bytes=workspace_bytes, text_sd=tsd)
+        return cls(cfg, usd, vsd, tokenizer=tok, device=device, workspace_bytes=workspace_bytes, text_sd=tsd, scheduler=sched_name)
 
 
     def to(self, device):
@@ -509,12 +529,20 @@ class StableDiffusionPipeline:
                 self._trace._on_generate(B, L, self._last_prompt)
             if self._hooker is not None:
                 self._hooker._on_generate(B, L, prompt_embeds.shape[1])
-        ts = self.scheduler.set_timesteps(num_inference_steps)
-        a_t, a_p = self.scheduler.step_coeffs()
-        self.engine.denoise(lat, ts, a_t, a_p, guidance_scale)
+        self._denoise(lat, num_inference_steps, guidance_scale)
         if output_type == "latent":
             return PipelineOutput(images=[], latents=lat)
         return self._finish(lat, B, output_type)
+
+    def _denoise(self, lat, num_inference_steps, guidance_scale):
+        """`for t in scheduler.timesteps: unet -> CFG -> scheduler.step`, fused on the device, under the pipeline's scheduler."""
+        ts = self.scheduler.set_timesteps(num_inference_steps)
+        if isinstance(self.scheduler, PNDMScheduler):
+            tsf, ca, cb = self.scheduler.plms_program()
+            self.engine.denoise_plms(lat, tsf, ca, cb, guidance_scale)
+        else:
+            a_t, a_p = self.scheduler.step_coeffs()
+            self.engine.denoise(lat, ts, a_t, a_p, guidance_scale)
 
     def _finish(self, lat, B, output_type):
         u8 = self.engine.vae_decode(lat)
@@ -533,6 +561,8 @@ class StableDiffusionPipeline:
                 noise_enc: Optional[torch.Tensor] = None, noise: Optional[torch.Tensor] = None, output_type: str = "pil"):
         """image: float [B,3,S,S] in [-1,1] (or uint8 [B,S,S,3]).  Noise draws come from a CPU generator (or are passed
         explicitly) for the same host-reproducibility reason as the txt2img latents."""
+        if not isinstance(self.scheduler, DDIMScheduler):
+            raise NotImplementedError("img2img runs the strength-truncated DDIM schedule; build the pipeline with scheduler='DDIMScheduler'")
         if image.dtype == torch.uint8:
             image = image.permute(0, 3, 1, 2).float() / 127.5 - 1.0
         B, _, S, _ = image.shape

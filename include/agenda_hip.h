@@ -83,6 +83,13 @@ int agd_cfg_ddim_step(agd_ctx* ctx, const float* eps, float* latents, int batch,
 int agd_denoise(agd_ctx* ctx, float* latents, int batch, int latent_side, int n_steps, const float* timesteps,
                 const float* alpha_t, const float* alpha_prev, float guidance, void* stream);
 
+/* ---- the same loop under the scheduler the reference actually runs: data_generation.py:59 calls the pipeline with the
+ * checkpoint's default PNDMScheduler (skip_prk_steps: PLMS) x 20.  n_evals = steps + 1 model evaluations; per evaluation the
+ * UNet timestep and the two `_get_prev_sample` coefficients (prev = sample_coeff * sample + eps_coeff * model_output) come
+ * from the host scheduler (agenda_amd/scheduler.py PNDMScheduler); the multistep weights are applied on the device. */
+int agd_denoise_plms(agd_ctx* ctx, float* latents, int batch, int latent_side, int n_evals, const float* timesteps,
+                     const float* sample_coeff, const float* eps_coeff, float guidance, void* stream);
+
 /* ---- `vae.decode(latents / scaling_factor)` + image post-process.
  * out_u8: [B, 8L, 8L, 3] uint8 (may be NULL); out_f32: [B, 8L, 8L, 3] fp32 in [-1,1] (may be NULL) */
 int agd_vae_decode(agd_ctx* ctx, const float* latents, int batch, int latent_side, unsigned char* out_u8,

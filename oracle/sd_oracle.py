@@ -266,6 +266,59 @@ class DDIM:
         return a_p ** 0.5 * x0 + (1 - a_p) ** 0.5 * e
 
 
+class PNDM:
+    """diffusers 0.21.2 `PNDMScheduler` with `skip_prk_steps=True` (pure PLMS), the scheduler the reference's own call
+    `pipeline(prompt, num_inference_steps=20)` (data_generation.py:59) runs for an SD-1.4 checkpoint [upstream-knowledge].
+    Restated method by method (`set_timesteps`, `step_plms`, `_get_prev_sample`) with the same state variables."""
+
+    def __init__(self, num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, steps_offset=1, set_alpha_to_one=False):
+        betas = torch.linspace(beta_start ** 0.5, beta_end ** 0.5, num_train_timesteps, dtype=torch.float32) ** 2
+        self.alphas_cumprod = torch.cumprod(1.0 - betas, dim=0)
+        self.final_alpha_cumprod = torch.tensor(1.0) if set_alpha_to_one else self.alphas_cumprod[0]
+        self.T, self.steps_offset, self.init_noise_sigma = num_train_timesteps, steps_offset, 1.0
+
+    def set_timesteps(self, n: int):
+        self.num_inference_steps = n
+        ratio = self.T // n
+        t = (np.arange(0, n) * ratio).round().astype(np.int64) + self.steps_offset
+        self.timesteps = np.concatenate([t[:-1], t[-2:-1], t[-1:]])[::-1].copy()      # prk_timesteps empty (skip_prk_steps)
+        self.ets, self.counter, self.cur_sample = [], 0, None
+        return self.timesteps
+
+    def _get_prev_sample(self, sample, timestep, prev_timestep, model_output):
+        a_t = self.alphas_cumprod[timestep]
+        a_p = self.alphas_cumprod[prev_timestep] if prev_timestep >= 0 else self.final_alpha_cumprod
+        b_t, b_p = 1 - a_t, 1 - a_p
+        sample_coeff = (a_p / a_t) ** 0.5
+        denom = a_t * b_p ** 0.5 + (a_t * b_t * a_p) ** 0.5
+        return sample_coeff * sample - (a_p - a_t) * model_output / denom
+
+    def step(self, model_output: Tensor, timestep: int, sample: Tensor) -> Tensor:
+        """`step_plms`."""
+        prev_timestep = timestep - self.T // self.num_inference_steps
+        if self.counter != 1:
+            self.ets = self.ets[-3:]
+            self.ets.append(model_output)
+        else:
+            prev_timestep = timestep
+            timestep = timestep + self.T // self.num_inference_steps
+        if len(self.ets) == 1 and self.counter == 0:
+            self.cur_sample = sample
+        elif len(self.ets) == 1 and self.counter == 1:
+            model_output = (model_output + self.ets[-1]) / 2
+            sample = self.cur_sample
+            self.cur_sample = None
+        elif len(self.ets) == 2:
+            model_output = (3 * self.ets[-1] - self.ets[-2]) / 2
+        elif len(self.ets) == 3:
+            model_output = (23 * self.ets[-1] - 16 * self.ets[-2] + 5 * self.ets[-3]) / 12
+        else:
+            model_output = (1 / 24) * (55 * self.ets[-1] - 59 * self.ets[-2] + 37 * self.ets[-3] - 9 * self.ets[-4])
+        prev = self._get_prev_sample(sample, timestep, prev_timestep, model_output)
+        self.counter += 1
+        return prev
+
+
 # ==========================================================================================
 # 5. UNet2DConditionModel forward (diffusers 0.21.2 semantics)  [upstream-knowledge]
 # ==========================================================================================
@@ -429,11 +482,16 @@ def vae_decode(sd: Dict[str, Tensor], vcfg, z: Tensor, taps: Optional[dict] = No
 # 7. txt2img loop  (reference data_generation.py:56-64 -> StableDiffusionPipeline.__call__)
 # ==========================================================================================
 def generate(unet_sd, vae_sd, cfg, ctx: Tensor, latents: Tensor, num_inference_steps: int,
-             guidance_scale: float = 7.5, recorder=None, decode: bool = True, eps_out: Optional[list] = None):
+             guidance_scale: float = 7.5, recorder=None, decode: bool = True, eps_out: Optional[list] = None, scheduler: str = "ddim"):
     """ctx [2B,T,D] ordered [uncond x B, cond x B]; latents [B,4,L,L] (explicit, CPU generator).
+    `scheduler`: "ddim" (BASELINE's metric) or "pndm" (what data_generation.py:59 runs for an SD-1.4 checkpoint).
     Returns (uint8 images [B,H,W,3] or None, final latents)."""
-    sch = DDIM(cfg.sched.num_train_timesteps, cfg.sched.beta_start, cfg.sched.beta_end, cfg.sched.steps_offset,
-               cfg.sched.set_alpha_to_one, cfg.sched.prediction_type)
+    if scheduler == "pndm":
+        sch = PNDM(cfg.sched.num_train_timesteps, cfg.sched.beta_start, cfg.sched.beta_end, cfg.sched.steps_offset,
+                   cfg.sched.set_alpha_to_one)
+    else:
+        sch = DDIM(cfg.sched.num_train_timesteps, cfg.sched.beta_start, cfg.sched.beta_end, cfg.sched.steps_offset,
+                   cfg.sched.set_alpha_to_one, cfg.sched.prediction_type)
     ts = sch.set_timesteps(num_inference_steps)
     x = latents.clone().float() * sch.init_noise_sigma
     with torch.no_grad():

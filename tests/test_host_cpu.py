@@ -108,6 +108,41 @@ def test_ddim_step_with_zero_eps_is_pure_rescale():
 
 
 # ---- tokenizer / token merge / driver semantics (reference data_generation.py) ----------------
+def test_pndm_scheduler_program_matches_oracle_restatement():
+    """The host PNDM/PLMS program (timesteps + the two `_get_prev_sample` coefficients per model evaluation) against the
+    oracle's step-by-step restatement of diffusers' `step_plms`, driven with a known eps sequence: same samples."""
+    from agenda_amd.scheduler import PNDMScheduler
+    from oracle import sd_oracle as O
+    n = 20
+    s = PNDMScheduler()
+    ts = s.set_timesteps(n)
+    o = O.PNDM()
+    assert list(ts) == list(o.set_timesteps(n)) and len(ts) == n + 1 and ts[1] == ts[2] == 901 and ts[0] == 951 and ts[-1] == 1
+    tsf, a, b = s.plms_program()
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(2, 4, 8, 8, generator=g)
+    eps = [torch.randn(2, 4, 8, 8, generator=g) for _ in ts]
+    want = x.clone()
+    for t, e in zip(ts, eps):
+        want = o.step(e, int(t), want)
+    # the device applies: i=0 e0 ; i=1 (e1+e0)/2 from the kept sample ; then the Adams-Bashforth weights on the history
+    got, kept, hist = x.clone(), None, []
+    for i, e in enumerate(eps):
+        if i == 1:
+            got = float(a[i]) * kept + float(b[i]) * (0.5 * e + 0.5 * hist[-1])
+            continue
+        if i == 0:
+            kept = got.clone()
+        h = hist[-3:]
+        w = {0: [1.0], 1: [1.5, -0.5], 2: [23 / 12, -16 / 12, 5 / 12], 3: [55 / 24, -59 / 24, 37 / 24, -9 / 24]}[len(h)]
+        comb = w[0] * e + sum(wk * hk for wk, hk in zip(w[1:], reversed(h)))
+        got = float(a[i]) * got + float(b[i]) * comb
+        hist.append(e)
+    assert float((got - want).abs().max()) < 1e-4 * float(want.abs().max())
+    with pytest.raises(ValueError):
+        PNDMScheduler(prediction_type="v_prediction")
+
+
 def test_compute_token_merge_indices():
     from agenda_amd.text import SimpleTokenizer
     from agenda_amd.trace import compute_token_merge_indices

@@ -186,8 +186,9 @@ def test_from_pretrained_roundtrip(tmp_path, tiny_pipe):
           "layers_per_block": cfg.vae.layers_per_block, "norm_num_groups": 32, "scaling_factor": cfg.vae.scaling_factor}
     json.dump(uc, open(tmp_path / "unet" / "config.json", "w"))
     json.dump(vc, open(tmp_path / "vae" / "config.json", "w"))
-    json.dump({"num_train_timesteps": 1000, "beta_start": 0.00085, "beta_end": 0.012, "steps_offset": 1,
-               "set_alpha_to_one": False, "prediction_type": "epsilon"}, open(tmp_path / "scheduler" / "scheduler_config.json", "w"))
+    json.dump({"_class_name": "PNDMScheduler", "num_train_timesteps": 1000, "beta_start": 0.00085, "beta_end": 0.012, "steps_offset": 1,
+               "set_alpha_to_one": False, "prediction_type": "epsilon", "skip_prk_steps": True},
+              open(tmp_path / "scheduler" / "scheduler_config.json", "w"))
     save_file({k: t.contiguous() for k, t in u.items()}, str(tmp_path / "unet" / "diffusion_pytorch_model.safetensors"))
     # store the VAE attention with the pre-0.18 names to exercise the renaming (decoder AND encoder mid blocks)
     old = {"to_q": "query", "to_k": "key", "to_v": "value", "to_out.0": "proj_attn"}
@@ -208,7 +209,12 @@ def test_from_pretrained_roundtrip(tmp_path, tiny_pipe):
     tsd = {"text_model." + k: t.contiguous() for k, t in synthetic.make_text_weights(tcfg, 3).items()}
     tsd["text_model.embeddings.position_ids"] = torch.arange(77)[None].float()
     save_file(tsd, str(tmp_path / "text_encoder" / "model.safetensors"))
-    p2 = StableDiffusionPipeline.from_pretrained(str(tmp_path), workspace_bytes=1 << 30)
+    from agenda_amd.scheduler import PNDMScheduler, DDIMScheduler
+    p0 = StableDiffusionPipeline.from_pretrained(str(tmp_path), workspace_bytes=1 << 30)
+    assert isinstance(p0.scheduler, PNDMScheduler)         # the checkpoint's own scheduler, as the reference's from_pretrained gives it
+    p0.engine.close()
+    p2 = StableDiffusionPipeline.from_pretrained(str(tmp_path), workspace_bytes=1 << 30, scheduler="DDIMScheduler")
+    assert isinstance(p2.scheduler, DDIMScheduler)
     assert isinstance(p2.text_encoder, HipCLIPTextEncoder) and p2.cfg.text.hidden_size == 64
     e = p2.text_encoder(["an aerial view image with cars"])
     assert e.shape == (1, 77, 64) and torch.isfinite(e).all()
@@ -443,4 +449,33 @@ def test_hooker_context_length_change_resizes_the_recorder():
         assert hk.cross_attn_maps[-1].shape == (2, T, 8, 8)
         assert float((hk.cross_attn_maps[-1].cpu() - rec.cross_attn_maps[0]).abs().max()) < 2e-3
         assert float((hk.compute_global_heat_map().cpu() - rec.compute_global_heat_map()).abs().max()) < 2e-3
+    pipe.engine.close()
+
+
+def test_pndm_generation_matches_oracle(tiny_pipe, tmp_path):
+    """The reference's own scheduler (data_generation.py:59: checkpoint default = PNDM/PLMS x 20): the fused device loop
+    (`agd_denoise_plms`, n + 1 model evaluations) vs the oracle's method-by-method restatement, DAAM recording on."""
+    from agenda_amd import StableDiffusionPipeline, synthetic, trace
+    from agenda_amd.scheduler import PNDMScheduler
+    from oracle import sd_oracle as O
+    _, cfg, u, v = tiny_pipe
+    pipe = StableDiffusionPipeline(cfg, u, v, workspace_bytes=1 << 30, scheduler="PNDMScheduler")
+    assert isinstance(pipe.scheduler, PNDMScheduler)
+    B, L, steps = 2, 16, 6
+    ctx = synthetic.make_context(cfg, B, seed=51)
+    lat = synthetic.make_latents(cfg, [1, 2], L)
+    rec = O.DaamRecorder(L * L, context_size=cfg.max_tokens)
+    want_img, want_lat = O.generate(u, v, cfg, ctx, lat, steps, 7.5, recorder=rec, scheduler="pndm")
+    with trace(pipe) as trc:
+        out = pipe(prompt_embeds=ctx, latents=lat, num_inference_steps=steps, output_type="np")
+        hm = torch.stack([trc.compute_global_heat_map(image_index=i).heat_maps for i in range(B)]).cpu()
+    assert _rms_rel(out.latents, want_lat) < 0.06, _rms_rel(out.latents, want_lat)
+    assert _psnr(out.images, want_img) > 30.0
+    whm = rec.compute_global_heat_map()
+    assert float(hm.sum(1).mean()) == pytest.approx(steps + 1, rel=0.02)          # steps + 1 UNet evaluations were recorded
+    assert _rel(hm, whm) < 0.06
+    with pytest.raises(NotImplementedError):
+        pipe.img2img(prompt_embeds=ctx, image=torch.zeros(B, 3, 128, 128), num_inference_steps=4)
+    with pytest.raises(ValueError, match="not implemented"):
+        StableDiffusionPipeline(cfg, u, v, workspace_bytes=1 << 28, scheduler="EulerDiscreteScheduler")
     pipe.engine.close()
