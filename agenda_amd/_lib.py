@@ -66,6 +66,12 @@ _SIGS = {
     "agd_hook_last_map": (C.c_int, [_P, _P, C.c_int, _P]),
     "agd_cross_attn": (C.c_int, [_P, C.c_char_p, _P, _P, C.c_int, C.c_int, C.c_int, _P, C.c_int, _P]),
     "agd_attn_processor": (C.c_int, [_P, C.c_char_p, _P, _P, _P, C.c_int, C.c_int, C.c_int, _P, C.c_int, _P]),
+    "agd_hook_reset": (C.c_int, [_P, C.c_int, C.c_int, _P]),
+    "agd_hook_num_maps": (C.c_int, [_P]),
+    "agd_hook_map_dims": (C.c_int, [_P, C.c_int, C.POINTER(C.c_int)]),
+    "agd_hook_map": (C.c_int, [_P, C.c_int, _P, _P]),
+    "agd_op_attn_reg_loss": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, _P, _P, C.c_float, _P, _P, _P]),
+    "agd_attn_processor_backward": (C.c_int, [_P, C.c_char_p, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P]),
     "agd_op_conv2d": (C.c_int, [_P, _P, _P, _P] + [C.c_int] * 9 + [_P]),
     "agd_op_linear": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "agd_op_groupnorm": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, _P]),

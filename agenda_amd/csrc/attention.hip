@@ -326,16 +326,6 @@ __global__ __launch_bounds__(256, (AMASK ? 1 : (QB == 1 && D <= 40 && !RECORD) ?
               __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, old[i] + sacc[0][kb][i] * inv), rsrc, off, 0, 0);
             }
           }
-        } else {
-          float* rp = p.rec + img * p.rec_img_stride + (q0 + c);
-          const float invh = inv / (float)p.H;
-#pragma unroll
-          for (int kb = 0; kb < KB; ++kb)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-              const int tok = kb * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
-              if (tok < p.rec_T) atomicAdd(rp + (long long)tok * p.Nq, sacc[0][kb][i] * invh);
-            }
         }
       }
     }

@@ -38,7 +38,7 @@ int launch_igemm(const IgemmP& p, hipStream_t st);
 // ---------------------------------------------------------------------------------------
 // Attention (flash, swapped-QK^T formulation).  Q [B][Nq][ldq] (+head*D), K/V [B][Nk][ldk].
 // record_mode: 0 none; 1 DAAM: acc[img][head][t][pix] += P for batch rows >= rec_b0;
-//              2 HOOK: hookmap[img][t][pix] += P / heads (atomic) for batch rows >= rec_b0.
+//              (hook.py mode records per-head rows the same way into a per-call buffer; the ordered head mean is train.hip's)
 // ---------------------------------------------------------------------------------------
 struct AttnP {
   const bf16_t* q; const bf16_t* k; const bf16_t* v; bf16_t* o;
@@ -99,5 +99,14 @@ int launch_pil_resample(const unsigned char* in, unsigned char* out, const int* 
                         long long n_outer, int in_len, int out_len, int inner, hipStream_t st);
 int launch_stack_heatmaps(const unsigned char* obj, const unsigned char* fg, const unsigned char* bg, long long npix,
                           unsigned char* rgb, unsigned char* inv, hipStream_t st);
+
+// training-mode seam (train.hip)
+int launch_hook_headmean(const float* heads, int Bp, int H, int T, int N, float* map, hipStream_t st);
+int launch_attn_reg_loss(const float* map, int B, int T, int P, const int* obj_idx, const int* fg_idx, const int* bg_idx, float coef,
+                         float* loss_out, float* dmap, hipStream_t st);
+int launch_attention_backward(const bf16_t* q, const bf16_t* kv, const bf16_t* dout, const float* dmap, int b0, int B, int H, int D, int N, int T,
+                              float scale, bf16_t* dq, bf16_t* dkv, float* part, hipStream_t st);
+long long attention_backward_ws_floats(int B, int H, int D, int N, int T);
+int launch_transpose_bf16(const bf16_t* in, int R, int Cc, bf16_t* out, hipStream_t st);
 
 int launch_embed_gather(const int* ids, const bf16_t* tok, const bf16_t* pos, bf16_t* out, int B, int T, int H, int vocab_cap, hipStream_t st);

@@ -62,6 +62,7 @@ struct DBuf {
 struct XLayer {
   std::string name; int C = 0, heads = 0, level = 0; bool mid = false;
   WMat wkv; DBuf kvb; bf16_t* kv = nullptr; DBuf accb; float* acc = nullptr; int acc_side = 0;
+  DBuf wqTb, wkvTb, woTb; WMat wqT, wkvT, woT;        // transposed weights for the input-gradient GEMMs (built on first backward)
 };
 
 struct ProfEv { int cls; double flops, bytes; hipEvent_t a, b; };   // algorithmic flop / HBM bytes of the launch
@@ -87,7 +88,10 @@ struct agd_ctx {
   DBuf ctxb; bf16_t* ctx_bf16 = nullptr; int ctx_B2 = 0, ctx_T = 0;
   // recorder
   int rec_mode = 0, rec_is_train = 0, rec_T_cfg = 0, rec_T = 0, rec_B = 0, rec_L = 0;   // rec_T: rows the accumulators were sized for (set by record_reset)
-  DBuf hook_sumb, hook_scratchb;
+  DBuf hook_sumb, hook_scratchb, hook_headsb, hook_storeb;     // hook_heads: per-head probabilities of one call; hook_store: kept per-call maps (train mode)
+  struct HookRec { size_t off; int Bp, T, N; };
+  std::vector<HookRec> hook_recs; size_t hook_store_used = 0;
+  DBuf bwd_wsb;                                                 // attention-backward workspace
   float* hook_sum = nullptr; float* hook_scratch = nullptr; int hook_count = 0, hook_Bp = 0, hook_T = 0;
   // denoise scratch
   DBuf latb, epsb, vae_imgb, plmsb;
@@ -256,15 +260,34 @@ static int cross_attention(agd_ctx* c, hipStream_t st, XLayer& xl, const bf16_t*
     const int b0 = c->rec_is_train ? 0 : B2 / 2;
     if (B2 - b0 == c->hook_Bp) {
       if (T != c->hook_T || side > c->rec_L) FAIL("hook recorder was reset for %d tokens / latent side %d but this call has %d tokens / side %d: call clear() (agd_record_reset) after changing the context", c->hook_T, c->rec_L, T, side);
-      a.record_mode = 2; a.rec_b0 = b0; a.rec = c->hook_scratch; a.rec_T = T;
-      a.rec_img_stride = (long long)T * N; a.rec_head_stride = 0;
-      if (hipMemsetAsync(c->hook_scratch, 0, (size_t)c->hook_Bp * T * N * 4, st) != hipSuccess) FAIL("memset hook scratch");
+      // per-head probabilities of this call (plain read-modify-write rows, like the DAAM accumulators), then an ORDERED
+      // head mean (hook.py:55): reproducible run to run, unlike float atomics across the head workgroups
+      const size_t nh = (size_t)c->hook_Bp * xl.heads * T * N;
+      CK(c->hook_headsb.ensure(nh * 4));
+      if (hipMemsetAsync(c->hook_headsb.p, 0, nh * 4, st) != hipSuccess) FAIL("memset hook heads");
+      a.record_mode = 1; a.rec_b0 = b0; a.rec = c->hook_headsb.as<float>(); a.rec_T = T;
+      a.rec_head_stride = (long long)T * N; a.rec_img_stride = a.rec_head_stride * xl.heads;
       hook_call = true;
     }
   }
   CK(run_attention(c, st, PC_ATTN_CROSS, a));
   if (hook_call) {
     ProfScope ps(c, st, PC_HEAT, 0);
+    CK(launch_hook_headmean(c->hook_headsb.as<float>(), c->hook_Bp, xl.heads, T, N, c->hook_scratch, st));
+    if (c->rec_is_train) {
+      // hook.py:110-112 `self.cross_attn_maps.append(maps)`: training reads every per-call map (finetune_sd_token.py:1043-1045),
+      // so they are kept (device memory, grown geometrically, earlier maps carried over)
+      const size_t bytes = (size_t)c->hook_Bp * T * N * 4, need = c->hook_store_used + bytes;
+      if (need > c->hook_storeb.cap) {
+        DBuf bigger; CK(bigger.ensure(need * 2 > ((size_t)64 << 20) ? need * 2 : ((size_t)64 << 20)));
+        if (c->hook_store_used && hipMemcpyAsync(bigger.p, c->hook_storeb.p, c->hook_store_used, hipMemcpyDeviceToDevice, st) != hipSuccess) FAIL("hook store copy");
+        hipStreamSynchronize(st);
+        c->hook_storeb.release(); c->hook_storeb = bigger;
+      }
+      if (hipMemcpyAsync((char*)c->hook_storeb.p + c->hook_store_used, c->hook_scratch, bytes, hipMemcpyDeviceToDevice, st) != hipSuccess) FAIL("hook store");
+      c->hook_recs.push_back({c->hook_store_used, c->hook_Bp, T, N});
+      c->hook_store_used = need;
+    }
     CK(launch_hook_accum(c->hook_scratch, c->hook_Bp, T, side, c->rec_L, c->hook_sum, st));
     c->hook_count++;
   }
@@ -595,7 +618,8 @@ AGD_API void agd_destroy(agd_ctx* c) {
   hipDeviceSynchronize();
   for (void* p : c->owned) hipFree(p);
   for (auto& xl : c->xl) { xl.kvb.release(); xl.accb.release(); }
-  c->ctxb.release(); c->hook_sumb.release(); c->hook_scratchb.release();
+  c->ctxb.release(); c->hook_sumb.release(); c->hook_scratchb.release(); c->hook_headsb.release(); c->hook_storeb.release(); c->bwd_wsb.release();
+  for (auto& xl : c->xl) { xl.wqTb.release(); xl.wkvTb.release(); xl.woTb.release(); }
   c->latb.release(); c->epsb.release(); c->vae_imgb.release(); c->plmsb.release();
   if (c->splitk.p) hipFree(c->splitk.p);
   if (c->arena.base) hipFree(c->arena.base);
@@ -884,6 +908,28 @@ AGD_API int agd_record_config(agd_ctx* c, int mode, int is_train, int rec_tokens
   return 0;
 }
 
+// hook.py recorder state for `rows` kept batch rows (B' of hook.py:48-55) at latent side L: running sum, per-call scratch
+static int hook_reset_rows(agd_ctx* c, int rows, int L, hipStream_t st) {
+  const int Tc = c->ctx_T > 0 ? c->ctx_T : c->cfg.max_tokens;
+  const size_t n = (size_t)rows * Tc * L * L;
+  CK(c->hook_sumb.ensure(n * 4)); CK(c->hook_scratchb.ensure(n * 4));
+  c->hook_sum = c->hook_sumb.as<float>(); c->hook_scratch = c->hook_scratchb.as<float>();
+  c->hook_Bp = rows; c->hook_T = Tc;
+  if (hipMemsetAsync(c->hook_sum, 0, n * 4, st) != hipSuccess) FAIL("memset hook");
+  c->hook_count = 0; c->hook_recs.clear(); c->hook_store_used = 0;
+  return 0;
+}
+
+// `hooker.clear()` with the number of recorded batch rows given explicitly (training calls the UNet without CFG: any batch)
+AGD_API int agd_hook_reset(agd_ctx* c, int rows, int L, void* stream) {
+  API_CK(c, need_final(c));
+  if (c->rec_mode != 2) { agd_set_error("hook_reset: recorder is not in hook.py mode (agd_record_config(2, ..))"); return fail_ctx(c); }
+  if (rows < 1 || L < 1) { agd_set_error("hook_reset: rows %d latent side %d", rows, L); return fail_ctx(c); }
+  API_CK(c, hook_reset_rows(c, rows, L, S(stream)));
+  c->rec_B = c->rec_is_train ? (rows + 1) / 2 : rows; c->rec_L = L;
+  return 0;
+}
+
 AGD_API int agd_record_reset(agd_ctx* c, int batch, int L, void* stream) {
   API_CK(c, need_final(c));
   hipStream_t st = S(stream);
@@ -901,14 +947,7 @@ AGD_API int agd_record_reset(agd_ctx* c, int batch, int L, void* stream) {
       if (hipMemsetAsync(xl.acc, 0, n * 4, st) != hipSuccess) { agd_set_error("memset acc"); return fail_ctx(c); }
     }
   } else if (c->rec_mode == 2) {
-    const int Bp = c->rec_is_train ? 2 * batch : batch;   // `batch` = images; UNet batch is 2*batch under CFG
-    const int Tc = c->ctx_T > 0 ? c->ctx_T : c->cfg.max_tokens;
-    const size_t n = (size_t)Bp * Tc * L * L;
-    API_CK(c, c->hook_sumb.ensure(n * 4)); API_CK(c, c->hook_scratchb.ensure(n * 4));
-    c->hook_sum = c->hook_sumb.as<float>(); c->hook_scratch = c->hook_scratchb.as<float>();
-    c->hook_Bp = Bp; c->hook_T = Tc;
-    if (hipMemsetAsync(c->hook_sum, 0, n * 4, st) != hipSuccess) { agd_set_error("memset hook"); return fail_ctx(c); }
-    c->hook_count = 0;
+    API_CK(c, hook_reset_rows(c, c->rec_is_train ? 2 * batch : batch, L, st));   // `batch` = images; UNet batch is 2*batch under CFG
   }
   c->rec_B = batch; c->rec_L = L;
   return 0;
@@ -1001,6 +1040,86 @@ AGD_API int agd_attn_processor(agd_ctx* c, const char* layer, const float* hidde
     API_CK(c, run_attention(c, st, PC_ATTN_SELF, a));
   }
   { GemmOpt o; o.bias = bo; o.out_f32 = 1; API_CK(c, run_conv(c, st, att, C, nullptr, 0, 1, 1, M, *wo, 1, out, o, c->zero_page)); }
+  return 0;
+}
+
+// ---- training-mode seam -------------------------------------------------------------------
+AGD_API int agd_hook_num_maps(agd_ctx* c) { return c ? (int)c->hook_recs.size() : 0; }
+
+// hook.py:110-112: the k-th map appended since the last clear() (train mode keeps them all): dims = {B', T, n_query}
+AGD_API int agd_hook_map_dims(agd_ctx* c, int k, int* dims) {
+  if (!c || !dims || k < 0 || k >= (int)c->hook_recs.size()) { agd_set_error("hook_map: no recorded map %d (have %d; is_train keeps per-call maps)", k, c ? (int)c->hook_recs.size() : 0); return fail_ctx(c); }
+  dims[0] = c->hook_recs[k].Bp; dims[1] = c->hook_recs[k].T; dims[2] = c->hook_recs[k].N;
+  return 0;
+}
+AGD_API int agd_hook_map(agd_ctx* c, int k, float* out, void* stream) {
+  API_CK(c, need_final(c));
+  if (k < 0 || k >= (int)c->hook_recs.size()) { agd_set_error("hook_map: no recorded map %d (have %d)", k, (int)c->hook_recs.size()); return fail_ctx(c); }
+  const auto& r = c->hook_recs[k];
+  if (hipMemcpyAsync(out, (const char*)c->hook_storeb.p + r.off, (size_t)r.Bp * r.T * r.N * 4, hipMemcpyDeviceToDevice, S(stream)) != hipSuccess) { agd_set_error("hook_map copy"); return fail_ctx(c); }
+  return 0;
+}
+
+// finetune_sd_token.py:1046-1066 for ONE recorded map [B][T][P] (P = h*w): loss_out [B][2] = {bg, fg} terms of each sample
+// (already times coef = reg_weight / #samples with an object), dmap [B][T][P] (may be NULL) = their gradient w.r.t. the map.
+// obj/fg/bg_idx: device int [B], obj < 0 skips the sample (no object in the image, :1048).
+AGD_API int agd_op_attn_reg_loss(const float* map, int B, int T, int P, const int* obj_idx, const int* fg_idx, const int* bg_idx, float coef,
+                                 float* loss_out, float* dmap, void* stream) {
+  if (!map || !obj_idx || !fg_idx || !bg_idx || !loss_out || B < 0 || T < 1 || P < 1) { agd_set_error("attn_reg_loss: bad argument"); return -1; }
+  CK(launch_attn_reg_loss(map, B, T, P, obj_idx, fg_idx, bg_idx, coef, loss_out, dmap, S(stream)));
+  return 0;
+}
+
+static int transposed(agd_ctx* c, hipStream_t st, const WMat& w, DBuf& buf, WMat& out) {
+  if (out.w) return 0;
+  const int K = w.taps * w.Cpad;
+  CK(buf.ensure((size_t)w.N * K * 2));
+  CK(launch_transpose_bf16(w.w, w.N, K, buf.as<bf16_t>(), st));
+  out.w = buf.as<bf16_t>(); out.N = K; out.Cin = w.N; out.Cpad = w.N; out.taps = 1;
+  return 0;
+}
+
+// Backward of one cross-attention call of the seam (hook.py:91-120) w.r.t. its inputs:
+//   d_out  [B2, N, C] fp32 or NULL: gradient of the returned hidden_states
+//   d_map  [B', T, N] fp32 or NULL: gradient of the recorded head-mean map (hook.py:55; B' = B2 in train mode, the
+//          conditional half B2/2 otherwise, hook.py:48-49) -- e.g. from agd_op_attn_reg_loss
+//   -> d_hidden [B2, N, C] and d_ctx [B2, T, ctx_dim] fp32 (either may be NULL)
+// P is recomputed from Q = to_q(hidden) and the cached K/V of `ctx_emb` (bf16 operands, fp32 arithmetic, like the forward).
+AGD_API int agd_attn_processor_backward(agd_ctx* c, const char* layer, const float* hidden, const float* ctx_emb, const float* d_out,
+                                        const float* d_map, int is_train, int batch2, int n_query, int tokens, float* d_hidden, float* d_ctx,
+                                        void* stream) {
+  API_CK(c, need_final(c));
+  hipStream_t st = S(stream);
+  if (!layer || !hidden || (!d_out && !d_map) || batch2 < 1 || n_query < 1) { agd_set_error("attn_processor_backward: bad argument"); return fail_ctx(c); }
+  std::string name(layer);
+  if (name.compare(0, 5, "unet.") != 0) name = "unet." + name;
+  auto it = c->xl_idx.find(name);
+  if (it == c->xl_idx.end() || !ends_with(name, "attn2")) { agd_set_error("attn_processor_backward: unknown cross-attention layer '%s'", layer); return fail_ctx(c); }
+  XLayer& xl = c->xl[it->second];
+  if (ctx_emb) API_CK(c, agd_set_context(c, ctx_emb, batch2, tokens, stream));
+  if (c->ctx_B2 != batch2 || c->ctx_T < 1) { agd_set_error("attn_processor_backward: context batch %d != %d", c->ctx_B2, batch2); return fail_ctx(c); }
+  const int C = xl.C, H = xl.heads, D = C / H, T = c->ctx_T, M = batch2 * n_query, Dc = c->cfg.cross_attention_dim;
+  const std::string t = xl.name.substr(0, xl.name.size() - 5);
+  const WMat* wq = getW(c, t + "attn2.to_q.weight"); const WMat* wo = getW(c, t + "attn2.to_out.0.weight");
+  if (!wq || !wo) return fail_ctx(c);
+  API_CK(c, transposed(c, st, *wq, xl.wqTb, xl.wqT)); API_CK(c, transposed(c, st, xl.wkv, xl.wkvTb, xl.wkvT)); API_CK(c, transposed(c, st, *wo, xl.woTb, xl.woT));
+  API_CK(c, c->bwd_wsb.ensure((size_t)attention_backward_ws_floats(batch2, H, D, n_query, T) * 4));
+  c->arena.release(0);
+  bf16_t* x = (bf16_t*)c->arena.alloc((size_t)M * C * 2); bf16_t* q = (bf16_t*)c->arena.alloc((size_t)M * C * 2);
+  bf16_t* dy = d_out ? (bf16_t*)c->arena.alloc((size_t)M * C * 2) : nullptr; bf16_t* dO = d_out ? (bf16_t*)c->arena.alloc((size_t)M * C * 2) : nullptr;
+  bf16_t* dq = (bf16_t*)c->arena.alloc((size_t)M * C * 2); bf16_t* dkv = (bf16_t*)c->arena.alloc((size_t)batch2 * T * 2 * C * 2);
+  if (!x || !q || !dq || !dkv || (d_out && (!dy || !dO))) return fail_ctx(c);
+  API_CK(c, launch_f32_to_bf16(hidden, x, (long long)M * C, st));
+  { GemmOpt o; API_CK(c, run_conv(c, st, x, C, nullptr, 0, 1, 1, M, *wq, 1, q, o, c->zero_page)); }                  // Q = to_q(hidden), hook.py:93
+  if (d_out) {                                                                                                       // dO = d_out . Wo  (hook.py:118)
+    API_CK(c, launch_f32_to_bf16(d_out, dy, (long long)M * C, st));
+    GemmOpt o; API_CK(c, run_conv(c, st, dy, C, nullptr, 0, 1, 1, M, xl.woT, 1, dO, o, c->zero_page));
+  }
+  API_CK(c, launch_attention_backward(q, xl.kv, dO, d_map, is_train ? 0 : batch2 / 2, batch2, H, D, n_query, T, 1.0f / sqrtf((float)D), dq, dkv,
+                                      c->bwd_wsb.as<float>(), st));
+  if (d_hidden) { GemmOpt o; o.out_f32 = 1; API_CK(c, run_conv(c, st, dq, C, nullptr, 0, 1, 1, M, xl.wqT, 1, d_hidden, o, c->zero_page)); }          // dX = dQ . Wq
+  if (d_ctx) { GemmOpt o; o.out_f32 = 1; API_CK(c, run_conv(c, st, dkv, 2 * C, nullptr, 0, 1, 1, batch2 * T, xl.wkvT, 1, d_ctx, o, c->zero_page)); } // dCtx = [dK | dV] . Wkv
+  (void)Dc;
   return 0;
 }
 

@@ -17,15 +17,57 @@ import math
 import torch
 
 
+class _SeamCall(torch.autograd.Function):
+    """One cross-attention call of the seam with autograd to its two inputs: forward = `agd_attn_processor` (+ the recorded
+    map), backward = `agd_attn_processor_backward` (HIP: recompute P, dS, dQ/dK/dV, input-gradient GEMMs).  This is the path
+    the reference's attention regulariser takes from `cross_attn_maps` back to the learned token embeddings
+    (finetune_sd_token.py:1043-1069,1089)."""
+
+    @staticmethod
+    def forward(ctx, hidden, enc, hooker, name, mask):
+        eng = hooker._pipe.engine
+        out = eng.attn_processor(name, hidden, enc, mask, record=True)
+        k = eng.hook_num_maps() - 1
+        amap = eng.hook_map(k) if hooker.is_train else eng.hook_last_map(hooker._bp, hooker._tokens, hidden.shape[1])
+        ctx.hooker, ctx.name, ctx.devs = hooker, name, (hidden.device, enc.device)
+        ctx.save_for_backward(hidden.detach(), enc.detach())
+        return out.to(hidden.device), amap
+
+    @staticmethod
+    def backward(ctx, d_out, d_map):
+        hidden, enc = ctx.saved_tensors
+        hk = ctx.hooker
+        zero = lambda g: g is None or not bool(torch.count_nonzero(g))
+        if zero(d_out) and zero(d_map):
+            return torch.zeros_like(hidden), torch.zeros_like(enc), None, None, None
+        dh, dc = hk._pipe.engine.attn_processor_backward(ctx.name, hidden, enc, None if zero(d_out) else d_out, None if zero(d_map) else d_map,
+                                                         hk.is_train, want_hidden=ctx.needs_input_grad[0], want_ctx=ctx.needs_input_grad[1])
+        return (dh.to(ctx.devs[0]) if dh is not None else None), (dc.to(ctx.devs[1]) if dc is not None else None), None, None, None
+
+
 class UNetCrossAttentionHooker:
     def __init__(self, is_train: bool = True, latent_hw: int = 64):
         self.is_train = is_train
         self.latent_hw = latent_hw
-        self.cross_attn_maps = []          # hook.py:19 -- filled by direct (seam) calls; the fused UNet walk streams instead
+        self._seam_maps = []               # inference mode: maps of direct (seam) calls (the fused UNet walk streams instead)
+        self._grad_maps = {}               # train mode: index in the device store -> autograd-connected map of a seam call
+        self._cache = (-1, [])
         self._pipe = None
         self._bp = 0
         self._tokens = 0
         self._side = 0
+
+    @property
+    def cross_attn_maps(self):
+        """hook.py:19,110-112: the per-call maps `[B', T, h, w]` since the last `clear()`.  Train mode (`is_train=True`, what
+        finetune_sd_token.py:755-757 installs) keeps every recorded call of the fused UNet walk and of direct seam calls on the
+        device, in call order; inference mode streams the fused walk's maps into the global heat map and lists seam calls only."""
+        if not self.is_train or self._pipe is None:
+            return self._seam_maps
+        n = self._pipe.engine.hook_num_maps()
+        if self._cache[0] != n:
+            self._cache = (n, [self._grad_maps[k] if k in self._grad_maps else self._pipe.engine.hook_map(k) for k in range(n)])
+        return self._cache[1]
 
     # -- wiring ---------------------------------------------------------------------------
     def _bind(self, pipe):
@@ -35,6 +77,15 @@ class UNetCrossAttentionHooker:
         self._bp = 2 * batch if self.is_train else batch
         self._tokens, self._side = tokens, latent_side
 
+    def _ensure(self, rows: int, side: int, tokens: int):
+        """(Re)size the device recorder when the kept batch rows / latent side / token count change; otherwise maps keep
+        accumulating until `clear()` (hook.py:25-26)."""
+        if self._bp != rows or self._side != side or self._tokens != tokens:
+            self._bp, self._side, self._tokens = rows, side, tokens
+            self._pipe._apply_record_mode()
+            self._pipe.engine.hook_reset(rows, side)
+            self._seam_maps.clear(); self._grad_maps.clear(); self._cache = (-1, [])
+
     def _need_pipe(self):
         if self._pipe is None:
             raise RuntimeError("hooker is not installed: call unet.set_attn_processor(hooker) first")
@@ -42,10 +93,10 @@ class UNetCrossAttentionHooker:
     # -- reference surface ----------------------------------------------------------------
     def clear(self):
         """hook.py:25-26"""
-        self.cross_attn_maps.clear()
+        self._seam_maps.clear(); self._grad_maps.clear(); self._cache = (-1, [])
         if self._pipe is not None and self._bp:
             self._pipe._apply_record_mode()
-            self._pipe.engine.record_reset(self._bp // 2 if self.is_train else self._bp, self._side)
+            self._pipe.engine.hook_reset(self._bp, self._side)
 
     @property
     def num_recorded(self) -> int:
@@ -85,10 +136,48 @@ class UNetCrossAttentionHooker:
             raise RuntimeError(f"shape '[-1, {side}, {side}]' is invalid for input of size {n} per map")
         bp = b2 if self.is_train else b2 // 2
         if self._bp != bp or self._side != self.latent_hw or self._tokens != encoder_hidden_states.shape[1]:
-            self._bp, self._side, self._tokens = bp, self.latent_hw, encoder_hidden_states.shape[1]
-            self._pipe._apply_record_mode()
             self._pipe.engine.set_context(encoder_hidden_states)
-            self._pipe.engine.record_reset(bp // 2 if self.is_train else bp, self.latent_hw)
-        out = self._pipe.engine.attn_processor(attn.name, hidden_states, encoder_hidden_states, mask, record=True)
-        self.cross_attn_maps.append(self._pipe.engine.hook_last_map(bp, self._tokens, n))     # hook.py:110-112
+            self._ensure(bp, self.latent_hw, encoder_hidden_states.shape[1])
+        if torch.is_grad_enabled() and (hidden_states.requires_grad or encoder_hidden_states.requires_grad):
+            if mask is not None:
+                raise NotImplementedError("autograd through the seam with an attention_mask")
+            out, amap = _SeamCall.apply(hidden_states, encoder_hidden_states, self, attn.name, None)
+        else:
+            out = self._pipe.engine.attn_processor(attn.name, hidden_states, encoder_hidden_states, mask, record=True)
+            amap = None if self.is_train else self._pipe.engine.hook_last_map(bp, self._tokens, n)
+        if self.is_train:                                          # hook.py:110-112: kept on the device, listed by the property
+            if amap is not None:
+                self._grad_maps[self._pipe.engine.hook_num_maps() - 1] = amap
+            self._cache = (-1, [])
+        else:
+            self._seam_maps.append(amap)
         return out
+
+    def attention_regulariser(self, new_tokens_start_indices, n_object_embedding: int, reg_weight: float, want_grads: bool = False):
+        """The cross-attention loss of finetune_sd_token.py:1040-1069 over the kept maps, on the device (`agd_op_attn_reg_loss`):
+        returns (attn_loss, bg_attn_loss, fg_attn_loss) as 0-d cuda tensors [+ the list of d attn_loss / d map when `want_grads`].
+        `new_tokens_start_indices`: int [B, n_new_tokens], -1 = token absent (dataset.py:88-97)."""
+        from . import ops
+        maps = [m.detach() for m in self.cross_attn_maps]
+        if not maps:
+            raise RuntimeError("No heat maps found.")
+        idx = torch.as_tensor(new_tokens_start_indices).to(torch.int64).cpu()
+        if idx.ndim != 2 or idx.shape[0] != maps[0].shape[0]:
+            raise ValueError(f"new_tokens_start_indices must be [B={maps[0].shape[0]}, n_tokens], got {tuple(idx.shape)}")
+        has = idx[:, 0] > 0                                                        # :1048 "whether there is a car in the image"
+        obj = torch.where(has, idx[:, 0] + n_object_embedding, torch.full_like(idx[:, 0], -1))          # :1049
+        fg = torch.where(has, idx[:, 0], torch.full_like(idx[:, 0], -1))                                 # :1055
+        last = torch.tensor([int(r[r > -1][-1]) if bool((r > -1).any()) else -1 for r in idx])          # :1059
+        bg = torch.where(has, last, torch.full_like(last, -1))
+        cnt = int(has.sum())
+        dev = maps[0].device
+        bg_l, fg_l, grads = torch.zeros((), device=dev), torch.zeros((), device=dev), []
+        for m in maps:
+            if cnt == 0:
+                grads.append(torch.zeros_like(m)); continue
+            loss, dmap = ops.attn_reg_loss(m, obj, fg, bg, reg_weight / cnt, want_grad=want_grads)           # :1064-1065
+            bg_l, fg_l = bg_l + loss[:, 0].sum(), fg_l + loss[:, 1].sum()
+            if want_grads:
+                grads.append(dmap / len(maps))                                     # :1068 attn_loss / len(cross_attn_maps)
+        attn = (bg_l + fg_l) / len(maps)
+        return (attn, bg_l, fg_l, grads) if want_grads else (attn, bg_l, fg_l)

@@ -90,3 +90,19 @@ def bicubic_clamp_mean(maps, out_side):
     _lib.check(lib.agd_op_bicubic_clamp_mean(_lib.ptr(maps), n, T, side, out_side, _lib.ptr(out),
                                              _lib.current_stream_ptr()), None, "agd_op_bicubic_clamp_mean")
     return out
+
+
+def attn_reg_loss(attn_map: torch.Tensor, obj_idx, fg_idx, bg_idx, coef: float, want_grad: bool = True):
+    """finetune_sd_token.py:1046-1066 on one recorded map [B, T, h, w] (cuda fp32): returns (loss [B, 2] = {bg, fg} per sample,
+    d_map [B, T, h, w] or None).  `*_idx`: int sequences / tensors of length B; obj < 0 skips the sample."""
+    lib = _lib.load()
+    m = attn_map.detach().to(torch.float32).contiguous()
+    assert m.is_cuda and m.ndim == 4
+    B, T = m.shape[:2]
+    P = m.shape[2] * m.shape[3]
+    idx = [torch.as_tensor(list(map(int, i)) if not torch.is_tensor(i) else i, dtype=torch.int32).to(m.device).contiguous() for i in (obj_idx, fg_idx, bg_idx)]
+    loss = torch.empty(B, 2, device=m.device, dtype=torch.float32)
+    dmap = torch.empty_like(m) if want_grad else None
+    _lib.check(lib.agd_op_attn_reg_loss(_lib.ptr(m), B, T, P, _lib.ptr(idx[0]), _lib.ptr(idx[1]), _lib.ptr(idx[2]), float(coef), _lib.ptr(loss),
+                                        _lib.ptr(dmap), _lib.current_stream_ptr()), None, "agd_op_attn_reg_loss")
+    return loss, dmap

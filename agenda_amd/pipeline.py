@@ -255,6 +255,41 @@ class Engine:
         self._keep = (hidden, ctx_emb, mask)
         return out
 
+    # training-mode seam
+    def hook_reset(self, rows: int, L: int):
+        self._ck(self.lib.agd_hook_reset(self.ctx, rows, L, self._stream()), "agd_hook_reset")
+
+    def hook_num_maps(self) -> int:
+        return int(self.lib.agd_hook_num_maps(self.ctx))
+
+    def hook_map(self, k: int) -> torch.Tensor:
+        """The k-th per-call map kept since the last reset (train mode): [B', T, h, w] fp32 (hook.py:110-112)."""
+        d = (C.c_int * 3)()
+        self._ck(self.lib.agd_hook_map_dims(self.ctx, k, d), "agd_hook_map_dims")
+        side = int(round(d[2] ** 0.5))
+        out = torch.empty(d[0], d[1], side, side, device=f"cuda:{self.device}", dtype=torch.float32)
+        self._ck(self.lib.agd_hook_map(self.ctx, k, _lib.ptr(out), self._stream()), "agd_hook_map")
+        return out
+
+    def attn_processor_backward(self, layer: str, hidden: torch.Tensor, ctx_emb: Optional[torch.Tensor], d_out: Optional[torch.Tensor],
+                                d_map: Optional[torch.Tensor], is_train: bool, want_hidden: bool = True, want_ctx: bool = True):
+        """Backward of one cross-attention seam call: (d_hidden [B2,N,C], d_ctx [B2,T,ctx_dim]) from d_out and/or d_map."""
+        dev = f"cuda:{self.device}"
+        f = lambda t: None if t is None else t.detach().to(device=dev, dtype=torch.float32).contiguous()
+        hidden, ctx_emb, d_out, d_map = f(hidden), f(ctx_emb), f(d_out), f(d_map)
+        b2, n, _ = hidden.shape
+        t = ctx_emb.shape[1] if ctx_emb is not None else self.cfg.max_tokens
+        if d_map is not None:
+            d_map = d_map.reshape(d_map.shape[0], d_map.shape[1], -1).contiguous()
+            if d_map.shape[0] != (b2 if is_train else b2 // 2) or d_map.shape[2] != n:
+                raise ValueError(f"d_map shape {tuple(d_map.shape)} does not match the recorded map of this call")
+        dh = torch.empty_like(hidden) if want_hidden else None
+        dc = torch.empty(b2, t, self.cfg.unet.cross_attention_dim, device=dev, dtype=torch.float32) if want_ctx else None
+        self._ck(self.lib.agd_attn_processor_backward(self.ctx, layer.encode(), _lib.ptr(hidden), _lib.ptr(ctx_emb), _lib.ptr(d_out), _lib.ptr(d_map),
+                                                      int(is_train), b2, n, t, _lib.ptr(dh), _lib.ptr(dc), self._stream()), "agd_attn_processor_backward")
+        self._keep = (hidden, ctx_emb, d_out, d_map)
+        return dh, dc
+
     def profile_begin(self):
         self._ck(self.lib.agd_profile_begin(self.ctx), "agd_profile_begin")
 
@@ -321,9 +356,18 @@ class UNetHandle:
         return self._attn2[name] if name in self._attn2 else self._attn1[name]
 
     def __call__(self, sample, timestep, encoder_hidden_states=None):
+        """`unet(sample, t, encoder_hidden_states)` (finetune_sd_token.py:1027 calls it like this, without CFG): one fused forward;
+        an installed hooker records its attn2 calls (train mode keeps the 16 per-call maps, hook.py:110-112)."""
         if encoder_hidden_states is not None:
             self._pipe.engine.set_context(encoder_hidden_states)
-        return self._pipe.engine.unet_forward(sample, float(timestep))
+        hk = self._pipe._hooker
+        if hk is not None and self._pipe._trace is None:
+            hk._ensure(sample.shape[0] if hk.is_train else sample.shape[0] // 2, sample.shape[-1],
+                       encoder_hidden_states.shape[1] if encoder_hidden_states is not None else self._pipe.cfg.max_tokens)
+        out = self._pipe.engine.unet_forward(sample, float(timestep))
+        if hk is not None:
+            hk._cache = (-1, [])
+        return out
 
 
 class VAEHandle:

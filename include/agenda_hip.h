@@ -131,6 +131,28 @@ int agd_attn_processor(agd_ctx* ctx, const char* layer, const float* hidden, con
 int agd_cross_attn(agd_ctx* ctx, const char* layer, const float* hidden, const float* ctx_emb, int batch2,
                    int n_query, int tokens, float* out, int record, void* stream);
 
+/* ---- training-mode seam (what finetune_sd_token.py does with hook.py's recorder)
+ * With agd_record_config(2, is_train = 1) every recorded attn2 call keeps its head-mean map [B', T, n_query] on the device
+ * (hook.py:110-112 `cross_attn_maps.append`), in call order, until the next agd_record_reset (`hooker.clear()`,
+ * finetune_sd_token.py:1024,1069). */
+int agd_hook_reset(agd_ctx* ctx, int rows, int latent_side, void* stream);   /* clear() with B' given explicitly (no CFG pairing) */
+int agd_hook_num_maps(agd_ctx* ctx);
+int agd_hook_map_dims(agd_ctx* ctx, int k, int* dims3);                 /* {B', T, n_query} of the k-th kept map */
+int agd_hook_map(agd_ctx* ctx, int k, float* out, void* stream);        /* out [B', T, n_query] fp32; stream-ordered */
+/* The attention regulariser of finetune_sd_token.py:1046-1066 on ONE recorded map [B, T, P = h*w]: per sample the object /
+ * foreground / background token rows are min-max normalised (+1e-8), L1-normalised, and compared:
+ *   bg = coef * mean|(1 - o^)/sum(1 - o^) - b~| ,  fg = coef * mean|o^/sum(o^) - f~|      (coef = reg_weight / #object samples)
+ * loss_out [B][2] = {bg, fg}; dmap [B, T, P] (may be NULL) = d(bg + fg)/d map (min/max paths included, as torch autograd).
+ * obj/fg/bg_idx: device int [B]; obj_idx < 0 skips the sample (:1048).  Stream-ordered. */
+int agd_op_attn_reg_loss(const float* map, int B, int T, int P, const int* obj_idx, const int* fg_idx, const int* bg_idx, float coef,
+                         float* loss_out, float* dmap, void* stream);
+/* Backward of one cross-attention call of the seam (hook.py:91-120) w.r.t. its inputs: given d_out [B2, N, C] (gradient of the
+ * returned hidden_states; may be NULL) and/or d_map [B', T, N] (gradient of the recorded map; B' = B2 if is_train else B2/2;
+ * may be NULL) -> d_hidden [B2, N, C] and d_ctx [B2, T, ctx_dim] fp32 (either may be NULL).  ctx_emb NULL = the cached context. */
+int agd_attn_processor_backward(agd_ctx* ctx, const char* layer, const float* hidden, const float* ctx_emb, const float* d_out,
+                                const float* d_map, int is_train, int batch2, int n_query, int tokens, float* d_hidden, float* d_ctx,
+                                void* stream);
+
 /* ---- single-op entry points (fp32 in/out, converted to the bf16 NHWC compute layout inside);
  * used by the parity tests, mirror torch.nn.functional signatures the oracle uses. */
 int agd_op_conv2d(const float* x_nchw, const float* w, const float* bias, float* y_nchw, int B, int Cin, int H, int W,

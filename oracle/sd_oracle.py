@@ -118,6 +118,42 @@ class HookRecorder:
         return hooker_global_heat_map(self.cross_attn_maps, self.latent_hw)
 
 
+def attention_regulariser(cross_attn_maps: Sequence[Tensor], new_tokens_start_indices: Tensor, n_object_embedding: int,
+                          reg_weight: float):
+    """The cross-attention loss of the token fine-tuning step, restated from reference
+    data_generation/finetune_sd_token.py:1040-1069 (inline in its training loop, so it cannot be imported; torch ops and their
+    order kept, so autograd through the maps gives the reference's gradients).  `cross_attn_maps`: the hooker's list of
+    [B, T, h, w] maps (is_train=True); `new_tokens_start_indices`: int [B, n_new_tokens], -1 = absent (dataset.py:88-97).
+    Returns (attn_loss, bg_attn_loss, fg_attn_loss)."""
+    dev = cross_attn_maps[0].device
+    attn_loss = torch.tensor(0.0, device=dev)                                      # :1041-1043
+    bg_attn_loss = torch.tensor(0.0, device=dev)
+    fg_attn_loss = torch.tensor(0.0, device=dev)
+    idx = new_tokens_start_indices
+    for attn_maps in cross_attn_maps:                                              # :1046
+        for sample_attn_map, sample_start_indices in zip(attn_maps, idx):          # :1047
+            if sample_start_indices[0] > 0:                                        # :1048
+                obj_index = sample_start_indices[0] + n_object_embedding           # :1049
+                obj = sample_attn_map[obj_index]
+                norm_obj = (obj - obj.min()) / (obj.max() - obj.min() + 1e-8)      # :1051
+                norm_bg_ref = 1 - norm_obj                                         # :1052
+                norm_bg_ref = norm_bg_ref / torch.sum(norm_bg_ref)                 # :1053
+                norm_obj = norm_obj / torch.sum(norm_obj)                          # :1054
+                fg = sample_attn_map[sample_start_indices[0]]                      # :1056
+                norm_fg = (fg - fg.min()) / (fg.max() - fg.min() + 1e-8)           # :1057
+                norm_fg = norm_fg / torch.sum(norm_fg)                             # :1058
+                bg_index = sample_start_indices[sample_start_indices > -1][-1]     # :1060
+                bg = sample_attn_map[bg_index]
+                norm_bg = (bg - bg.min()) / (bg.max() - bg.min() + 1e-8)           # :1062
+                norm_bg = norm_bg / torch.sum(norm_bg)                             # :1063
+                n_obj = torch.sum(idx[:, 0] > 0)
+                bg_attn_loss = bg_attn_loss + reg_weight * torch.mean(torch.abs(norm_bg_ref - norm_bg)) / n_obj       # :1065
+                fg_attn_loss = fg_attn_loss + reg_weight * torch.mean(torch.abs(norm_obj - norm_fg)) / n_obj          # :1066
+                attn_loss = bg_attn_loss + fg_attn_loss                            # :1067
+    attn_loss = attn_loss / len(cross_attn_maps)                                   # :1069
+    return attn_loss, bg_attn_loss, fg_attn_loss
+
+
 # ==========================================================================================
 # 2. DAAM accumulation (third-party `daam`, call sites data_generation.py:57,64,74)  [upstream-knowledge]
 # ==========================================================================================
