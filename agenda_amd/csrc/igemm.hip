@@ -63,7 +63,13 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_kernel(const IgemmP p) 
   }
   const int tiles_n = (p.N + BN - 1) / BN;
   const int bid = xcd_remap(blockIdx.x, gridDim.x);
-  const int tn = bid % tiles_n, tm = bid / tiles_n;
+  // consecutive logical ids share an XCD's L2 (xcd_remap): walk the tiles so that they share the LARGER operand panel --
+  // A-major (same im2col rows, all N tiles) for the big feature maps, W-major (same weight rows, all M tiles) where the
+  // weights outweigh the activations (16x16 / 8x8 maps): otherwise every XCD streams the whole weight matrix from the
+  // fabric (rocprofv3 FETCH_SIZE: 211 MB per launch for a 29 MB weight matrix)
+  int tn, tm;
+  if (p.wmajor) { const int tiles_m = (p.M + BM - 1) / BM; tm = bid % tiles_m; tn = bid / tiles_m; }
+  else { tn = bid % tiles_n; tm = bid / tiles_n; }
   const int bz = blockIdx.y;
   const int m0 = tm * BM, n0 = tn * BN;
 
@@ -389,6 +395,16 @@ int launch_igemm(const IgemmP& p_in, hipStream_t st) {
   if (p.rowadd && p.M >= (1 << 24)) { agd_set_error("igemm: rowadd needs M < 2^24"); return -1; }
   if (p.geglu && (p.N % 128)) { agd_set_error("igemm: geglu needs N %% 128 == 0"); return -1; }
   const int batch = p.batch > 0 ? p.batch : 1;
+  {  // tile walk order: W-major when the weight matrix is the larger operand (bytes fetched once per XCD either way)
+    const double a_bytes = 2.0 * p.M * (double)(p.C0 + p.C1);   // ~ the input pixels (each fetched once from the fabric per XCD)
+    const double w_bytes = 2.0 * p.N * (double)p.K;
+    // measured (tools/kb_lin.py, AGD_IGEMM_WMAJOR): M=2048 K=1280 GEGLU 79.6 -> 66.8 us, qkv 25.4 -> 24.6; 3x3 convs get SLOWER W-major
+    // (72.0 -> 74.6: their tap re-reads of the A rows stop hitting in L2), so 1x1 only
+    p.wmajor = (batch == 1 && p.ksize == 1 && w_bytes > 1.5 * a_bytes) ? 1 : 0;
+#ifdef AGD_EXPERIMENTS
+    { static int f = -2; if (f == -2) { const char* e = getenv("AGD_IGEMM_WMAJOR"); f = e ? atoi(e) : -1; } if (f >= 0) p.wmajor = f && batch == 1; }
+#endif
+  }
   const long long t128 = (long long)((p.M + 127) / 128) * ((p.N + 127) / 128) * batch;
   const int nk = p.K >> 6;
 #ifdef AGD_EXPERIMENTS

@@ -30,6 +30,7 @@ struct IgemmP {
   const bf16_t* zero_page;          // >= 256 B of zeros
   SplitKWs* ws;                     // caller's split-K workspace (grown on demand); NULL: a per-device default
   float* splitk_ws;                 // set by the launcher: fp32 partial slabs [S][M][N]
+  int wmajor;                       // set by the launcher: 1 = consecutive tiles share the weight panel (W-major walk), else the A panel
   int stagger;                      // set by the launcher: start delay of the CU's second workgroup, x1024 cycles (speed only)
   int dbg;                          // timing experiments only (builds with -DAGD_EXPERIMENTS)
 };
