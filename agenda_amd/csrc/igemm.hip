@@ -285,7 +285,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_kernel(const IgemmP p) 
     return;
   }
 #endif
-  igemm_epilogue<BM, BN, WM, WN, GEGLU, SPLITK>(p, acc, lane, wm, wn, m0, n0, bz);
+  igemm_epilogue<BM, BN, WM, WN, GEGLU, SPLITK>(p, acc, smem, lane, wm, wn, m0, n0, tn, bz);
 }
 
 // split-K second pass: out = epilogue(sum_s partial[s])   (deterministic slab sum, no atomics)
@@ -330,6 +330,9 @@ static int launch_one(const IgemmP& p, int splits, hipStream_t st) {
 
 template <int BM, int BN, int WM, int WN, int STAGES = 2>
 static int launch_cfg(const IgemmP& p, int splits, hipStream_t st) {
+  if (p.cfg_out) { p.cfg_out[0] = BM; p.cfg_out[1] = BN; p.cfg_out[2] = splits; return 0; }   // igemm_query: report the dispatch decision only
+  if ((p.rowstat_out || p.ln_stats) && splits > 1) { agd_set_error("igemm: LayerNorm fold on a split-K launch"); return -1; }
+  if (p.rowstat_out && p.rowstat_slots != (p.N + BN - 1) / BN) { agd_set_error("igemm: rowstat_slots %d != N tiles %d", p.rowstat_slots, (p.N + BN - 1) / BN); return -1; }
   static const bool logit = getenv("AGD_IGEMM_LOG") != nullptr;      // tools/layer_report.py joins this with a kernel trace
   if (logit) fprintf(stderr, "IGEMM M=%d N=%d K=%d ks=%d stride=%d up=%d geglu=%d res=%d tile=%dx%d splits=%d batch=%d\n", p.M, p.N, p.K, p.ksize,
                      p.stride, p.up, p.geglu, p.residual ? 1 : 0, BM, BN, splits, p.batch > 0 ? p.batch : 1);
@@ -394,6 +397,8 @@ int launch_igemm(const IgemmP& p_in, hipStream_t st) {
   if (p.M < 1 || p.N < 1) { agd_set_error("igemm: empty problem M=%d N=%d", p.M, p.N); return -1; }
   if (p.rowadd && p.M >= (1 << 24)) { agd_set_error("igemm: rowadd needs M < 2^24"); return -1; }
   if (p.geglu && (p.N % 128)) { agd_set_error("igemm: geglu needs N %% 128 == 0"); return -1; }
+  if (p.rowstat_out && (p.geglu || p.out_f32 || p.batch > 1)) { agd_set_error("igemm: row statistics only for plain bf16 launches"); return -1; }
+  if (p.ln_stats && (!p.ln_cs || p.ln_slots < 1 || p.batch > 1)) { agd_set_error("igemm: LayerNorm fold needs colsum + slots"); return -1; }
   const int batch = p.batch > 0 ? p.batch : 1;
   {  // tile walk order: W-major when the weight matrix is the larger operand (bytes fetched once per XCD either way)
     const double a_bytes = 2.0 * p.M * (double)(p.C0 + p.C1);   // ~ the input pixels (each fetched once from the fabric per XCD)
@@ -462,7 +467,8 @@ int launch_igemm(const IgemmP& p_in, hipStream_t st) {
       const long long mt = (p.M + 127) / 128;
       const long long T8 = mt * (p.N / 128) * batch, T0 = mt * (p.N / 160) * batch;
       auto cost = [](long long T, double w) { return w * (T <= 256 ? 1.33 : (double)((T + 255) / 256)); };
-      if (p.ksize == 3 || KNOB(10)) n160 = cost(T0, 1.25) < cost(T8, 1.0) - 1e-9;   // measured: helps 3x3, hurts / neutral for 1x1
+      // measured: helps 3x3 and long-K 1x1 (M=8192 K=2560 N=640: 39.3 -> 34.0 us as 256 tiles on the deep ring), neutral for short-K 1x1
+      if (p.ksize == 3 || nk >= 32 || KNOB(10)) n160 = cost(T0, 1.25) < cost(T8, 1.0) - 1e-9;
     }
     // <= 256 tiles: one workgroup per CU whatever the ring -> take the 4-stage ring (147 / 128 KB LDS)
     const long long Tsel = (long long)((p.M + 127) / 128) * ((p.N + (n160 ? 159 : 127)) / (n160 ? 160 : 128)) * batch;
@@ -470,5 +476,15 @@ int launch_igemm(const IgemmP& p_in, hipStream_t st) {
     if (n160) return deep ? launch_cfg<128, 160, 2, 2, 4>(p, 1, st) : launch_cfg<128, 160, 2, 2>(p, 1, st);
     return deep ? launch_cfg<128, 128, 2, 2, 4>(p, 1, st) : launch_cfg<128, 128, 2, 2>(p, 1, st);
   }
+  // 128..191 tiles of 128x128 with a long K (M=2048 K=1280 N=1280: 160 tiles): one workgroup per CU on the deep ring beats 640
+  // tiles of 64x64, whose LDS traffic per MFMA is twice as high (19.7 -> 16.5 us)
+  if (t128 >= 128 && nk >= 16 && !KNOB(13)) return launch_cfg<128, 128, 2, 2, 4>(p, 1, st);
   return launch_cfg<64, 64, 2, 2, 4>(p, 1, st);
+}
+
+// the tile configuration launch_igemm would pick for this problem: cfg3 = {BM, BN, K splits} (nothing is launched)
+int igemm_query(const IgemmP& p_in, int* cfg3) {
+  IgemmP p = p_in;
+  p.cfg_out = cfg3;
+  return launch_igemm(p, nullptr);
 }

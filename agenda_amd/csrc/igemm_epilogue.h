@@ -13,8 +13,8 @@
 #include "kernels.h"
 
 template <int BM, int BN, int WM, int WN, int GEGLU, int SPLITK>
-AGD_DEV void igemm_epilogue(const IgemmP& p, f32x4 (&acc)[BM / WM / 16][BN / WN / 16], int lane, int wm, int wn, int m0, int n0,
-                            int bz) {
+AGD_DEV void igemm_epilogue(const IgemmP& p, f32x4 (&acc)[BM / WM / 16][BN / WN / 16], char* smem, int lane, int wm, int wn, int m0,
+                            int n0, int tn, int bz) {
   constexpr int WTM = BM / WM, WTN = BN / WN;
   constexpr int MI = WTM / 16, NI = WTN / 16;
   static_assert(!GEGLU || NI == 4, "GEGLU epilogue: a lane's 16 columns must be one [8 values | 8 gates] group");
@@ -45,6 +45,10 @@ AGD_DEV void igemm_epilogue(const IgemmP& p, f32x4 (&acc)[BM / WM / 16][BN / WN 
     }
     return;
   } else {
+    // producer side of the LayerNorm fold: per-row (sum, sum of squares) of the bf16-rounded outputs, this lane's share
+    float rs[MI], rq[MI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) { rs[i] = 0.f; rq[i] = 0.f; }
     const bool full = no + CW <= Nout;
     const bool fast = full && (no % SV) == 0 && (p.ldo % (p.out_f32 ? 4 : SV)) == 0 && (!p.residual || (p.ldr % SV) == 0);
     if (fast) {
@@ -65,6 +69,30 @@ AGD_DEV void igemm_epilogue(const IgemmP& p, f32x4 (&acc)[BM / WM / 16][BN / WN 
         }
       }
       float hb[CW], hg[GEGLU ? CW : 1];
+      // LayerNorm folded into this GEMM (A rows are raw, W carries gamma): per-row mean / rstd from the producer's partial sums,
+      // out = rstd (acc - mean colsum[n]) + bias'[n]
+      const bool lnf = p.ln_stats != nullptr;
+      float lmu[MI], lrs[MI], cs[CW], csg[GEGLU ? CW : 1];
+      if (lnf) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+          const int m = mrow0 + i * 16;
+          float S = 0.f, Q = 0.f;
+          if (m < p.M) {
+            const float* sp = p.ln_stats + (long long)m * p.ln_slots * 2;
+            for (int k = 0; k < p.ln_slots; ++k) { S += sp[2 * k]; Q += sp[2 * k + 1]; }
+          }
+          const float mu = S * p.ln_invC;
+          float var = Q * p.ln_invC - mu * mu; var = var < 0.f ? 0.f : var;
+          lmu[i] = mu; lrs[i] = rsqrtf(var + p.ln_eps);
+        }
+#pragma unroll
+        for (int c = 0; c < CW / 4; ++c) *(f32x4*)&cs[4 * c] = *(const f32x4*)(p.ln_cs + no + 4 * c);
+        if constexpr (GEGLU) {
+#pragma unroll
+          for (int c = 0; c < CW / 4; ++c) *(f32x4*)&csg[4 * c] = *(const f32x4*)(p.ln_cs + Nout + no + 4 * c);
+        }
+      }
 #pragma unroll
       for (int e = 0; e < CW; ++e) hb[e] = 0.f;
       if (p.bias && p.bias_mode == 1) {
@@ -81,13 +109,25 @@ AGD_DEV void igemm_epilogue(const IgemmP& p, f32x4 (&acc)[BM / WM / 16][BN / WN 
         if (m >= p.M) continue;
         float v[CW];
         if constexpr (GEGLU) {
+          if (lnf) {
 #pragma unroll
-          for (int e = 0; e < CW; ++e)
-            v[e] = (acc[i][e >> 2][e & 3] * p.alpha + hb[e]) * gelu_erf_f(acc[i][NI / 2 + (e >> 2)][e & 3] * p.alpha + hg[e]);
+            for (int e = 0; e < CW; ++e)
+              v[e] = (lrs[i] * (acc[i][e >> 2][e & 3] - lmu[i] * cs[e]) + hb[e]) *
+                     gelu_erf_f(lrs[i] * (acc[i][NI / 2 + (e >> 2)][e & 3] - lmu[i] * csg[e]) + hg[e]);
+          } else {
+#pragma unroll
+            for (int e = 0; e < CW; ++e)
+              v[e] = (acc[i][e >> 2][e & 3] * p.alpha + hb[e]) * gelu_erf_f(acc[i][NI / 2 + (e >> 2)][e & 3] * p.alpha + hg[e]);
+          }
         } else {
           const float bm = p.bias_mode == 2 ? p.bias[m] : 0.f;
+          if (lnf) {
 #pragma unroll
-          for (int e = 0; e < CW; ++e) v[e] = acc[i][e >> 2][e & 3] * p.alpha + hb[e] + bm;
+            for (int e = 0; e < CW; ++e) v[e] = lrs[i] * (acc[i][e >> 2][e & 3] - lmu[i] * cs[e]) + hb[e];
+          } else {
+#pragma unroll
+            for (int e = 0; e < CW; ++e) v[e] = acc[i][e >> 2][e & 3] * p.alpha + hb[e] + bm;
+          }
           if (p.rowadd) {
             const float* ra = p.rowadd + (long long)fast_udiv(m, HWo, inv_hwo) * p.rowadd_ld + no;
 #pragma unroll
@@ -114,6 +154,10 @@ AGD_DEV void igemm_epilogue(const IgemmP& p, f32x4 (&acc)[BM / WM / 16][BN / WN 
 #pragma unroll
           for (int e = 0; e < CW; ++e) v[e] = gelu_erf_f(v[e]);
         }
+        if (p.rowstat_out) {
+#pragma unroll
+          for (int e = 0; e < CW; ++e) { const float r = bf2f(f2bf(v[e])); rs[i] += r; rq[i] += r * r; }
+        }
         if (p.out_f32) {
           float* op = (float*)p.out + bz * p.sO + (long long)m * p.ldo + no;
 #pragma unroll
@@ -135,30 +179,77 @@ AGD_DEV void igemm_epilogue(const IgemmP& p, f32x4 (&acc)[BM / WM / 16][BN / WN 
           }
         }
       }
-      return;
-    }
-    // ragged / unaligned tiles (conv_out's 4 channels, N tails): element by element
+    } else {
+      // ragged / unaligned tiles (conv_out's 4 channels, N tails): element by element
+      float lmu[MI], lrs[MI];
+      if (p.ln_stats) {
 #pragma unroll
-    for (int i = 0; i < MI; ++i) {
-      const int m = mrow0 + i * 16;
-      if (m >= p.M) continue;
-      const int img = p.rowadd ? fast_udiv(m, HWo, inv_hwo) : 0;
-#pragma unroll
-      for (int e = 0; e < CW; ++e) {
-        const int n = no + e;
-        if (n >= Nout) continue;
-        float x;
-        if constexpr (GEGLU) {
-          x = (acc[i][e >> 2][e & 3] * p.alpha + p.bias[n]) * gelu_erf_f(acc[i][NI / 2 + (e >> 2)][e & 3] * p.alpha + p.bias[Nout + n]);
-        } else {
-          x = acc[i][e >> 2][e & 3] * p.alpha;
-          if (p.bias_mode == 1) x += p.bias[n]; else if (p.bias_mode == 2) x += p.bias[m];
-          if (p.rowadd) x += p.rowadd[(long long)img * p.rowadd_ld + n];
+        for (int i = 0; i < MI; ++i) {
+          const int m = mrow0 + i * 16;
+          float S = 0.f, Q = 0.f;
+          if (m < p.M) {
+            const float* sp = p.ln_stats + (long long)m * p.ln_slots * 2;
+            for (int k = 0; k < p.ln_slots; ++k) { S += sp[2 * k]; Q += sp[2 * k + 1]; }
+          }
+          const float mu = S * p.ln_invC;
+          float var = Q * p.ln_invC - mu * mu; var = var < 0.f ? 0.f : var;
+          lmu[i] = mu; lrs[i] = rsqrtf(var + p.ln_eps);
         }
-        if (p.residual) x += bf2f(p.residual[bz * p.sR + (long long)m * p.ldr + n]);
-        if (p.act == 1) x = silu_f(x); else if (p.act == 2) x = x / (1.0f + __expf(-1.702f * x)); else if (p.act == 3) x = gelu_erf_f(x);
-        if (p.out_f32) ((float*)p.out)[bz * p.sO + (long long)m * p.ldo + n] = x;
-        else ((bf16_t*)p.out)[bz * p.sO + (long long)m * p.ldo + n] = f2bf(x);
+      }
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        const int m = mrow0 + i * 16;
+        if (m >= p.M) continue;
+        const int img = p.rowadd ? fast_udiv(m, HWo, inv_hwo) : 0;
+#pragma unroll
+        for (int e = 0; e < CW; ++e) {
+          const int n = no + e;
+          if (n >= Nout) continue;
+          float x;
+          if constexpr (GEGLU) {
+            float xv = acc[i][e >> 2][e & 3] * p.alpha, xg = acc[i][NI / 2 + (e >> 2)][e & 3] * p.alpha;
+            if (p.ln_stats) { xv = lrs[i] * (xv - lmu[i] * p.ln_cs[n]); xg = lrs[i] * (xg - lmu[i] * p.ln_cs[Nout + n]); }
+            x = (xv + p.bias[n]) * gelu_erf_f(xg + p.bias[Nout + n]);
+          } else {
+            x = acc[i][e >> 2][e & 3] * p.alpha;
+            if (p.ln_stats) x = lrs[i] * (x - lmu[i] * p.ln_cs[n]);
+            if (p.bias_mode == 1) x += p.bias[n]; else if (p.bias_mode == 2) x += p.bias[m];
+            if (p.rowadd) x += p.rowadd[(long long)img * p.rowadd_ld + n];
+          }
+          if (p.residual) x += bf2f(p.residual[bz * p.sR + (long long)m * p.ldr + n]);
+          if (p.act == 1) x = silu_f(x); else if (p.act == 2) x = x / (1.0f + __expf(-1.702f * x)); else if (p.act == 3) x = gelu_erf_f(x);
+          if (p.rowstat_out) { const float r = bf2f(f2bf(x)); rs[i] += r; rq[i] += r * r; }
+          if (p.out_f32) ((float*)p.out)[bz * p.sO + (long long)m * p.ldo + n] = x;
+          else ((bf16_t*)p.out)[bz * p.sO + (long long)m * p.ldo + n] = f2bf(x);
+        }
+      }
+    }
+    if (p.rowstat_out) {          // wave-uniform (kernel argument)
+      constexpr int NT = WM * WN * 64;
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {                   // the 4 lanes (q) that share a pixel row
+        rs[i] += __shfl_xor(rs[i], 16); rs[i] += __shfl_xor(rs[i], 32);
+        rq[i] += __shfl_xor(rq[i], 16); rq[i] += __shfl_xor(rq[i], 32);
+      }
+      __syncthreads();                                 // every wave has left the K loop: the LDS ring is free
+      float* stg = (float*)smem;                       // [WN][BM][2]
+      if (q == 0) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+          const int row = wm * WTM + i * 16 + px;
+          stg[(wn * BM + row) * 2] = rs[i]; stg[(wn * BM + row) * 2 + 1] = rq[i];
+        }
+      }
+      __syncthreads();
+      for (int r = threadIdx.x; r < BM; r += NT) {     // fixed order over the waves of the tile: reproducible
+        const int m = m0 + r;
+        if (m < p.M) {
+          float S = 0.f, Q = 0.f;
+#pragma unroll
+          for (int w = 0; w < WN; ++w) { S += stg[(w * BM + r) * 2]; Q += stg[(w * BM + r) * 2 + 1]; }
+          float* op = p.rowstat_out + ((long long)m * p.rowstat_slots + tn) * 2;
+          op[0] = S; op[1] = Q;
+        }
       }
     }
   }

@@ -30,11 +30,19 @@ struct IgemmP {
   const bf16_t* zero_page;          // >= 256 B of zeros
   SplitKWs* ws;                     // caller's split-K workspace (grown on demand); NULL: a per-device default
   float* splitk_ws;                 // set by the launcher: fp32 partial slabs [S][M][N]
+  // LayerNorm folded into the GEMMs around it (model.hip transformer()):
+  //  producer side: rowstat_out [M][rowstat_slots] float2 = per-row (sum, sum of squares) of the bf16-rounded outputs of each N tile
+  //  consumer side: A rows are RAW (un-normalised), W = W.diag(gamma); out = rstd (acc - mean colsum[n]) + bias[n] with
+  //                 mean / rstd from ln_stats [M][ln_slots] float2, colsum = ln_cs [N] (GEGLU: values then gates, like bias)
+  float* rowstat_out; int rowstat_slots;
+  const float* ln_stats; int ln_slots; const float* ln_cs; float ln_invC, ln_eps;
+  int* cfg_out;                     // host pointer: igemm_query() -- report {BM, BN, splits} instead of launching
   int wmajor;                       // set by the launcher: 1 = consecutive tiles share the weight panel (W-major walk), else the A panel
   int stagger;                      // set by the launcher: start delay of the CU's second workgroup, x1024 cycles (speed only)
   int dbg;                          // timing experiments only (builds with -DAGD_EXPERIMENTS)
 };
 int launch_igemm(const IgemmP& p, hipStream_t st);
+int igemm_query(const IgemmP& p, int* cfg3);       // {BM, BN, K splits} launch_igemm would use; launches nothing
 
 // ---------------------------------------------------------------------------------------
 // Attention (flash, swapped-QK^T formulation).  Q [B][Nq][ldq] (+head*D), K/V [B][Nk][ldk].
@@ -84,6 +92,8 @@ int launch_cfg_ddim(const float* eps_nhwc, int ldc, float* lat_nchw, int B, int 
                     float a_t, float a_p, int vpred, hipStream_t st);
 int launch_cfg_plms(const float* eps_nhwc, int ldc, float* lat, const float* src, const float* h1, const float* h2, const float* h3,
                     float* store, int B, int C, int HW, float guidance, const float* w4, float a, float b, hipStream_t st);
+int launch_ln_fold_weight(const bf16_t* W, const float* gamma, const float* beta, const float* bias, int N, int K, int geglu_bn, bf16_t* Wf,
+                          float* colsum, float* bias_f, hipStream_t st);
 int launch_image_u8(const float* x_nhwc, int ldc, unsigned char* out, long long npix, int C, hipStream_t st);
 int launch_nchw_from_nhwc_f32(const float* x, int ldc, float* out, int B, int C, int HW, hipStream_t st);
 int launch_softmax_rows(const float* s, bf16_t* p, int rows, int cols, hipStream_t st);

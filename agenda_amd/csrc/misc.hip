@@ -406,3 +406,34 @@ int launch_embed_gather(const int* ids, const bf16_t* tok, const bf16_t* pos, bf
   hipLaunchKernelGGL(embed_gather_kernel, dim3(grid_for((long long)B * T * (H / 8))), dim3(256), 0, st, ids, tok, pos, out, B * T, T, H, vocab_cap);
   HIP_CHECK_RET(hipGetLastError()); return 0;
 }
+
+// ---------------------------------------------------------------------------------------
+// LayerNorm folded into the GEMM it feeds (model.hip transformer()): W'[n][k] = bf16(W[n][k] gamma[k]),
+// colsum[r] = sum_k W'[n][k], bias'[r] = bias[r] + sum_k beta[k] W[n][k]   (r = the row's ORIGINAL index: GEGLU
+// projections are stored in [8 values | 8 gates] row groups, the epilogue indexes bias / colsum in original order)
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ln_fold_weight_kernel(const bf16_t* __restrict__ W, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, const float* __restrict__ bias, int N, int K,
+                                                            int geglu_bn, bf16_t* __restrict__ Wf, float* __restrict__ cs, float* __restrict__ bf) {
+  const int lane = threadIdx.x & 63;
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= N) return;
+  float a = 0.f, b = 0.f;
+  for (int k = lane; k < K; k += 64) {
+    const float w = bf2f(W[(long long)n * K + k]);
+    const bf16_t wp = f2bf(w * gamma[k]);
+    Wf[(long long)n * K + k] = wp;
+    a += bf2f(wp); b += beta[k] * w;
+  }
+  for (int o = 32; o >= 1; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
+  if (lane == 0) {
+    int r = n;
+    if (geglu_bn > 0) { const int half = geglu_bn / 2, j = n / geglu_bn, wi = n % geglu_bn; r = (wi < half) ? j * half + wi : N / 2 + j * half + (wi - half); }
+    cs[r] = a; bf[r] = (bias ? bias[r] : 0.f) + b;
+  }
+}
+int launch_ln_fold_weight(const bf16_t* W, const float* gamma, const float* beta, const float* bias, int N, int K, int geglu_bn, bf16_t* Wf,
+                          float* cs, float* bf, hipStream_t st) {
+  hipLaunchKernelGGL(ln_fold_weight_kernel, dim3((N + 3) / 4), dim3(256), 0, st, W, gamma, beta, bias, N, K, geglu_bn, Wf, cs, bf);
+  HIP_CHECK_RET(hipGetLastError()); return 0;
+}

@@ -98,6 +98,7 @@ struct agd_ctx {
   bf16_t* lat_bf16 = nullptr; float* eps_nhwc = nullptr;
   SplitKWs splitk;                                    // split-K partial slabs of this ctx (stream-ordered reuse)
   int opt_cfg_share = 1;                              // agd_set_option("cfg_shared_prefix")
+  int opt_ln_fold = 1;                                // agd_set_option("ln_fold"): LayerNorm folded into the GEMMs around it
   // profiling
   bool prof_on = false; std::vector<ProfEv> prof; std::vector<hipEvent_t> ev_pool; size_t ev_used = 0;
   long long launches[AGD_N_CLASSES] = {0};
@@ -139,6 +140,9 @@ struct GemmOpt {
   const float* bias = nullptr; const float* rowadd = nullptr; int rowadd_ld = 0;
   const bf16_t* residual = nullptr; int ldr = 0; int geglu = 0; int act = 0; int out_f32 = 0; int ldo = 0;
   int stride = 1, up = 1; float alpha = 1.f;
+  int* query_cfg = nullptr;                                                              // igemm_query only: {BM, BN, splits}
+  float* rowstat_out = nullptr; int rowstat_slots = 0;                                   // producer side of the LayerNorm fold
+  const float* ln_stats = nullptr; int ln_slots = 0; const float* ln_cs = nullptr; float ln_invC = 0.f, ln_eps = 0.f;   // consumer side
   int pad = -1;                 // -1: 1 for 3x3, 0 for 1x1
   int hout = 0, wout = 0;       // >0: override (asymmetric (0,1,0,1) padding of the VAE encoder's stride-2 convs)
 };
@@ -156,6 +160,9 @@ static int run_conv(agd_ctx* c, hipStream_t st, const bf16_t* s0, int C0, const 
   const int nout = o.geglu ? w.N / 2 : w.N;
   p.ldr = o.ldr ? o.ldr : nout; p.out = out; p.out_f32 = o.out_f32; p.ldo = o.ldo ? o.ldo : nout;
   p.alpha = o.alpha; p.geglu = o.geglu; p.act = o.act; p.batch = 1; p.zero_page = zero_page; p.ws = c ? &c->splitk : nullptr;
+  p.rowstat_out = o.rowstat_out; p.rowstat_slots = o.rowstat_slots;
+  p.ln_stats = o.ln_stats; p.ln_slots = o.ln_slots; p.ln_cs = o.ln_cs; p.ln_invC = o.ln_invC; p.ln_eps = o.ln_eps;
+  if (o.query_cfg) return igemm_query(p, o.query_cfg);
   if (w.taps != ksize * ksize || w.Cpad != C0 + C1) FAIL("conv: weight [N=%d taps=%d Cpad=%d] does not match input C=%d+%d ksize=%d", w.N, w.taps, w.Cpad, C0, C1, ksize);
   // algorithmic HBM bytes: every input pixel / weight read once, the output written once (+ the residual read)
   const double in_b = 2.0 * B * Hin * Win * (double)(C0 + C1), w_b = 2.0 * p.N * (double)p.K;
@@ -319,26 +326,56 @@ static int transformer(agd_ctx* c, hipStream_t st, const std::string& pre, const
   GETV(gg, pre + "norm.weight"); GETV(gb, pre + "norm.bias");
   CK(run_gn(c, st, x.p, C, nullptr, 0, Bs, HW, gg, gb, groups, 1e-6f, 0, n.p));
   Act h = alloc_act(c, B, x.H, x.W, C); if (!h.p) return -1;
-  { GETW(w, pre + "proj_in.weight"); GETV(b, pre + "proj_in.bias"); GemmOpt o; o.bias = b;
-    CK(run_conv(c, st, n.p, C, nullptr, 0, 1, 1, M, *w, 1, h.p, o, c->zero_page)); }
-  Act ln = n;  // reuse
+  Act ln = n;  // reuse (only the unfolded path normalises into it)
   bf16_t* qkv = (bf16_t*)c->arena.alloc((size_t)B * HW * 3 * C * 2); if (!qkv) return -1;
   bf16_t* att = (bf16_t*)c->arena.alloc((size_t)B * HW * C * 2); if (!att) return -1;
   const bf16_t* xres = x.p;                            // residual of proj_out
+  // LayerNorm folded into the GEMMs around it (opt "ln_fold"): the GEMM that writes h also emits per-row (sum, sum of
+  // squares) of its bf16 outputs per N tile; the GEMM that would read LayerNorm(h) reads h itself with W diag(gamma) and
+  // finishes  rstd (acc - mean colsum) + (bias + W beta)  in its epilogue.  The three LayerNorm launches (and their
+  // read + write of the activation) per block disappear; h is still rounded to bf16 exactly once.
+  const bool fold = c->opt_ln_fold != 0;
+  const float lneps = 1e-5f;
+  float* stats = nullptr; int slots = 0;               // row statistics of the current h
+  // h_out = A . W^T (+ bias, + residual): writes h and, when folding, its row statistics
+  auto produce = [&](const bf16_t* A, int K, const WMat& w, GemmOpt o, bf16_t* hout) -> int {
+    if (fold) {
+      int cfg[3] = {0, 0, 0}; GemmOpt qo = o; qo.query_cfg = cfg;
+      CK(run_conv(c, st, A, K, nullptr, 0, 1, 1, M, w, 1, hout, qo, c->zero_page));
+      slots = (w.N + cfg[1] - 1) / cfg[1];
+      stats = (float*)c->arena.alloc((size_t)B * HW * slots * 2 * sizeof(float)); if (!stats) return -1;   // B*HW rows: room for the CFG duplicate
+      o.rowstat_out = stats; o.rowstat_slots = slots;
+    }
+    return run_conv(c, st, A, K, nullptr, 0, 1, 1, M, w, 1, hout, o, c->zero_page);
+  };
+  // out = LayerNorm(h) . W^T (+ bias) [GEGLU]: folded, or the LayerNorm kernel followed by the plain GEMM
+  auto consume = [&](const std::string& lnkey, const std::string& wkey, const float* bias, int geglu, bf16_t* outp) -> int {
+    if (fold) {
+      const std::string k = wkey + ".lnfold";
+      GETW(wf, k); GETV(cs, k + ".cs"); GETV(bf, k + ".bias");
+      GemmOpt o; o.bias = bf; o.geglu = geglu; o.ln_stats = stats; o.ln_slots = slots; o.ln_cs = cs; o.ln_invC = 1.0f / (float)C; o.ln_eps = lneps;
+      return run_conv(c, st, h.p, C, nullptr, 0, 1, 1, M, *wf, 1, outp, o, c->zero_page);
+    }
+    GETV(g, lnkey + ".weight"); GETV(b, lnkey + ".bias");
+    { ProfScope ps(c, st, PC_LN, 0, 4.0 * M * (double)C); CK(launch_layernorm(h.p, ln.p, g, b, M, C, lneps, st)); }
+    GETW(w, wkey); GemmOpt o; o.bias = bias; o.geglu = geglu;
+    return run_conv(c, st, ln.p, C, nullptr, 0, 1, 1, M, *w, 1, outp, o, c->zero_page);
+  };
+  { GETW(w, pre + "proj_in.weight"); GETV(b, pre + "proj_in.bias"); GemmOpt o; o.bias = b;
+    CK(produce(n.p, C, *w, o, h.p)); }
   // --- self attention ---
-  { GETV(g, t + "norm1.weight"); GETV(b, t + "norm1.bias");
-    { ProfScope ps(c, st, PC_LN, 0, 4.0 * M * (double)C); CK(launch_layernorm(h.p, ln.p, g, b, M, C, 1e-5f, st)); }
-    GETW(w, t + "attn1.qkv"); GemmOpt o;
-    CK(run_conv(c, st, ln.p, C, nullptr, 0, 1, 1, M, *w, 1, qkv, o, c->zero_page));
+  { CK(consume(t + "norm1", t + "attn1.qkv", nullptr, 0, qkv));
     AttnP a{}; a.q = qkv; a.k = qkv + C; a.v = qkv + 2 * C; a.o = att;
     a.ldq = a.ldk = a.ldv = 3 * C; a.ldo = C; a.sq = a.sk = a.sv = (long long)HW * 3 * C; a.so = (long long)HW * C;
     a.B = Bs; a.H = heads; a.D = C / heads; a.Nq = HW; a.Nk = HW; a.scale = 1.0f / sqrtf((float)(C / heads));
     CK(run_attention(c, st, PC_ATTN_SELF, a));
     GETW(wo, t + "attn1.to_out.0.weight"); GETV(bo, t + "attn1.to_out.0.bias");
     GemmOpt oo; oo.bias = bo; oo.residual = h.p;
-    CK(run_conv(c, st, att, C, nullptr, 0, 1, 1, M, *wo, 1, h.p, oo, c->zero_page)); }
+    CK(produce(att, C, *wo, oo, h.p)); }
   if (dup) {                                           // the halves diverge from here on (text context)
     CK(dup_half(c, st, h.p, (long long)M * C));
+    if (fold) { ProfScope ps(c, st, PC_ELEM, 0);
+      if (hipMemcpyAsync(stats + (size_t)M * slots * 2, stats, (size_t)M * slots * 2 * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) FAIL("dup stats copy failed"); }
     Act x2 = alloc_act(c, B, x.H, x.W, C); if (!x2.p) return -1;
     { ProfScope ps(c, st, PC_ELEM, 0);
       if (hipMemcpyAsync(x2.p, x.p, (size_t)M * C * 2, hipMemcpyDeviceToDevice, st) != hipSuccess) FAIL("dup copy failed"); }
@@ -347,25 +384,19 @@ static int transformer(agd_ctx* c, hipStream_t st, const std::string& pre, const
     M = B * HW;
   }
   // --- cross attention (the processor seam) ---
-  { GETV(g, t + "norm2.weight"); GETV(b, t + "norm2.bias");
-    { ProfScope ps(c, st, PC_LN, 0, 4.0 * M * (double)C); CK(launch_layernorm(h.p, ln.p, g, b, M, C, 1e-5f, st)); }
-    GETW(wq, t + "attn2.to_q.weight"); GemmOpt o;
-    bf16_t* q = qkv;
-    CK(run_conv(c, st, ln.p, C, nullptr, 0, 1, 1, M, *wq, 1, q, o, c->zero_page));
+  { bf16_t* q = qkv;
+    CK(consume(t + "norm2", t + "attn2.to_q.weight", nullptr, 0, q));
     auto it = c->xl_idx.find(t + "attn2");
     if (it == c->xl_idx.end()) FAIL("cross-attn layer %s not registered", (t + "attn2").c_str());
     if (c->ctx_B2 != B) FAIL("context batch %d != unet batch %d (call agd_set_context)", c->ctx_B2, B);
     CK(cross_attention(c, st, c->xl[it->second], q, B, HW, att, true));
     GETW(wo, t + "attn2.to_out.0.weight"); GETV(bo, t + "attn2.to_out.0.bias");
     GemmOpt oo; oo.bias = bo; oo.residual = h.p;
-    CK(run_conv(c, st, att, C, nullptr, 0, 1, 1, M, *wo, 1, h.p, oo, c->zero_page)); }
+    CK(produce(att, C, *wo, oo, h.p)); }
   // --- GEGLU feed-forward ---
-  { GETV(g, t + "norm3.weight"); GETV(b, t + "norm3.bias");
-    { ProfScope ps(c, st, PC_LN, 0, 4.0 * M * (double)C); CK(launch_layernorm(h.p, ln.p, g, b, M, C, 1e-5f, st)); }
-    bf16_t* ff = (bf16_t*)c->arena.alloc((size_t)M * 4 * C * 2); if (!ff) return -1;
-    GETW(w1, t + "ff.net.0.proj.weight"); GETV(b1, t + "ff.net.0.proj.bias");
-    GemmOpt o1; o1.bias = b1; o1.geglu = 1;
-    CK(run_conv(c, st, ln.p, C, nullptr, 0, 1, 1, M, *w1, 1, ff, o1, c->zero_page));
+  { bf16_t* ff = (bf16_t*)c->arena.alloc((size_t)M * 4 * C * 2); if (!ff) return -1;
+    GETV(b1, t + "ff.net.0.proj.bias");
+    CK(consume(t + "norm3", t + "ff.net.0.proj.weight", b1, 1, ff));
     GETW(w2, t + "ff.net.2.weight"); GETV(b2, t + "ff.net.2.bias");
     GemmOpt o2; o2.bias = b2; o2.residual = h.p;
     CK(run_conv(c, st, ff, 4 * C, nullptr, 0, 1, 1, M, *w2, 1, h.p, o2, c->zero_page)); }
@@ -697,6 +728,22 @@ AGD_API int agd_finalize(agd_ctx* c) {
     API_CK(c, concat_rows(c, {ck, cv}, xl.wkv));
     if (xl.C % xl.heads) { agd_set_error("%s: C %d not divisible by heads %d", xl.name.c_str(), xl.C, xl.heads); return fail_ctx(c); }
     c->xl_idx[xl.name] = (int)c->xl.size(); c->xl.push_back(xl);
+    // LayerNorm folded into the three GEMMs it feeds: W' = W diag(gamma), colsum(W'), bias' = bias + W beta
+    struct Fold { const char* w; const char* bias; const char* ln; int geglu; };
+    const Fold folds[3] = {{"attn1.qkv", nullptr, "norm1", 0}, {"attn2.to_q.weight", nullptr, "norm2", 0}, {"ff.net.0.proj.weight", "ff.net.0.proj.bias", "norm3", 16}};
+    for (const Fold& f : folds) {
+      const WMat* w = getW(c, t + f.w); const float* ga = getV(c, t + f.ln + ".weight"); const float* be = getV(c, t + f.ln + ".bias");
+      if (!w || !ga || !be) return fail_ctx(c);
+      const float* b0 = f.bias ? getV(c, t + f.bias) : nullptr;
+      if (f.bias && !b0) return fail_ctx(c);
+      if (w->taps != 1 || w->Cpad != w->Cin) { agd_set_error("%s: cannot fold LayerNorm (padded K)", (t + f.w).c_str()); return fail_ctx(c); }
+      WMat wf = *w; wf.w = dmalloc<bf16_t>(c, (size_t)w->N * w->Cpad);
+      float* cs = dmalloc<float>(c, w->N); float* bf = dmalloc<float>(c, w->N);
+      if (!wf.w || !cs || !bf) return fail_ctx(c);
+      API_CK(c, launch_ln_fold_weight(w->w, ga, be, b0, w->N, w->Cpad, f.geglu, wf.w, cs, bf, 0));
+      const std::string k = t + f.w + ".lnfold";
+      c->W[k] = wf; c->V[k + ".cs"] = cs; c->V[k + ".bias"] = bf; c->Vn[k + ".cs"] = w->N; c->Vn[k + ".bias"] = w->N;
+    }
   }
   // ---- all time_emb_proj stacked into one [sum Cout][4*dim] matrix
   { std::vector<const WMat*> parts; std::vector<std::string> pres; int total = 0;
@@ -896,6 +943,7 @@ AGD_API int agd_vae_decode(agd_ctx* c, const float* latents, int batch, int L, u
 AGD_API int agd_set_option(agd_ctx* c, const char* name, int value) {
   if (!c || !name) { agd_set_error("set_option: null argument"); return fail_ctx(c); }
   if (!strcmp(name, "cfg_shared_prefix")) { c->opt_cfg_share = value != 0; return 0; }
+  if (!strcmp(name, "ln_fold")) { c->opt_ln_fold = value != 0; return 0; }
   agd_set_error("set_option: unknown option '%s'", name);
   return fail_ctx(c);
 }
@@ -1290,7 +1338,7 @@ AGD_API int agd_bench_conv(int B, int H, int W, int C0, int C1, int Cout, int ks
   const int Ctot = C0 + C1, taps = ksize * ksize, pad = ksize == 3 ? 1 : 0;
   const int Ho = (H * up + 2 * pad - ksize) / stride + 1, Wo = (W * up + 2 * pad - ksize) / stride + 1;
   const long long M = (long long)B * Ho * Wo;
-  const int Nout = geglu ? Cout / 2 : Cout;
+  const int Nout = (geglu & 1) ? Cout / 2 : Cout;
   bf16_t* x0 = tmp.get<bf16_t>((size_t)B * H * W * C0); bf16_t* x1 = C1 ? tmp.get<bf16_t>((size_t)B * H * W * C1) : nullptr;
   bf16_t* w = tmp.get<bf16_t>((size_t)Cout * taps * Ctot); bf16_t* y = tmp.get<bf16_t>((size_t)M * Nout);
   bf16_t* r = with_residual ? tmp.get<bf16_t>((size_t)M * Nout) : nullptr;
@@ -1300,7 +1348,20 @@ AGD_API int agd_bench_conv(int B, int H, int W, int C0, int C1, int Cout, int ks
   fill_rand(w, (long long)Cout * taps * Ctot, 3, 0.05f); if (r) fill_rand(r, M * Nout, 4, 1.0f);
   hipMemset(bias, 0, Cout * 4);
   WMat wm; wm.w = w; wm.N = Cout; wm.Cin = Ctot; wm.Cpad = Ctot; wm.taps = taps;
+  // geglu bit 1 = GEGLU; bit 2 = also emit LayerNorm row statistics (producer); bit 4 = LayerNorm-folded consumer epilogue
+  const int mode = geglu; geglu &= 1;
   GemmOpt o; o.bias = bias; o.stride = stride; o.up = up; o.geglu = geglu; o.residual = r;
+  float* stats = nullptr; float* cs = nullptr;
+  if (mode & 6) {
+    int cfg[3] = {0, 0, 0}; GemmOpt qo = o; qo.query_cfg = cfg;
+    CK(run_conv(nullptr, 0, x0, C0, x1, C1, B, H, W, wm, ksize, y, qo, op_zero_page()));
+    const int slots = (mode & 2) ? (Cout + cfg[1] - 1) / cfg[1] : 2;
+    stats = tmp.get<float>((size_t)M * slots * 2); cs = tmp.get<float>(Cout);
+    if (!stats || !cs) return -1;
+    hipMemset(stats, 0, (size_t)M * slots * 2 * 4); hipMemset(cs, 0, Cout * 4);
+    if (mode & 2) { o.rowstat_out = stats; o.rowstat_slots = slots; }
+    if (mode & 4) { o.ln_stats = stats; o.ln_slots = slots; o.ln_cs = cs; o.ln_invC = 1.0f / Ctot; o.ln_eps = 1e-5f; }
+  }
   hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
   for (int i = 0; i < 2; ++i) CK(run_conv(nullptr, 0, x0, C0, x1, C1, B, H, W, wm, ksize, y, o, op_zero_page()));
   hipEventRecord(a, 0);

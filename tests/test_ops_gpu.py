@@ -63,6 +63,12 @@ def test_conv2d(ops, B, Cin, H, Cout, k, stride, up):
     (8192, 320, 320, False, True),       # BN=160 tile path
     (8192, 320, 960, False, False),      # BN=160, fused qkv width
     (512, 5120, 1280, False, True),      # split-K linear
+    (2048, 1280, 1280, False, True),     # 160 tiles of 128x128 on the deep ring (one workgroup per CU)
+    (2048, 1280, 3840, False, False),    # weights outweigh activations: W-major tile walk
+    (2048, 1280, 10240, True, False),    # W-major + GEGLU ([8 values | 8 gates] row groups)
+    (8192, 2560, 640, False, True),      # long-K 1x1 -> 256 tiles of 128x160
+    (300, 128, 200, False, True),        # ragged M and N tail (N % 16 != 0: element-wise epilogue on the last lanes)
+    (130, 64, 72, False, False),         # N < one tile, 8-column remainder
 ])
 def test_linear(ops, M, K, N, geglu, res):
     g = torch.Generator().manual_seed(M + K + N)

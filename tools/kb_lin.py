@@ -33,6 +33,9 @@ shapes = [("L0 C->C   M32768 K320  N320 ", (8, 64, 320, 320, 1, 0, 1)),
           ("conv3 L0  M32768 K2880 N320 ", (8, 64, 320, 320, 3, 0, 1)),
           ("conv3 L1  M8192  K5760 N640 ", (8, 32, 640, 640, 3, 0, 1)),
           ("conv3 L2  M2048  K11520 N1280", (8, 16, 1280, 1280, 3, 0, 1))]
+if os.environ.get("KB_LN"):      # LayerNorm-fold overheads: producers (C->C with residual) +2, consumers (qkv / geglu) +4
+    shapes = [(n + " plain", a) for n, a in shapes[:11]] + [(n + " +stat", a[:5] + (a[5] | 2,) + a[6:]) for n, a in shapes[:11] if "C->C" in n] + \
+             [(n + " +lnf ", a[:5] + (a[5] | 4,) + a[6:]) for n, a in shapes[:11] if "qkv" in n or "geglu" in n]
 cfgs = [int(x) for x in os.environ.get("KB_CFGS", "0,16,32,48,64,512,1024").split(",")] if has_cfg else [0]
 print(f"{'shape':34s}" + "".join(f"{('cfg' + str(c)):>9s}" for c in cfgs) + "   TF/s(cfg0)")
 for name, a in shapes:
