@@ -332,6 +332,7 @@ template <int BM, int BN, int WM, int WN, int STAGES = 2>
 static int launch_cfg(const IgemmP& p, int splits, hipStream_t st) {
   if (p.cfg_out) { p.cfg_out[0] = BM; p.cfg_out[1] = BN; p.cfg_out[2] = splits; return 0; }   // igemm_query: report the dispatch decision only
   if ((p.rowstat_out || p.ln_stats) && splits > 1) { agd_set_error("igemm: LayerNorm fold on a split-K launch"); return -1; }
+  if (p.colstat_out && (splits > 1 || p.colstat_rows < 1 || p.colstat_rows % BM)) { agd_set_error("igemm: column statistics need an unsplit launch whose M tiles stay inside one image"); return -1; }
   if (p.rowstat_out && p.rowstat_slots != (p.N + BN - 1) / BN) { agd_set_error("igemm: rowstat_slots %d != N tiles %d", p.rowstat_slots, (p.N + BN - 1) / BN); return -1; }
   static const bool logit = getenv("AGD_IGEMM_LOG") != nullptr;      // tools/layer_report.py joins this with a kernel trace
   if (logit) fprintf(stderr, "IGEMM M=%d N=%d K=%d ks=%d stride=%d up=%d geglu=%d res=%d tile=%dx%d splits=%d batch=%d\n", p.M, p.N, p.K, p.ksize,
@@ -397,7 +398,7 @@ int launch_igemm(const IgemmP& p_in, hipStream_t st) {
   if (p.M < 1 || p.N < 1) { agd_set_error("igemm: empty problem M=%d N=%d", p.M, p.N); return -1; }
   if (p.rowadd && p.M >= (1 << 24)) { agd_set_error("igemm: rowadd needs M < 2^24"); return -1; }
   if (p.geglu && (p.N % 128)) { agd_set_error("igemm: geglu needs N %% 128 == 0"); return -1; }
-  if (p.rowstat_out && (p.geglu || p.out_f32 || p.batch > 1)) { agd_set_error("igemm: row statistics only for plain bf16 launches"); return -1; }
+  if ((p.rowstat_out || p.colstat_out) && (p.geglu || p.out_f32 || p.batch > 1)) { agd_set_error("igemm: row / column statistics only for plain bf16 launches"); return -1; }
   if (p.ln_stats && (!p.ln_cs || p.ln_slots < 1 || p.batch > 1)) { agd_set_error("igemm: LayerNorm fold needs colsum + slots"); return -1; }
   const int batch = p.batch > 0 ? p.batch : 1;
   {  // tile walk order: W-major when the weight matrix is the larger operand (bytes fetched once per XCD either way)

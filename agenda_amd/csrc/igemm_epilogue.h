@@ -45,6 +45,13 @@ AGD_DEV void igemm_epilogue(const IgemmP& p, f32x4 (&acc)[BM / WM / 16][BN / WN 
     }
     return;
   } else {
+    // producer side of the GroupNorm statistics (p.colstat_out): the wave's bf16-rounded output tile goes to LDS as well, then
+    // lane = column sums the rows -- costs registers for nothing else; the ring is free once every wave has left the K loop
+    bf16_t* ctile = nullptr;
+    if (p.colstat_out) {
+      __syncthreads();
+      ctile = (bf16_t*)smem + (wm * WN + wn) * (WTM * WTN);
+    }
     // producer side of the LayerNorm fold: per-row (sum, sum of squares) of the bf16-rounded outputs, this lane's share
     float rs[MI], rq[MI];
 #pragma unroll
@@ -106,7 +113,10 @@ AGD_DEV void igemm_epilogue(const IgemmP& p, f32x4 (&acc)[BM / WM / 16][BN / WN 
 #pragma unroll
       for (int i = 0; i < MI; ++i) {
         const int m = mrow0 + i * 16;
-        if (m >= p.M) continue;
+        if (m >= p.M) {
+          if (ctile) { for (int e = 0; e < CA; ++e) ctile[(i * 16 + px) * WTN + q * CA + e] = 0; }
+          continue;
+        }
         float v[CW];
         if constexpr (GEGLU) {
           if (lnf) {
@@ -164,6 +174,7 @@ AGD_DEV void igemm_epilogue(const IgemmP& p, f32x4 (&acc)[BM / WM / 16][BN / WN 
           for (int c = 0; c < CW / 4; ++c) *(f32x4*)(op + 4 * c) = f32x4{v[4 * c], v[4 * c + 1], v[4 * c + 2], v[4 * c + 3]};
         } else {
           bf16_t* op = (bf16_t*)p.out + bz * p.sO + (long long)m * p.ldo + no;
+          bf16_t* lp = ctile ? ctile + (i * 16 + px) * WTN + q * CA : nullptr;
 #pragma unroll
           for (int c = 0; c < CW / SV; ++c) {
             if constexpr (SV == 8) {
@@ -171,10 +182,12 @@ AGD_DEV void igemm_epilogue(const IgemmP& p, f32x4 (&acc)[BM / WM / 16][BN / WN 
               pk[0] = pack_bf2(v[8 * c], v[8 * c + 1]); pk[1] = pack_bf2(v[8 * c + 2], v[8 * c + 3]);
               pk[2] = pack_bf2(v[8 * c + 4], v[8 * c + 5]); pk[3] = pack_bf2(v[8 * c + 6], v[8 * c + 7]);
               *(u32x4*)(op + 8 * c) = pk;
+              if (lp) *(u32x4*)(lp + 8 * c) = pk;
             } else {
               u32x2 pk;
               pk[0] = pack_bf2(v[4 * c], v[4 * c + 1]); pk[1] = pack_bf2(v[4 * c + 2], v[4 * c + 3]);
               *(u32x2*)(op + 4 * c) = pk;
+              if (lp) *(u32x2*)(lp + 4 * c) = pk;
             }
           }
         }
@@ -199,6 +212,7 @@ AGD_DEV void igemm_epilogue(const IgemmP& p, f32x4 (&acc)[BM / WM / 16][BN / WN 
 #pragma unroll
       for (int i = 0; i < MI; ++i) {
         const int m = mrow0 + i * 16;
+        if (ctile) { for (int e = 0; e < CA; ++e) ctile[(i * 16 + px) * WTN + q * CA + e] = 0; }
         if (m >= p.M) continue;
         const int img = p.rowadd ? fast_udiv(m, HWo, inv_hwo) : 0;
 #pragma unroll
@@ -219,8 +233,31 @@ AGD_DEV void igemm_epilogue(const IgemmP& p, f32x4 (&acc)[BM / WM / 16][BN / WN 
           if (p.residual) x += bf2f(p.residual[bz * p.sR + (long long)m * p.ldr + n]);
           if (p.act == 1) x = silu_f(x); else if (p.act == 2) x = x / (1.0f + __expf(-1.702f * x)); else if (p.act == 3) x = gelu_erf_f(x);
           if (p.rowstat_out) { const float r = bf2f(f2bf(x)); rs[i] += r; rq[i] += r * r; }
+          if (ctile) ctile[(i * 16 + px) * WTN + q * CA + e] = f2bf(x);
           if (p.out_f32) ((float*)p.out)[bz * p.sO + (long long)m * p.ldo + n] = x;
           else ((bf16_t*)p.out)[bz * p.sO + (long long)m * p.ldo + n] = f2bf(x);
+        }
+      }
+    }
+    if (p.colstat_out) {          // wave-uniform (kernel argument): per-(tile, channel) sum and sum of squares over the tile's rows
+      constexpr int NT = WM * WN * 64;
+      __syncthreads();                                 // tiles written
+      float* cst = (float*)((bf16_t*)smem + WM * WN * WTM * WTN);   // [WM][BN][2]
+      for (int col = lane; col < WTN; col += 64) {
+        float S = 0.f, Q = 0.f;
+        for (int r = 0; r < WTM; ++r) { const float x = bf2f(ctile[r * WTN + col]); S += x; Q += x * x; }
+        cst[(wm * BN + wn * WTN + col) * 2] = S; cst[(wm * BN + wn * WTN + col) * 2 + 1] = Q;
+      }
+      __syncthreads();
+      const int tm_ = m0 / BM;
+      for (int t = threadIdx.x; t < BN; t += NT) {     // fixed order over the tile's row waves: reproducible
+        const int n = n0 + t;
+        if (n < p.N) {
+          float S = 0.f, Q = 0.f;
+#pragma unroll
+          for (int w = 0; w < WM; ++w) { S += cst[(w * BN + t) * 2]; Q += cst[(w * BN + t) * 2 + 1]; }
+          float* op = p.colstat_out + ((long long)tm_ * p.N + n) * 2;
+          op[0] = S; op[1] = Q;
         }
       }
     }

@@ -34,6 +34,8 @@ struct IgemmP {
   //  producer side: rowstat_out [M][rowstat_slots] float2 = per-row (sum, sum of squares) of the bf16-rounded outputs of each N tile
   //  consumer side: A rows are RAW (un-normalised), W = W.diag(gamma); out = rstd (acc - mean colsum[n]) + bias[n] with
   //                 mean / rstd from ln_stats [M][ln_slots] float2, colsum = ln_cs [N] (GEGLU: values then gates, like bias)
+  int colstat_rows;                 // rows of one image (M tiles must not straddle images)
+  float* colstat_out;               // GroupNorm statistics from the producer: [M tiles][N] float2 = per-channel (sum, sum of squares) of each M tile's bf16 outputs
   float* rowstat_out; int rowstat_slots;
   const float* ln_stats; int ln_slots; const float* ln_cs; float ln_invC, ln_eps;
   int* cfg_out;                     // host pointer: igemm_query() -- report {BM, BN, splits} instead of launching
@@ -73,6 +75,9 @@ struct GroupNormP {
   const float* gamma; const float* beta;
   int B, HW, groups; float eps; int silu;
   float* ws;                                         // workspace: B*C*2 (sums) + B*C*2 (scale/shift)
+  // per-channel partial sums emitted by the igemm launches that produced x0 / x1 ([HW*B / bm tiles][Cs] float2, bm rows per
+  // tile): when given for every source, the statistics pass over the activation is skipped (one kernel instead of two)
+  const float* part0; const float* part1; int bm0, bm1;
 };
 int launch_groupnorm(const GroupNormP& p, hipStream_t st);
 long long groupnorm_ws_floats(int B, int C, int HW, int groups);   // workspace floats a launch_groupnorm call needs

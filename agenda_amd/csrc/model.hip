@@ -26,7 +26,10 @@ extern "C" void agd_set_error(const char* fmt, ...) {
 #define FAIL(...) do { agd_set_error(__VA_ARGS__); return -1; } while (0)
 
 struct WMat { bf16_t* w = nullptr; int N = 0, Cin = 0, Cpad = 0, taps = 0; };
-struct Act { bf16_t* p = nullptr; int B = 0, H = 0, W = 0, C = 0; long long n() const { return (long long)B * H * W * C; } };
+// cpart: per-(M tile, channel) partial sums the producing igemm launch leaves for a following GroupNorm
+// ([B*H*W / cpart_bm][C] float2; cpart_bm = 0: none were produced -> the GroupNorm runs its own statistics pass)
+struct Act { bf16_t* p = nullptr; int B = 0, H = 0, W = 0, C = 0; float* cpart = nullptr; int cpart_bm = 0;
+             long long n() const { return (long long)B * H * W * C; } };
 
 struct Arena {
   char* base = nullptr; size_t cap = 0, off = 0, peak = 0;
@@ -99,6 +102,7 @@ struct agd_ctx {
   SplitKWs splitk;                                    // split-K partial slabs of this ctx (stream-ordered reuse)
   int opt_cfg_share = 1;                              // agd_set_option("cfg_shared_prefix")
   int opt_ln_fold = 1;                                // agd_set_option("ln_fold"): LayerNorm folded into the GEMMs around it
+  int opt_gn_fused = 1;                               // agd_set_option("gn_fused_stats"): GroupNorm statistics from the producing igemm's epilogue
   // profiling
   bool prof_on = false; std::vector<ProfEv> prof; std::vector<hipEvent_t> ev_pool; size_t ev_used = 0;
   long long launches[AGD_N_CLASSES] = {0};
@@ -127,9 +131,14 @@ template <typename T> static T* dmalloc(agd_ctx* c, size_t n) {
   return (T*)p;
 }
 
-static Act alloc_act(agd_ctx* c, int B, int H, int W, int C) {
+// stats: the activation will be written by an igemm launch and read by a GroupNorm -> room for the producer's partial sums
+static Act alloc_act(agd_ctx* c, int B, int H, int W, int C, bool stats = false) {
   Act a; a.B = B; a.H = H; a.W = W; a.C = C;
   a.p = (bf16_t*)c->arena.alloc((size_t)a.n() * 2);
+  if (a.p && stats && c->opt_gn_fused && ((long long)H * W) % 64 == 0) {
+    a.cpart = (float*)c->arena.alloc((size_t)((long long)B * H * W / 64) * C * 2 * sizeof(float));     // worst case: 64-row tiles
+    if (!a.cpart) a.p = nullptr;
+  }
   return a;
 }
 
@@ -141,6 +150,8 @@ struct GemmOpt {
   const bf16_t* residual = nullptr; int ldr = 0; int geglu = 0; int act = 0; int out_f32 = 0; int ldo = 0;
   int stride = 1, up = 1; float alpha = 1.f;
   int* query_cfg = nullptr;                                                              // igemm_query only: {BM, BN, splits}
+  Act* out_act = nullptr;                                                                // output feeds a GroupNorm: leave per-channel partial sums in it
+  int rows_per_image = 0;                                                                // for out_act on linear-shaped launches (B=1, W=M): rows of one image
   float* rowstat_out = nullptr; int rowstat_slots = 0;                                   // producer side of the LayerNorm fold
   const float* ln_stats = nullptr; int ln_slots = 0; const float* ln_cs = nullptr; float ln_invC = 0.f, ln_eps = 0.f;   // consumer side
   int pad = -1;                 // -1: 1 for 3x3, 0 for 1x1
@@ -163,6 +174,15 @@ static int run_conv(agd_ctx* c, hipStream_t st, const bf16_t* s0, int C0, const 
   p.rowstat_out = o.rowstat_out; p.rowstat_slots = o.rowstat_slots;
   p.ln_stats = o.ln_stats; p.ln_slots = o.ln_slots; p.ln_cs = o.ln_cs; p.ln_invC = o.ln_invC; p.ln_eps = o.ln_eps;
   if (o.query_cfg) return igemm_query(p, o.query_cfg);
+  if (o.out_act) {
+    o.out_act->cpart_bm = 0;
+    if (o.out_act->cpart && !o.out_f32 && !o.geglu) {
+      int cfg[3] = {0, 0, 0};
+      CK(igemm_query(p, cfg));
+      const int rpi = o.rows_per_image > 0 ? o.rows_per_image : p.Hout * p.Wout;
+      if (cfg[2] == 1 && cfg[0] > 0 && rpi % cfg[0] == 0) { p.colstat_out = o.out_act->cpart; p.colstat_rows = rpi; o.out_act->cpart_bm = cfg[0]; }
+    }
+  }
   if (w.taps != ksize * ksize || w.Cpad != C0 + C1) FAIL("conv: weight [N=%d taps=%d Cpad=%d] does not match input C=%d+%d ksize=%d", w.N, w.taps, w.Cpad, C0, C1, ksize);
   // algorithmic HBM bytes: every input pixel / weight read once, the output written once (+ the residual read)
   const double in_b = 2.0 * B * Hin * Win * (double)(C0 + C1), w_b = 2.0 * p.N * (double)p.K;
@@ -172,9 +192,14 @@ static int run_conv(agd_ctx* c, hipStream_t st, const bf16_t* s0, int C0, const 
 }
 
 static int run_gn(agd_ctx* c, hipStream_t st, const bf16_t* x0, int C0, const bf16_t* x1, int C1, int B, int HW,
-                  const float* gamma, const float* beta, int groups, float eps, int silu, bf16_t* y) {
+                  const float* gamma, const float* beta, int groups, float eps, int silu, bf16_t* y,
+                  const Act* a0 = nullptr, const Act* a1 = nullptr) {
   GroupNormP g{}; g.x0 = x0; g.x1 = x1; g.C0 = C0; g.C1 = C1; g.y = y; g.gamma = gamma; g.beta = beta;
   g.B = B; g.HW = HW; g.groups = groups; g.eps = eps; g.silu = silu;
+  if (c->opt_gn_fused && a0 && a0->cpart_bm > 0 && (!x1 || (a1 && a1->cpart_bm > 0))) {      // every source brought its partial sums
+    g.part0 = a0->cpart; g.bm0 = a0->cpart_bm;
+    if (x1) { g.part1 = a1->cpart; g.bm1 = a1->cpart_bm; }
+  }
   const long long wsf = groupnorm_ws_floats(B, C0 + C1, HW, groups);
   const size_t mk = c->arena.mark();
   g.ws = (float*)c->arena.alloc((size_t)wsf * 4);
@@ -203,14 +228,14 @@ static int resnet(agd_ctx* c, hipStream_t st, const std::string& pre, const Act&
                   bool has_temb, int groups, Act& out) {
   const int B = x0.B, H = x0.H, Wd = x0.W, HW = H * Wd;
   const int C1 = x1 ? x1->C : 0, Cin = x0.C + C1;
-  out = alloc_act(c, B, H, Wd, Cout); if (!out.p) return -1;
+  out = alloc_act(c, B, H, Wd, Cout, true); if (!out.p) return -1;
   const size_t mk = c->arena.mark();
   Act n1 = alloc_act(c, B, H, Wd, Cin); if (!n1.p) return -1;
   GETV(g1, pre + "norm1.weight"); GETV(b1, pre + "norm1.bias");
-  CK(run_gn(c, st, x0.p, x0.C, x1 ? x1->p : nullptr, C1, B, HW, g1, b1, groups, eps, 1, n1.p));
-  Act h = alloc_act(c, B, H, Wd, Cout); if (!h.p) return -1;
+  CK(run_gn(c, st, x0.p, x0.C, x1 ? x1->p : nullptr, C1, B, HW, g1, b1, groups, eps, 1, n1.p, &x0, x1));
+  Act h = alloc_act(c, B, H, Wd, Cout, true); if (!h.p) return -1;
   GETW(w1, pre + "conv1.weight"); GETV(cb1, pre + "conv1.bias");
-  GemmOpt o1; o1.bias = cb1;
+  GemmOpt o1; o1.bias = cb1; o1.out_act = &h;
   if (has_temb) {
     auto it = c->tproj_off.find(pre);
     if (it == c->tproj_off.end()) FAIL("no time_emb_proj for %s", pre.c_str());
@@ -219,7 +244,7 @@ static int resnet(agd_ctx* c, hipStream_t st, const std::string& pre, const Act&
   CK(run_conv(c, st, n1.p, Cin, nullptr, 0, B, H, Wd, *w1, 3, h.p, o1, c->zero_page));
   Act n2 = alloc_act(c, B, H, Wd, Cout); if (!n2.p) return -1;
   GETV(g2, pre + "norm2.weight"); GETV(b2, pre + "norm2.bias");
-  CK(run_gn(c, st, h.p, Cout, nullptr, 0, B, HW, g2, b2, groups, eps, 1, n2.p));
+  CK(run_gn(c, st, h.p, Cout, nullptr, 0, B, HW, g2, b2, groups, eps, 1, n2.p, &h));
   const bf16_t* res = x0.p;
   if (c->W.count(pre + "conv_shortcut.weight")) {
     GETW(ws, pre + "conv_shortcut.weight"); GETV(bs, pre + "conv_shortcut.bias");
@@ -230,7 +255,7 @@ static int resnet(agd_ctx* c, hipStream_t st, const std::string& pre, const Act&
     FAIL("resnet %s: channel change %d->%d without conv_shortcut", pre.c_str(), Cin, Cout);
   }
   GETW(w2, pre + "conv2.weight"); GETV(cb2, pre + "conv2.bias");
-  GemmOpt o2; o2.bias = cb2; o2.residual = res;
+  GemmOpt o2; o2.bias = cb2; o2.residual = res; o2.out_act = &out;
   CK(run_conv(c, st, n2.p, Cout, nullptr, 0, B, H, Wd, *w2, 3, out.p, o2, c->zero_page));
   c->arena.release(mk);
   return 0;
@@ -319,12 +344,12 @@ static int transformer(agd_ctx* c, hipStream_t st, const std::string& pre, const
   int B = dup ? 2 * x.B : x.B;
   const int HW = x.H * x.W, C = x.C;
   int M = Bs * HW;                                     // rows until the duplication point, B*HW after it
-  out = alloc_act(c, B, x.H, x.W, C); if (!out.p) return -1;
+  out = alloc_act(c, B, x.H, x.W, C, true); if (!out.p) return -1;
   const size_t mk = c->arena.mark();
   const std::string t = pre + "transformer_blocks.0.";
   Act n = alloc_act(c, B, x.H, x.W, C); if (!n.p) return -1;
   GETV(gg, pre + "norm.weight"); GETV(gb, pre + "norm.bias");
-  CK(run_gn(c, st, x.p, C, nullptr, 0, Bs, HW, gg, gb, groups, 1e-6f, 0, n.p));
+  CK(run_gn(c, st, x.p, C, nullptr, 0, Bs, HW, gg, gb, groups, 1e-6f, 0, n.p, &x));
   Act h = alloc_act(c, B, x.H, x.W, C); if (!h.p) return -1;
   Act ln = n;  // reuse (only the unfolded path normalises into it)
   bf16_t* qkv = (bf16_t*)c->arena.alloc((size_t)B * HW * 3 * C * 2); if (!qkv) return -1;
@@ -400,7 +425,7 @@ static int transformer(agd_ctx* c, hipStream_t st, const std::string& pre, const
     GETW(w2, t + "ff.net.2.weight"); GETV(b2, t + "ff.net.2.bias");
     GemmOpt o2; o2.bias = b2; o2.residual = h.p;
     CK(run_conv(c, st, ff, 4 * C, nullptr, 0, 1, 1, M, *w2, 1, h.p, o2, c->zero_page)); }
-  { GETW(w, pre + "proj_out.weight"); GETV(b, pre + "proj_out.bias"); GemmOpt o; o.bias = b; o.residual = xres;
+  { GETW(w, pre + "proj_out.weight"); GETV(b, pre + "proj_out.bias"); GemmOpt o; o.bias = b; o.residual = xres; o.out_act = &out; o.rows_per_image = HW;
     CK(run_conv(c, st, h.p, C, nullptr, 0, 1, 1, M, *w, 1, out.p, o, c->zero_page)); }
   c->arena.release(mk);
   return 0;
@@ -435,10 +460,16 @@ static int unet_walk(agd_ctx* c, hipStream_t st, const bf16_t* xin, int B2, int 
   std::vector<Act> skips;
   const bool shared = cfg_shared && (B2 % 2) == 0 && g.down_cross[0] && c->opt_cfg_share;
   const int Bh = shared ? B2 / 2 : B2;
-  Act h = alloc_act(c, B2, L, L, g.block_out_channels[0]); if (!h.p) return -1;
-  { GETW(w, u + "conv_in.weight"); GETV(b, u + "conv_in.bias"); GemmOpt o; o.bias = b;
+  Act h = alloc_act(c, B2, L, L, g.block_out_channels[0], true); if (!h.p) return -1;
+  { GETW(w, u + "conv_in.weight"); GETV(b, u + "conv_in.bias"); GemmOpt o; o.bias = b; o.out_act = &h;
     CK(run_conv(c, st, xin, 64, nullptr, 0, Bh, L, L, *w, 3, h.p, o, c->zero_page)); }
-  if (shared) CK(dup_half(c, st, h.p, (long long)Bh * L * L * h.C));       // the skip connection needs all B2 rows
+  if (shared) {                                                             // the skip connection needs all B2 rows (and their partial sums)
+    CK(dup_half(c, st, h.p, (long long)Bh * L * L * h.C));
+    if (h.cpart_bm > 0) {
+      const size_t nb = (size_t)((long long)Bh * L * L / h.cpart_bm) * h.C * 2 * sizeof(float);
+      if (hipMemcpyAsync((char*)h.cpart + nb, h.cpart, nb, hipMemcpyDeviceToDevice, st) != hipSuccess) FAIL("dup partials copy failed");
+    }
+  }
   skips.push_back(h);
   for (int i = 0; i < nl; ++i) {
     const int co = g.block_out_channels[i];
@@ -456,8 +487,8 @@ static int unet_walk(agd_ctx* c, hipStream_t st, const bf16_t* xin, int B2, int 
     if (i != nl - 1) {
       const std::string k = u + "down_blocks." + std::to_string(i) + ".downsamplers.0.conv.";
       GETW(w, k + "weight"); GETV(b, k + "bias");
-      Act d = alloc_act(c, B2, h.H / 2, h.W / 2, co); if (!d.p) return -1;
-      GemmOpt o; o.bias = b; o.stride = 2;
+      Act d = alloc_act(c, B2, h.H / 2, h.W / 2, co, true); if (!d.p) return -1;
+      GemmOpt o; o.bias = b; o.stride = 2; o.out_act = &d;
       CK(run_conv(c, st, h.p, co, nullptr, 0, B2, h.H, h.W, *w, 3, d.p, o, c->zero_page));
       h = d; skips.push_back(h);
     }
@@ -480,15 +511,15 @@ static int unet_walk(agd_ctx* c, hipStream_t st, const bf16_t* xin, int B2, int 
     if (i != nl - 1) {
       const std::string k = u + "up_blocks." + std::to_string(i) + ".upsamplers.0.conv.";
       GETW(w, k + "weight"); GETV(b, k + "bias");
-      Act d = alloc_act(c, B2, h.H * 2, h.W * 2, co); if (!d.p) return -1;
-      GemmOpt o; o.bias = b; o.up = 2;
+      Act d = alloc_act(c, B2, h.H * 2, h.W * 2, co, true); if (!d.p) return -1;
+      GemmOpt o; o.bias = b; o.up = 2; o.out_act = &d;
       CK(run_conv(c, st, h.p, co, nullptr, 0, B2, h.H, h.W, *w, 3, d.p, o, c->zero_page));
       h = d;
     }
   }
   { Act n = alloc_act(c, B2, L, L, h.C); if (!n.p) return -1;
     GETV(gg, u + "conv_norm_out.weight"); GETV(gb, u + "conv_norm_out.bias");
-    CK(run_gn(c, st, h.p, h.C, nullptr, 0, B2, L * L, gg, gb, G, 1e-5f, 1, n.p));
+    CK(run_gn(c, st, h.p, h.C, nullptr, 0, B2, L * L, gg, gb, G, 1e-5f, 1, n.p, &h));
     GETW(w, u + "conv_out.weight"); GETV(b, u + "conv_out.bias");
     GemmOpt o; o.bias = b; o.out_f32 = 1; o.ldo = g.out_channels;
     CK(run_conv(c, st, n.p, h.C, nullptr, 0, B2, L, L, *w, 3, eps_out, o, c->zero_page)); }
@@ -498,11 +529,11 @@ static int unet_walk(agd_ctx* c, hipStream_t st, const bf16_t* xin, int B2, int 
 // AutoencoderKL mid-block attention: single head over N = L*L tokens, C channels, through batched GEMMs
 static int vae_mid_attention(agd_ctx* c, hipStream_t st, const std::string& a, int G, int B, int L, int top, Act& h) {
     const int N = L * L, C = top, M = B * N;
-    Act out = alloc_act(c, B, L, L, C); if (!out.p) return -1;
+    Act out = alloc_act(c, B, L, L, C, true); if (!out.p) return -1;
     const size_t mk = c->arena.mark();
     Act n = alloc_act(c, B, L, L, C); if (!n.p) return -1;
     GETV(gg, a + "group_norm.weight"); GETV(gb, a + "group_norm.bias");
-    CK(run_gn(c, st, h.p, C, nullptr, 0, B, N, gg, gb, G, 1e-6f, 0, n.p));
+    CK(run_gn(c, st, h.p, C, nullptr, 0, B, N, gg, gb, G, 1e-6f, 0, n.p, &h));
     bf16_t* q = (bf16_t*)c->arena.alloc((size_t)M * C * 2); bf16_t* k = (bf16_t*)c->arena.alloc((size_t)M * C * 2);
     bf16_t* vT = (bf16_t*)c->arena.alloc((size_t)M * C * 2); bf16_t* att = (bf16_t*)c->arena.alloc((size_t)M * C * 2);
     float* S = (float*)c->arena.alloc((size_t)B * N * N * 4); bf16_t* P = (bf16_t*)c->arena.alloc((size_t)B * N * N * 2);
@@ -527,7 +558,7 @@ static int vae_mid_attention(agd_ctx* c, hipStream_t st, const std::string& a, i
       p.W = vT; p.out = att; p.ldo = C; p.ldr = C; p.M = N; p.N = C; p.K = N; p.alpha = 1.f;
       p.batch = B; p.sA0 = (long long)N * N; p.sW = (long long)C * N; p.sO = (long long)N * C; p.zero_page = c->zero_page;
       ProfScope ps(c, st, PC_VAE_ATTN, 2.0 * B * N * (double)N * C); CK(launch_igemm(p, st)); }
-    { GemmOpt o; o.bias = bo; o.residual = h.p; CK(run_conv(c, st, att, C, nullptr, 0, 1, 1, M, *wo, 1, out.p, o, c->zero_page)); }
+    { GemmOpt o; o.bias = bo; o.residual = h.p; o.out_act = &out; o.rows_per_image = N; CK(run_conv(c, st, att, C, nullptr, 0, 1, 1, M, *wo, 1, out.p, o, c->zero_page)); }
     c->arena.release(mk);
     h = out;
   return 0;
@@ -545,8 +576,8 @@ static int vae_walk(agd_ctx* c, hipStream_t st, const bf16_t* zin, int B, int L,
   if (hipMemsetAsync(pq, 0, (size_t)B * L * L * 64 * 2, st) != hipSuccess) FAIL("memset pq");
   { GETW(w, v + "post_quant_conv.weight"); GETV(b, v + "post_quant_conv.bias"); GemmOpt o; o.bias = b; o.ldo = 64;
     CK(run_conv(c, st, zin, 64, nullptr, 0, B, L, L, *w, 1, pq, o, c->zero_page)); }
-  Act h = alloc_act(c, B, L, L, top); if (!h.p) return -1;
-  { GETW(w, v + "decoder.conv_in.weight"); GETV(b, v + "decoder.conv_in.bias"); GemmOpt o; o.bias = b;
+  Act h = alloc_act(c, B, L, L, top, true); if (!h.p) return -1;
+  { GETW(w, v + "decoder.conv_in.weight"); GETV(b, v + "decoder.conv_in.bias"); GemmOpt o; o.bias = b; o.out_act = &h;
     CK(run_conv(c, st, pq, 64, nullptr, 0, B, L, L, *w, 3, h.p, o, c->zero_page)); }
   { Act r; CK(resnet(c, st, v + "decoder.mid_block.resnets.0.", h, nullptr, top, 1e-6f, false, G, r)); h = r; }
   CK(vae_mid_attention(c, st, v + "decoder.mid_block.attentions.0.", G, B, L, top, h));
@@ -560,15 +591,15 @@ static int vae_walk(agd_ctx* c, hipStream_t st, const bf16_t* zin, int B, int L,
     if (i != nl - 1) {
       const std::string k = v + "decoder.up_blocks." + std::to_string(i) + ".upsamplers.0.conv.";
       GETW(w, k + "weight"); GETV(b, k + "bias");
-      Act d = alloc_act(c, B, h.H * 2, h.W * 2, co); if (!d.p) return -1;
-      GemmOpt o; o.bias = b; o.up = 2;
+      Act d = alloc_act(c, B, h.H * 2, h.W * 2, co, true); if (!d.p) return -1;
+      GemmOpt o; o.bias = b; o.up = 2; o.out_act = &d;
       CK(run_conv(c, st, h.p, co, nullptr, 0, B, h.H, h.W, *w, 3, d.p, o, c->zero_page));
       h = d;
     }
   }
   { Act n = alloc_act(c, B, h.H, h.W, h.C); if (!n.p) return -1;
     GETV(gg, v + "decoder.conv_norm_out.weight"); GETV(gb, v + "decoder.conv_norm_out.bias");
-    CK(run_gn(c, st, h.p, h.C, nullptr, 0, B, h.H * h.W, gg, gb, G, 1e-6f, 1, n.p));
+    CK(run_gn(c, st, h.p, h.C, nullptr, 0, B, h.H * h.W, gg, gb, G, 1e-6f, 1, n.p, &h));
     GETW(w, v + "decoder.conv_out.weight"); GETV(b, v + "decoder.conv_out.bias");
     GemmOpt o; o.bias = b; o.out_f32 = 1; o.ldo = 4;
     CK(run_conv(c, st, n.p, h.C, nullptr, 0, B, h.H, h.W, *w, 3, img_out, o, c->zero_page)); }
@@ -581,8 +612,8 @@ static int vae_encode_walk(agd_ctx* c, hipStream_t st, const bf16_t* xin, int B,
   const int nl = g.vae_n_levels, G = g.vae_norm_num_groups, lc = g.vae_latent_channels;
   const std::string v = "vae.";
   c->arena.release(0);
-  Act h = alloc_act(c, B, S_, S_, g.vae_block_out_channels[0]); if (!h.p) return -1;
-  { GETW(w, v + "encoder.conv_in.weight"); GETV(b, v + "encoder.conv_in.bias"); GemmOpt o; o.bias = b;
+  Act h = alloc_act(c, B, S_, S_, g.vae_block_out_channels[0], true); if (!h.p) return -1;
+  { GETW(w, v + "encoder.conv_in.weight"); GETV(b, v + "encoder.conv_in.bias"); GemmOpt o; o.bias = b; o.out_act = &h;
     CK(run_conv(c, st, xin, 64, nullptr, 0, B, S_, S_, *w, 3, h.p, o, c->zero_page)); }
   for (int i = 0; i < nl; ++i) {
     const int co = g.vae_block_out_channels[i];
@@ -593,8 +624,8 @@ static int vae_encode_walk(agd_ctx* c, hipStream_t st, const bf16_t* xin, int B,
     if (i != nl - 1) {   // Downsample2D(padding=0) after F.pad(x, (0,1,0,1)): taps beyond the bottom/right edge read zeros
       const std::string k = v + "encoder.down_blocks." + std::to_string(i) + ".downsamplers.0.conv.";
       GETW(w, k + "weight"); GETV(b, k + "bias");
-      Act d = alloc_act(c, B, h.H / 2, h.W / 2, co); if (!d.p) return -1;
-      GemmOpt o; o.bias = b; o.stride = 2; o.pad = 0; o.hout = h.H / 2; o.wout = h.W / 2;
+      Act d = alloc_act(c, B, h.H / 2, h.W / 2, co, true); if (!d.p) return -1;
+      GemmOpt o; o.bias = b; o.stride = 2; o.pad = 0; o.hout = h.H / 2; o.wout = h.W / 2; o.out_act = &d;
       CK(run_conv(c, st, h.p, co, nullptr, 0, B, h.H, h.W, *w, 3, d.p, o, c->zero_page));
       h = d;
     }
@@ -605,7 +636,7 @@ static int vae_encode_walk(agd_ctx* c, hipStream_t st, const bf16_t* xin, int B,
   { Act r; CK(resnet(c, st, v + "encoder.mid_block.resnets.1.", h, nullptr, top, 1e-6f, false, G, r)); h = r; }
   Act n = alloc_act(c, B, L, L, top); if (!n.p) return -1;
   GETV(gg, v + "encoder.conv_norm_out.weight"); GETV(gb, v + "encoder.conv_norm_out.bias");
-  CK(run_gn(c, st, h.p, top, nullptr, 0, B, L * L, gg, gb, G, 1e-6f, 1, n.p));
+  CK(run_gn(c, st, h.p, top, nullptr, 0, B, L * L, gg, gb, G, 1e-6f, 1, n.p, &h));
   // conv_out (top -> 2*lc) into a zeroed 64-channel buffer, then quant_conv 1x1 (2*lc -> 2*lc) in fp32 out
   bf16_t* co64 = (bf16_t*)c->arena.alloc((size_t)B * L * L * 64 * 2); if (!co64) return -1;
   if (hipMemsetAsync(co64, 0, (size_t)B * L * L * 64 * 2, st) != hipSuccess) FAIL("memset enc");
@@ -944,6 +975,7 @@ AGD_API int agd_set_option(agd_ctx* c, const char* name, int value) {
   if (!c || !name) { agd_set_error("set_option: null argument"); return fail_ctx(c); }
   if (!strcmp(name, "cfg_shared_prefix")) { c->opt_cfg_share = value != 0; return 0; }
   if (!strcmp(name, "ln_fold")) { c->opt_ln_fold = value != 0; return 0; }
+  if (!strcmp(name, "gn_fused_stats")) { c->opt_gn_fused = value != 0; return 0; }
   agd_set_error("set_option: unknown option '%s'", name);
   return fail_ctx(c);
 }
@@ -1271,6 +1303,41 @@ AGD_API int agd_op_groupnorm(const float* x, const float* gamma, const float* be
   CK(launch_groupnorm(g, st));
   CK(launch_bf16_to_f32(yb, yf, (long long)B * HW * C, st));
   CK(launch_nchw_from_nhwc_f32(yf, C, y, B, C, HW, st));
+  hipStreamSynchronize(st);
+  return 0;
+}
+
+// conv3x3 (+bias) -> GroupNorm(+SiLU) as the graph walk chains them: with fused != 0 the conv launch leaves per-channel partial
+// sums and the GroupNorm skips its statistics pass; with fused == 0 the two-kernel GroupNorm runs on the same conv output.
+// y_nchw fp32 [B, Cout, H, W].  (Test entry point for the producer-statistics path.)
+AGD_API int agd_op_conv_groupnorm(const float* x, const float* w, const float* bias, const float* gamma, const float* beta, float* y, int B,
+                                  int Cin, int H, int W, int Cout, int groups, float eps, int silu, int fused, void* stream) {
+  hipStream_t st = S(stream); Tmp tmp;
+  const int Cpad = (Cin + 63) / 64 * 64, HW = H * W;
+  bf16_t* xb = tmp.get<bf16_t>((size_t)B * HW * Cpad); bf16_t* wb = tmp.get<bf16_t>((size_t)Cout * 9 * Cpad);
+  bf16_t* hb = tmp.get<bf16_t>((size_t)B * HW * Cout); bf16_t* yb = tmp.get<bf16_t>((size_t)B * HW * Cout);
+  float* part = tmp.get<float>((size_t)((long long)B * HW / 64 + 1) * Cout * 2); float* yf = tmp.get<float>((size_t)B * HW * Cout);
+  float* ws = tmp.get<float>((size_t)groupnorm_ws_floats(B, Cout, HW, groups));
+  if (!xb || !wb || !hb || !yb || !part || !yf || !ws) return -1;
+  CK(to_nhwc_bf16(x, xb, B, Cin, HW, Cpad, st));
+  CK(launch_convert_weight(w, wb, Cout, Cin, 9, Cpad, 0, st));
+  IgemmP p{};
+  p.src0 = xb; p.C0 = Cpad; p.Hin = H; p.Win = W; p.Hout = H; p.Wout = W; p.ksize = 3; p.stride = 1; p.pad = 1; p.up = 1;
+  p.W = wb; p.bias = bias; p.bias_mode = bias ? 1 : 0; p.N = Cout; p.K = 9 * Cpad; p.M = B * HW; p.ldr = Cout; p.out = hb; p.ldo = Cout;
+  p.alpha = 1.f; p.batch = 1; p.zero_page = op_zero_page();
+  int bm = 0;
+  if (fused) {
+    int cfg[3] = {0, 0, 0};
+    CK(igemm_query(p, cfg));
+    if (cfg[2] != 1 || HW % cfg[0] || HW % 64) { agd_set_error("op_conv_groupnorm: shape not eligible for producer statistics (tile %d, splits %d)", cfg[0], cfg[2]); return -1; }
+    p.colstat_out = part; p.colstat_rows = HW; bm = cfg[0];
+  }
+  CK(launch_igemm(p, st));
+  GroupNormP g{}; g.x0 = hb; g.C0 = Cout; g.y = yb; g.gamma = gamma; g.beta = beta; g.B = B; g.HW = HW; g.groups = groups; g.eps = eps; g.silu = silu; g.ws = ws;
+  if (fused) { g.part0 = part; g.bm0 = bm; }
+  CK(launch_groupnorm(g, st));
+  CK(launch_bf16_to_f32(yb, yf, (long long)B * HW * Cout, st));
+  CK(launch_nchw_from_nhwc_f32(yf, Cout, y, B, Cout, HW, st));
   hipStreamSynchronize(st);
   return 0;
 }

@@ -144,11 +144,102 @@ __global__ __launch_bounds__(512) void gn_apply_kernel(const bf16_t* __restrict_
   for (; px < p1; px += PR) one(*(const s16x8*)(base + (long long)px * Cs), px);
 }
 
+// GroupNorm whose statistics pass is already done: the igemm launches that produced x0 / x1 left per-(M tile, channel)
+// partial sums (igemm_epilogue.h, colstat_out).  grid (pixel chunks, images, 4 channel slices); the 8 waves of a block
+// first reduce the partials of the slice's groups (one wave per group, fixed order, fp64), then stream
+// y = silu?(x * scale + shift) over the slice's channels.  One kernel, one read + one write of the activation.
+#define GN_SLICES 4
+__global__ __launch_bounds__(512) void gn_apply_part_kernel(const bf16_t* __restrict__ x0, const bf16_t* __restrict__ x1,
+                                                            int C0, int C1, int HW, int ppb, int groups, float eps,
+                                                            const float* __restrict__ part0, const float* __restrict__ part1, int bm0, int bm1,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            int silu, bf16_t* __restrict__ y) {
+  __shared__ float smean[8], srstd[8];
+  const int C = C0 + C1, cpg = C / groups, gps = groups / GN_SLICES, Cs = C / GN_SLICES;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.y, slice = blockIdx.z;
+  if (wave < gps) {
+    const int g = slice * gps + wave;
+    const int nt0 = HW / bm0, nt1 = C1 ? HW / bm1 : 0;
+    const int ntm = nt0 > nt1 ? nt0 : nt1;
+    double a = 0.0, q = 0.0;
+    for (int idx = lane; idx < cpg * ntm; idx += 64) {
+      const int tile = idx / cpg, ch = g * cpg + (idx - tile * cpg);
+      const float* pp = nullptr;
+      if (ch < C0) { if (tile < nt0) pp = part0 + (((long long)b * nt0 + tile) * C0 + ch) * 2; }
+      else if (tile < nt1) pp = part1 + (((long long)b * nt1 + tile) * C1 + (ch - C0)) * 2;
+      if (pp) { a += (double)pp[0]; q += (double)pp[1]; }
+    }
+    for (int o = 32; o >= 1; o >>= 1) { a += __shfl_xor(a, o); q += __shfl_xor(q, o); }
+    if (lane == 0) {
+      const double n = (double)HW * cpg;
+      const double mean = a / n;
+      double var = q / n - mean * mean;
+      if (var < 0) var = 0;
+      smean[wave] = (float)mean; srstd[wave] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+  }
+  __syncthreads();
+  const int nvec = Cs >> 3, PR = 512 / nvec;
+  const int vcol = tid % nvec, prow = tid / nvec;
+  if (prow >= PR) return;
+  const int p0 = blockIdx.x * ppb, p1 = min(HW, p0 + ppb);
+  const int ch = slice * Cs + vcol * 8;
+  const bf16_t* base; int Csrc, cc;
+  if (ch < C0) { base = x0; Csrc = C0; cc = ch; } else { base = x1; Csrc = C1; cc = ch - C0; }
+  base += (long long)b * HW * Csrc + cc;
+  bf16_t* yb = y + (long long)b * HW * C + ch;
+  float sc[8], sh[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int gl = (ch + e) / cpg - slice * gps;
+    sc[e] = srstd[gl] * gamma[ch + e];
+    sh[e] = beta[ch + e] - smean[gl] * sc[e];
+  }
+  auto one = [&](const s16x8 v, int px) {
+    float o[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { const float r = fmaf(bf2f((bf16_t)v[e]), sc[e], sh[e]); o[e] = silu ? silu_f(r) : r; }
+    u32x4 pk;
+    pk[0] = pack_bf2(o[0], o[1]); pk[1] = pack_bf2(o[2], o[3]); pk[2] = pack_bf2(o[4], o[5]); pk[3] = pack_bf2(o[6], o[7]);
+    *(u32x4*)(yb + (long long)px * C) = pk;
+  };
+  int px = p0 + prow;
+  for (; px + 3 * PR < p1; px += 4 * PR) {
+    s16x8 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = *(const s16x8*)(base + (long long)(px + u * PR) * Csrc);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) one(v[u], px + u * PR);
+  }
+  for (; px < p1; px += PR) one(*(const s16x8*)(base + (long long)px * Csrc), px);
+}
+
+// true when launch_groupnorm can use the producers' partial sums for this problem
+static bool gn_part_ok(const GroupNormP& p) {
+  const int C = p.C0 + p.C1;
+  if (!p.part0 || p.bm0 <= 0 || (p.C1 && (!p.part1 || p.bm1 <= 0))) return false;
+  if (p.groups % GN_SLICES || p.groups / GN_SLICES > 8 || C % (8 * GN_SLICES) || C % p.groups) return false;
+  if ((C / GN_SLICES) % (C / p.groups)) return false;                 // a slice holds whole groups
+  if (p.HW % p.bm0 || (p.C1 && p.HW % p.bm1) || (p.C0 % 8)) return false;
+  return (C / GN_SLICES) / 8 <= 512;
+}
+
 int launch_groupnorm(const GroupNormP& p, hipStream_t st) {
   const int C = p.C0 + p.C1;
   const int nvec = C / 8;
   if (C % 8 || p.C0 % 8 || nvec > 512 || C % p.groups || p.groups > 64) {
     agd_set_error("groupnorm: unsupported C0=%d C1=%d groups=%d", p.C0, p.C1, p.groups); return -1;
+  }
+  if (gn_part_ok(p)) {
+    const int nvs = C / GN_SLICES / 8, PR = 512 / nvs;
+    const long long target = ((long long)p.HW * p.B + 255) / 256;
+    int it = (int)((target + PR - 1) / PR); if (it < 1) it = 1; if (it > 16) it = 16;
+    const int ppb = it * PR, nchunk = (p.HW + ppb - 1) / ppb;
+    hipLaunchKernelGGL(gn_apply_part_kernel, dim3(nchunk, p.B, GN_SLICES), dim3(512), 0, st, p.x0, p.x1, p.C0, p.C1, p.HW, ppb, p.groups, p.eps,
+                       p.part0, p.part1, p.bm0, p.bm1 > 0 ? p.bm1 : 1, p.gamma, p.beta, p.silu, p.y);
+    HIP_CHECK_RET(hipGetLastError());
+    return 0;
   }
   const GnGeom g = gn_geom(p.B, C, p.HW);
   float* part = p.ws;

@@ -106,3 +106,17 @@ def attn_reg_loss(attn_map: torch.Tensor, obj_idx, fg_idx, bg_idx, coef: float, 
     _lib.check(lib.agd_op_attn_reg_loss(_lib.ptr(m), B, T, P, _lib.ptr(idx[0]), _lib.ptr(idx[1]), _lib.ptr(idx[2]), float(coef), _lib.ptr(loss),
                                         _lib.ptr(dmap), _lib.current_stream_ptr()), None, "agd_op_attn_reg_loss")
     return loss, dmap
+
+
+def conv_groupnorm(x, w, bias, gamma, beta, groups=32, eps=1e-5, silu=True, fused=True):
+    """conv3x3 -> GroupNorm(+SiLU) chained like the graph walk; `fused`: GroupNorm statistics from the conv launch's epilogue."""
+    lib = _lib.load()
+    x, w = _f32c(x), _f32c(w)
+    b = _f32c(bias) if bias is not None else None
+    ga, be = _f32c(gamma), _f32c(beta)
+    B, Cin, H, W = x.shape
+    Cout = w.shape[0]
+    y = torch.empty(B, Cout, H, W, device=x.device, dtype=torch.float32)
+    _lib.check(lib.agd_op_conv_groupnorm(_lib.ptr(x), _lib.ptr(w), _lib.ptr(b), _lib.ptr(ga), _lib.ptr(be), _lib.ptr(y), B, Cin, H, W, Cout,
+                                         groups, float(eps), int(silu), int(fused), _lib.current_stream_ptr()), None, "agd_op_conv_groupnorm")
+    return y

@@ -161,6 +161,10 @@ int agd_op_linear(const float* x, const float* w, const float* bias, const float
                   int N, int geglu, void* stream);
 int agd_op_groupnorm(const float* x_nchw, const float* gamma, const float* beta, float* y_nchw, int B, int C, int HW,
                      int groups, float eps, int silu, void* stream);
+/* conv3x3(+bias) -> GroupNorm(+SiLU), chained as the graph walk chains them; fused != 0: the conv launch emits the per-channel
+ * partial sums and the GroupNorm skips its statistics pass (the production path), fused == 0: the two-kernel GroupNorm. */
+int agd_op_conv_groupnorm(const float* x_nchw, const float* w, const float* bias, const float* gamma, const float* beta, float* y_nchw,
+                          int B, int Cin, int H, int W, int Cout, int groups, float eps, int silu, int fused, void* stream);
 int agd_op_layernorm(const float* x, const float* gamma, const float* beta, float* y, int rows, int C, float eps,
                      void* stream);
 /* q [B,Nq,H*D], k/v [B,Nk,H*D] fp32 -> o [B,Nq,H*D]; probs_out (may be NULL): [B,H,Nk,Nq] fp32, needs Nk<=96 */

@@ -508,3 +508,29 @@ def test_layernorm_fold_matches_the_separate_layernorm_kernels(cfgname):
     # two independent bf16-noise realisations of the same fp32 function: each within 2^-6 of the oracle, ~sqrt(2) x that apart
     assert e_a < 2.0 ** -6 and e_b < 2.0 ** -6 and e_ab < 2.0 ** -5
     pipe.engine.close()
+
+
+def test_groupnorm_statistics_from_producer_epilogues(tiny_pipe):
+    """opt "gn_fused_stats" (default on): the igemm launch that writes an activation also leaves per-(M tile, channel) partial
+    sums, and the GroupNorm that reads it skips its statistics pass (one kernel instead of two).  The statistics are sums of
+    the same bf16 values in a different (fixed) order: results agree to fp32 rounding of the group mean / rstd, runs are
+    bitwise reproducible, and the VAE decode (512-channel, many-tile images) agrees too."""
+    from agenda_amd import synthetic
+    pipe, cfg = tiny_pipe[0], tiny_pipe[1]
+    ctx = synthetic.make_context(cfg, 2, seed=3)
+    x = synthetic.make_latents(cfg, [0, 1, 2, 3], 16).to(torch.bfloat16).float()
+    pipe.engine.set_context(ctx)
+    a = pipe.engine.unet_forward(x, 501.0).clone()
+    a2 = pipe.engine.unet_forward(x, 501.0).clone()
+    z = synthetic.make_latents(cfg, [5, 6], 32).to(torch.bfloat16).float() * 0.18215
+    va = pipe.engine.vae_decode(z, want_f32=True)[1].clone()
+    pipe.engine.set_option("gn_fused_stats", 0)
+    b = pipe.engine.unet_forward(x, 501.0).clone()
+    vb = pipe.engine.vae_decode(z, want_f32=True)[1].clone()
+    pipe.engine.set_option("gn_fused_stats", 1)
+    assert torch.equal(a, a2)
+    e, ev = _rms_rel(a, b.cpu()), _rms_rel(va, vb.cpu())
+    print(f"gn_fused_stats: unet fused vs separate rms rel {e:.6f}, vae {ev:.6f}")
+    # a last-bit change of a group's mean / rstd flips isolated bf16 roundings, which the next ~60 layers amplify to the bf16
+    # noise floor: the two paths are two realisations of that noise (exactness of the statistics: tests/test_ops_gpu.py)
+    assert e < 2.0 ** -5 and ev < 2.0 ** -5

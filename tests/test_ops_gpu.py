@@ -102,6 +102,28 @@ def test_groupnorm(ops, B, C, H, groups, silu, eps):
     assert rel_err(got, want) < REL
 
 
+@pytest.mark.parametrize("B,Cin,H,Cout", [(2, 64, 16, 320), (8, 320, 32, 320), (2, 128, 16, 640), (1, 64, 8, 1280), (3, 64, 16, 128)])
+def test_groupnorm_statistics_from_the_conv_epilogue(ops, B, Cin, H, Cout):
+    """The production GroupNorm path: the conv launch leaves per-(M tile, channel) partial sums of its bf16 outputs, the
+    GroupNorm kernel reduces them instead of re-reading the activation.  vs torch (conv -> bf16 -> group_norm -> silu) and vs
+    the two-kernel GroupNorm on the same conv output: the statistics are the same sums in another order, so the two HIP
+    paths agree except for isolated 1-ulp bf16 flips."""
+    g = torch.Generator().manual_seed(B + Cin + Cout)
+    x = bfr(torch.randn(B, Cin, H, H, generator=g))
+    w = bfr(torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(Cin * 9))
+    b = torch.randn(Cout, generator=g) * 0.1
+    ga = torch.randn(Cout, generator=g) * 0.2 + 1
+    be = torch.randn(Cout, generator=g) * 0.2
+    h = bfr(F.conv2d(x, w, b, padding=1))
+    want = F.silu(F.group_norm(h, 32, ga, be, 1e-5))
+    fused = ops.conv_groupnorm(x.cuda(), w.cuda(), b.cuda(), ga.cuda(), be.cuda(), fused=True)
+    sep = ops.conv_groupnorm(x.cuda(), w.cuda(), b.cuda(), ga.cuda(), be.cuda(), fused=False)
+    assert rel_err(fused, want) < REL and rel_err(sep, want) < REL
+    d = (fused - sep).abs().cpu()
+    assert float(d.max()) <= float(want.abs().max()) * 2.0 ** -7                      # at most a bf16 ulp of the largest value
+    assert float((d > 0).float().mean()) < 0.02                                       # ... and only on isolated elements
+
+
 @pytest.mark.parametrize("rows,C", [(64, 320), (10, 1280), (7, 64), (33, 640)])
 def test_layernorm(ops, rows, C):
     g = torch.Generator().manual_seed(rows + C)
