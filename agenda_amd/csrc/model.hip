@@ -180,6 +180,8 @@ static int run_conv(agd_ctx* c, hipStream_t st, const bf16_t* s0, int C0, const 
       int cfg[3] = {0, 0, 0};
       CK(igemm_query(p, cfg));
       const int rpi = o.rows_per_image > 0 ? o.rows_per_image : p.Hout * p.Wout;
+      // split-K launches keep the separate statistics kernel: a reduce pass that also emits partial sums was measured
+      // slower than the two it replaces (+5.7 ms per batch, tools/ab_option.py)
       if (cfg[2] == 1 && cfg[0] > 0 && rpi % cfg[0] == 0) { p.colstat_out = o.out_act->cpart; p.colstat_rows = rpi; o.out_act->cpart_bm = cfg[0]; }
     }
   }
@@ -1329,8 +1331,9 @@ AGD_API int agd_op_conv_groupnorm(const float* x, const float* w, const float* b
   if (fused) {
     int cfg[3] = {0, 0, 0};
     CK(igemm_query(p, cfg));
-    if (cfg[2] != 1 || HW % cfg[0] || HW % 64) { agd_set_error("op_conv_groupnorm: shape not eligible for producer statistics (tile %d, splits %d)", cfg[0], cfg[2]); return -1; }
-    p.colstat_out = part; p.colstat_rows = HW; bm = cfg[0];
+    bm = cfg[0];
+    if (cfg[2] != 1 || bm < 1 || HW % bm || HW % 64) { agd_set_error("op_conv_groupnorm: shape not eligible for producer statistics (tile %d, splits %d)", cfg[0], cfg[2]); return -1; }
+    p.colstat_out = part; p.colstat_rows = HW;
   }
   CK(launch_igemm(p, st));
   GroupNormP g{}; g.x0 = hb; g.C0 = Cout; g.y = yb; g.gamma = gamma; g.beta = beta; g.B = B; g.HW = HW; g.groups = groups; g.eps = eps; g.silu = silu; g.ws = ws;
