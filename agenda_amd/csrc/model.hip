@@ -361,7 +361,7 @@ static int transformer(agd_ctx* c, hipStream_t st, const std::string& pre, const
   // squares) of its bf16 outputs per N tile; the GEMM that would read LayerNorm(h) reads h itself with W diag(gamma) and
   // finishes  rstd (acc - mean colsum) + (bias + W beta)  in its epilogue.  The three LayerNorm launches (and their
   // read + write of the activation) per block disappear; h is still rounded to bf16 exactly once.
-  const bool fold = c->opt_ln_fold != 0;
+  const bool fold = c->opt_ln_fold == 1 || (c->opt_ln_fold == 2 && C <= 320) || (c->opt_ln_fold == 3 && C <= 640);
   const float lneps = 1e-5f;
   float* stats = nullptr; int slots = 0;               // row statistics of the current h
   // h_out = A . W^T (+ bias, + residual): writes h and, when folding, its row statistics
@@ -976,7 +976,7 @@ AGD_API int agd_vae_decode(agd_ctx* c, const float* latents, int batch, int L, u
 AGD_API int agd_set_option(agd_ctx* c, const char* name, int value) {
   if (!c || !name) { agd_set_error("set_option: null argument"); return fail_ctx(c); }
   if (!strcmp(name, "cfg_shared_prefix")) { c->opt_cfg_share = value != 0; return 0; }
-  if (!strcmp(name, "ln_fold")) { c->opt_ln_fold = value != 0; return 0; }
+  if (!strcmp(name, "ln_fold")) { c->opt_ln_fold = value; return 0; }       // 0 off, 1 on; 2 / 3: only blocks with C <= 320 / 640 (A/B)
   if (!strcmp(name, "gn_fused_stats")) { c->opt_gn_fused = value != 0; return 0; }
   agd_set_error("set_option: unknown option '%s'", name);
   return fail_ctx(c);
