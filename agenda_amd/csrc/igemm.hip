@@ -224,8 +224,13 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_kernel(const IgemmP p) 
     for (int j = 0; j < NI; ++j) b0[j] = *(const bf16x8*)(sB + j * 512 + foffB[0]);
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
+#if defined(AGD_EXPERIMENTS) && defined(EXP_SKIP_DMA)   // timing only: 1 = no A pieces, 2 = no B pieces, 3 = none (results are garbage)
+      if (g < A_IT) { if (!(EXP_SKIP_DMA & 1)) bufdma16(baseA, dA + (g * NW + wid) * 1024, av[g < A_IT ? g : 0], aso, nrA); }
+      else if (g < ND) { if (!(EXP_SKIP_DMA & 2)) bufdma16(baseW, dB + ((g - A_IT) * NW + wid) * 1024, bvoff[(g >= A_IT && g < ND) ? g - A_IT : 0], bso, nrB); }
+#else
       if (g < A_IT) bufdma16(baseA, dA + (g * NW + wid) * 1024, av[g < A_IT ? g : 0], aso, nrA);
       else if (g < ND) bufdma16(baseW, dB + ((g - A_IT) * NW + wid) * 1024, bvoff[(g >= A_IT && g < ND) ? g - A_IT : 0], bso, nrB);
+#endif
       if (g < MI) a1[g] = *(const bf16x8*)(sA + g * 2048 + foff[1]);
       else if (g < NF) b1[g - MI] = *(const bf16x8*)(sB + (g - MI) * 512 + foffB[1]);
     }
