@@ -1470,13 +1470,27 @@ AGD_API int agd_bench_attention(int B, int H, int D, int Nq, int Nk, int record,
   return 0;
 }
 
-AGD_API int agd_bench_groupnorm(int B, int HW, int C, int iters, double* ms_out) {
+// GroupNorm(+SiLU) of a [B][HW][C0 (+ C1 concatenated)] activation; fused_stats != 0 takes the one-kernel path that reads the
+// producing igemm launches' per-(128-row tile, channel) partial sums (here: arbitrary values -- timing only)
+AGD_API int agd_bench_groupnorm_ex(int B, int HW, int C0, int C1, int fused_stats, int iters, double* ms_out) {
   Tmp tmp;
-  bf16_t* x = tmp.get<bf16_t>((size_t)B * HW * C); bf16_t* y = tmp.get<bf16_t>((size_t)B * HW * C);
+  const int C = C0 + C1;
+  if (B < 1 || HW < 1 || C0 < 8 || C1 < 0 || iters < 1 || !ms_out) { agd_set_error("bench_groupnorm: bad arguments"); return -1; }
+  bf16_t* x0 = tmp.get<bf16_t>((size_t)B * HW * C0); bf16_t* x1 = C1 ? tmp.get<bf16_t>((size_t)B * HW * C1) : nullptr;
+  bf16_t* y = tmp.get<bf16_t>((size_t)B * HW * C);
   float* ws = tmp.get<float>((size_t)groupnorm_ws_floats(B, C, HW, 32)); float* g = tmp.get<float>(2 * C);
-  if (!x || !y || !ws || !g) return -1;
-  fill_rand(x, (long long)B * HW * C, 7, 1.0f); hipMemset(g, 0, 2 * C * 4);
-  GroupNormP p{}; p.x0 = x; p.C0 = C; p.y = y; p.gamma = g; p.beta = g + C; p.B = B; p.HW = HW; p.groups = 32; p.eps = 1e-5f; p.silu = 1; p.ws = ws;
+  if (!x0 || (C1 && !x1) || !y || !ws || !g) return -1;
+  fill_rand(x0, (long long)B * HW * C0, 7, 1.0f); if (C1) fill_rand(x1, (long long)B * HW * C1, 8, 1.0f);
+  hipMemset(g, 0, 2 * C * 4);
+  GroupNormP p{}; p.x0 = x0; p.x1 = x1; p.C0 = C0; p.C1 = C1; p.y = y; p.gamma = g; p.beta = g + C; p.B = B; p.HW = HW; p.groups = 32; p.eps = 1e-5f; p.silu = 1; p.ws = ws;
+  if (fused_stats) {
+    if (HW % 128) { agd_set_error("bench_groupnorm: fused_stats needs HW %% 128 == 0"); return -1; }
+    const size_t n0 = (size_t)B * (HW / 128) * C0 * 2, n1 = (size_t)B * (HW / 128) * C1 * 2;
+    float* p0 = tmp.get<float>(n0); float* p1 = C1 ? tmp.get<float>(n1) : nullptr;
+    if (!p0 || (C1 && !p1)) return -1;
+    hipMemset(p0, 0, n0 * 4); if (C1) hipMemset(p1, 0, n1 * 4);
+    p.part0 = p0; p.part1 = p1; p.bm0 = 128; p.bm1 = C1 ? 128 : 0;
+  }
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   for (int i = 0; i < 2; ++i) CK(launch_groupnorm(p, 0));
   hipEventRecord(e0, 0);
@@ -1487,6 +1501,7 @@ AGD_API int agd_bench_groupnorm(int B, int HW, int C, int iters, double* ms_out)
   hipEventDestroy(e0); hipEventDestroy(e1);
   return 0;
 }
+AGD_API int agd_bench_groupnorm(int B, int HW, int C, int iters, double* ms_out) { return agd_bench_groupnorm_ex(B, HW, C, 0, 0, iters, ms_out); }
 
 
 // ---------------------------------------------------------------------------------------

@@ -198,6 +198,7 @@ int agd_bench_conv(int B, int H, int W, int C0, int C1, int Cout, int ksize, int
                    int iters, double* ms_out);
 int agd_bench_attention(int B, int H, int D, int Nq, int Nk, int record, int iters, double* ms_out);
 int agd_bench_groupnorm(int B, int HW, int C, int iters, double* ms_out);
+int agd_bench_groupnorm_ex(int B, int HW, int C0, int C1, int fused_stats, int iters, double* ms_out);
 
 const char* agd_version(void);
 
