@@ -80,48 +80,57 @@ int launch_timestep_embed(float t, float* out, int dim, hipStream_t st) {
   HIP_CHECK_RET(hipGetLastError()); return 0;
 }
 
-// Small-M linear (time embedding MLP, per-resnet time_emb_proj): out[m][n] = act(W[n].act_in(x[m]) + b[n])
-// one wave per output column n, M <= 8, W streamed once with 16-B loads.
+// Small-M linear (time embedding MLP, per-resnet time_emb_proj): out[m][n] = act(W[n].act_in(x[m]) + b[n]),  M <= 8.
+// The block stages act_in(x) in LDS once (the activation is applied M*K times, not M*K*N times); one wave per output column
+// (several columns in turn when N is large), W streamed once with 16-B loads, fp32 accumulate in a fixed order.
 __global__ __launch_bounds__(256) void small_linear_kernel(const float* __restrict__ x, const bf16_t* __restrict__ W,
                                                            const float* __restrict__ bias, float* __restrict__ out,
-                                                           int M, int N, int K, int silu_in, int silu_out) {
+                                                           int M, int N, int K, int silu_in, int silu_out, int cpw) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* xs = (float*)smem;                        // [M][K]
+  for (int i = threadIdx.x; i < M * K; i += 256) { const float v = x[i]; xs[i] = silu_in ? silu_f(v) : v; }
+  __syncthreads();
   const int lane = threadIdx.x & 63;
-  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (n >= N) return;
-  float acc[8];
+  const int nb = (blockIdx.x * 4 + (threadIdx.x >> 6)) * cpw;
+  for (int c = 0; c < cpw; ++c) {
+    const int n = nb + c;
+    if (n >= N) return;
+    float acc[8];
 #pragma unroll
-  for (int m = 0; m < 8; ++m) acc[m] = 0.f;
-  for (int k0 = lane * 8; k0 < K; k0 += 512) {
-    const s16x8 wv = *(const s16x8*)(W + (long long)n * K + k0);
-    float wf[8];
+    for (int m = 0; m < 8; ++m) acc[m] = 0.f;
+    for (int k0 = lane * 8; k0 < K; k0 += 512) {
+      const s16x8 wv = *(const s16x8*)(W + (long long)n * K + k0);
+      float wf[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) wf[e] = bf2f((bf16_t)wv[e]);
+      for (int e = 0; e < 8; ++e) wf[e] = bf2f((bf16_t)wv[e]);
 #pragma unroll
-    for (int m = 0; m < 8; ++m) {
-      if (m < M) {
+      for (int m = 0; m < 8; ++m) {
+        if (m < M) {
+          const f32x4 x0 = *(const f32x4*)&xs[m * K + k0], x1 = *(const f32x4*)&xs[m * K + k0 + 4];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          float xv = x[(long long)m * K + k0 + e];
-          if (silu_in) xv = silu_f(xv);
-          acc[m] += wf[e] * xv;
+          for (int e = 0; e < 4; ++e) acc[m] += wf[e] * x0[e];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[m] += wf[4 + e] * x1[e];
         }
       }
     }
-  }
 #pragma unroll
-  for (int m = 0; m < 8; ++m) {
-    float a = acc[m];
-    for (int o = 32; o >= 1; o >>= 1) a += __shfl_xor(a, o);
-    if (lane == 0 && m < M) {
-      a += bias ? bias[n] : 0.f;
-      out[(long long)m * N + n] = silu_out ? silu_f(a) : a;
+    for (int m = 0; m < 8; ++m) {
+      float a = acc[m];
+      for (int o = 32; o >= 1; o >>= 1) a += __shfl_xor(a, o);
+      if (lane == 0 && m < M) {
+        a += bias ? bias[n] : 0.f;
+        out[(long long)m * N + n] = silu_out ? silu_f(a) : a;
+      }
     }
   }
 }
 int launch_small_linear(const float* x, const bf16_t* W, const float* bias, float* out, int M, int N, int K, int silu_in,
                         int silu_out, hipStream_t st) {
-  if (M > 8 || (K & 7)) { agd_set_error("small_linear: M=%d K=%d unsupported", M, K); return -1; }
-  hipLaunchKernelGGL(small_linear_kernel, dim3((N + 3) / 4), dim3(256), 0, st, x, W, bias, out, M, N, K, silu_in, silu_out);
+  if (M < 1 || M > 8 || (K & 7) || (size_t)M * K * 4 > 65536) { agd_set_error("small_linear: M=%d K=%d unsupported", M, K); return -1; }
+  const int cpw = N > 4096 ? (N + 4095) / 4096 : 1;            // ~1024 blocks at most
+  hipLaunchKernelGGL(small_linear_kernel, dim3((N + 4 * cpw - 1) / (4 * cpw)), dim3(256), (size_t)M * K * 4, st, x, W, bias, out, M, N, K,
+                     silu_in, silu_out, cpw);
   HIP_CHECK_RET(hipGetLastError()); return 0;
 }
 
