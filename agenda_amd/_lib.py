@@ -78,6 +78,7 @@ _SIGS = {
     "agd_op_conv_groupnorm": (C.c_int, [_P] * 6 + [C.c_int] * 6 + [C.c_float, C.c_int, C.c_int, _P]),
     "agd_op_layernorm": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_float, _P]),
     "agd_op_attention": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _P, _P]),
+    "agd_op_attention_headsum": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _P, _P]),
     "agd_op_bicubic_clamp_mean": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
     "agd_op_heatmap_u8": (C.c_int, [_P, C.c_int, C.c_int, _P, _P]),
     "agd_op_resize_u8_pil": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),

@@ -43,6 +43,10 @@ template <int D> struct AttnCfg {
 
 // AMASK: additive attention mask [B][Nk] (diffusers `attention_mask` after prepare_attention_mask, hook.py:92,108:
 // broadcast over heads and queries) -- a separate instantiation so the production kernels carry none of it.
+// RECORD: 0 = plain flash attention; 1 = single key tile, probabilities added into per-(image, head) rows (DAAM) or written per
+// head (hook.py mode); 2 = single key tile, the block walks ALL heads of its (batch row, query tile) and adds the head SUM of the
+// probabilities into per-image rows once -- the DAAM layers at latent resolution, where the aggregation is linear in the heads
+// (bicubic to the same size is the identity and clamp(min=0) cannot fire), so 1/8 of the accumulator traffic.
 template <int D, int KB, int QB, int RECORD, int AMASK = 0>
 __global__ __launch_bounds__(256, (AMASK ? 1 : (QB == 1 && D <= 40 && !RECORD) ? 4 : (QB == 1 && D <= 64 && !RECORD) ? 3 : (QB == 1 && D <= 80) ? 2 : 1)) void attn_kernel(const AttnP p) {
   using C = AttnCfg<D>;
@@ -54,14 +58,16 @@ __global__ __launch_bounds__(256, (AMASK ? 1 : (QB == 1 && D <= 40 && !RECORD) ?
   constexpr int NCHUNK = KEYS * CH;                      // 16-B chunks per K (or V) tile
   constexpr int LD_IT = (NCHUNK + 255) / 256;
   constexpr int STAGE = KEYS * (KPITCH + VPITCH);
-  constexpr int NSTAGE = RECORD ? 1 : 2;
+  constexpr int NSTAGE = (RECORD == 1) ? 1 : 2;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int c = lane & 31, hh = lane >> 5;
   // XCD-aware 1-D grid: blocks are dealt round-robin over the 8 XCDs, so give every (batch, head) pair --
   // whose query tiles all stream the same K/V -- to ONE XCD (its L2 then serves K/V after the first tile).
-  const int nqt = p.nqt, nbh = p.B * p.H;
+  // RECORD 2: one block per (batch row, group of rec_hpb heads, query tile), the group's heads inside the block
+  const int HPB = (RECORD == 2) ? p.H / p.rec_hpb : p.H;
+  const int nqt = p.nqt, nbh = p.B * HPB;
   int bh, qt;
   {
     const int id = blockIdx.x, x = id & 7, j = id >> 3;
@@ -71,9 +77,11 @@ __global__ __launch_bounds__(256, (AMASK ? 1 : (QB == 1 && D <= 40 && !RECORD) ?
     bh = x * per + lb;                                 // may exceed nbh for the last groups: exit
   }
   if (bh >= nbh) return;
-  const int head = bh % p.H, b = bh / p.H;
+  const int hgrp = bh % HPB;                             // RECORD 2: head group; else the head
+  int head = (RECORD == 2) ? hgrp * p.rec_hpb : hgrp;
+  const int hend = (RECORD == 2) ? head + p.rec_hpb : head + 1;
+  const int b = bh / HPB;
   const int q0 = qt * (128 * QB) + wid * (32 * QB);
-  const bf16_t* qp = p.q + b * p.sq + head * D;
   const bf16_t* kp = p.k + b * p.sk + head * D;
   const bf16_t* vp = p.v + b * p.sv + head * D;
 
@@ -99,24 +107,39 @@ __global__ __launch_bounds__(256, (AMASK ? 1 : (QB == 1 && D <= 40 && !RECORD) ?
   const float qscale = p.scale * 1.44269504088896340736f;   // exp(x) = exp2(x*log2e)
   // Q fragments: lane (c, hh) holds Q[q0 + 32*qb + c][16s + 8hh .. +8]
   bf16x8 qf[QB][KSTEPS];
+  u32x4 qnext[RECORD == 2 ? KSTEPS : 1];                 // RECORD 2: the next head's Q fragments, fetched under this head's work
+  auto load_q = [&]() {
+    const bf16_t* qp = p.q + b * p.sq + head * D;
 #pragma unroll
-  for (int qb = 0; qb < QB; ++qb) {
-    const int qrow = q0 + qb * 32 + c;
-    const bool qok = qrow < p.Nq;
+    for (int qb = 0; qb < QB; ++qb) {
+      const int qrow = q0 + qb * 32 + c;
+      const bool qok = qrow < p.Nq;
 #pragma unroll
-    for (int s = 0; s < KSTEPS; ++s) {
-      const int d0 = 16 * s + 8 * hh;
-      u32x4 v = u32x4{0, 0, 0, 0};
-      if (qok && d0 < D) v = *(const u32x4*)(qp + (long long)qrow * p.ldq + d0);
-      qf[qb][s] = __builtin_bit_cast(bf16x8, v);
-      if constexpr (!RECORD) {
-        // fold scale*log2(e) into Q once (fp32 multiply, RNE back to bf16): the QK^T accumulator then holds
-        // log2-domain logits and the per-score v_fma in the softmax disappears (that kernel is VALU-bound).
+      for (int s = 0; s < KSTEPS; ++s) {
+        const int d0 = 16 * s + 8 * hh;
+        u32x4 v = u32x4{0, 0, 0, 0};
+        if (qok && d0 < D) v = *(const u32x4*)(qp + (long long)qrow * p.ldq + d0);
+        qf[qb][s] = __builtin_bit_cast(bf16x8, v);
+        if constexpr (!RECORD) {
+          // fold scale*log2(e) into Q once (fp32 multiply, RNE back to bf16): the QK^T accumulator then holds
+          // log2-domain logits and the per-score v_fma in the softmax disappears (that kernel is VALU-bound).
 #pragma unroll
-        for (int j = 0; j < 8; ++j) qf[qb][s][j] = (__bf16)((float)qf[qb][s][j] * qscale);
+          for (int j = 0; j < 8; ++j) qf[qb][s][j] = (__bf16)((float)qf[qb][s][j] * qscale);
+        }
       }
     }
-  }
+  };
+  auto prefetch_q = [&](int h) {                          // RECORD 2 (QB = 1)
+    const bf16_t* qp = p.q + b * p.sq + h * D;
+    const int qrow = q0 + c;
+#pragma unroll
+    for (int s = 0; s < (RECORD == 2 ? KSTEPS : 1); ++s) {
+      const int d0 = 16 * s + 8 * hh;
+      qnext[s] = u32x4{0, 0, 0, 0};
+      if (qrow < p.Nq && d0 < D) qnext[s] = *(const u32x4*)(qp + (long long)qrow * p.ldq + d0);
+    }
+  };
+  load_q();
 
   // K/V tile prefetch through buffer descriptors: per-lane 32-bit offset fixed for the kernel, the tile
   // advance in an SGPR soffset; rows >= Nk fall outside num_records and read as zeros.
@@ -139,6 +162,16 @@ __global__ __launch_bounds__(256, (AMASK ? 1 : (QB == 1 && D <= 40 && !RECORD) ?
     for (int it = 0; it < LD_IT; ++it) {
       kreg[it] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(krs, kvoff[it], ks_, 0));
       vreg[it] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(vrs, vvoff[it], vs_, 0));
+    }
+  };
+  // RECORD 2: the K/V slice of head h (one tile: Nk <= KEYS); same per-lane offsets, the head shifts the descriptor base
+  auto gload_head = [&](int h) {
+    const auto krh = __builtin_amdgcn_make_buffer_rsrc((void*)(p.k + b * p.sk + h * D), 0, k_bytes, 0x00020000);
+    const auto vrh = __builtin_amdgcn_make_buffer_rsrc((void*)(p.v + b * p.sv + h * D), 0, v_bytes, 0x00020000);
+#pragma unroll
+    for (int it = 0; it < LD_IT; ++it) {
+      kreg[it] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(krh, kvoff[it], 0, 0));
+      vreg[it] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(vrh, vvoff[it], 0, 0));
     }
   };
   auto lstore = [&](int stage) {
@@ -175,6 +208,14 @@ __global__ __launch_bounds__(256, (AMASK ? 1 : (QB == 1 && D <= 40 && !RECORD) ?
     }
   }
   const float sc = qscale;
+  f32x16 pacc[RECORD == 2 ? KB : 1];                     // RECORD 2: head sum of this lane's probabilities
+  const bool recb = RECORD == 2 && p.record_mode == 3 && b >= p.rec_b0;
+  if constexpr (RECORD == 2) {
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) pacc[kb][j] = 0.f;
+  }
 
   const int ntiles = RECORD ? 1 : (p.Nk + KEYS - 1) / KEYS;   // RECORD: host guarantees Nk <= KEYS
   const bool ragged = (p.Nk % KEYS) != 0 || p.causal || AMASK;   // causal / additive mask: every tile takes the masked path
@@ -189,10 +230,11 @@ __global__ __launch_bounds__(256, (AMASK ? 1 : (QB == 1 && D <= 40 && !RECORD) ?
 
   auto tile_body = [&](int t, auto mask_tag) {
     constexpr bool MASK = decltype(mask_tag)::value;
-    const int cur = RECORD ? 0 : (t & 1);
+    const int cur = (RECORD == 1) ? 0 : (RECORD == 2) ? ((t - (hend - p.rec_hpb)) & 1) : (t & 1);   // RECORD 2: t is the head
     const char* sK = smem + cur * STAGE;
     const char* sV = sK + KEYS * KPITCH;
-    if (t + 1 < ntiles) gload(t + 1);
+    if constexpr (RECORD == 2) { if (t + 1 < hend) { gload_head(t + 1); prefetch_q(t + 1); } }
+    else if (t + 1 < ntiles) gload(t + 1);
     // ---- S^T = K . Q^T ----
     f32x16 sacc[QB][KB];
 #pragma unroll
@@ -216,7 +258,7 @@ __global__ __launch_bounds__(256, (AMASK ? 1 : (QB == 1 && D <= 40 && !RECORD) ?
         for (int kb = 0; kb < KB; ++kb)
 #pragma unroll
           for (int i = 0; i < 16; ++i) {
-            const int key = t * KEYS + kb * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+            const int key = (RECORD ? 0 : t * KEYS) + kb * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
             if (key >= p.Nk || (p.causal && key > q0 + qb * 32 + c)) sacc[qb][kb][i] = -INFINITY;
             else if constexpr (AMASK) {
               // RECORD keeps raw logits (scaled below): pre-divide so that (s + a/scale)*scale = s*scale + a
@@ -235,6 +277,7 @@ __global__ __launch_bounds__(256, (AMASK ? 1 : (QB == 1 && D <= 40 && !RECORD) ?
       if constexpr (RECORD) {
         mx = xhalf_max(mx) * sc;
         m_run[qb] = mx;                                   // single tile: no running state to rescale
+        if constexpr (RECORD == 2) l_run[qb] = 0.f;       // per head
         const float nm = -mx;
         float rs = 0.f;
 #pragma unroll
@@ -297,7 +340,15 @@ __global__ __launch_bounds__(256, (AMASK ? 1 : (QB == 1 && D <= 40 && !RECORD) ?
       }
     }
 
-    if constexpr (RECORD) {
+    if constexpr (RECORD == 2) {
+      if (recb) {
+        const float inv = 1.0f / xhalf_sum(l_run[0]);
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) pacc[kb][i] += sacc[0][kb][i] * inv;
+      }
+    } else if constexpr (RECORD) {
       // single-tile case (host guarantees Nk <= KEYS): probabilities are final here.
       // All old values are loaded first, then added, then stored: the RMW chains overlap.
       if (p.record_mode != 0 && b >= p.rec_b0 && (q0 + c) < p.Nq) {
@@ -352,14 +403,80 @@ __global__ __launch_bounds__(256, (AMASK ? 1 : (QB == 1 && D <= 40 && !RECORD) ?
             oacc[qb][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a4), pf[qb], oacc[qb][db], 0, 0, 0);
         }
       }
-    if (t + 1 < ntiles) {
+    if ((RECORD == 2) ? (t + 1 < hend) : (t + 1 < ntiles)) {
       lstore(cur ^ 1);      // the other stage was last read in iteration t-1 (all waves passed its barrier)
       __syncthreads();
     }
   };
+  // ---- finalize + store O[query][d] of the current head ----
+  auto store_o = [&]() {
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+      float lt;
+      if constexpr (ONES) {
+        constexpr int ld = D % 32;
+        const float lv = oacc[qb][D / 32][4 * (ld / 8)];     // row D of O^T lives in lanes 0..31 (hh = 0)
+        lt = __shfl(lv, c);
+      } else {
+        lt = xhalf_sum(l_run[qb]);
+      }
+      const float inv = 1.0f / lt;
+      const int qrow = q0 + qb * 32 + c;
+      if (qrow < p.Nq) {
+        bf16_t* op = p.o + b * p.so + (long long)qrow * p.ldo + head * D;
+#pragma unroll
+        for (int db = 0; db < DBLK; ++db)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int d0 = db * 32 + 8 * g + 4 * hh;
+            if (d0 < D) {
+              u32x2 pk;
+              pk[0] = pack_bf2(oacc[qb][db][4 * g + 0] * inv, oacc[qb][db][4 * g + 1] * inv);
+              pk[1] = pack_bf2(oacc[qb][db][4 * g + 2] * inv, oacc[qb][db][4 * g + 3] * inv);
+              *(u32x2*)(op + d0) = pk;
+            }
+          }
+      }
+    }
+  };
   {
     using T_ = std::integral_constant<bool, true>; using F_ = std::integral_constant<bool, false>;
-    if constexpr (RECORD) {
+    if constexpr (RECORD == 2) {
+      const int h0 = head;
+      for (; head < hend; ++head) {                    // K/V of the first head are staged; tile_body prefetches head + 1
+        if (head > h0) {
+#pragma unroll
+          for (int s = 0; s < KSTEPS; ++s) qf[0][s] = __builtin_bit_cast(bf16x8, qnext[s]);
+#pragma unroll
+          for (int db = 0; db < DBLK; ++db)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) oacc[0][db][j] = 0.f;
+        }
+        tile_body(head, T_{});
+        store_o();
+      }
+      // one read-modify-write of the per-image rows with the head sum: all loads first, then the stores
+      if (recb && (q0 + c) < p.Nq) {
+        float* base = p.rec + (long long)(b - p.rec_b0) * p.rec_img_stride + hgrp * p.rec_head_stride;
+        const unsigned nbytes = (unsigned)p.rec_T * (unsigned)p.Nq * 4u;       // token rows >= rec_T are dropped by the range check
+        const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(base, 0, nbytes, 0x00020000);
+        const unsigned rowb = (unsigned)p.Nq * 4u;
+        const unsigned voff0 = (unsigned)(q0 + c) * 4u + (unsigned)(4 * hh) * rowb;
+        float old[KB][16];
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+          for (int i = 0; i < 16; ++i)
+            old[kb][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff0 + (unsigned)(kb * 32 + (i & 3) + 8 * (i >> 2)) * rowb, 0, 0));
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+          for (int i = 0; i < 16; ++i)
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, old[kb][i] + pacc[kb][i]), rsrc,
+                                                  voff0 + (unsigned)(kb * 32 + (i & 3) + 8 * (i >> 2)) * rowb, 0, 0);
+      }
+      return;
+    } else if constexpr (RECORD) {
       tile_body(0, T_{});                              // single (always key-masked) tile
     } else {
       if (p.causal || AMASK) { for (int t = 0; t < ntiles - 1; ++t) tile_body(t, T_{}); }
@@ -367,46 +484,17 @@ __global__ __launch_bounds__(256, (AMASK ? 1 : (QB == 1 && D <= 40 && !RECORD) ?
       if (ragged) tile_body(ntiles - 1, T_{}); else tile_body(ntiles - 1, F_{});
     }
   }
-
-  // ---- finalize + store O[query][d] ----
-#pragma unroll
-  for (int qb = 0; qb < QB; ++qb) {
-    float lt;
-    if constexpr (ONES) {
-      constexpr int ld = D % 32;
-      const float lv = oacc[qb][D / 32][4 * (ld / 8)];     // row D of O^T lives in lanes 0..31 (hh = 0)
-      lt = __shfl(lv, c);
-    } else {
-      lt = xhalf_sum(l_run[qb]);
-    }
-    const float inv = 1.0f / lt;
-    const int qrow = q0 + qb * 32 + c;
-    if (qrow < p.Nq) {
-      bf16_t* op = p.o + b * p.so + (long long)qrow * p.ldo + head * D;
-#pragma unroll
-      for (int db = 0; db < DBLK; ++db)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int d0 = db * 32 + 8 * g + 4 * hh;
-          if (d0 < D) {
-            u32x2 pk;
-            pk[0] = pack_bf2(oacc[qb][db][4 * g + 0] * inv, oacc[qb][db][4 * g + 1] * inv);
-            pk[1] = pack_bf2(oacc[qb][db][4 * g + 2] * inv, oacc[qb][db][4 * g + 3] * inv);
-            *(u32x2*)(op + d0) = pk;
-          }
-        }
-    }
-  }
+  store_o();
 }
 
 
 template <int D, int KB, int QB, int RECORD, int AMASK = 0>
 static int launch_attn_t(const AttnP& p, hipStream_t st) {
   using C = AttnCfg<D>;
-  constexpr int lds = (RECORD ? 1 : 2) * KB * 32 * (C::KPITCH + C::VPITCH);
+  constexpr int lds = (RECORD == 1 ? 1 : 2) * KB * 32 * (C::KPITCH + C::VPITCH);
   AttnP pp = p;
   pp.nqt = (p.Nq + 128 * QB - 1) / (128 * QB);
-  const int per = (p.B * p.H + 7) / 8;
+  const int per = (p.B * (RECORD == 2 ? p.H / p.rec_hpb : p.H) + 7) / 8;
   dim3 grid(8 * per * pp.nqt);
   auto kfn = attn_kernel<D, KB, QB, RECORD, AMASK>;
   if (lds > 65536) {                                   // per (instantiation, device) latch
@@ -424,6 +512,11 @@ template <int D>
 static int launch_attn_d(const AttnP& p, hipStream_t st) {
   if (p.record_mode != 0) {
     if (p.Nk > 96) { agd_set_error("attention: recording needs Nk <= 96 (got %d)", p.Nk); return -1; }
+    if (p.record_mode == 3) {                    // head-summed rows: the block walks the heads
+      if (p.mask) { agd_set_error("attention: head-summed recording does not take an attention mask"); return -1; }
+      if (p.rec_hpb < 1 || p.H % p.rec_hpb) { agd_set_error("attention: rec_hpb %d does not divide %d heads", p.rec_hpb, p.H); return -1; }
+      return launch_attn_t<D, 3, 1, 2>(p, st);
+    }
     return p.mask ? launch_attn_t<D, 3, 1, 1, 1>(p, st) : launch_attn_t<D, 3, 1, 1>(p, st);
   }
   if (p.mask) {                                  // processor-seam calls with an attention_mask (never on the SD hot path)

@@ -57,9 +57,11 @@ struct AttnP {
   long long sq, sk, sv, so;         // per-batch strides in elements
   int B, H, D, Nq, Nk;
   float scale;
-  int record_mode; int rec_b0;      // first batch row that records (B/2 for CFG inference, 0 for train)
+  int record_mode; int rec_b0;      // 0 none, 1 per-(image, head) rows += P, 2 hook.py (per-head rows = P), 3 per-image rows += sum over heads of P;
+                                    // rec_b0 = first batch row that records (B/2 for CFG inference, 0 for train)
   float* rec; long long rec_img_stride; long long rec_head_stride;  // DAAM: [img][head][T][Nq]
   int rec_T;                        // number of token rows to record (<= Nk)
+  int rec_hpb;                      // record_mode 3: heads summed per block (divides H); rows [img][H / rec_hpb][T][Nq]
   int nqt;                          // set by the launcher: query tiles per (batch, head)
   int causal;                       // 1: key j attends only to queries i >= j (CLIP text encoder)
   const float* mask;                // additive fp32 [B][Nk] (broadcast over heads and queries) or NULL

@@ -65,6 +65,7 @@ struct DBuf {
 struct XLayer {
   std::string name; int C = 0, heads = 0, level = 0; bool mid = false;
   WMat wkv; DBuf kvb; bf16_t* kv = nullptr; DBuf accb; float* acc = nullptr; int acc_side = 0;
+  int acc_heads = 0;                                  // slices in acc per image: `heads`, or fewer = head-group sums (layers at latent resolution)
   DBuf wqTb, wkvTb, woTb; WMat wqT, wkvT, woT;        // transposed weights for the input-gradient GEMMs (built on first backward)
 };
 
@@ -268,7 +269,7 @@ static int run_attention(agd_ctx* c, hipStream_t st, int cls, AttnP& a) {
   // q read + o written + k/v read once per (batch, head); the recorder's read-modify-write of its fp32 rows on top
   double by = 2.0 * a.B * a.H * (double)a.D * (2.0 * a.Nq + 2.0 * a.Nk);
   if (a.record_mode == 1) by += 8.0 * (a.B - a.rec_b0) * a.H * (double)a.rec_T * a.Nq;
-  else if (a.record_mode == 2) by += 8.0 * (a.B - a.rec_b0) * (double)a.rec_T * a.Nq;
+  else if (a.record_mode == 2 || a.record_mode == 3) by += 8.0 * (a.B - a.rec_b0) * (double)a.rec_T * a.Nq;
   ProfScope ps(c, st, cls, fl, by);
   return launch_attention(a, st);
 }
@@ -287,8 +288,12 @@ static int cross_attention(agd_ctx* c, hipStream_t st, XLayer& xl, const bf16_t*
   if (record && c->rec_mode == 1 && !xl.mid && xl.acc) {
     // daam: factor = latent_side / side; recorded iff factor != 8 (mid block); conditional half only
     if (c->rec_L / side != 8 && side == xl.acc_side && B2 / 2 == c->rec_B) {
-      a.record_mode = 1; a.rec_b0 = B2 / 2; a.rec = xl.acc; a.rec_T = c->rec_T;
-      a.rec_head_stride = (long long)c->rec_T * N; a.rec_img_stride = a.rec_head_stride * xl.heads;
+      a.rec_b0 = B2 / 2; a.rec = xl.acc; a.rec_T = c->rec_T;
+      a.rec_head_stride = (long long)c->rec_T * N; a.rec_img_stride = a.rec_head_stride * xl.acc_heads;
+      if (xl.acc_heads < xl.heads) {                 // latent-resolution layer: head-group sums (attention.hip RECORD 2)
+        if (mask) FAIL("attention_mask together with daam recording at latent resolution is not supported");
+        a.record_mode = 3; a.rec_hpb = xl.heads / xl.acc_heads;
+      } else a.record_mode = 1;
     }
   } else if (record && c->rec_mode == 2 && c->hook_scratch) {
     const int b0 = c->rec_is_train ? 0 : B2 / 2;
@@ -1024,7 +1029,15 @@ AGD_API int agd_record_reset(agd_ctx* c, int batch, int L, void* stream) {
       const int side = L >> xl.level;
       if (side < 1 || (L / side) == 8) { xl.acc = nullptr; xl.acc_side = 0; continue; }
       // capacity-tracked: a larger batch / token count / side than the block was allocated for reallocates it
-      const size_t n = (size_t)batch * xl.heads * T * side * side;
+      // daam averages clamp(bicubic(map), 0) over every (layer, head) map.  At latent resolution the resize is the identity and the
+      // clamp cannot fire (sums of probabilities), so heads are summed in the recording kernel: down to 1/8 of the state and traffic
+      xl.acc_heads = xl.heads;
+      if (side == L) {       // heads per workgroup: as many as still leave >= 256 workgroups (UNet batch x head groups x 128-query tiles)
+        int hpb = xl.heads;
+        while (hpb > 1 && hpb % 2 == 0 && (long long)2 * batch * (xl.heads / hpb) * ((side * side + 127) / 128) < 256) hpb /= 2;
+        xl.acc_heads = xl.heads / hpb;
+      }
+      const size_t n = (size_t)batch * xl.acc_heads * T * side * side;
       API_CK(c, xl.accb.ensure(n * 4)); xl.acc = xl.accb.as<float>(); xl.acc_side = side;
       if (hipMemsetAsync(xl.acc, 0, n * 4, st) != hipSuccess) { agd_set_error("memset acc"); return fail_ctx(c); }
     }
@@ -1041,9 +1054,9 @@ AGD_API int agd_daam_global(agd_ctx* c, int img, int rows, float* out, void* str
   std::vector<HeatLayer> hl; int total = 0;
   for (auto& xl : c->xl) {
     if (!xl.acc || xl.mid) continue;
-    HeatLayer h; h.acc = xl.acc; h.side = xl.acc_side; h.heads = xl.heads;
-    h.head_stride = (long long)c->rec_T * xl.acc_side * xl.acc_side; h.img_stride = h.head_stride * xl.heads;
-    hl.push_back(h); total += xl.heads;
+    HeatLayer h; h.acc = xl.acc; h.side = xl.acc_side; h.heads = xl.acc_heads;
+    h.head_stride = (long long)c->rec_T * xl.acc_side * xl.acc_side; h.img_stride = h.head_stride * xl.acc_heads;
+    hl.push_back(h); total += xl.heads;                            // the mean is over (layer, head) maps either way
   }
   if (hl.empty() || c->rec_mode != 1) { agd_set_error("No heat maps found. Did you forget to call `with trace(...)`?"); c->err = g_err; return -2; }
   if (rows > c->rec_T || img >= c->rec_B) { agd_set_error("daam_global: rows %d > recorded %d or img %d >= %d", rows, c->rec_T, img, c->rec_B); return fail_ctx(c); }
@@ -1380,6 +1393,29 @@ AGD_API int agd_op_attention(const float* q, const float* k, const float* v, flo
   return 0;
 }
 
+// as agd_op_attention with the probabilities summed over the heads: probs_sum_out [B][Nk][Nq] (attention.hip RECORD 2)
+AGD_API int agd_op_attention_headsum(const float* q, const float* k, const float* v, float* o, int B, int H, int D, int Nq, int Nk,
+                                     float scale, float* probs_sum_out, void* stream) {
+  hipStream_t st = S(stream); Tmp tmp;
+  const int C = H * D;
+  if (!probs_sum_out) { agd_set_error("attention_headsum: probs_sum_out is required"); return -1; }
+  bf16_t* qb = tmp.get<bf16_t>((size_t)B * Nq * C); bf16_t* kb = tmp.get<bf16_t>((size_t)B * Nk * C);
+  bf16_t* vb = tmp.get<bf16_t>((size_t)B * Nk * C); bf16_t* ob = tmp.get<bf16_t>((size_t)B * Nq * C);
+  if (!qb || !kb || !vb || !ob) return -1;
+  CK(launch_f32_to_bf16(q, qb, (long long)B * Nq * C, st));
+  CK(launch_f32_to_bf16(k, kb, (long long)B * Nk * C, st));
+  CK(launch_f32_to_bf16(v, vb, (long long)B * Nk * C, st));
+  AttnP a{}; a.q = qb; a.k = kb; a.v = vb; a.o = ob; a.ldq = a.ldk = a.ldv = a.ldo = C;
+  a.sq = (long long)Nq * C; a.so = a.sq; a.sk = (long long)Nk * C; a.sv = a.sk;
+  a.B = B; a.H = H; a.D = D; a.Nq = Nq; a.Nk = Nk; a.scale = scale;
+  if (hipMemsetAsync(probs_sum_out, 0, (size_t)B * Nk * Nq * 4, st) != hipSuccess) { agd_set_error("memset probs"); return -1; }
+  a.record_mode = 3; a.rec_hpb = H; a.rec_b0 = 0; a.rec = probs_sum_out; a.rec_T = Nk; a.rec_img_stride = (long long)Nk * Nq;
+  CK(launch_attention(a, st));
+  CK(launch_bf16_to_f32(ob, o, (long long)B * Nq * C, st));
+  hipStreamSynchronize(st);
+  return 0;
+}
+
 AGD_API int agd_op_bicubic_clamp_mean(const float* maps, int n_maps, int T, int side, int S_, float* out, void* stream) {
   hipStream_t st = S(stream);
   // n_maps accumulators of [T][side][side]: treat as one layer with n_maps "heads"
@@ -1450,7 +1486,7 @@ AGD_API int agd_bench_attention(int B, int H, int D, int Nq, int Nk, int record,
   // self: packed qkv rows [3C]; cross: q [C], kv [2C]
   bf16_t* q = tmp.get<bf16_t>((size_t)B * Nq * (self ? 3 * C : C)); bf16_t* kv = self ? nullptr : tmp.get<bf16_t>((size_t)B * Nk * 2 * C);
   bf16_t* o = tmp.get<bf16_t>((size_t)B * Nq * C);
-  float* rec = record ? tmp.get<float>((size_t)B * H * Nk * Nq) : nullptr;
+  float* rec = record ? tmp.get<float>((size_t)B * H * Nk * Nq) : nullptr;     // record: 1 per-head rows, 2 head-summed rows
   if (!q || !o || (!self && !kv) || (record && !rec)) return -1;
   fill_rand(q, (long long)B * Nq * (self ? 3 * C : C), 5, 1.0f); if (kv) fill_rand(kv, (long long)B * Nk * 2 * C, 6, 1.0f);
   if (rec) hipMemset(rec, 0, (size_t)B * H * Nk * Nq * 4);
@@ -1458,7 +1494,9 @@ AGD_API int agd_bench_attention(int B, int H, int D, int Nq, int Nk, int record,
   if (self) { a.q = q; a.k = q + C; a.v = q + 2 * C; a.ldq = a.ldk = a.ldv = 3 * C; a.sq = a.sk = a.sv = (long long)Nq * 3 * C; }
   else { a.q = q; a.k = kv; a.v = kv + C; a.ldq = C; a.ldk = a.ldv = 2 * C; a.sq = (long long)Nq * C; a.sk = a.sv = (long long)Nk * 2 * C; }
   a.o = o; a.ldo = C; a.so = (long long)Nq * C; a.B = B; a.H = H; a.D = D; a.Nq = Nq; a.Nk = Nk; a.scale = 1.0f / sqrtf((float)D);
-  if (record) { a.record_mode = 1; a.rec_b0 = B / 2; a.rec = rec; a.rec_T = Nk; a.rec_head_stride = (long long)Nk * Nq; a.rec_img_stride = a.rec_head_stride * H; }
+  // record: 1 per-head rows; 2, 3, 4 = head-group sums with 8, 4, 2 heads per workgroup
+  if (record) { a.record_mode = record >= 2 ? 3 : 1; a.rec_hpb = record >= 2 ? (16 >> record < H ? 16 >> record : H) : 0; a.rec_b0 = B / 2; a.rec = rec;
+                a.rec_T = Nk; a.rec_head_stride = (long long)Nk * Nq; a.rec_img_stride = a.rec_head_stride * (record >= 2 ? H / a.rec_hpb : H); }
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   for (int i = 0; i < 2; ++i) CK(launch_attention(a, 0));
   hipEventRecord(e0, 0);

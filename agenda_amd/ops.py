@@ -81,6 +81,22 @@ def attention(q, k, v, heads, scale=None, return_probs=False):
     return (o, probs) if return_probs else o
 
 
+def attention_headsum(q, k, v, heads, scale=None):
+    """As `attention(..., return_probs=True)` with the probabilities summed over the heads: probs [B,Nk,Nq] (Nk<=96) -- the form
+    the daam recorder keeps for the layers at latent resolution."""
+    lib = _lib.load()
+    q, k, v = _f32c(q), _f32c(k), _f32c(v)
+    B, Nq, Cc = q.shape
+    Nk = k.shape[1]
+    D = Cc // heads
+    scale = D ** -0.5 if scale is None else scale
+    o = torch.empty_like(q)
+    probs = torch.empty(B, Nk, Nq, device=q.device, dtype=torch.float32)
+    _lib.check(lib.agd_op_attention_headsum(_lib.ptr(q), _lib.ptr(k), _lib.ptr(v), _lib.ptr(o), B, heads, D, Nq, Nk, float(scale),
+                                            _lib.ptr(probs), _lib.current_stream_ptr()), None, "agd_op_attention_headsum")
+    return o, probs
+
+
 def bicubic_clamp_mean(maps, out_side):
     """maps [n_maps, T, side, side] -> mean_n clamp(bicubic(maps[n]), 0) : [T, S, S]"""
     lib = _lib.load()

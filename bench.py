@@ -211,6 +211,9 @@ def main():
         gbs = gb / (table["attn_cross_daam"]["ms"] * 1e-3)
         daam = {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
                 "algorithmic_GB_per_batch": round(gb, 2), "kernel": "attn_kernel<RECORD> (cross-attention + fused accumulate)",
+                # the 5 layers at latent resolution keep ONE head-summed accumulator per image (the aggregation is linear there):
+                # 5 x 77 x 4096 + (5 x 1024 + 5 x 256) x 8 x 77 fp32, read + written = 44.1 MB per image and step actually moved
+                "accumulator_rmw_GB_per_batch": round(44.1e-3 * args.ddim_steps * B, 2),
                 "traffic": pmc_traffic("attn_cross_daam")}
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -170,6 +170,9 @@ int agd_op_layernorm(const float* x, const float* gamma, const float* beta, floa
 /* q [B,Nq,H*D], k/v [B,Nk,H*D] fp32 -> o [B,Nq,H*D]; probs_out (may be NULL): [B,H,Nk,Nq] fp32, needs Nk<=96 */
 int agd_op_attention(const float* q, const float* k, const float* v, float* o, int B, int H, int D, int Nq, int Nk,
                      float scale, float* probs_out, void* stream);
+/* same, the probabilities summed over the heads (the recording form of the daam layers at latent resolution): probs_sum_out [B,Nk,Nq] */
+int agd_op_attention_headsum(const float* q, const float* k, const float* v, float* o, int B, int H, int D, int Nq, int Nk,
+                             float scale, float* probs_sum_out, void* stream);
 int agd_op_bicubic_clamp_mean(const float* maps, int n_maps, int T, int side, int S, float* out, void* stream);
 
 /* ---- export path on device, bit-exact with the reference's host code:

@@ -182,6 +182,24 @@ def test_cross_attention_with_probs(ops, B, H, D, Nq, Nk):
     assert float((probs.cpu().sum(2) - 1).abs().max()) < 1e-3   # rows of P sum to 1
 
 
+@pytest.mark.parametrize("B,H,D,Nq,Nk", [(2, 8, 40, 256, 77), (2, 8, 80, 200, 77), (2, 8, 160, 16, 77), (4, 5, 64, 130, 77), (1, 2, 32, 64, 20)])
+def test_cross_attention_head_summed_probs(ops, B, H, D, Nq, Nk):
+    """The recording form of the daam layers at latent resolution: one workgroup walks all heads of its query tile and adds the
+    head SUM of the probabilities once; the per-head outputs must be those of the per-head kernel."""
+    g = torch.Generator().manual_seed(3 * D + Nq)
+    q = bfr(torch.randn(B, Nq, H * D, generator=g))
+    k, v = (bfr(torch.randn(B, Nk, H * D, generator=g)) for _ in range(2))
+    want, p = _attn_ref(q, k, v, H)                       # p [B*H, Nq, Nk]
+    got, psum = ops.attention_headsum(q.cuda(), k.cuda(), v.cuda(), H)
+    assert rel_err(got, want) < REL
+    want_p = p.reshape(B, H, Nq, Nk).sum(1).permute(0, 2, 1)      # [B, Nk, Nq]
+    assert float((psum.cpu() - want_p).abs().max()) < 2e-3 * H
+    assert float((psum.cpu().sum(1) - H).abs().max()) < 1e-3 * H  # every head's row of P sums to 1
+    got1, probs = ops.attention(q.cuda(), k.cuda(), v.cuda(), H, return_probs=True)
+    assert torch.equal(got, got1)                                  # same arithmetic per head
+    assert float((psum - probs.sum(1)).abs().max()) < 1e-5
+
+
 def test_bicubic_clamp_mean_matches_torch(ops):
     g = torch.Generator().manual_seed(3)
     for side in (8, 16, 32, 64):
