@@ -160,6 +160,12 @@ struct GemmOpt {
 };
 static const int kTextExtraRows = 256;   // room for tokenizer.add_tokens() (learned tokens)
 
+// streams `n16` 16-byte words through the memory hierarchy and keeps nothing
+__global__ __launch_bounds__(256) void touch_kernel(const u32x4* __restrict__ p, long long n16, unsigned* __restrict__ sink) {
+  unsigned a = 0;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n16; i += (long long)gridDim.x * 256) { const u32x4 v = p[i]; a |= v[0] ^ v[1] ^ v[2] ^ v[3]; }
+  if (a == 0x9E3779B9u) *sink = a;
+}
 static int run_conv(agd_ctx* c, hipStream_t st, const bf16_t* s0, int C0, const bf16_t* s1, int C1, int B, int Hin, int Win,
                     const WMat& w, int ksize, void* out, const GemmOpt& o, const bf16_t* zero_page) {
   IgemmP p{};
@@ -1475,6 +1481,43 @@ AGD_API int agd_bench_conv(int B, int H, int W, int C0, int C1, int Cout, int ks
   hipEventRecord(b, 0); hipEventSynchronize(b);
   float t = 0; hipEventElapsedTime(&t, a, b);
   *ms_out = t / iters;
+  hipEventDestroy(a); hipEventDestroy(b);
+  return 0;
+}
+
+// One 1x1 / 3x3 launch with COLD weights, as inside the UNet walk (1.7 GB of weights per forward against 256 MB of Infinity Cache):
+// every iteration first overwrites a 1 GiB scratch (evicts L2 + Infinity Cache), rewrites the activation (hot, as after its
+// producer), then times [optional streaming touch of the weight matrix] + the launch.  warm: 0 = cold weights, 1 = touch then launch
+// (both timed), 2 = weights left hot (no flush of them: the touch runs untimed).  ms_out = mean of the timed regions.
+AGD_API int agd_bench_conv_cold(int B, int H, int W, int C0, int Cout, int ksize, int geglu, int with_residual, int warm, int iters, double* ms_out) {
+  Tmp tmp;
+  const int taps = ksize * ksize;
+  const long long M = (long long)B * H * W;
+  const int Nout = geglu ? Cout / 2 : Cout;
+  const size_t xn = (size_t)M * C0, wn = (size_t)Cout * taps * C0, flush_bytes = (size_t)1 << 30;
+  bf16_t* x0 = tmp.get<bf16_t>(xn); bf16_t* xs = tmp.get<bf16_t>(xn); bf16_t* w = tmp.get<bf16_t>(wn); bf16_t* y = tmp.get<bf16_t>((size_t)M * Nout);
+  bf16_t* r = with_residual ? tmp.get<bf16_t>((size_t)M * Nout) : nullptr;
+  float* bias = tmp.get<float>(Cout); char* scratch = tmp.get<char>(flush_bytes); unsigned* sink = tmp.get<unsigned>(64);
+  if (!x0 || !xs || !w || !y || !bias || !scratch || !sink || (with_residual && !r)) return -1;
+  fill_rand(xs, (long long)xn, 1, 1.0f); fill_rand(w, (long long)wn, 3, 0.05f); if (r) fill_rand(r, M * Nout, 4, 1.0f);
+  hipMemset(bias, 0, Cout * 4);
+  WMat wm; wm.w = w; wm.N = Cout; wm.Cin = C0; wm.Cpad = C0; wm.taps = taps;
+  GemmOpt o; o.bias = bias; o.geglu = geglu; o.residual = r;
+  hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+  double tot = 0;
+  for (int i = 0; i < iters + 1; ++i) {
+    hipMemsetAsync(scratch, i, flush_bytes, 0);
+    hipMemcpyAsync(x0, xs, xn * 2, hipMemcpyDeviceToDevice, 0);
+    if (r) hipMemcpyAsync(y, r, (size_t)M * Nout * 2, hipMemcpyDeviceToDevice, 0);       // touches the residual / output lines
+    if (warm == 2) hipLaunchKernelGGL(touch_kernel, dim3(1024), dim3(256), 0, 0, (const u32x4*)w, (long long)(wn * 2 / 16), sink);
+    hipEventRecord(a, 0);
+    if (warm == 1) hipLaunchKernelGGL(touch_kernel, dim3(1024), dim3(256), 0, 0, (const u32x4*)w, (long long)(wn * 2 / 16), sink);
+    CK(run_conv(nullptr, 0, x0, C0, nullptr, 0, B, H, W, wm, ksize, y, o, op_zero_page()));
+    hipEventRecord(b, 0); hipEventSynchronize(b);
+    float t = 0; hipEventElapsedTime(&t, a, b);
+    if (i > 0) tot += t;
+  }
+  *ms_out = tot / iters;
   hipEventDestroy(a); hipEventDestroy(b);
   return 0;
 }

@@ -116,6 +116,7 @@ def main():
     ap.add_argument("--ddim-steps", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE", help="engine option (agd_set_option), for A/B runs")
     args = ap.parse_args()
 
     import torch                                             # device_count() does not initialise the GPU on this image
@@ -149,6 +150,9 @@ def main():
     B = args.batch
     pipe = StableDiffusionPipeline.from_synthetic("sd15", seed=1234, device=local, weights_device="cuda", keep_weights=True,
                                                   workspace_bytes=12 << 30)
+    for kv in args.option:
+        name, _, val = kv.partition("=")
+        pipe.engine.set_option(name, int(val))
     cfg = pipe.cfg
     ctx = synthetic.make_context(cfg, B, seed=7)
     word_rows = [[5], [8, 9]]                      # two "words" (one single-token, one two-token)

@@ -100,7 +100,8 @@ int agd_vae_decode(agd_ctx* ctx, const float* latents, int batch, int latent_sid
 int agd_vae_encode(agd_ctx* ctx, const float* image, int batch, int side, float* mean_out, float* logvar_out, void* stream);
 
 /* ---- per-ctx options (no environment variables steer the library).  "cfg_shared_prefix" (default 1): agd_denoise runs the
- * layers ahead of the first cross-attention once for the identical unconditional / conditional halves (bit-identical to 0). */
+ * layers ahead of the first cross-attention once for the identical unconditional / conditional halves (bit-identical to 0).
+ * "ln_fold", "gn_fused_stats" (default 1): LayerNorm / GroupNorm statistics produced by the GEMM that writes the activation. */
 int agd_set_option(agd_ctx* ctx, const char* name, int value);
 
 /* ---- heat-map recording (daam.trace / hook.py UNetCrossAttentionHooker state)
@@ -200,6 +201,8 @@ const char* agd_profile_class_name(int cls);
 int agd_bench_conv(int B, int H, int W, int C0, int C1, int Cout, int ksize, int stride, int up, int geglu, int with_residual,
                    int iters, double* ms_out);
 int agd_bench_attention(int B, int H, int D, int Nq, int Nk, int record, int iters, double* ms_out);
+/* one launch with cold weights (caches flushed per iteration); warm: 0 cold, 1 streaming touch of the weights timed with the launch, 2 weights hot */
+int agd_bench_conv_cold(int B, int H, int W, int C0, int Cout, int ksize, int geglu, int with_residual, int warm, int iters, double* ms_out);
 int agd_bench_groupnorm(int B, int HW, int C, int iters, double* ms_out);
 int agd_bench_groupnorm_ex(int B, int HW, int C0, int C1, int fused_stats, int iters, double* ms_out);
 
