@@ -104,6 +104,8 @@ struct agd_ctx {
   int opt_cfg_share = 1;                              // agd_set_option("cfg_shared_prefix")
   int opt_ln_fold = 1;                                // agd_set_option("ln_fold"): LayerNorm folded into the GEMMs around it
   int opt_gn_fused = 1;                               // agd_set_option("gn_fused_stats"): GroupNorm statistics from the producing igemm's epilogue
+  int opt_touch = 3;                                  // agd_set_option("weight_touch"): n > 0 = stream 1x1 weight matrices of >= n MB through the caches right before their launch
+  unsigned* touch_sink = nullptr;
   // profiling
   bool prof_on = false; std::vector<ProfEv> prof; std::vector<hipEvent_t> ev_pool; size_t ev_used = 0;
   long long launches[AGD_N_CLASSES] = {0};
@@ -196,6 +198,14 @@ static int run_conv(agd_ctx* c, hipStream_t st, const bf16_t* s0, int C0, const 
   // algorithmic HBM bytes: every input pixel / weight read once, the output written once (+ the residual read)
   const double in_b = 2.0 * B * Hin * Win * (double)(C0 + C1), w_b = 2.0 * p.N * (double)p.K;
   const double out_b = (double)p.M * nout * (o.out_f32 ? 4.0 : 2.0) + (o.residual ? 2.0 * p.M * nout : 0.0);
+  if (c && c->opt_touch > 0 && ksize == 1 && p.M <= 8192 && w_b >= c->opt_touch * 1e6) {
+    // the weights arrive cold (1.7 GB per forward against 256 MB of Infinity Cache): a full-rate streaming read in front of the launch
+    // costs less than the tile-by-tile cold misses inside it (tools/kb_cold.py; in situ 575.5 -> 572.3 ms per batch, tools/ab_option.py;
+    // touching the 3x3 matrices of the 16x16 maps as well gave the gain back)
+    if (!c->touch_sink) c->touch_sink = dmalloc<unsigned>(c, 64);
+    if (c->touch_sink) { ProfScope pt(c, st, PC_ELEM, 0, w_b);
+      hipLaunchKernelGGL(touch_kernel, dim3(1024), dim3(256), 0, st, (const u32x4*)w.w, (long long)(w_b / 16), c->touch_sink); }
+  }
   ProfScope ps(c, st, ksize == 3 ? PC_CONV3 : PC_GEMM, 2.0 * p.M * (double)p.N * p.K, in_b + w_b + out_b);
   return launch_igemm(p, st);
 }
@@ -989,6 +999,7 @@ AGD_API int agd_set_option(agd_ctx* c, const char* name, int value) {
   if (!strcmp(name, "cfg_shared_prefix")) { c->opt_cfg_share = value != 0; return 0; }
   if (!strcmp(name, "ln_fold")) { c->opt_ln_fold = value; return 0; }       // 0 off, 1 on; 2 / 3: only blocks with C <= 320 / 640 (A/B)
   if (!strcmp(name, "gn_fused_stats")) { c->opt_gn_fused = value != 0; return 0; }
+  if (!strcmp(name, "weight_touch")) { c->opt_touch = value < 0 ? 0 : value; return 0; }
   agd_set_error("set_option: unknown option '%s'", name);
   return fail_ctx(c);
 }

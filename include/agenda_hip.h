@@ -101,7 +101,9 @@ int agd_vae_encode(agd_ctx* ctx, const float* image, int batch, int side, float*
 
 /* ---- per-ctx options (no environment variables steer the library).  "cfg_shared_prefix" (default 1): agd_denoise runs the
  * layers ahead of the first cross-attention once for the identical unconditional / conditional halves (bit-identical to 0).
- * "ln_fold", "gn_fused_stats" (default 1): LayerNorm / GroupNorm statistics produced by the GEMM that writes the activation. */
+ * "ln_fold", "gn_fused_stats" (default 1): LayerNorm / GroupNorm statistics produced by the GEMM that writes the activation.
+ * "weight_touch" (default 3; 0 off): 1x1 weight matrices of at least that many MB are streamed through the caches by a read-only
+ * kernel right in front of the launch that uses them (the UNet's 1.7 GB of weights never stay in the 256 MB Infinity Cache). */
 int agd_set_option(agd_ctx* ctx, const char* name, int value);
 
 /* ---- heat-map recording (daam.trace / hook.py UNetCrossAttentionHooker state)
