@@ -423,6 +423,7 @@ int launch_igemm(const IgemmP& p_in, hipStream_t st) {
     static int f_bn = -1, f_s = 1, f_st = 2;
     if (f_bn < 0) { const char* e = getenv("AGD_IGEMM_FORCE"); f_bn = 0; if (e) sscanf(e, "%d:%d:%d", &f_bn, &f_s, &f_st); }
     if (f_bn == 256 && batch == 1) return f_st == 2 ? launch_cfg<256, 128, 4, 2, 2>(p, 1, st) : launch_cfg<256, 128, 4, 2, 3>(p, 1, st);
+    if (f_bn == 128 && p.geglu && batch == 1) return f_st == 4 ? launch_cfg<128, 128, 2, 2, 4>(p, 1, st) : launch_cfg<128, 128, 2, 2>(p, 1, st);
     if (f_bn > 0 && !p.geglu && batch == 1) {
       int S = f_s; if (S > nk / 2) S = nk / 2; if (S < 1) S = 1;
       if (S >= 2) CK0(ensure_splitk(p, S));
