@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libagenda_hip.so")
 AGD_MAX_LEVELS = 8
-AGD_N_CLASSES = 10
+AGD_N_CLASSES = 11
 
 
 class AgdConfig(C.Structure):

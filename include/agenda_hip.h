@@ -189,7 +189,7 @@ int agd_op_stack_heatmaps(const unsigned char* obj, const unsigned char* fg, con
                           unsigned char* rgb, unsigned char* inv, void* stream);
 
 /* ---- per-kernel-class timing (HIP events on the launch stream) */
-#define AGD_N_CLASSES 10
+#define AGD_N_CLASSES 11
 int agd_profile_begin(agd_ctx* ctx);
 int agd_profile_end(agd_ctx* ctx, double* ms, double* flops, long long* launches);  /* arrays of AGD_N_CLASSES; syncs */
 /* the same plus, per class, the algorithmic HBM bytes and roof_ms = Sum over launches of max(flop / mfma_peak_flops,
