@@ -159,6 +159,26 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_kernel(const IgemmP p) 
     bsoff = (unsigned)ks0 * 128u;
   }
 
+  // Cold-weight warm-up (W-major launches: the weight matrix is the big operand and arrives from HBM -- the UNet's 1.7 GB of weights never
+  // stay in the 256 MB Infinity Cache).  The launch's first ~512 workgroups (co-resident) stream the contiguous slice of W that THEIR
+  // XCD's tiles will read (xcd_remap gives every XCD a contiguous range of logical ids, W-major = a contiguous row range) through the
+  // XCD's L2 at full memory-level parallelism, instead of every tile meeting its rows cold one 16 KB K step at a time.  The pieces land
+  // in a scratch KiB per wave behind the ring; speed only (any block placement is correct).
+  if (p.warm && blockIdx.y == 0 && blockIdx.z == 0 && (blockIdx.x >> 3) < 64) {
+    const int nwg = gridDim.x, x = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int q8 = nwg >> 3, r8 = nwg & 7;
+    const int lbase = x < r8 ? x * (q8 + 1) : r8 * (q8 + 1) + (x - r8) * q8, lcnt = q8 + (x < r8 ? 1 : 0);
+    if (lcnt > 0) {
+      const int tiles_m = (p.M + BM - 1) / BM;
+      const int tn0 = lbase / tiles_m, tn1 = (lbase + lcnt - 1) / tiles_m;
+      const int r0 = tn0 * BN, r1 = (tn1 + 1) * BN < p.N ? (tn1 + 1) * BN : p.N;
+      const long long b0 = (long long)r0 * p.K * 2, pieces = ((long long)(r1 - r0) * p.K * 2) >> 10;
+      const long long p0 = pieces * j / 64, p1 = pieces * (j + 1) / 64;
+      char* wl = smem + STAGES * STAGE + wid * 1024;
+      for (long long pc = p0 + wid; pc < p1; pc += NW) bufdma16(baseW, wl, (unsigned)(b0 + pc * 1024 + lane * 16), 0u);
+    }
+  }
+
   // prologue stage fill; live == false issues the same instructions through a zero-record descriptor (dropped):
   // keeps the per-wave vmcnt arithmetic of the deeper rings uniform when the K range is shorter than the ring
   auto issue = [&](int slot, bool live) {
@@ -319,7 +339,7 @@ template <int BM, int BN, int WM, int WN, int KS, int STAGES, int GEGLU, int SPL
 static int launch_one(const IgemmP& p, int splits, hipStream_t st) {
   constexpr int NT = WM * WN * 64;
   constexpr int stage = (BM + BN) * 128;
-  constexpr int lds = STAGES * stage;
+  constexpr int lds = STAGES * stage + 4096;             // + one scratch KiB per wave (cold-weight warm-up pieces)
   const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
   dim3 grid(tiles, p.batch > 0 ? p.batch : 1, splits);
   auto kfn = igemm_kernel<BM, BN, WM, WN, KS, STAGES, GEGLU, SPLITK>;
@@ -412,6 +432,7 @@ int launch_igemm(const IgemmP& p_in, hipStream_t st) {
     // measured (tools/kb_lin.py, AGD_IGEMM_WMAJOR): M=2048 K=1280 GEGLU 79.6 -> 66.8 us, qkv 25.4 -> 24.6; 3x3 convs get SLOWER W-major
     // (72.0 -> 74.6: their tap re-reads of the A rows stop hitting in L2), so 1x1 only
     p.wmajor = (batch == 1 && p.ksize == 1 && w_bytes > 1.5 * a_bytes) ? 1 : 0;
+    if (!p.wmajor || w_bytes < (double)(1 << 20) || w_bytes >= 2147483648.0) p.warm = 0;
 #ifdef AGD_EXPERIMENTS
     { static int f = -2; if (f == -2) { const char* e = getenv("AGD_IGEMM_WMAJOR"); f = e ? atoi(e) : -1; } if (f >= 0) p.wmajor = f && batch == 1; }
 #endif

@@ -40,6 +40,7 @@ struct IgemmP {
   const float* ln_stats; int ln_slots; const float* ln_cs; float ln_invC, ln_eps;
   int* cfg_out;                     // host pointer: igemm_query() -- report {BM, BN, splits} instead of launching
   int wmajor;                       // set by the launcher: 1 = consecutive tiles share the weight panel (W-major walk), else the A panel
+  int warm;                         // caller: 1 = cold weights expected; the launcher keeps it only for W-major launches (in-kernel warm-up of the XCD's W slice)
   int stagger;                      // set by the launcher: start delay of the CU's second workgroup, x1024 cycles (speed only)
   int dbg;                          // timing experiments only (builds with -DAGD_EXPERIMENTS)
 };
