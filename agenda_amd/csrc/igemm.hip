@@ -164,7 +164,18 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_kernel(const IgemmP p) 
   // XCD's tiles will read (xcd_remap gives every XCD a contiguous range of logical ids, W-major = a contiguous row range) through the
   // XCD's L2 at full memory-level parallelism, instead of every tile meeting its rows cold one 16 KB K step at a time.  The pieces land
   // in a scratch KiB per wave behind the ring; speed only (any block placement is correct).
-  if (p.warm && blockIdx.y == 0 && blockIdx.z == 0 && (blockIdx.x >> 3) < 64) {
+  if (p.warm == 2) {
+    // A-major launches with a large weight matrix (every XCD reads all of W): the first workgroups stream W once, 1/nb each, so the
+    // other XCDs and later tiles find it in the Infinity Cache instead of HBM
+    const int lin = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    const int tot = gridDim.x * gridDim.y * gridDim.z, nb = tot < 512 ? tot : 512;
+    if (lin < nb) {
+      const long long pieces = ((long long)p.N * p.K * 2) >> 10;
+      const long long p0 = pieces * lin / nb, p1 = pieces * (lin + 1) / nb;
+      char* wl = smem + STAGES * STAGE + wid * 1024;
+      for (long long pc = p0 + wid; pc < p1; pc += NW) bufdma16(baseW, wl, (unsigned)(pc * 1024 + lane * 16), 0u);
+    }
+  } else if (p.warm && blockIdx.y == 0 && blockIdx.z == 0 && (blockIdx.x >> 3) < 64) {
     const int nwg = gridDim.x, x = blockIdx.x & 7, j = blockIdx.x >> 3;
     const int q8 = nwg >> 3, r8 = nwg & 7;
     const int lbase = x < r8 ? x * (q8 + 1) : r8 * (q8 + 1) + (x - r8) * q8, lcnt = q8 + (x < r8 ? 1 : 0);
@@ -432,7 +443,16 @@ int launch_igemm(const IgemmP& p_in, hipStream_t st) {
     // measured (tools/kb_lin.py, AGD_IGEMM_WMAJOR): M=2048 K=1280 GEGLU 79.6 -> 66.8 us, qkv 25.4 -> 24.6; 3x3 convs get SLOWER W-major
     // (72.0 -> 74.6: their tap re-reads of the A rows stop hitting in L2), so 1x1 only
     p.wmajor = (batch == 1 && p.ksize == 1 && w_bytes > 1.5 * a_bytes) ? 1 : 0;
-    if (!p.wmajor || w_bytes < (double)(1 << 20) || w_bytes >= 2147483648.0) p.warm = 0;
+    if (p.warm) {   // 1: W-major, per-XCD slices; 2: A-major with a matrix worth streaming once (p.warm as given: 1 = W-major only, 3 = both)
+      const int req = p.warm;
+      p.warm = 0;
+      if (w_bytes < 2147483648.0 && batch == 1) {
+        // measured in situ (tools/ab_option.py weight_warm): W-major only 571.4; + A-major >= 3 MB, M <= 8192: 565.6; M >= 1024 only: ~563;
+        // M <= 32768: 560.6; >= 1 MB: -2.7 more; 0.25 .. 1 MB thresholds equal, 2 MB worse; the 8x8 maps (M = 512, split-K 8) lose
+        if (p.wmajor && w_bytes >= (double)(1 << 20)) p.warm = 1;
+        else if (!p.wmajor && req == 3 && w_bytes >= 1e6 && p.M >= 1024 && p.M <= 32768) p.warm = 2;
+      }
+    }
 #ifdef AGD_EXPERIMENTS
     { static int f = -2; if (f == -2) { const char* e = getenv("AGD_IGEMM_WMAJOR"); f = e ? atoi(e) : -1; } if (f >= 0) p.wmajor = f && batch == 1; }
 #endif

@@ -104,7 +104,7 @@ struct agd_ctx {
   int opt_cfg_share = 1;                              // agd_set_option("cfg_shared_prefix")
   int opt_ln_fold = 1;                                // agd_set_option("ln_fold"): LayerNorm folded into the GEMMs around it
   int opt_gn_fused = 1;                               // agd_set_option("gn_fused_stats"): GroupNorm statistics from the producing igemm's epilogue
-  int opt_warm = 1;                                   // agd_set_option("weight_warm"): in-kernel warm-up of the XCD's weight slice on W-major launches (replaces the touch there)
+  int opt_warm = 3;                                   // agd_set_option("weight_warm"): in-kernel cold-weight warm-up: 1 = W-major launches (per-XCD slices), 3 = A-major launches too
   int opt_touch = 3;                                  // agd_set_option("weight_touch"): n > 0 = stream 1x1 weight matrices of >= n MB through the caches right before their launch
   unsigned* touch_sink = nullptr;
   // profiling
@@ -202,8 +202,9 @@ static int run_conv(agd_ctx* c, hipStream_t st, const bf16_t* s0, int C0, const 
   const double out_b = (double)p.M * nout * (o.out_f32 ? 4.0 : 2.0) + (o.residual ? 2.0 * p.M * nout : 0.0);
   // W-major launches (weights >= 1.5x the activations) warm their weights inside the kernel; the launcher's rule restated here
   const bool wmaj = ksize == 1 && w_b > 1.5 * in_b && w_b >= (double)(1 << 20);
-  if ((c && c->opt_warm && wmaj) || o.warm) p.warm = 1;
-  if (c && c->opt_touch > 0 && ksize == 1 && p.M <= 8192 && w_b >= c->opt_touch * 1e6 && !p.warm) {
+  if (c && c->opt_warm) p.warm = c->opt_warm == 1 ? 1 : 3;      // 1: W-major launches only; 3: also A-major launches with >= 1 MB of weights (the launcher decides)
+  if (o.warm) p.warm = o.warm;
+  if (c && c->opt_touch > 0 && ksize == 1 && p.M <= 8192 && w_b >= c->opt_touch * 1e6 && !(c->opt_warm && wmaj) && c->opt_warm != 3) {
     // the weights arrive cold (1.7 GB per forward against 256 MB of Infinity Cache): a full-rate streaming read in front of the launch
     // costs less than the tile-by-tile cold misses inside it (tools/kb_cold.py; in situ 575.5 -> 572.3 ms per batch, tools/ab_option.py;
     // touching the 3x3 matrices of the 16x16 maps as well gave the gain back)
@@ -1005,7 +1006,7 @@ AGD_API int agd_set_option(agd_ctx* c, const char* name, int value) {
   if (!strcmp(name, "ln_fold")) { c->opt_ln_fold = value; return 0; }       // 0 off, 1 on; 2 / 3: only blocks with C <= 320 / 640 (A/B)
   if (!strcmp(name, "gn_fused_stats")) { c->opt_gn_fused = value != 0; return 0; }
   if (!strcmp(name, "weight_touch")) { c->opt_touch = value < 0 ? 0 : value; return 0; }
-  if (!strcmp(name, "weight_warm")) { c->opt_warm = value != 0; return 0; }
+  if (!strcmp(name, "weight_warm")) { c->opt_warm = value; return 0; }
   agd_set_error("set_option: unknown option '%s'", name);
   return fail_ctx(c);
 }
@@ -1519,7 +1520,7 @@ AGD_API int agd_bench_conv_cold(int B, int H, int W, int C0, int Cout, int ksize
   fill_rand(xs, (long long)xn, 1, 1.0f); fill_rand(w, (long long)wn, 3, 0.05f); if (r) fill_rand(r, M * Nout, 4, 1.0f);
   hipMemset(bias, 0, Cout * 4);
   WMat wm; wm.w = w; wm.N = Cout; wm.Cin = C0; wm.Cpad = C0; wm.taps = taps;
-  GemmOpt o; o.bias = bias; o.geglu = geglu; o.residual = r; o.warm = warm == 3;      // warm 3: cold weights, in-kernel warm-up
+  GemmOpt o; o.bias = bias; o.geglu = geglu; o.residual = r; o.warm = warm == 3 ? 3 : 0;      // warm 3: cold weights, in-kernel warm-up
   hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
   double tot = 0;
   for (int i = 0; i < iters + 1; ++i) {

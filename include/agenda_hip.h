@@ -104,8 +104,9 @@ int agd_vae_encode(agd_ctx* ctx, const float* image, int batch, int side, float*
  * "ln_fold", "gn_fused_stats" (default 1): LayerNorm / GroupNorm statistics produced by the GEMM that writes the activation.
  * "weight_touch" (default 3; 0 off): 1x1 weight matrices of at least that many MB are streamed through the caches by a read-only
  * kernel right in front of the launch that uses them (the UNet's 1.7 GB of weights never stay in the 256 MB Infinity Cache).
- * "weight_warm" (default 1): launches whose weights outweigh their activations warm the weights inside the kernel instead (the first
- * workgroups stream their XCD's slice of the matrix through that XCD's L2). */
+ * "weight_warm" (default 3; 0 off): the first workgroups of a launch stream its weight matrix through the caches before their main
+ * loops -- 1: only launches whose weights outweigh their activations (each XCD its own slice, into its L2); 3: every launch with
+ * >= 1 MB of weights and 1024 <= M <= 32768 (the touch launches then disappear). */
 int agd_set_option(agd_ctx* ctx, const char* name, int value);
 
 /* ---- heat-map recording (daam.trace / hook.py UNetCrossAttentionHooker state)
