@@ -105,6 +105,28 @@ def sd15_pipe(sd15_host_weights):
     pipe.engine.close()
 
 
+def test_cold_weight_warmup_options_do_not_change_results(sd15_cuda):
+    """`weight_warm` (in-kernel streaming of the weight matrix ahead of the main loops) and `weight_touch` (a read-only launch in
+    front of a weight-heavy launch) only move bytes through the caches: the UNet output must be bit-identical with them off."""
+    from agenda_amd import synthetic
+    pipe = sd15_cuda
+    cfg = pipe.cfg
+    ctx = synthetic.make_context(cfg, 1, seed=11)
+    lat = synthetic.make_latents(cfg, [3], 64)
+    x = torch.cat([lat, lat]).to(torch.bfloat16).float()
+    pipe.engine.set_context(ctx)
+    outs = []
+    for warm, touch in ((3, 3), (0, 0), (1, 3), (0, 3)):
+        pipe.engine.set_option("weight_warm", warm)
+        pipe.engine.set_option("weight_touch", touch)
+        outs.append(pipe.engine.unet_forward(x, 500.0).clone())
+    pipe.engine.set_option("weight_warm", 3)
+    pipe.engine.set_option("weight_touch", 3)
+    assert torch.isfinite(outs[0]).all()
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0])
+
+
 def test_sd15_unet_forward_512px_matches_oracle(sd15_host_weights, sd15_pipe):
     """BASELINE config 2 at ITS OWN size: SD-1.5, 512 px (latent 64, 4096 tokens), CFG batch 2, one UNet forward with the
     DAAM recorder on -- the forward bench.py times -- against the fp32 CPU oracle (data_generation.py:57-64 semantics)."""
