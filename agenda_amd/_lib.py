@@ -73,6 +73,7 @@ _SIGS = {
     "agd_op_attn_reg_loss": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, _P, _P, C.c_float, _P, _P, _P]),
     "agd_attn_processor_backward": (C.c_int, [_P, C.c_char_p, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P]),
     "agd_op_conv2d": (C.c_int, [_P, _P, _P, _P] + [C.c_int] * 9 + [_P]),
+    "agd_op_conv2d_ex": (C.c_int, [_P, _P, _P, _P] + [C.c_int] * 10 + [_P]),
     "agd_op_linear": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "agd_op_groupnorm": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, _P]),
     "agd_op_conv_groupnorm": (C.c_int, [_P] * 6 + [C.c_int] * 6 + [C.c_float, C.c_int, C.c_int, _P]),

@@ -26,6 +26,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include "igemm_epilogue.h"
+#include "igemm_halo.h"
 #include <cstdlib>
 #define CK0(expr) do { if ((expr) != 0) return -1; } while (0)
 
@@ -364,6 +365,28 @@ static int launch_one(const IgemmP& p, int splits, hipStream_t st) {
   return 0;
 }
 
+// row-halo 3x3 kernel (igemm_halo.h): stride 1, pad 1, no upsample, tile rows = whole image rows (or 128-pixel row segments)
+static bool halo_ok(const IgemmP& p) {
+  return p.halo && p.ksize == 3 && p.stride == 1 && p.up == 1 && p.pad == 1 && p.Hin == p.Hout && p.Win == p.Wout && p.batch <= 1 &&
+         !p.geglu && p.Win >= 16 && (p.Win <= 128 ? 128 % p.Win == 0 : p.Win % 128 == 0) &&      // 8x8 maps (8-way split-K) measured 4 % slower
+         (long long)p.Hin * p.Win * (p.C0 > p.C1 ? p.C0 : p.C1) * (p.M / (p.Hin * p.Win) + 1) < (1LL << 30);   // 32-bit byte offsets per source
+}
+template <int BN, int SPLITK, int BST>
+static int launch_halo(const IgemmP& p, int splits, hipStream_t st) {
+  const int Wt = p.Win < 128 ? p.Win : 128;
+  const int hr = (128 / Wt) * (Wt + 2), HRP = (hr + 7) & ~7;
+  const int lds = 2 * HRP * 128 + BST * BN * 128 + 4096;   // two A images of the tile's halo rows + the weight ring + the dead-piece sink
+  const int tiles = ((p.M + 127) / 128) * ((p.N + BN - 1) / BN);
+  auto kfn = igemm_halo_kernel<BN, SPLITK, BST>;
+  static bool attr[AGD_MAX_DEVICES] = {};
+  int dev = 0; HIP_CHECK_RET(hipGetDevice(&dev));
+  if (dev < 0 || dev >= AGD_MAX_DEVICES) { agd_set_error("igemm: device ordinal %d out of range", dev); return -1; }
+  if (!attr[dev]) { HIP_CHECK_RET(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 160 * 128 + BST * BN * 128 + 4096)); attr[dev] = true; }
+  hipLaunchKernelGGL(kfn, dim3(tiles, 1, splits), dim3(256), lds, st, p, Wt, HRP);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+
 template <int BM, int BN, int WM, int WN, int STAGES = 2>
 static int launch_cfg(const IgemmP& p, int splits, hipStream_t st) {
   if (p.cfg_out) { p.cfg_out[0] = BM; p.cfg_out[1] = BN; p.cfg_out[2] = splits; return 0; }   // igemm_query: report the dispatch decision only
@@ -373,8 +396,11 @@ static int launch_cfg(const IgemmP& p, int splits, hipStream_t st) {
   static const bool logit = getenv("AGD_IGEMM_LOG") != nullptr;      // tools/layer_report.py joins this with a kernel trace
   if (logit) fprintf(stderr, "IGEMM M=%d N=%d K=%d ks=%d stride=%d up=%d geglu=%d res=%d tile=%dx%d splits=%d batch=%d\n", p.M, p.N, p.K, p.ksize,
                      p.stride, p.up, p.geglu, p.residual ? 1 : 0, BM, BN, splits, p.batch > 0 ? p.batch : 1);
+  constexpr bool HALO_TILE = BM == 128 && WM == 2 && WN == 2 && (BN == 128 || BN == 160);
   if (splits > 1) {
-    int rc = (p.ksize == 3) ? launch_one<BM, BN, WM, WN, 3, STAGES, 0, 1>(p, splits, st) : launch_one<BM, BN, WM, WN, 1, STAGES, 0, 1>(p, splits, st);
+    int rc;
+    if constexpr (HALO_TILE) { rc = halo_ok(p) ? launch_halo<BN, 1, STAGES == 4 ? 4 : 2>(p, splits, st) : (p.ksize == 3) ? launch_one<BM, BN, WM, WN, 3, STAGES, 0, 1>(p, splits, st) : launch_one<BM, BN, WM, WN, 1, STAGES, 0, 1>(p, splits, st); }
+    else rc = (p.ksize == 3) ? launch_one<BM, BN, WM, WN, 3, STAGES, 0, 1>(p, splits, st) : launch_one<BM, BN, WM, WN, 1, STAGES, 0, 1>(p, splits, st);
     if (rc) return rc;
     const long long total = (long long)p.M * (p.N >> 2);
     const int grid = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
@@ -386,6 +412,7 @@ static int launch_cfg(const IgemmP& p, int splits, hipStream_t st) {
     if constexpr (BN / WN == 64) { if (p.ksize == 1) return launch_one<BM, BN, WM, WN, 1, STAGES, 1, 0>(p, 1, st); }
     agd_set_error("igemm: geglu only on 1x1 with the 128-wide tile"); return -1;
   }
+  if constexpr (HALO_TILE) { if (halo_ok(p)) return launch_halo<BN, 0, STAGES == 4 ? 4 : 2>(p, 1, st); }
   if (p.ksize == 3) return launch_one<BM, BN, WM, WN, 3, STAGES, 0, 0>(p, 1, st);
   return launch_one<BM, BN, WM, WN, 1, STAGES, 0, 0>(p, 1, st);
 }

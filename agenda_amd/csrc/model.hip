@@ -105,6 +105,7 @@ struct agd_ctx {
   int opt_ln_fold = 1;                                // agd_set_option("ln_fold"): LayerNorm folded into the GEMMs around it
   int opt_gn_fused = 1;                               // agd_set_option("gn_fused_stats"): GroupNorm statistics from the producing igemm's epilogue
   int opt_warm = 3;                                   // agd_set_option("weight_warm"): in-kernel cold-weight warm-up: 1 = W-major launches (per-XCD slices), 3 = A-major launches too
+  int opt_halo = 1;                                   // agd_set_option("conv_halo"): 3x3 stride-1 convs through the row-halo kernel (igemm_halo.h)
   int opt_touch = 3;                                  // agd_set_option("weight_touch"): n > 0 = stream 1x1 weight matrices of >= n MB through the caches right before their launch
   unsigned* touch_sink = nullptr;
   // profiling
@@ -159,6 +160,7 @@ struct GemmOpt {
   float* rowstat_out = nullptr; int rowstat_slots = 0;                                   // producer side of the LayerNorm fold
   const float* ln_stats = nullptr; int ln_slots = 0; const float* ln_cs = nullptr; float ln_invC = 0.f, ln_eps = 0.f;   // consumer side
   int warm = 0;                 // benches: request the in-kernel cold-weight warm-up (the walk sets it through the ctx option)
+  int halo = 0;                 // benches: allow the row-halo 3x3 kernel (the walk sets it through the ctx option)
   int pad = -1;                 // -1: 1 for 3x3, 0 for 1x1
   int hout = 0, wout = 0;       // >0: override (asymmetric (0,1,0,1) padding of the VAE encoder's stride-2 convs)
 };
@@ -204,6 +206,7 @@ static int run_conv(agd_ctx* c, hipStream_t st, const bf16_t* s0, int C0, const 
   const bool wmaj = ksize == 1 && w_b > 1.5 * in_b && w_b >= (double)(1 << 20);
   if (c && c->opt_warm) p.warm = c->opt_warm == 1 ? 1 : 3;      // 1: W-major launches only; 3: also A-major launches with >= 1 MB of weights (the launcher decides)
   if (o.warm) p.warm = o.warm;
+  p.halo = (c && c->opt_halo) || o.halo;
   if (c && c->opt_touch > 0 && ksize == 1 && p.M <= 8192 && w_b >= c->opt_touch * 1e6 && !(c->opt_warm && wmaj) && c->opt_warm != 3) {
     // the weights arrive cold (1.7 GB per forward against 256 MB of Infinity Cache): a full-rate streaming read in front of the launch
     // costs less than the tile-by-tile cold misses inside it (tools/kb_cold.py; in situ 575.5 -> 572.3 ms per batch, tools/ab_option.py;
@@ -1007,6 +1010,7 @@ AGD_API int agd_set_option(agd_ctx* c, const char* name, int value) {
   if (!strcmp(name, "gn_fused_stats")) { c->opt_gn_fused = value != 0; return 0; }
   if (!strcmp(name, "weight_touch")) { c->opt_touch = value < 0 ? 0 : value; return 0; }
   if (!strcmp(name, "weight_warm")) { c->opt_warm = value; return 0; }
+  if (!strcmp(name, "conv_halo")) { c->opt_halo = value != 0; return 0; }
   agd_set_error("set_option: unknown option '%s'", name);
   return fail_ctx(c);
 }
@@ -1294,8 +1298,15 @@ static bf16_t* op_zero_page() {
 // NCHW fp32 <-> NHWC bf16 (padded) helpers built from the library kernels
 static int to_nhwc_bf16(const float* x, bf16_t* y, int B, int C, int HW, int Cpad, hipStream_t st) { return launch_prep_latents(x, y, B, C, HW, Cpad, 1, 1.0f, st); }
 
+AGD_API int agd_op_conv2d_ex(const float* x, const float* w, const float* bias, float* y, int B, int Cin, int H, int W, int Cout,
+                                int ksize, int stride, int pad, int upsample, int flags, void* stream);
 AGD_API int agd_op_conv2d(const float* x, const float* w, const float* bias, float* y, int B, int Cin, int H, int W, int Cout,
                              int ksize, int stride, int pad, int upsample, void* stream) {
+  return agd_op_conv2d_ex(x, w, bias, y, B, Cin, H, W, Cout, ksize, stride, pad, upsample, 0, stream);
+}
+// flags bit 0: 3x3 stride-1 launches take the row-halo kernel (igemm_halo.h) where it applies
+AGD_API int agd_op_conv2d_ex(const float* x, const float* w, const float* bias, float* y, int B, int Cin, int H, int W, int Cout,
+                                int ksize, int stride, int pad, int upsample, int flags, void* stream) {
   hipStream_t st = S(stream); Tmp tmp;
   if (pad != (ksize == 3 ? 1 : 0)) { agd_set_error("op_conv2d: pad must be 1 for 3x3, 0 for 1x1"); return -1; }
   const int Cpad = (Cin + 63) / 64 * 64, taps = ksize * ksize, up = upsample ? 2 : 1;
@@ -1306,7 +1317,7 @@ AGD_API int agd_op_conv2d(const float* x, const float* w, const float* bias, flo
   CK(to_nhwc_bf16(x, xb, B, Cin, H * W, Cpad, st));
   CK(launch_convert_weight(w, wb, Cout, Cin, taps, Cpad, 0, st));
   WMat wm; wm.w = wb; wm.N = Cout; wm.Cin = Cin; wm.Cpad = Cpad; wm.taps = taps;
-  GemmOpt o; o.bias = bias; o.stride = stride; o.up = up; o.out_f32 = 1;
+  GemmOpt o; o.bias = bias; o.stride = stride; o.up = up; o.out_f32 = 1; o.halo = flags & 1;
   CK(run_conv(nullptr, st, xb, Cpad, nullptr, 0, B, H, W, wm, ksize, yn, o, op_zero_page()));
   CK(launch_nchw_from_nhwc_f32(yn, Cout, y, B, Cout, Ho * Wo, st));
   hipStreamSynchronize(st);
@@ -1480,7 +1491,7 @@ AGD_API int agd_bench_conv(int B, int H, int W, int C0, int C1, int Cout, int ks
   WMat wm; wm.w = w; wm.N = Cout; wm.Cin = Ctot; wm.Cpad = Ctot; wm.taps = taps;
   // geglu bit 1 = GEGLU; bit 2 = also emit LayerNorm row statistics (producer); bit 4 = LayerNorm-folded consumer epilogue
   const int mode = geglu; geglu &= 1;
-  GemmOpt o; o.bias = bias; o.stride = stride; o.up = up; o.geglu = geglu; o.residual = r;
+  GemmOpt o; o.bias = bias; o.stride = stride; o.up = up; o.geglu = geglu; o.residual = r; o.halo = (mode & 8) ? 1 : 0;
   float* stats = nullptr; float* cs = nullptr;
   if (mode & 6) {
     int cfg[3] = {0, 0, 0}; GemmOpt qo = o; qo.query_cfg = cfg;

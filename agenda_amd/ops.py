@@ -13,7 +13,7 @@ def _f32c(t):
     return t.detach().to(torch.float32).contiguous()
 
 
-def conv2d(x, w, bias=None, stride=1, padding=None, upsample=False):
+def conv2d(x, w, bias=None, stride=1, padding=None, upsample=False, halo=False):
     lib = _lib.load()
     x, w = _f32c(x), _f32c(w)
     b = _f32c(bias) if bias is not None else None
@@ -24,8 +24,8 @@ def conv2d(x, w, bias=None, stride=1, padding=None, upsample=False):
     Ho = (H * up + 2 * pad - k) // stride + 1
     Wo = (W * up + 2 * pad - k) // stride + 1
     y = torch.empty(B, Cout, Ho, Wo, device=x.device, dtype=torch.float32)
-    _lib.check(lib.agd_op_conv2d(_lib.ptr(x), _lib.ptr(w), _lib.ptr(b), _lib.ptr(y), B, Cin, H, W, Cout, k, stride,
-                                 pad, int(upsample), _lib.current_stream_ptr()), None, "agd_op_conv2d")
+    _lib.check(lib.agd_op_conv2d_ex(_lib.ptr(x), _lib.ptr(w), _lib.ptr(b), _lib.ptr(y), B, Cin, H, W, Cout, k, stride,
+                                    pad, int(upsample), 1 if halo else 0, _lib.current_stream_ptr()), None, "agd_op_conv2d")
     return y
 
 

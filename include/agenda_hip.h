@@ -104,6 +104,8 @@ int agd_vae_encode(agd_ctx* ctx, const float* image, int batch, int side, float*
  * "ln_fold", "gn_fused_stats" (default 1): LayerNorm / GroupNorm statistics produced by the GEMM that writes the activation.
  * "weight_touch" (default 3; 0 off): 1x1 weight matrices of at least that many MB are streamed through the caches by a read-only
  * kernel right in front of the launch that uses them (the UNet's 1.7 GB of weights never stay in the 256 MB Infinity Cache).
+ * "conv_halo" (default 1): 3x3 stride-1 convolutions run the row-halo kernel (one LDS image of the tile's pixel rows serves the three
+ * horizontal taps) where its geometry applies.
  * "weight_warm" (default 3; 0 off): the first workgroups of a launch stream its weight matrix through the caches before their main
  * loops -- 1: only launches whose weights outweigh their activations (each XCD its own slice, into its L2); 3: every launch with
  * >= 1 MB of weights and 1024 <= M <= 32768 (the touch launches then disappear). */
@@ -163,6 +165,9 @@ int agd_attn_processor_backward(agd_ctx* ctx, const char* layer, const float* hi
  * used by the parity tests, mirror torch.nn.functional signatures the oracle uses. */
 int agd_op_conv2d(const float* x_nchw, const float* w, const float* bias, float* y_nchw, int B, int Cin, int H, int W,
                   int Cout, int ksize, int stride, int pad, int upsample, void* stream);
+/* flags bit 0: 3x3 stride-1 launches take the row-halo kernel where it applies */
+int agd_op_conv2d_ex(const float* x, const float* w, const float* bias, float* y, int B, int Cin, int H, int W, int Cout,
+                     int ksize, int stride, int pad, int upsample, int flags, void* stream);
 int agd_op_linear(const float* x, const float* w, const float* bias, const float* residual, float* y, int M, int K,
                   int N, int geglu, void* stream);
 int agd_op_groupnorm(const float* x_nchw, const float* gamma, const float* beta, float* y_nchw, int B, int C, int HW,

@@ -210,6 +210,24 @@ def test_bicubic_clamp_mean_matches_torch(ops):
         assert float((got.cpu() - want).abs().max()) < 2e-5
 
 
+@pytest.mark.parametrize("B,C,H,Co", [(8, 128, 64, 160), (8, 192, 32, 320), (8, 128, 16, 1280), (1, 128, 512, 128), (2, 128, 128, 256),
+                                      (8, 320, 64, 320), (3, 192, 64, 200), (16, 256, 16, 640), (8, 512, 16, 1280)])
+def test_conv3x3_row_halo_kernel(ops, B, C, H, Co):
+    """igemm_halo.h: one LDS image of the tile's pixel rows (+ one halo pixel each side) per (ky, channel chunk) serves the three kx
+    taps.  Shapes that dispatch to it with two workgroups per CU, with the deep weight ring (<= 256 tiles), with split-K (last case),
+    with row segments (W > 128), whole rows (W = 128) and several rows per tile, an M tail and an N tail."""
+    g = torch.Generator().manual_seed(B * 1000 + C + H + Co)
+    x = bfr(torch.randn(B, C, H, H, generator=g))
+    w = bfr(torch.randn(Co, C, 3, 3, generator=g) / (3 * C ** 0.5))
+    b = torch.randn(Co, generator=g)
+    want = F.conv2d(x, w, b, padding=1)
+    got = ops.conv2d(x.cuda(), w.cuda(), b.cuda(), halo=True).cpu()
+    ref = ops.conv2d(x.cuda(), w.cuda(), b.cuda()).cpu()                 # the general tap-by-tap kernel
+    scale = float(want.abs().max())
+    assert float((got - want).abs().max()) / scale < 2e-6                # fp32 accumulation of exact bf16 products
+    assert float((got - ref).abs().max()) / scale < 1e-5 and not torch.equal(got, ref)   # a different K order: not the same kernel
+
+
 def test_igemm_random_shape_sweep(ops):
     """Randomised conv / linear shapes: tails in M and N, every (ksize, stride, upsample) combination the path uses,
     channel counts that are / are not multiples of 64, and sizes on both sides of the tile and split-K thresholds."""
