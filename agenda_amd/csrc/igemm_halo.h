@@ -167,6 +167,15 @@ __global__ __launch_bounds__(256, BST == 2 ? 2 : 1) void igemm_halo_kernel(const
 
   using K0 = std::integral_constant<int, 0>; using K1 = std::integral_constant<int, 1>; using K2 = std::integral_constant<int, 2>;
   constexpr unsigned LIVE = 0x7FFFFFF0u;
+  if (p.warm == 2) {                                    // cold-weight warm-up (see igemm.hip): the first workgroups stream W once
+    const int lin = blockIdx.z * gridDim.x + blockIdx.x;
+    const int tot = gridDim.x * gridDim.z, nb = tot < 512 ? tot : 512;
+    if (lin < nb) {
+      const long long pieces = ((long long)p.N * p.K * 2) >> 10;
+      const long long p0 = pieces * lin / nb, p1 = pieces * (lin + 1) / nb;
+      for (long long pc = p0 + wid; pc < p1; pc += NW) bufdma16(p.W, scr + wid * 1024, (unsigned)(pc * 1024 + lane * 16), 0u);
+    }
+  }
   int ky = g0 / gpk, r = g0 - ky * gpk;                 // current group
   unsigned bso = (unsigned)(((ky * 3) * Ct + r * 64) * 2);   // weights of (ky, kx = 0, r)
   const unsigned tapb = (unsigned)(Ct * 2);            // one tap further
