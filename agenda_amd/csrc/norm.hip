@@ -12,7 +12,7 @@
 struct GnGeom { int nvec, PR, ppb, nchunk; };
 static GnGeom gn_geom(int B, int C, int HW) {
   GnGeom g; g.nvec = C / 8; g.PR = 512 / g.nvec;
-  constexpr int nblk = 256;   // one 512-thread block per CU measured best (kbench gn: 0.96 -> 0.88 ms per forward vs 512)
+  constexpr int nblk = 256;   // one 512-thread block per CU measured best (kbench gn: 0.96 -> 0.88 ms per forward vs 512; 128 / 64: +10 / +21 %)
   const long long target = ((long long)HW * B + nblk - 1) / nblk;    // pixels per block for ~nblk blocks
   int it = (int)((target + g.PR - 1) / g.PR); if (it < 1) it = 1; if (it > 16) it = 16;
   g.ppb = it * g.PR; g.nchunk = (HW + g.ppb - 1) / g.ppb;
@@ -233,8 +233,12 @@ int launch_groupnorm(const GroupNormP& p, hipStream_t st) {
   }
   if (gn_part_ok(p)) {
     const int nvs = C / GN_SLICES / 8, PR = 512 / nvs;
-    const long long target = ((long long)p.HW * p.B + 255) / 256;
-    int it = (int)((target + PR - 1) / PR); if (it < 1) it = 1; if (it > 16) it = 16;
+    // pixel chunks per channel slice: ~128 for the 64x64 maps (UNet batch 8), ~64 below (tools/kb_gn.py: 256 -> 128: 16.9 -> 15.4 us at 64x64
+    // C = 320, 64: 10.6 -> 9.4 at 32x32 C = 640, 8.4 -> 6.9 at 16x16 C = 1280; 32 and 512 are 20-50 % slower): every block pays the
+    // statistics finalize once, so fewer, fatter blocks win until the grid stops covering the CUs
+    const int tdiv = (long long)p.HW * p.B >= 32768 ? 128 : 64;
+    const long long target = ((long long)p.HW * p.B + tdiv - 1) / tdiv;
+    int it = (int)((target + PR - 1) / PR); if (it < 1) it = 1; if (it > 64) it = 64;
     const int ppb = it * PR, nchunk = (p.HW + ppb - 1) / ppb;
     hipLaunchKernelGGL(gn_apply_part_kernel, dim3(nchunk, p.B, GN_SLICES), dim3(512), 0, st, p.x0, p.x1, p.C0, p.C1, p.HW, ppb, p.groups, p.eps,
                        p.part0, p.part1, p.bm0, p.bm1 > 0 ? p.bm1 : 1, p.gamma, p.beta, p.silu, p.y);
