@@ -365,15 +365,15 @@ static int launch_one(const IgemmP& p, int splits, hipStream_t st) {
   return 0;
 }
 
-// row-halo 3x3 kernel (igemm_halo.h): stride 1, pad 1, no upsample, tile rows = whole image rows (or 128-pixel row segments)
+// row-halo 3x3 kernel (igemm_halo.h): stride 1, pad 1, optional nearest-2x upsample, tile rows = whole output rows (or 128-pixel segments)
 static bool halo_ok(const IgemmP& p) {
-  return p.halo && p.ksize == 3 && p.stride == 1 && p.up == 1 && p.pad == 1 && p.Hin == p.Hout && p.Win == p.Wout && p.batch <= 1 &&
-         !p.geglu && p.Win >= 16 && (p.Win <= 128 ? 128 % p.Win == 0 : p.Win % 128 == 0) &&      // 8x8 maps (8-way split-K) measured 4 % slower
+  return p.halo && p.ksize == 3 && p.stride == 1 && p.pad == 1 && p.Hin * p.up == p.Hout && p.Win * p.up == p.Wout && p.batch <= 1 &&
+         !p.geglu && p.Wout >= 16 && (p.Wout <= 128 ? 128 % p.Wout == 0 : p.Wout % 128 == 0) &&      // 8x8 maps (8-way split-K) measured 4 % slower
          (long long)p.Hin * p.Win * (p.C0 > p.C1 ? p.C0 : p.C1) * (p.M / (p.Hin * p.Win) + 1) < (1LL << 30);   // 32-bit byte offsets per source
 }
 template <int BN, int SPLITK, int BST>
 static int launch_halo(const IgemmP& p, int splits, hipStream_t st) {
-  const int Wt = p.Win < 128 ? p.Win : 128;
+  const int Wt = p.Wout < 128 ? p.Wout : 128;
   const int hr = (128 / Wt) * (Wt + 2), HRP = (hr + 7) & ~7;
   const int lds = 2 * HRP * 128 + BST * BN * 128 + 4096;   // two A images of the tile's halo rows + the weight ring + the dead-piece sink
   const int tiles = ((p.M + 127) / 128) * ((p.N + BN - 1) / BN);

@@ -1,4 +1,4 @@
-// 3x3 / stride 1 / pad 1 implicit GEMM with a ROW-HALO A tile (included by igemm.hip).
+// 3x3 / stride 1 / pad 1 implicit GEMM (optionally on the nearest-2x upsampled input) with a ROW-HALO A tile (included by igemm.hip).
 //
 // The general kernel streams one 128-row im2col tile per tap: nine LDS-DMA images of (almost) the same pixels per 64-channel chunk.
 // Here the K loop runs (ky, source, channel chunk) groups; per group ONE A image holds the tile's pixel rows with one halo pixel on
@@ -33,7 +33,8 @@ __global__ __launch_bounds__(256, BST == 2 ? 2 : 1) void igemm_halo_kernel(const
   const int bid = xcd_remap(blockIdx.x, gridDim.x);
   const int tn = bid % tiles_n, tm = bid / tiles_n;    // A-major walk: consecutive tiles share the pixel rows
   const int m0 = tm * BM, n0 = tn * BN;
-  const int W = p.Win, H = p.Hin, HW = H * W;
+  const int W = p.Wout, H = p.Hout, HW = H * W;         // output grid (= the nearest-2x upsampled input grid when p.up == 2)
+  const int ush = p.up == 2 ? 1 : 0;
   const int hw2 = Wt + 2;
   const int trows = BM / Wt;                            // image rows (or row segments) per tile
   const int Ct = p.C0 + p.C1;
@@ -42,7 +43,7 @@ __global__ __launch_bounds__(256, BST == 2 ? 2 : 1) void igemm_halo_kernel(const
   // Rows past the tile's halo (and padding pixels) get an out-of-range offset: the hardware range check writes zeros.
   const int lrow = lane >> 3;
   const int lchunk = (lane & 7) ^ lrow;                 // swizzle on the source side (LDS-DMA writes lane-linear)
-  int a_pix[A_ITH], a_y[A_ITH];
+  int a_brow[A_ITH], a_ix[A_ITH], a_y[A_ITH];           // image's first source row, source column, output row of tap ky = 0
   unsigned a_ok = 0;
 #pragma unroll
   for (int i = 0; i < A_ITH; ++i) {
@@ -54,7 +55,7 @@ __global__ __launch_bounds__(256, BST == 2 ? 2 : 1) void igemm_halo_kernel(const
     if (ok) { b = pm / HW; const int rem = pm - b * HW; y = rem / W; x0 = rem - y * W; }
     const int ix = x0 + col - 1;
     ok = ok && (unsigned)ix < (unsigned)W;
-    a_pix[i] = (b * H + y - 1) * W + ix;                // ky = 0 pixel (row y - 1); + ky * W for the others
+    a_brow[i] = b * p.Hin; a_ix[i] = ix >> ush;         // the upsample is folded into the gather: source pixel = (row >> 1, col >> 1)
     a_y[i] = y - 1;
     a_ok |= (ok ? 1u : 0u) << i;
   }
@@ -91,7 +92,8 @@ __global__ __launch_bounds__(256, BST == 2 ? 2 : 1) void igemm_halo_kernel(const
 #pragma unroll
     for (int i = 0; i < A_ITH; ++i) {
       const bool ok = ((a_ok >> i) & 1) && (unsigned)(a_y[i] + ky) < (unsigned)H;
-      avoff[i] = ok ? (unsigned)((a_pix[i] + ky * W) * Cs + lchunk * 8) * 2u : 0x80000000u;     // < 2^31 bytes per source (launcher)
+      const int pix = (a_brow[i] + ((a_y[i] + ky) >> ush)) * p.Win + a_ix[i];
+      avoff[i] = ok ? (unsigned)(pix * Cs + lchunk * 8) * 2u : 0x80000000u;                      // < 2^31 bytes per source (launcher)
     }
   };
 

@@ -228,6 +228,22 @@ def test_conv3x3_row_halo_kernel(ops, B, C, H, Co):
     assert float((got - ref).abs().max()) / scale < 1e-5 and not torch.equal(got, ref)   # a different K order: not the same kernel
 
 
+@pytest.mark.parametrize("B,C,H,Co", [(8, 128, 32, 160), (8, 192, 16, 320), (2, 128, 128, 256), (8, 64, 8, 1280)])
+def test_conv3x3_row_halo_kernel_upsampled(ops, B, C, H, Co):
+    """The same kernel on the nearest-2x upsampled input (Upsample2D.conv, folded into the gather): halo columns / rows map to
+    source pixel (row >> 1, col >> 1)."""
+    g = torch.Generator().manual_seed(B * 77 + C + H + Co)
+    x = bfr(torch.randn(B, C, H, H, generator=g))
+    w = bfr(torch.randn(Co, C, 3, 3, generator=g) / (3 * C ** 0.5))
+    b = torch.randn(Co, generator=g)
+    want = F.conv2d(F.interpolate(x, scale_factor=2.0, mode="nearest"), w, b, padding=1)
+    got = ops.conv2d(x.cuda(), w.cuda(), b.cuda(), upsample=True, halo=True).cpu()
+    ref = ops.conv2d(x.cuda(), w.cuda(), b.cuda(), upsample=True).cpu()
+    scale = float(want.abs().max())
+    assert float((got - want).abs().max()) / scale < 2e-6
+    assert float((got - ref).abs().max()) / scale < 1e-5
+
+
 def test_igemm_random_shape_sweep(ops):
     """Randomised conv / linear shapes: tails in M and N, every (ksize, stride, upsample) combination the path uses,
     channel counts that are / are not multiples of 64, and sizes on both sides of the tile and split-K thresholds."""
