@@ -1532,13 +1532,22 @@ AGD_API int agd_bench_conv_cold(int B, int H, int W, int C0, int Cout, int ksize
   hipMemset(bias, 0, Cout * 4);
   WMat wm; wm.w = w; wm.N = Cout; wm.Cin = C0; wm.Cpad = C0; wm.taps = taps;
   GemmOpt o; o.bias = bias; o.geglu = geglu; o.residual = r; o.warm = warm == 3 ? 3 : 0;      // warm 3: cold weights, in-kernel warm-up
+  // the intervening layer (warm >= 4): conv3x3 640 -> 640 on 8 x 32 x 32
+  bf16_t* ix = tmp.get<bf16_t>((size_t)8 * 1024 * 640); bf16_t* iy = tmp.get<bf16_t>((size_t)8 * 1024 * 640); bf16_t* iw = tmp.get<bf16_t>((size_t)640 * 9 * 640);
+  if (!ix || !iy || !iw) return -1;
+  fill_rand(ix, (long long)8 * 1024 * 640, 11, 1.0f); fill_rand(iw, (long long)640 * 9 * 640, 12, 0.05f);
+  WMat iwm; iwm.w = iw; iwm.N = 640; iwm.Cin = 640; iwm.Cpad = 640; iwm.taps = 9;
+  GemmOpt io; io.bias = bias;
   hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
   double tot = 0;
   for (int i = 0; i < iters + 1; ++i) {
     hipMemsetAsync(scratch, i, flush_bytes, 0);
     hipMemcpyAsync(x0, xs, xn * 2, hipMemcpyDeviceToDevice, 0);
     if (r) hipMemcpyAsync(y, r, (size_t)M * Nout * 2, hipMemcpyDeviceToDevice, 0);       // touches the residual / output lines
-    if (warm == 2) hipLaunchKernelGGL(touch_kernel, dim3(1024), dim3(256), 0, 0, (const u32x4*)w, (long long)(wn * 2 / 16), sink);
+    if (warm == 2 || warm >= 4) hipLaunchKernelGGL(touch_kernel, dim3(1024), dim3(256), 0, 0, (const u32x4*)w, (long long)(wn * 2 / 16), sink);
+    // warm 4 / 5 / 6: the touch is followed by 1 / 2 / 4 intervening launches of a typical layer (an L1 3x3 conv: ~100 MB through the
+    // caches each) before the timed launch: does the Infinity Cache still hold the matrix?
+    for (int k = 0; k < (warm == 4 ? 1 : warm == 5 ? 2 : warm == 6 ? 4 : 0); ++k) CK(run_conv(nullptr, 0, ix, 640, nullptr, 0, 8, 32, 32, iwm, 3, iy, io, op_zero_page()));
     hipEventRecord(a, 0);
     if (warm == 1) hipLaunchKernelGGL(touch_kernel, dim3(1024), dim3(256), 0, 0, (const u32x4*)w, (long long)(wn * 2 / 16), sink);
     CK(run_conv(nullptr, 0, x0, C0, nullptr, 0, B, H, W, wm, ksize, y, o, op_zero_page()));

@@ -12,11 +12,11 @@ shapes = [("L2 C->C  M2048 K1280 N1280 +res", (8, 16, 16, 1280, 1280, 1, 0, 1)),
           ("conv3 L2 1280->1280 +res", (8, 16, 16, 1280, 1280, 3, 0, 1)), ("conv3 L3 M512 1280->1280 +res", (8, 8, 8, 1280, 1280, 3, 0, 1)),
           ("L3 C->C M512 +res", (8, 8, 8, 1280, 1280, 1, 0, 1)), ("L3 geglu", (8, 8, 8, 1280, 10240, 1, 1, 0)),
           ("conv3 L0 320->320 +res", (8, 64, 64, 320, 320, 3, 0, 1))]
-print(f"{'shape':36s}{'cold':>9s}{'touch+run':>11s}{'hot':>9s}{'in-kernel':>11s}  (us)")
+print(f"{'shape':36s}{'cold':>9s}{'touch+run':>11s}{'hot':>9s}{'in-kernel':>11s}{'hot+1':>8s}{'hot+2':>8s}{'hot+4':>8s}  (us)")
 for name, a in shapes:
     row = []
-    for warm in (0, 1, 2, 3):
+    for warm in (0, 1, 2, 3, 4, 5, 6):
         ms = C.c_double()
         rc = lib.agd_bench_conv_cold(*a, warm, 10, C.byref(ms))
         row.append(ms.value * 1e3 if rc == 0 else float("nan"))
-    print(f"{name:36s}{row[0]:9.1f}{row[1]:11.1f}{row[2]:9.1f}{row[3]:11.1f}", flush=True)
+    print(f"{name:36s}{row[0]:9.1f}{row[1]:11.1f}{row[2]:9.1f}{row[3]:11.1f}{row[4]:8.1f}{row[5]:8.1f}{row[6]:8.1f}", flush=True)
