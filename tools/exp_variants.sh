@@ -5,7 +5,7 @@ bash tools/build_exp.sh
 for v in "$@"; do
   tag=${v%%:*}; fl=${v#*:}
   if [ -n "$fl" ]; then
-    rm -rf /tmp/exp_$tag && cp -r /tmp/exp /tmp/exp_$tag && cd /tmp/exp_$tag/csrc && rm -f igemm.o && make EXTRA="-DAGD_EXPERIMENTS $fl" OUT=/tmp/exp_$tag/libagenda_hip.so > /tmp/exp_$tag/build.log 2>&1; tail -1 /tmp/exp_$tag/build.log; cd $GRAFT_REPO_ROOT
+    rm -rf /tmp/exp_$tag && cp -r /tmp/exp /tmp/exp_$tag && cd /tmp/exp_$tag/csrc && rm -f igemm.o attention.o && make EXTRA="-DAGD_EXPERIMENTS $fl" OUT=/tmp/exp_$tag/libagenda_hip.so > /tmp/exp_$tag/build.log 2>&1; tail -1 /tmp/exp_$tag/build.log; cd $GRAFT_REPO_ROOT
   else
     rm -rf /tmp/exp_$tag && ln -s /tmp/exp /tmp/exp_$tag
   fi
