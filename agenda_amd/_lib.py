@@ -91,6 +91,7 @@ _SIGS = {
     "agd_bench_conv": (C.c_int, [C.c_int] * 12 + [C.POINTER(C.c_double)]),
     "agd_bench_attention": (C.c_int, [C.c_int] * 7 + [C.POINTER(C.c_double)]),
     "agd_bench_groupnorm": (C.c_int, [C.c_int] * 4 + [C.POINTER(C.c_double)]),
+    "agd_bench_ff": (C.c_int, [C.c_int] * 4 + [C.POINTER(C.c_double)]),
     "agd_bench_conv_cold": (C.c_int, [C.c_int] * 10 + [C.POINTER(C.c_double)]),
     "agd_bench_groupnorm_ex": (C.c_int, [C.c_int] * 6 + [C.POINTER(C.c_double)]),
     "agd_version": (C.c_char_p, []),
