@@ -24,13 +24,14 @@ template <int C>
 __global__ __launch_bounds__(256, 1) void ff_fused_kernel(const FfP p) {
   constexpr int KS1 = C / 64, HID = 4 * C, NCH = HID / 64;
   constexpr int MI = 2, NI1 = 8, NI2 = C / 16, LC = C / 4;       // LC: consecutive output channels per lane
-  constexpr int W1_STAGE = 16384, W1_ST = 4, W2_BYTES = C * 128;
+  constexpr int W1_STAGE = 16384, W1_ST = 3, W2_BYTES = C * 128;
   constexpr int W2_IT = C / 32;                                   // W2 pieces (8 rows each) per wave and chunk
   constexpr int W2_PS = W2_IT / KS1;                              // ... per K step
-  static_assert(C % 64 == 0 && NI2 % 2 == 0 && W2_IT % KS1 == 0 && W2_IT - 3 * W2_PS >= 0, "panel geometry");
+  static_assert(C % 64 == 0 && NI2 % 2 == 0 && W2_IT % KS1 == 0 && W2_IT - 2 * W2_PS >= 0, "panel geometry");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const sW1 = smem;                                         // weight ring of GEMM1: W1_ST tiles of [128 rows][64 k]
   char* const sW2 = sW1 + W1_ST * W1_STAGE;                       // two chunk tiles [C rows][64 hidden] of GEMM2
+  float* const sK = (float*)(sW2 + 2 * W2_BYTES);                 // GEGLU constants: colsum values | colsum gates | bias values | bias gates, HID each
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -72,18 +73,21 @@ __global__ __launch_bounds__(256, 1) void ff_fused_kernel(const FfP p) {
     const int c = tt / KS1, ks = tt - c * KS1;
     const unsigned so = __builtin_amdgcn_readfirstlane((unsigned)((c * 128 * C + ks * 64) * 2));
 #pragma unroll
-    for (int i = 0; i < 4; ++i) bufdma16(p.w1, sW1 + (tt & (W1_ST - 1)) * W1_STAGE + (i * 4 + wid) * 1024, b1v[i], so, nr);
+    for (int i = 0; i < 4; ++i) bufdma16(p.w1, sW1 + (tt % W1_ST) * W1_STAGE + (i * 4 + wid) * 1024, b1v[i], so, nr);
   };
   auto issue_w2 = [&](int c, int first, int n, unsigned nr) {       // pieces [first, first + n) of chunk c's W2 tile
     const unsigned so = __builtin_amdgcn_readfirstlane((unsigned)(c * 128));
 #pragma unroll
     for (int u = 0; u < W2_IT; ++u) if (u >= first && u < first + n) bufdma16(p.w2p, sW2 + (c & 1) * W2_BYTES + (u * 4 + wid) * 1024, w2v[u], so, nr);
   };
+  // GEGLU constants into LDS (read back per chunk through the LDS counter, not vmcnt)
+  for (int i = tid; i < HID; i += 256) { sK[i] = p.ln_cs[i]; sK[HID + i] = p.ln_cs[HID + i]; sK[2 * HID + i] = p.bias1[i]; sK[3 * HID + i] = p.bias1[HID + i]; }
+  __syncthreads();
   // prologue in the steady-state order (4 W1 pieces then W2_PS W2 pieces per step), so that ONE wait count serves every step
-  issue_w2(0, 0, W2_IT - 3 * W2_PS, LIVE);
+  issue_w2(0, 0, W2_IT - 2 * W2_PS, LIVE);
 #pragma unroll
-  for (int s0 = 0; s0 < 3; ++s0) { issue_w1(s0, LIVE); issue_w2(0, W2_IT - 3 * W2_PS + s0 * W2_PS, W2_PS, LIVE); }
-  constexpr int WAITN = 2 * (4 + W2_PS) + W2_PS;                    // younger than the W1 tile a step needs: its own step's W2 pieces + two steps
+  for (int s0 = 0; s0 < 2; ++s0) { issue_w1(s0, LIVE); issue_w2(0, W2_IT - 2 * W2_PS + s0 * W2_PS, W2_PS, LIVE); }
+  constexpr int WAITN = (4 + W2_PS) + W2_PS;                        // younger than the W1 tile a step needs: its own step's W2 pieces + one step
 
   // ---- LayerNorm statistics of this lane's two rows
   float lmu[MI], lrs[MI];
@@ -115,7 +119,6 @@ __global__ __launch_bounds__(256, 1) void ff_fused_kernel(const FfP p) {
   constexpr int TOT = NCH * KS1;
   int t = 0;                                                         // global K step
   for (int c = 0; c < NCH; ++c) {
-    float csv[2][8], csg[2][8], hbv[2][8], hbg[2][8];    // GEGLU constants of this lane's 16 hidden channels: fetched at the chunk's last K step
     f32x4 acc1[MI][NI1];
 #pragma unroll
     for (int i = 0; i < MI; ++i)
@@ -123,50 +126,52 @@ __global__ __launch_bounds__(256, 1) void ff_fused_kernel(const FfP p) {
       for (int j = 0; j < NI1; ++j) acc1[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int ks = 0; ks < KS1; ++ks, ++t) {
-      // the plain loads above sit between this chunk's pieces and the previous chunk's: only the first step of a chunk has them
-      // among the WAITN youngest operations, where they make the wait stricter, never weaker
       ff_wait_vm<WAITN>();
       asm volatile("s_barrier" ::: "memory");
-      const char* sb = sW1 + (t & (W1_ST - 1)) * W1_STAGE;
-      if (ks == KS1 - 1) {                                           // older than this step's pieces: never among the WAITN youngest later on
-#pragma unroll
-        for (int g2 = 0; g2 < 2; ++g2) {
-          const int hid0 = c * 64 + q * 16 + g2 * 8;
-#pragma unroll
-          for (int v4 = 0; v4 < 2; ++v4) {
-            *(f32x4*)&csv[g2][4 * v4] = *(const f32x4*)(p.ln_cs + hid0 + 4 * v4);
-            *(f32x4*)&csg[g2][4 * v4] = *(const f32x4*)(p.ln_cs + HID + hid0 + 4 * v4);
-            *(f32x4*)&hbv[g2][4 * v4] = *(const f32x4*)(p.bias1 + hid0 + 4 * v4);
-            *(f32x4*)&hbg[g2][4 * v4] = *(const f32x4*)(p.bias1 + HID + hid0 + 4 * v4);
-          }
-        }
-      }
-      // weight fragments three ahead, then (1 fragment read, 2 MFMA) with the step's LDS-DMA pieces spread over the first MFMAs
+      const char* sb = sW1 + (t % W1_ST) * W1_STAGE;
+      // weight fragments eight ahead, then (1 fragment read, 2 MFMA) with the step's LDS-DMA pieces spread over the first MFMAs
       constexpr int ND = 4 + W2_PS;
-      const int tn = t + 3;                                          // the W1 tile three steps ahead; the NEXT chunk's W2 tile in instalments
+      const int tn = t + 2;                                          // the W1 tile two steps ahead; the NEXT chunk's W2 tile in instalments
       const int cn = tn / KS1, ksn = tn - cn * KS1;
       const unsigned so1 = __builtin_amdgcn_readfirstlane((unsigned)((cn * 128 * C + ksn * 64) * 2));
       const unsigned so2 = __builtin_amdgcn_readfirstlane((unsigned)((c + 1) * 128));
       const unsigned nr1 = tn < TOT ? LIVE : 0u, nr2 = c + 1 < NCH ? LIVE : 0u;
-      char* d1 = sW1 + (tn & (W1_ST - 1)) * W1_STAGE;
+      char* d1 = sW1 + (tn % W1_ST) * W1_STAGE;
       char* d2 = sW2 + ((c + 1) & 1) * W2_BYTES;
 #pragma unroll
       for (int x = 0; x < 2 * NI1; ++x) {
+#if defined(AGD_EXPERIMENTS) && defined(EXP_FF_NODMA)      // timing only: no LDS-DMA in the loop (garbage results)
+        if (false) {} else if (false) {
+#else
         if (x < 4) bufdma16(p.w1, d1 + (x * 4 + wid) * 1024, b1v[x < 4 ? x : 0], so1, nr1);
-        else if (x < ND) { const int u = ks * W2_PS + (x - 4); bufdma16(p.w2p, d2 + (u * 4 + wid) * 1024, w2v[(x >= 4 && x < ND) ? u : 0], so2, nr2); }
+        else if (x < ND) {
+#endif
+          const int u = ks * W2_PS + (x - 4); bufdma16(p.w2p, d2 + (u * 4 + wid) * 1024, w2v[(x >= 4 && x < ND) ? u : 0], so2, nr2); }
         const bf16x8 w = *(const bf16x8*)(sb + (x % NI1) * 512 + foffB1[x / NI1]);
 #pragma unroll
         for (int i = 0; i < MI; ++i) acc1[i][x % NI1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, afr[ks][x / NI1][i], acc1[i][x % NI1], 0, 0, 0);
       }
-      __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);            // eight weight fragments ahead (LDS latency ~ 8 MFMA pairs)
 #pragma unroll
       for (int x = 0; x < 2 * NI1; ++x) {
         __builtin_amdgcn_sched_group_barrier(0x8, 2, 0);
         if (x < ND) __builtin_amdgcn_sched_group_barrier(0x20, 1, 0);
-        if (x < 2 * NI1 - 3) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        if (x < 2 * NI1 - 8) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
       }
     }
     // ---- GEGLU (LayerNorm folded) in registers -> the pixel-side fragments of GEMM2
+    float csv[2][8], csg[2][8], hbv[2][8], hbg[2][8];
+#pragma unroll
+    for (int g2 = 0; g2 < 2; ++g2) {
+      const int hid0 = c * 64 + q * 16 + g2 * 8;
+#pragma unroll
+      for (int v4 = 0; v4 < 2; ++v4) {
+        *(f32x4*)&csv[g2][4 * v4] = *(const f32x4*)(sK + hid0 + 4 * v4);
+        *(f32x4*)&csg[g2][4 * v4] = *(const f32x4*)(sK + HID + hid0 + 4 * v4);
+        *(f32x4*)&hbv[g2][4 * v4] = *(const f32x4*)(sK + 2 * HID + hid0 + 4 * v4);
+        *(f32x4*)&hbg[g2][4 * v4] = *(const f32x4*)(sK + 3 * HID + hid0 + 4 * v4);
+      }
+    }
     bf16x8 hf[MI][2];
 #pragma unroll
     for (int i = 0; i < MI; ++i)
@@ -176,7 +181,11 @@ __global__ __launch_bounds__(256, 1) void ff_fused_kernel(const FfP p) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           const float xv = acc1[i][4 * g2 + (e >> 2)][e & 3], xg = acc1[i][4 * g2 + 2 + (e >> 2)][e & 3];
+#if defined(AGD_EXPERIMENTS) && defined(EXP_FF_NOGELU)     // timing only: no gelu
+          v[e] = (lrs[i] * (xv - lmu[i] * csv[g2][e]) + hbv[g2][e]) * (lrs[i] * (xg - lmu[i] * csg[g2][e]) + hbg[g2][e]);
+#else
           v[e] = (lrs[i] * (xv - lmu[i] * csv[g2][e]) + hbv[g2][e]) * gelu_erf_f(lrs[i] * (xg - lmu[i] * csg[g2][e]) + hbg[g2][e]);
+#endif
         }
         u32x4 pk;
         pk[0] = pack_bf2(v[0], v[1]); pk[1] = pack_bf2(v[2], v[3]); pk[2] = pack_bf2(v[4], v[5]); pk[3] = pack_bf2(v[6], v[7]);
@@ -192,10 +201,10 @@ __global__ __launch_bounds__(256, 1) void ff_fused_kernel(const FfP p) {
 #pragma unroll
         for (int i = 0; i < MI; ++i) acc2[i][x % NI2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, hf[i][x / NI2], acc2[i][x % NI2], 0, 0, 0);
       }
-      __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);             // four fragments ahead, then one read per two MFMAs
+      __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);             // eight fragments ahead, then one read per two MFMAs
 #pragma unroll
-      for (int x = 0; x < 2 * NI2 - 4; ++x) { __builtin_amdgcn_sched_group_barrier(0x8, 2, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
-      __builtin_amdgcn_sched_group_barrier(0x8, 8, 0);
+      for (int x = 0; x < 2 * NI2 - 8; ++x) { __builtin_amdgcn_sched_group_barrier(0x8, 2, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
+      __builtin_amdgcn_sched_group_barrier(0x8, 16, 0);
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -571,7 +571,7 @@ int launch_ff_fused(const FfP& p, int C, hipStream_t st) {
   if (!ff_fused_supported(C)) { agd_set_error("ff_fused: C = %d unsupported", C); return -1; }
   if (p.M < 1 || !p.h || !p.out || !p.w1 || !p.w2p || !p.ln_stats || p.ln_slots < 1 || !p.ln_cs || !p.bias1 || !p.bias2) { agd_set_error("ff_fused: bad arguments"); return -1; }
   if ((long long)p.M * C * 2 >= (1LL << 31)) { agd_set_error("ff_fused: activation beyond 32-bit byte offsets"); return -1; }
-  constexpr int lds = 4 * 16384 + 2 * 320 * 128;          // GEMM1 weight ring + two GEMM2 chunk tiles
+  constexpr int lds = 3 * 16384 + 2 * 320 * 128 + 4 * 1280 * 4;   // GEMM1 weight ring + two GEMM2 chunk tiles + GEGLU constants
   auto kfn = ff_fused_kernel<320>;
   static bool attr[AGD_MAX_DEVICES] = {};
   int dev = 0; HIP_CHECK_RET(hipGetDevice(&dev));

@@ -10,4 +10,4 @@ for v in "$@"; do
     rm -rf /tmp/exp_$tag && ln -s /tmp/exp /tmp/exp_$tag
   fi
 done
-for v in "$@"; do tag=${v%%:*}; echo "== $v"; AGD_LIB=/tmp/exp_$tag/libagenda_hip.so KB_CFGS=${KB_CFGS:-0} timeout -k 10 300 python3 tools/kb_lin.py; done
+for v in "$@"; do tag=${v%%:*}; echo "== $v"; AGD_LIB=/tmp/exp_$tag/libagenda_hip.so KB_CFGS=${KB_CFGS:-0} timeout -k 10 300 python3 ${KB_TOOL:-tools/kb_lin.py}; done
