@@ -27,6 +27,7 @@
 #include <cstdlib>
 #include "igemm_epilogue.h"
 #include "igemm_halo.h"
+#include "igemm8p.h"
 #include "ff_fused.h"
 #include <cstdlib>
 #define CK0(expr) do { if ((expr) != 0) return -1; } while (0)
@@ -440,6 +441,63 @@ static int ensure_splitk(IgemmP& p, int S) {
   return 0;
 }
 
+// ---- 8-wave / 8-phase kernel (igemm8p.h): 256 x 256 tiles (2 x 4 waves) and 256 x 160 tiles (4 x 2 waves)
+template <int WM, int WN, int MI, int NI0, int NI1>
+static int launch_8p(const IgemmP& p, hipStream_t st) {
+  using G = P8Geom<WM, WN, MI, NI0, NI1>;
+  if (p.cfg_out) { p.cfg_out[0] = G::BM; p.cfg_out[1] = G::BN; p.cfg_out[2] = 1; return 0; }
+  if (p.colstat_out && (p.colstat_rows < 1 || p.colstat_rows % G::BM)) { agd_set_error("igemm8p: column statistics need M tiles inside one image"); return -1; }
+  if (p.rowstat_out && p.rowstat_slots != (p.N + G::BN - 1) / G::BN) { agd_set_error("igemm8p: rowstat_slots %d != N tiles %d", p.rowstat_slots, (p.N + G::BN - 1) / G::BN); return -1; }
+  static const bool logit = getenv("AGD_IGEMM_LOG") != nullptr;
+  if (logit) fprintf(stderr, "IGEMM M=%d N=%d K=%d ks=%d stride=%d up=%d geglu=%d res=%d tile=%dx%d splits=1 batch=1\n", p.M, p.N, p.K, p.ksize, p.stride, p.up,
+                     p.geglu, p.residual ? 1 : 0, G::BM, G::BN);
+  const int tiles = ((p.M + G::BM - 1) / G::BM) * ((p.N + G::BN - 1) / G::BN);
+  const void* kfn = nullptr;
+  if (p.geglu) {
+    if constexpr (G::NI == 4) kfn = (const void*)igemm8p_kernel<WM, WN, MI, NI0, NI1, 1, 1>;
+    if (!kfn || p.ksize != 1) { agd_set_error("igemm8p: geglu only on 1x1 with the 256-wide tile"); return -1; }
+  } else kfn = p.ksize == 3 ? (const void*)igemm8p_kernel<WM, WN, MI, NI0, NI1, 3, 0> : (const void*)igemm8p_kernel<WM, WN, MI, NI0, NI1, 1, 0>;
+  static bool attr[AGD_MAX_DEVICES][3] = {};
+  int dev = 0; HIP_CHECK_RET(hipGetDevice(&dev));
+  if (dev < 0 || dev >= AGD_MAX_DEVICES) { agd_set_error("igemm8p: device ordinal %d out of range", dev); return -1; }
+  const int slot = p.geglu ? 2 : p.ksize == 3 ? 1 : 0;
+  if (!attr[dev][slot]) { HIP_CHECK_RET(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS)); attr[dev][slot] = true; }
+  IgemmP pp = p;
+  void* args[] = {&pp};
+  HIP_CHECK_RET(hipLaunchKernel(kfn, dim3(tiles), dim3(512), args, G::LDS, st));
+  return 0;
+}
+// 0: not for this launch; 1: 256 x 256 tiles; 2: 256 x 160 tiles.  One workgroup per CU, no split-K: the launch must bring enough
+// tiles, and the share of MFMA slots doing useful work (tile padding in M and N x the last, partial wave of tiles) decides.
+static int pick_8p(const IgemmP& p) {
+  const bool lin = p.ksize == 1 && p.stride == 1 && p.up == 1 && p.pad == 0 && p.Hin == p.Hout && p.Win == p.Wout;
+  if (!(p.ksize == 3 || lin) || p.batch > 1) return 0;
+  if (p.M >= (1 << 24) || (long long)p.N * p.K * 2 >= (1LL << 31)) return 0;
+  const long long amax = (long long)p.Hin * p.Win * (p.C0 > p.C1 ? p.C0 : p.C1) * 2;       // bytes of one image of the wider source
+  if (amax * ((long long)p.M / (p.Hout * p.Wout) + 1) >= (1LL << 31)) return 0;                // 32-bit byte offsets per source
+  // the 8-phase kernels carry only the vector epilogue: every lane's channel run (16 / 20 wide) must be whole and 16- / 8-byte aligned
+  const int nout = p.geglu ? p.N / 2 : p.N;
+  auto vec_ok = [&](int run, int sv) { return p.N % run == 0 && p.ldo % (p.out_f32 ? 4 : sv) == 0 && (!p.residual || p.ldr % sv == 0) && nout % sv == 0; };
+  const bool okA = vec_ok(16, 8), okB = !p.geglu && vec_ok(20, 4);
+  if (p.p8 == 2) return okA ? 1 : 0;
+  if (p.p8 == 3) return okB ? 2 : 0;
+  auto eff = [&](int bn) {
+    const long long t = (long long)((p.M + 255) / 256) * ((p.N + bn - 1) / bn), waves = (t + 255) / 256;
+    return (double)p.M * p.N / ((double)waves * 256.0 * 256.0 * bn);
+  };
+  const double eA = okA ? eff(256) : 0.0, eB = okB ? eff(160) : 0.0;
+  if (p.p8 == 4) return (okA || okB) ? (eA >= eB ? 1 : 2) : 0;       // tests: every legal launch
+  // Measured against the 4-wave kernels on the SD-1.5 / VAE shapes (tools/kb_8p.py, hot operands): the 256-wide tile wins on wide
+  // 1x1 launches (L0 qkv 46.9 -> 37.0 us, L0 GEGLU 92 -> 81, L1 qkv 29.6 -> 26.5, L1 GEGLU 74 -> 70) and on 3x3 convs whose N is a
+  // multiple of 256 (VAE 128 px 512 -> 512: 275 -> 248, VAE up-conv 256: 1090 -> 997); the 160-wide tile (12- and 8-MFMA phases) only
+  // ties the 128 x 160 row-halo kernel on the N = 320 convs (62.4 vs 63.3, 155 vs 150) and wins on the upsampling conv, which has no
+  // whole-row halo image at 256 rows (216 -> 194).  Launches with fewer than ~200 tiles lose everywhere (one workgroup per CU, no split-K).
+  if ((p.K >> 6) < 4) return 0;
+  if (eA >= 0.78 && (p.ksize == 3 || p.N >= 768)) return 1;
+  if (eB >= 0.9 && p.ksize == 3 && p.up == 2) return 2;
+  return 0;
+}
+
 #ifdef AGD_EXPERIMENTS
 int g_igemm_cfg = 0;   // experiment knob (tools/ only; production builds have no run-time dispatch knobs)
 extern "C" __attribute__((visibility("default"))) void agd_set_igemm_cfg(int v) { g_igemm_cfg = v; }
@@ -502,6 +560,7 @@ int launch_igemm(const IgemmP& p_in, hipStream_t st) {
     }
   }
 #endif
+  if (p.p8) { const int c8 = pick_8p(p); if (c8 == 1) return launch_8p<2, 4, 8, 2, 2>(p, st); if (c8 == 2) return launch_8p<4, 2, 4, 3, 2>(p, st); }
   if (p.geglu) return launch_cfg<128, 128, 2, 2>(p, 1, st);
   // Small-M launches (8x8 / 16x16 feature maps): ONE workgroup per CU on the 4-stage ring, tile width and K split
   // chosen so that the launch has as close to 256 workgroups as possible.  These launches are a load-latency chain:

@@ -12,7 +12,9 @@
 #pragma once
 #include "kernels.h"
 
-template <int BM, int BN, int WM, int WN, int GEGLU, int SPLITK>
+// FAST_ONLY: the launcher guarantees that every lane's channel run is whole and aligned (N, ldo, ldr multiples of the run): the
+// element-by-element path for ragged tiles is compiled out (igemm8p.h: with 128 accumulators per lane it would put them in scratch)
+template <int BM, int BN, int WM, int WN, int GEGLU, int SPLITK, int FAST_ONLY = 0>
 AGD_DEV void igemm_epilogue(const IgemmP& p, f32x4 (&acc)[BM / WM / 16][BN / WN / 16], char* smem, int lane, int wm, int wn, int m0,
                             int n0, int tn, int bz) {
   constexpr int WTM = BM / WM, WTN = BN / WN;
@@ -57,23 +59,26 @@ AGD_DEV void igemm_epilogue(const IgemmP& p, f32x4 (&acc)[BM / WM / 16][BN / WN 
 #pragma unroll
     for (int i = 0; i < MI; ++i) { rs[i] = 0.f; rq[i] = 0.f; }
     const bool full = no + CW <= Nout;
-    const bool fast = full && (no % SV) == 0 && (p.ldo % (p.out_f32 ? 4 : SV)) == 0 && (!p.residual || (p.ldr % SV) == 0);
+    const bool fast = FAST_ONLY ? full : (full && (no % SV) == 0 && (p.ldo % (p.out_f32 ? 4 : SV)) == 0 && (!p.residual || (p.ldr % SV) == 0));
     if (fast) {
-      // residual chunks first: their latency overlaps the bias loads and the arithmetic
-      unsigned rres[MI][CW / 2];
-      if (p.residual) {
+      // residual chunks first: their latency overlaps the bias loads and the arithmetic.  Tall wave tiles (MI = 8, igemm8p.h) keep
+      // only RA rows in flight -- all eight would cost 64 registers beside the 128 accumulators -- and refill a slot once it is consumed
+      constexpr int RA = MI > 4 ? 2 : MI;
+      unsigned rres[RA][CW / 2];
+      auto load_res = [&](int i, int slot) {
+        const int m = mrow0 + i * 16;
+        if (m < p.M) {
+          const bf16_t* rp = p.residual + bz * p.sR + (long long)m * p.ldr + no;
 #pragma unroll
-        for (int i = 0; i < MI; ++i) {
-          const int m = mrow0 + i * 16;
-          if (m < p.M) {
-            const bf16_t* rp = p.residual + bz * p.sR + (long long)m * p.ldr + no;
-#pragma unroll
-            for (int c = 0; c < CW / SV; ++c) {
-              if constexpr (SV == 8) { const u32x4 t = *(const u32x4*)(rp + 8 * c); rres[i][4 * c] = t[0]; rres[i][4 * c + 1] = t[1]; rres[i][4 * c + 2] = t[2]; rres[i][4 * c + 3] = t[3]; }
-              else { const u32x2 t = *(const u32x2*)(rp + 4 * c); rres[i][2 * c] = t[0]; rres[i][2 * c + 1] = t[1]; }
-            }
+          for (int c = 0; c < CW / SV; ++c) {
+            if constexpr (SV == 8) { const u32x4 t = *(const u32x4*)(rp + 8 * c); rres[slot][4 * c] = t[0]; rres[slot][4 * c + 1] = t[1]; rres[slot][4 * c + 2] = t[2]; rres[slot][4 * c + 3] = t[3]; }
+            else { const u32x2 t = *(const u32x2*)(rp + 4 * c); rres[slot][2 * c] = t[0]; rres[slot][2 * c + 1] = t[1]; }
           }
         }
+      };
+      if (p.residual) {
+#pragma unroll
+        for (int i = 0; i < RA; ++i) load_res(i, i);
       }
       float hb[CW], hg[GEGLU ? CW : 1];
       // LayerNorm folded into this GEMM (A rows are raw, W carries gamma): per-row mean / rstd from the producer's partial sums,
@@ -150,9 +155,10 @@ AGD_DEV void igemm_epilogue(const IgemmP& p, f32x4 (&acc)[BM / WM / 16][BN / WN 
         if (p.residual) {
 #pragma unroll
           for (int e = 0; e < CW; e += 2) {
-            v[e] += __uint_as_float(rres[i][e >> 1] << 16);
-            v[e + 1] += __uint_as_float(rres[i][e >> 1] & 0xFFFF0000u);
+            v[e] += __uint_as_float(rres[i % RA][e >> 1] << 16);
+            v[e + 1] += __uint_as_float(rres[i % RA][e >> 1] & 0xFFFF0000u);
           }
+          if (i + RA < MI) load_res(i + RA, i % RA);
         }
         if (p.act == 1) {
 #pragma unroll
@@ -192,7 +198,7 @@ AGD_DEV void igemm_epilogue(const IgemmP& p, f32x4 (&acc)[BM / WM / 16][BN / WN 
           }
         }
       }
-    } else {
+    } else if constexpr (!FAST_ONLY) {
       // ragged / unaligned tiles (conv_out's 4 channels, N tails): element by element
       float lmu[MI], lrs[MI];
       if (p.ln_stats) {

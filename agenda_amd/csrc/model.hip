@@ -106,6 +106,7 @@ struct agd_ctx {
   int opt_gn_fused = 1;                               // agd_set_option("gn_fused_stats"): GroupNorm statistics from the producing igemm's epilogue
   int opt_warm = 3;                                   // agd_set_option("weight_warm"): in-kernel cold-weight warm-up: 1 = W-major launches (per-XCD slices), 3 = A-major launches too
   int opt_ff_fused = 0;                               // agd_set_option("ff_fused"): GEGLU feed-forward of the C = 320 blocks as one kernel (ff_fused.h)
+  int opt_p8 = 1;                                     // agd_set_option("igemm8p"): 256-row 8-wave / 8-phase igemm for launches with enough tiles (igemm8p.h)
   int opt_halo = 1;                                   // agd_set_option("conv_halo"): 3x3 stride-1 convs through the row-halo kernel (igemm_halo.h)
   int opt_touch = 3;                                  // agd_set_option("weight_touch"): n > 0 = stream 1x1 weight matrices of >= n MB through the caches right before their launch
   unsigned* touch_sink = nullptr;
@@ -162,6 +163,7 @@ struct GemmOpt {
   const float* ln_stats = nullptr; int ln_slots = 0; const float* ln_cs = nullptr; float ln_invC = 0.f, ln_eps = 0.f;   // consumer side
   int warm = 0;                 // benches: request the in-kernel cold-weight warm-up (the walk sets it through the ctx option)
   int halo = 0;                 // benches: allow the row-halo 3x3 kernel (the walk sets it through the ctx option)
+  int p8 = 0;                   // benches: 1 = allow the 8-phase kernel, 2 / 3 = force its 256- / 160-wide tile (the walk sets it through the ctx option)
   int pad = -1;                 // -1: 1 for 3x3, 0 for 1x1
   int hout = 0, wout = 0;       // >0: override (asymmetric (0,1,0,1) padding of the VAE encoder's stride-2 convs)
 };
@@ -187,6 +189,8 @@ static int run_conv(agd_ctx* c, hipStream_t st, const bf16_t* s0, int C0, const 
   p.alpha = o.alpha; p.geglu = o.geglu; p.act = o.act; p.batch = 1; p.zero_page = zero_page; p.ws = c ? &c->splitk : nullptr;
   p.rowstat_out = o.rowstat_out; p.rowstat_slots = o.rowstat_slots;
   p.ln_stats = o.ln_stats; p.ln_slots = o.ln_slots; p.ln_cs = o.ln_cs; p.ln_invC = o.ln_invC; p.ln_eps = o.ln_eps;
+  p.halo = (c && c->opt_halo) || o.halo;
+  p.p8 = o.p8 ? o.p8 : c ? c->opt_p8 : 0;          // before any igemm_query: the tile shape depends on it
   if (o.query_cfg) return igemm_query(p, o.query_cfg);
   if (o.out_act) {
     o.out_act->cpart_bm = 0;
@@ -207,7 +211,6 @@ static int run_conv(agd_ctx* c, hipStream_t st, const bf16_t* s0, int C0, const 
   const bool wmaj = ksize == 1 && w_b > 1.5 * in_b && w_b >= (double)(1 << 20);
   if (c && c->opt_warm) p.warm = c->opt_warm == 1 ? 1 : 3;      // 1: W-major launches only; 3: also A-major launches with >= 1 MB of weights (the launcher decides)
   if (o.warm) p.warm = o.warm;
-  p.halo = (c && c->opt_halo) || o.halo;
   if (c && c->opt_touch > 0 && ksize == 1 && p.M <= 8192 && w_b >= c->opt_touch * 1e6 && !(c->opt_warm && wmaj) && c->opt_warm != 3) {
     // the weights arrive cold (1.7 GB per forward against 256 MB of Infinity Cache): a full-rate streaming read in front of the launch
     // costs less than the tile-by-tile cold misses inside it (tools/kb_cold.py; in situ 575.5 -> 572.3 ms per batch, tools/ab_option.py;
@@ -1032,6 +1035,7 @@ AGD_API int agd_set_option(agd_ctx* c, const char* name, int value) {
   if (!strcmp(name, "weight_touch")) { c->opt_touch = value < 0 ? 0 : value; return 0; }
   if (!strcmp(name, "weight_warm")) { c->opt_warm = value; return 0; }
   if (!strcmp(name, "conv_halo")) { c->opt_halo = value != 0; return 0; }
+  if (!strcmp(name, "igemm8p")) { c->opt_p8 = value < 0 ? 0 : value; return 0; }   // 0 off, 1 on (the launcher decides per launch); tests: 2 / 3 / 4 force the 256-wide / 160-wide / any legal tile
   if (!strcmp(name, "ff_fused")) { c->opt_ff_fused = value != 0; return 0; }
   agd_set_error("set_option: unknown option '%s'", name);
   return fail_ctx(c);
@@ -1326,7 +1330,8 @@ AGD_API int agd_op_conv2d(const float* x, const float* w, const float* bias, flo
                              int ksize, int stride, int pad, int upsample, void* stream) {
   return agd_op_conv2d_ex(x, w, bias, y, B, Cin, H, W, Cout, ksize, stride, pad, upsample, 0, stream);
 }
-// flags bit 0: 3x3 stride-1 launches take the row-halo kernel (igemm_halo.h) where it applies
+// flags bit 0: 3x3 stride-1 launches take the row-halo kernel (igemm_halo.h) where it applies; bits 1..3: the 8-phase kernel
+// (igemm8p.h) -- 2 = where the launcher would pick it, 4 / 8 = force its 256- / 160-wide tile
 AGD_API int agd_op_conv2d_ex(const float* x, const float* w, const float* bias, float* y, int B, int Cin, int H, int W, int Cout,
                                 int ksize, int stride, int pad, int upsample, int flags, void* stream) {
   hipStream_t st = S(stream); Tmp tmp;
@@ -1339,7 +1344,7 @@ AGD_API int agd_op_conv2d_ex(const float* x, const float* w, const float* bias, 
   CK(to_nhwc_bf16(x, xb, B, Cin, H * W, Cpad, st));
   CK(launch_convert_weight(w, wb, Cout, Cin, taps, Cpad, 0, st));
   WMat wm; wm.w = wb; wm.N = Cout; wm.Cin = Cin; wm.Cpad = Cpad; wm.taps = taps;
-  GemmOpt o; o.bias = bias; o.stride = stride; o.up = up; o.out_f32 = 1; o.halo = flags & 1;
+  GemmOpt o; o.bias = bias; o.stride = stride; o.up = up; o.out_f32 = 1; o.halo = flags & 1; o.p8 = (flags & 4) ? 2 : (flags & 8) ? 3 : (flags & 2) ? 1 : 0;
   CK(run_conv(nullptr, st, xb, Cpad, nullptr, 0, B, H, W, wm, ksize, yn, o, op_zero_page()));
   CK(launch_nchw_from_nhwc_f32(yn, Cout, y, B, Cout, Ho * Wo, st));
   hipStreamSynchronize(st);
@@ -1349,6 +1354,7 @@ AGD_API int agd_op_conv2d_ex(const float* x, const float* w, const float* bias, 
 AGD_API int agd_op_linear(const float* x, const float* w, const float* bias, const float* residual, float* y, int M, int K, int N,
                              int geglu, void* stream) {
   hipStream_t st = S(stream); Tmp tmp;
+  const int flags = geglu; geglu &= 1;            // bit 0: GEGLU; bits 1..3: the 8-phase kernel, as in agd_op_conv2d_ex
   if (K % 64) { agd_set_error("op_linear: K must be a multiple of 64"); return -1; }
   const int Nout = geglu ? N / 2 : N;
   bf16_t* xb = tmp.get<bf16_t>((size_t)M * K); bf16_t* wb = tmp.get<bf16_t>((size_t)N * K);
@@ -1358,7 +1364,7 @@ AGD_API int agd_op_linear(const float* x, const float* w, const float* bias, con
   CK(launch_convert_weight(w, wb, N, K, 1, K, geglu ? 16 : 0, st));
   if (residual) CK(launch_f32_to_bf16(residual, rb, (long long)M * Nout, st));
   WMat wm; wm.w = wb; wm.N = N; wm.Cin = K; wm.Cpad = K; wm.taps = 1;
-  GemmOpt o; o.bias = bias; o.residual = rb; o.geglu = geglu; o.out_f32 = 1;
+  GemmOpt o; o.bias = bias; o.residual = rb; o.geglu = geglu; o.out_f32 = 1; o.p8 = (flags & 4) ? 2 : (flags & 8) ? 3 : (flags & 2) ? 1 : 0;
   CK(run_conv(nullptr, st, xb, K, nullptr, 0, 1, 1, M, wm, 1, y, o, op_zero_page()));
   hipStreamSynchronize(st);
   return 0;
@@ -1397,6 +1403,7 @@ AGD_API int agd_op_conv_groupnorm(const float* x, const float* w, const float* b
   p.src0 = xb; p.C0 = Cpad; p.Hin = H; p.Win = W; p.Hout = H; p.Wout = W; p.ksize = 3; p.stride = 1; p.pad = 1; p.up = 1;
   p.W = wb; p.bias = bias; p.bias_mode = bias ? 1 : 0; p.N = Cout; p.K = 9 * Cpad; p.M = B * HW; p.ldr = Cout; p.out = hb; p.ldo = Cout;
   p.alpha = 1.f; p.batch = 1; p.zero_page = op_zero_page();
+  p.p8 = (fused & 4) ? 2 : (fused & 8) ? 3 : (fused & 2) ? 1 : 0; fused &= 1;      // bits 1..3: the 8-phase kernel, as in agd_op_conv2d_ex
   int bm = 0;
   if (fused) {
     int cfg[3] = {0, 0, 0};
@@ -1514,6 +1521,7 @@ AGD_API int agd_bench_conv(int B, int H, int W, int C0, int C1, int Cout, int ks
   // geglu bit 1 = GEGLU; bit 2 = also emit LayerNorm row statistics (producer); bit 4 = LayerNorm-folded consumer epilogue
   const int mode = geglu; geglu &= 1;
   GemmOpt o; o.bias = bias; o.stride = stride; o.up = up; o.geglu = geglu; o.residual = r; o.halo = (mode & 8) ? 1 : 0;
+  o.p8 = (mode & 32) ? 2 : (mode & 64) ? 3 : (mode & 16) ? 1 : 0;
   float* stats = nullptr; float* cs = nullptr;
   if (mode & 6) {
     int cfg[3] = {0, 0, 0}; GemmOpt qo = o; qo.query_cfg = cfg;

@@ -13,7 +13,10 @@ def _f32c(t):
     return t.detach().to(torch.float32).contiguous()
 
 
-def conv2d(x, w, bias=None, stride=1, padding=None, upsample=False, halo=False):
+_P8 = {0: 0, 1: 2, 2: 4, 3: 8}      # igemm8p.h: 1 = where the launcher would pick it, 2 / 3 = force the 256- / 160-wide tile
+
+
+def conv2d(x, w, bias=None, stride=1, padding=None, upsample=False, halo=False, p8=0):
     lib = _lib.load()
     x, w = _f32c(x), _f32c(w)
     b = _f32c(bias) if bias is not None else None
@@ -25,11 +28,11 @@ def conv2d(x, w, bias=None, stride=1, padding=None, upsample=False, halo=False):
     Wo = (W * up + 2 * pad - k) // stride + 1
     y = torch.empty(B, Cout, Ho, Wo, device=x.device, dtype=torch.float32)
     _lib.check(lib.agd_op_conv2d_ex(_lib.ptr(x), _lib.ptr(w), _lib.ptr(b), _lib.ptr(y), B, Cin, H, W, Cout, k, stride,
-                                    pad, int(upsample), 1 if halo else 0, _lib.current_stream_ptr()), None, "agd_op_conv2d")
+                                    pad, int(upsample), (1 if halo else 0) | _P8[p8], _lib.current_stream_ptr()), None, "agd_op_conv2d")
     return y
 
 
-def linear(x, w, bias=None, residual=None, geglu=False):
+def linear(x, w, bias=None, residual=None, geglu=False, p8=0):
     lib = _lib.load()
     x2 = _f32c(x).reshape(-1, x.shape[-1])
     w = _f32c(w)
@@ -39,7 +42,7 @@ def linear(x, w, bias=None, residual=None, geglu=False):
     b = _f32c(bias) if bias is not None else None
     r = _f32c(residual).reshape(M, Nout) if residual is not None else None
     y = torch.empty(M, Nout, device=x.device, dtype=torch.float32)
-    _lib.check(lib.agd_op_linear(_lib.ptr(x2), _lib.ptr(w), _lib.ptr(b), _lib.ptr(r), _lib.ptr(y), M, K, N, int(geglu),
+    _lib.check(lib.agd_op_linear(_lib.ptr(x2), _lib.ptr(w), _lib.ptr(b), _lib.ptr(r), _lib.ptr(y), M, K, N, int(geglu) | _P8[p8],
                                  _lib.current_stream_ptr()), None, "agd_op_linear")
     return y.reshape(*x.shape[:-1], Nout)
 
@@ -124,7 +127,7 @@ def attn_reg_loss(attn_map: torch.Tensor, obj_idx, fg_idx, bg_idx, coef: float, 
     return loss, dmap
 
 
-def conv_groupnorm(x, w, bias, gamma, beta, groups=32, eps=1e-5, silu=True, fused=True):
+def conv_groupnorm(x, w, bias, gamma, beta, groups=32, eps=1e-5, silu=True, fused=True, p8=0):
     """conv3x3 -> GroupNorm(+SiLU) chained like the graph walk; `fused`: GroupNorm statistics from the conv launch's epilogue."""
     lib = _lib.load()
     x, w = _f32c(x), _f32c(w)
@@ -134,5 +137,5 @@ def conv_groupnorm(x, w, bias, gamma, beta, groups=32, eps=1e-5, silu=True, fuse
     Cout = w.shape[0]
     y = torch.empty(B, Cout, H, W, device=x.device, dtype=torch.float32)
     _lib.check(lib.agd_op_conv_groupnorm(_lib.ptr(x), _lib.ptr(w), _lib.ptr(b), _lib.ptr(ga), _lib.ptr(be), _lib.ptr(y), B, Cin, H, W, Cout,
-                                         groups, float(eps), int(silu), int(fused), _lib.current_stream_ptr()), None, "agd_op_conv_groupnorm")
+                                         groups, float(eps), int(silu), int(fused) | _P8[p8], _lib.current_stream_ptr()), None, "agd_op_conv_groupnorm")
     return y

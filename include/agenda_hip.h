@@ -167,7 +167,8 @@ int agd_attn_processor_backward(agd_ctx* ctx, const char* layer, const float* hi
  * used by the parity tests, mirror torch.nn.functional signatures the oracle uses. */
 int agd_op_conv2d(const float* x_nchw, const float* w, const float* bias, float* y_nchw, int B, int Cin, int H, int W,
                   int Cout, int ksize, int stride, int pad, int upsample, void* stream);
-/* flags bit 0: 3x3 stride-1 launches take the row-halo kernel where it applies */
+/* flags bit 0: 3x3 stride-1 launches take the row-halo kernel where it applies; bits 1..3: the 256-row 8-wave / 8-phase kernel --
+   2 = where the launcher would pick it, 4 / 8 = force its 256- / 160-wide tile (agd_op_linear: the same bits in `geglu`, bit 0 = GEGLU) */
 int agd_op_conv2d_ex(const float* x, const float* w, const float* bias, float* y, int B, int Cin, int H, int W, int Cout,
                      int ksize, int stride, int pad, int upsample, int flags, void* stream);
 int agd_op_linear(const float* x, const float* w, const float* bias, const float* residual, float* y, int M, int K,

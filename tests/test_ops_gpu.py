@@ -122,6 +122,10 @@ def test_groupnorm_statistics_from_the_conv_epilogue(ops, B, Cin, H, Cout):
     d = (fused - sep).abs().cpu()
     assert float(d.max()) <= float(want.abs().max()) * 2.0 ** -7                      # at most a bf16 ulp of the largest value
     assert float((d > 0).float().mean()) < 0.02                                       # ... and only on isolated elements
+    if B * H * H >= 2048 and Cout % 20 == 0:          # the same through the 8-phase kernel: partial sums per 256-row tile
+        f8 = ops.conv_groupnorm(x.cuda(), w.cuda(), b.cuda(), ga.cuda(), be.cuda(), fused=True, p8=3)
+        assert rel_err(f8, want) < REL
+        assert float((f8 - sep).abs().max()) <= float(want.abs().max()) * 2.0 ** -7
 
 
 @pytest.mark.parametrize("rows,C", [(64, 320), (10, 1280), (7, 64), (33, 640)])
@@ -293,3 +297,59 @@ def test_igemm_random_shape_sweep(ops):
         assert rel_err(got, y) < 1e-4, (M, K, N, geglu, res, rel_err(got, y))
         n_lin += 1
     assert n_conv == 28 and n_lin == 16
+
+
+@pytest.mark.parametrize("B,Cin,H,Cout,k,stride,up,p8", [
+    (8, 128, 32, 256, 3, 1, False, 2),     # 256 x 256 tiles, 32 M tiles x 1
+    (8, 128, 32, 320, 3, 1, False, 3),     # 256 x 160 tiles (4 x 2 waves, 12 + 8 MFMA phases)
+    (3, 192, 20, 160, 3, 1, False, 3),     # M tail (1200 rows), odd number of K tiles (27)
+    (3, 64, 20, 512, 3, 1, False, 2),      # nk = 9 (odd), M tail
+    (2, 64, 32, 256, 3, 2, False, 2),      # stride 2
+    (2, 128, 16, 320, 3, 1, True, 3),      # nearest-2x upsample folded into the gather
+    (2, 64, 32, 96, 3, 1, False, 2),       # N tail inside the only N tile (96 of 256 columns)
+    (4, 320, 32, 640, 1, 1, False, 3),     # 1x1: im2col row = pixel
+    (2, 64, 64, 1280, 1, 1, False, 2),     # one K tile only (nk = 1)
+    (2, 128, 64, 400, 1, 1, False, 3),     # N tail across tiles (400 = 2.5 x 160), nk = 2
+])
+def test_igemm8p_conv(ops, B, Cin, H, Cout, k, stride, up, p8):
+    """igemm8p.h (256-row tiles, 8 waves, 8-phase schedule) forced through the op entry point, against F.conv2d and against the
+    4-wave kernels: 3x3 / 1x1, stride, upsample, M and N tails, odd / tiny K-tile counts, both tile widths."""
+    g = torch.Generator().manual_seed(B * 1000 + Cin + Cout + k + p8)
+    x = bfr(torch.randn(B, Cin, H, H, generator=g))
+    w = bfr(torch.randn(Cout, Cin, k, k, generator=g) / math.sqrt(Cin * k * k))
+    b = torch.randn(Cout, generator=g) * 0.1
+    xi = F.interpolate(x, scale_factor=2.0, mode="nearest") if up else x
+    want = F.conv2d(xi, w, b, stride=stride, padding=1 if k == 3 else 0)
+    got = ops.conv2d(x.cuda(), w.cuda(), b.cuda(), stride=stride, upsample=up, p8=p8).cpu()
+    ref = ops.conv2d(x.cuda(), w.cuda(), b.cuda(), stride=stride, upsample=up).cpu()
+    assert got.shape == want.shape
+    scale = float(want.abs().max())
+    assert float((got - want).abs().max()) / scale < 2e-6                # fp32 accumulation of exact bf16 products
+    assert float((got - ref).abs().max()) / scale < 1e-5
+
+
+@pytest.mark.parametrize("M,K,N,geglu,res,p8", [
+    (4096, 1280, 320, False, True, 3),
+    (2048, 320, 2560, True, False, 2),       # GEGLU ([8 values | 8 gates] row groups in a lane's 16 columns)
+    (1000, 640, 5120, True, False, 2),       # GEGLU, M tail
+    (8192, 320, 960, False, False, 3),
+    (777, 2560, 640, False, True, 3),        # ragged M, residual, 40 K tiles
+    (4096, 256, 512, False, True, 2),
+    (300, 64, 1280, False, False, 2),        # nk = 1
+])
+def test_igemm8p_linear(ops, M, K, N, geglu, res, p8):
+    g = torch.Generator().manual_seed(M + K + N + p8)
+    x = bfr(torch.randn(M, K, generator=g))
+    w = bfr(torch.randn(N, K, generator=g) / math.sqrt(K))
+    b = torch.randn(N, generator=g) * 0.1
+    y = F.linear(x, w, b)
+    if geglu:
+        val, gate = y.chunk(2, dim=-1)
+        y = val * F.gelu(gate)
+    r = bfr(torch.randn(M, y.shape[1], generator=g)) if res else None
+    if res:
+        y = y + r
+    got = ops.linear(x.cuda(), w.cuda(), b.cuda(), r.cuda() if res else None, geglu=geglu, p8=p8)
+    ref = ops.linear(x.cuda(), w.cuda(), b.cuda(), r.cuda() if res else None, geglu=geglu)
+    assert rel_err(got, y) < 1e-4
+    assert rel_err(got, ref.cpu()) < 1e-5
