@@ -9,7 +9,9 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libagenda_hip.so")
+# AGD_LIB: developer override of the library path (tools/ point it at the experiments build, `make -C agenda_amd/csrc exp`);
+# whatever the path, a missing or unloadable library raises -- there is no fallback
+LIB_PATH = os.environ.get("AGD_LIB") or os.path.join(_HERE, "libagenda_hip.so")
 AGD_MAX_LEVELS = 8
 AGD_N_CLASSES = 11
 
@@ -88,12 +90,6 @@ _SIGS = {
     "agd_profile_end": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_longlong)]),
     "agd_profile_end_ex": (C.c_int, [_P, C.c_double, C.c_double] + [C.POINTER(C.c_double)] * 5 + [C.POINTER(C.c_longlong)]),
     "agd_profile_class_name": (C.c_char_p, [C.c_int]),
-    "agd_bench_conv": (C.c_int, [C.c_int] * 12 + [C.POINTER(C.c_double)]),
-    "agd_bench_attention": (C.c_int, [C.c_int] * 7 + [C.POINTER(C.c_double)]),
-    "agd_bench_groupnorm": (C.c_int, [C.c_int] * 4 + [C.POINTER(C.c_double)]),
-    "agd_bench_ff": (C.c_int, [C.c_int] * 4 + [C.POINTER(C.c_double)]),
-    "agd_bench_conv_cold": (C.c_int, [C.c_int] * 10 + [C.POINTER(C.c_double)]),
-    "agd_bench_groupnorm_ex": (C.c_int, [C.c_int] * 6 + [C.POINTER(C.c_double)]),
     "agd_version": (C.c_char_p, []),
 }
 

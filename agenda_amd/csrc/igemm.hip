@@ -61,9 +61,11 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_kernel(const IgemmP p) 
   // lockstep and stay there -- both in the LDS/MFMA-bound main loop, then both in the store/VALU-bound epilogue.  The
   // second occupant of each CU (blocks 256..511 of the first dispatch wave) starts `stagger` x 1024 cycles late, so one
   // workgroup's epilogue runs beside the other's main loop for the rest of the launch.  Speed only: any placement is correct.
+#ifdef AGD_EXPERIMENTS   // measured: no effect at any delay; kept for the experiments library only
   if (p.stagger > 0 && blockIdx.y == 0 && blockIdx.z == 0 && (blockIdx.x >> 8) == 1) {
     for (int i = 0; i < p.stagger; ++i) __builtin_amdgcn_s_sleep(16);
   }
+#endif
   const int tiles_n = (p.N + BN - 1) / BN;
   const int bid = xcd_remap(blockIdx.x, gridDim.x);
   // consecutive logical ids share an XCD's L2 (xcd_remap): walk the tiles so that they share the LARGER operand panel --
@@ -395,9 +397,11 @@ static int launch_cfg(const IgemmP& p, int splits, hipStream_t st) {
   if ((p.rowstat_out || p.ln_stats) && splits > 1) { agd_set_error("igemm: LayerNorm fold on a split-K launch"); return -1; }
   if (p.colstat_out && (splits > 1 || p.colstat_rows < 1 || p.colstat_rows % BM)) { agd_set_error("igemm: column statistics need an unsplit launch whose M tiles stay inside one image"); return -1; }
   if (p.rowstat_out && p.rowstat_slots != (p.N + BN - 1) / BN) { agd_set_error("igemm: rowstat_slots %d != N tiles %d", p.rowstat_slots, (p.N + BN - 1) / BN); return -1; }
+#ifdef AGD_EXPERIMENTS
   static const bool logit = getenv("AGD_IGEMM_LOG") != nullptr;      // tools/layer_report.py joins this with a kernel trace
   if (logit) fprintf(stderr, "IGEMM M=%d N=%d K=%d ks=%d stride=%d up=%d geglu=%d res=%d tile=%dx%d splits=%d batch=%d\n", p.M, p.N, p.K, p.ksize,
                      p.stride, p.up, p.geglu, p.residual ? 1 : 0, BM, BN, splits, p.batch > 0 ? p.batch : 1);
+#endif
   constexpr bool HALO_TILE = BM == 128 && WM == 2 && WN == 2 && (BN == 128 || BN == 160);
   if (splits > 1) {
     int rc;
@@ -448,9 +452,11 @@ static int launch_8p(const IgemmP& p, hipStream_t st) {
   if (p.cfg_out) { p.cfg_out[0] = G::BM; p.cfg_out[1] = G::BN; p.cfg_out[2] = 1; return 0; }
   if (p.colstat_out && (p.colstat_rows < 1 || p.colstat_rows % G::BM)) { agd_set_error("igemm8p: column statistics need M tiles inside one image"); return -1; }
   if (p.rowstat_out && p.rowstat_slots != (p.N + G::BN - 1) / G::BN) { agd_set_error("igemm8p: rowstat_slots %d != N tiles %d", p.rowstat_slots, (p.N + G::BN - 1) / G::BN); return -1; }
+#ifdef AGD_EXPERIMENTS
   static const bool logit = getenv("AGD_IGEMM_LOG") != nullptr;
   if (logit) fprintf(stderr, "IGEMM M=%d N=%d K=%d ks=%d stride=%d up=%d geglu=%d res=%d tile=%dx%d splits=1 batch=1\n", p.M, p.N, p.K, p.ksize, p.stride, p.up,
                      p.geglu, p.residual ? 1 : 0, G::BM, G::BN);
+#endif
   const int tiles = ((p.M + G::BM - 1) / G::BM) * ((p.N + G::BN - 1) / G::BN);
   const void* kfn = nullptr;
   if (p.geglu) {

@@ -42,7 +42,8 @@ struct P8Geom {
   static constexpr int IT0 = (NP0 + 7) / 8, IT1 = (NP1 + 7) / 8;            // piece slots per wave (piece = wid + 8 i, live while < NP)
   static constexpr int RING = 2 * KT;
   static constexpr int EPI = BM * BN * 2 + WM * BN * 8;                     // epilogue staging (GroupNorm statistics: bf16 tile + column sums)
-  static constexpr int LDS = (RING > EPI ? RING : EPI) + 8192;              // + one scratch KiB per wave (cold-weight warm-up pieces)
+  static constexpr int STATS_OFF = (RING > EPI ? RING : EPI);                // LayerNorm-fold consumers: (mean, rstd) of the tile's 256 rows, 2 KiB
+  static constexpr int LDS = STATS_OFF + 2048 + 8192;                        // + one scratch KiB per wave (cold-weight warm-up pieces)
   static_assert(WM * WN == 8 && BM == 256 && (MI % 2) == 0, "8 waves, 256-row tile");
   static_assert((NP0 % 8 == 0 || NP0 % 8 == 4) && (NP1 % 8 == 0 || NP1 % 8 == 4), "piece counts must be uniform per wave group");
 };
@@ -239,6 +240,17 @@ __global__ __launch_bounds__(512, 2) void igemm8p_kernel(const IgemmP p) {
   const bool live1 = nk > 1;
   if (live1) advance();
   stageB0(1, live1); stageA(1, 0, live1); stageB1(1, live1);
+  // LayerNorm-fold consumer: one thread per tile row sums the producer's partial sums (its `slots` dependent loads run beside the
+  // prologue's LDS-DMA) and leaves (mean, rstd) in LDS for the epilogue -- the eight rows of a lane would otherwise cost the epilogue
+  // eight x slots exposed L2 round trips with nothing to overlap them (one workgroup per CU)
+  if (p.ln_stats && tid < BM) {
+    const int m = m0 + tid;
+    float S = 0.f, Q = 0.f;
+    if (m < p.M) for (int k = 0; k < p.ln_slots; ++k) { const f32x2 v = *(const f32x2*)(p.ln_stats + ((long long)m * p.ln_slots + k) * 2); S += v[0]; Q += v[1]; }
+    const float mu = S * p.ln_invC;
+    float var = Q * p.ln_invC - mu * mu; var = var < 0.f ? 0.f : var;
+    *(f32x2*)(smem + G::STATS_OFF + tid * 8) = f32x2{mu, rsqrtf(var + p.ln_eps)};
+  }
   if (grp == 0) p8_wait_vm<INFL_G0>(); else p8_wait_vm<INFL_G1>();
   P8_BAR();
   if (grp == 1) P8_BAR();
@@ -248,5 +260,5 @@ __global__ __launch_bounds__(512, 2) void igemm8p_kernel(const IgemmP p) {
   if (grp == 0) P8_BAR();
   p8_wait_vm<0>();                                   // dead tail pieces still write zeros into LDS: let them land before the epilogue reuses it
 
-  igemm_epilogue<BM, BN, WM, WN, GEGLU, 0, 1>(p, acc, smem, lane, wm, wn, m0, n0, tn, 0);
+  igemm_epilogue<BM, BN, WM, WN, GEGLU, 0, 1>(p, acc, smem, lane, wm, wn, m0, n0, tn, 0, p.ln_stats ? (const float*)(smem + G::STATS_OFF) : nullptr);
 }

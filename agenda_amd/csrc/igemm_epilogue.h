@@ -12,11 +12,42 @@
 #pragma once
 #include "kernels.h"
 
+// LayerNorm-fold consumer: per-row mean / rstd of the A rows from the producer's per-N-tile partial sums [M][slots] float2.
+// The slot loop is OUTSIDE the (unrolled) row loop, so the MI loads of one slot are independent and in flight together: with the
+// rows outside, every row paid `slots` dependent L2 round trips one after the other (8-row wave tiles: +17 us on an L0 qkv launch).
+// Summation order per row is unchanged (slot 0, 1, ...).  lds_stats != nullptr: the kernel prologue already left (mean, rstd) of
+// the tile's rows in LDS (igemm8p.h).
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+template <int MI>
+AGD_DEV void ln_row_stats(const IgemmP& p, int mrow0, int row0_tile, const float* lds_stats, float (&lmu)[MI], float (&lrs)[MI]) {
+  if (lds_stats) {
+#pragma unroll
+    for (int i = 0; i < MI; ++i) { const f32x2 v = *(const f32x2*)(lds_stats + (row0_tile + i * 16) * 2); lmu[i] = v[0]; lrs[i] = v[1]; }
+    return;
+  }
+  float S[MI], Q[MI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i) { S[i] = 0.f; Q[i] = 0.f; }
+  for (int k = 0; k < p.ln_slots; ++k) {
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      const int m = mrow0 + i * 16;
+      if (m < p.M) { const f32x2 v = *(const f32x2*)(p.ln_stats + ((long long)m * p.ln_slots + k) * 2); S[i] += v[0]; Q[i] += v[1]; }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    const float mu = S[i] * p.ln_invC;
+    float var = Q[i] * p.ln_invC - mu * mu; var = var < 0.f ? 0.f : var;
+    lmu[i] = mu; lrs[i] = rsqrtf(var + p.ln_eps);
+  }
+}
+
 // FAST_ONLY: the launcher guarantees that every lane's channel run is whole and aligned (N, ldo, ldr multiples of the run): the
 // element-by-element path for ragged tiles is compiled out (igemm8p.h: with 128 accumulators per lane it would put them in scratch)
 template <int BM, int BN, int WM, int WN, int GEGLU, int SPLITK, int FAST_ONLY = 0>
 AGD_DEV void igemm_epilogue(const IgemmP& p, f32x4 (&acc)[BM / WM / 16][BN / WN / 16], char* smem, int lane, int wm, int wn, int m0,
-                            int n0, int tn, int bz) {
+                            int n0, int tn, int bz, const float* lds_stats = nullptr) {
   constexpr int WTM = BM / WM, WTN = BN / WN;
   constexpr int MI = WTM / 16, NI = WTN / 16;
   static_assert(!GEGLU || NI == 4, "GEGLU epilogue: a lane's 16 columns must be one [8 values | 8 gates] group");
@@ -86,18 +117,7 @@ AGD_DEV void igemm_epilogue(const IgemmP& p, f32x4 (&acc)[BM / WM / 16][BN / WN 
       const bool lnf = p.ln_stats != nullptr;
       float lmu[MI], lrs[MI], cs[CW], csg[GEGLU ? CW : 1];
       if (lnf) {
-#pragma unroll
-        for (int i = 0; i < MI; ++i) {
-          const int m = mrow0 + i * 16;
-          float S = 0.f, Q = 0.f;
-          if (m < p.M) {
-            const float* sp = p.ln_stats + (long long)m * p.ln_slots * 2;
-            for (int k = 0; k < p.ln_slots; ++k) { S += sp[2 * k]; Q += sp[2 * k + 1]; }
-          }
-          const float mu = S * p.ln_invC;
-          float var = Q * p.ln_invC - mu * mu; var = var < 0.f ? 0.f : var;
-          lmu[i] = mu; lrs[i] = rsqrtf(var + p.ln_eps);
-        }
+        ln_row_stats<MI>(p, mrow0, wm * WTM + px, lds_stats, lmu, lrs);
 #pragma unroll
         for (int c = 0; c < CW / 4; ++c) *(f32x4*)&cs[4 * c] = *(const f32x4*)(p.ln_cs + no + 4 * c);
         if constexpr (GEGLU) {
@@ -201,20 +221,7 @@ AGD_DEV void igemm_epilogue(const IgemmP& p, f32x4 (&acc)[BM / WM / 16][BN / WN 
     } else if constexpr (!FAST_ONLY) {
       // ragged / unaligned tiles (conv_out's 4 channels, N tails): element by element
       float lmu[MI], lrs[MI];
-      if (p.ln_stats) {
-#pragma unroll
-        for (int i = 0; i < MI; ++i) {
-          const int m = mrow0 + i * 16;
-          float S = 0.f, Q = 0.f;
-          if (m < p.M) {
-            const float* sp = p.ln_stats + (long long)m * p.ln_slots * 2;
-            for (int k = 0; k < p.ln_slots; ++k) { S += sp[2 * k]; Q += sp[2 * k + 1]; }
-          }
-          const float mu = S * p.ln_invC;
-          float var = Q * p.ln_invC - mu * mu; var = var < 0.f ? 0.f : var;
-          lmu[i] = mu; lrs[i] = rsqrtf(var + p.ln_eps);
-        }
-      }
+      if (p.ln_stats) ln_row_stats<MI>(p, mrow0, wm * WTM + px, lds_stats, lmu, lrs);
 #pragma unroll
       for (int i = 0; i < MI; ++i) {
         const int m = mrow0 + i * 16;

@@ -43,7 +43,7 @@ struct IgemmP {
   int warm;                         // caller: 1 = cold weights expected; the launcher keeps it only for W-major launches (in-kernel warm-up of the XCD's W slice)
   int halo;                         // caller: 1 = 3x3 stride-1 launches may take the row-halo kernel (igemm_halo.h)
   int p8;                           // caller: 1 = launches with enough 256-row tiles take the 8-wave / 8-phase kernel (igemm8p.h); 2 / 3 force its 256- / 160-wide tile, 4 = any legal tile (benches, tests)
-  int stagger;                      // set by the launcher: start delay of the CU's second workgroup, x1024 cycles (speed only)
+  int stagger;                      // timing experiments only: start delay of the CU's second workgroup, x1024 cycles
   int dbg;                          // timing experiments only (builds with -DAGD_EXPERIMENTS)
 };
 int launch_igemm(const IgemmP& p, hipStream_t st);

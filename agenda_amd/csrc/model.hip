@@ -1489,6 +1489,7 @@ AGD_API int agd_op_bicubic_clamp_mean(const float* maps, int n_maps, int T, int 
   return 0;
 }
 
+#ifdef AGD_EXPERIMENTS   // the micro-benchmark entry points exist only in the experiments library (make exp): tools/kb*.py
 // ---------------------------------------------------------------------------------------
 // kernel micro-benchmarks (random bf16 operands; HIP-event timing on the launch stream)
 // ---------------------------------------------------------------------------------------
@@ -1689,6 +1690,7 @@ AGD_API int agd_bench_groupnorm_ex(int B, int HW, int C0, int C1, int fused_stat
   return 0;
 }
 AGD_API int agd_bench_groupnorm(int B, int HW, int C, int iters, double* ms_out) { return agd_bench_groupnorm_ex(B, HW, C, 0, 0, iters, ms_out); }
+#endif  // AGD_EXPERIMENTS
 
 
 // ---------------------------------------------------------------------------------------

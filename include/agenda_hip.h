@@ -210,6 +210,8 @@ int agd_profile_end_ex(agd_ctx* ctx, double mfma_peak_flops, double hbm_peak_byt
                        double* roof_ms, double* roof_ms_hbm_bound, long long* launches);
 const char* agd_profile_class_name(int cls);
 
+#ifdef AGD_EXPERIMENTS
+/* Only in the experiments library (`make -C agenda_amd/csrc exp` -> agenda_amd/libagenda_hip_exp.so); the product library exports none of these. */
 /* ---- kernel micro-benchmarks (tools/kbench.py): random bf16 operands, HIP-event timing of `iters` launches -> ms per launch */
 int agd_bench_conv(int B, int H, int W, int C0, int C1, int Cout, int ksize, int stride, int up, int geglu, int with_residual,
                    int iters, double* ms_out);
@@ -220,6 +222,7 @@ int agd_bench_groupnorm(int B, int HW, int C, int iters, double* ms_out);
 /* GEGLU feed-forward (M rows, C channels): fused = 1 one kernel (C = 320), 0 = GEGLU projection + ff.net.2 launches */
 int agd_bench_ff(int M, int C, int fused, int iters, double* ms_out);
 int agd_bench_groupnorm_ex(int B, int HW, int C0, int C1, int fused_stats, int iters, double* ms_out);
+#endif /* AGD_EXPERIMENTS */
 
 const char* agd_version(void);
 

@@ -16,6 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _declared_symbols():
     txt = open(os.path.join(ROOT, "include", "agenda_hip.h")).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    txt = re.sub(r"#ifdef AGD_EXPERIMENTS.*?#endif", "", txt, flags=re.S)      # micro-benchmark entry points: experiments library only
     return sorted(set(re.findall(r"\b(agd_[a-z0-9_]+)\s*\(", txt)))
 
 

@@ -1,1 +1,3 @@
-mkdir -p /tmp/exp && cp -r agenda_amd/csrc /tmp/exp/csrc && mkdir -p /tmp/exp/include && cp include/agenda_hip.h /tmp/exp/include/ && cd /tmp/exp/csrc && sed -i "s#../../include/agenda_hip.h#../include/agenda_hip.h#" model.hip Makefile && rm -f *.o && make -j16 EXTRA=-DAGD_EXPERIMENTS OUT=/tmp/exp/libagenda_hip.so > /tmp/exp/build.log 2>&1; tail -1 /tmp/exp/build.log; cd $GRAFT_REPO_ROOT
+# experiments library (agd_bench_* entry points, AGD_IGEMM_LOG, timing knobs): agenda_amd/libagenda_hip_exp.so.  Build it in the
+# container before a gpurun call (in-tree .so files travel to the GPU box) or on the box itself.
+make -C "$(dirname "$0")/../agenda_amd/csrc" -j8 exp

@@ -1,6 +1,6 @@
 import ctypes as C, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-lib = C.CDLL(os.path.join(ROOT, "agenda_amd", "libagenda_hip.so"))
+lib = C.CDLL(os.environ.get("AGD_LIB", os.path.join(ROOT, "agenda_amd", "libagenda_hip_exp.so")))
 lib.agd_bench_attention.argtypes = [C.c_int] * 7 + [C.POINTER(C.c_double)]
 def attn(B, H, D, Nq, Nk, record=0, iters=10):
     ms = C.c_double(); lib.agd_bench_attention(B, H, D, Nq, Nk, record, iters, C.byref(ms))

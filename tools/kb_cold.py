@@ -3,7 +3,7 @@
 matrix in front: python tools/kb_cold.py"""
 import ctypes as C, os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-lib = C.CDLL(os.environ.get("AGD_LIB", os.path.join(ROOT, "agenda_amd", "libagenda_hip.so")))
+lib = C.CDLL(os.environ.get("AGD_LIB", os.path.join(ROOT, "agenda_amd", "libagenda_hip_exp.so")))
 lib.agd_bench_conv_cold.argtypes = [C.c_int] * 10 + [C.POINTER(C.c_double)]
 shapes = [("L2 C->C  M2048 K1280 N1280 +res", (8, 16, 16, 1280, 1280, 1, 0, 1)), ("L2 qkv   N3840", (8, 16, 16, 1280, 3840, 1, 0, 0)),
           ("L2 geglu N10240", (8, 16, 16, 1280, 10240, 1, 1, 0)), ("L2 ff2   K5120 +res", (8, 16, 16, 5120, 1280, 1, 0, 1)),

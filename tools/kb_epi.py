@@ -1,6 +1,6 @@
 import ctypes as C, os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-lib = C.CDLL(os.path.join(ROOT, "agenda_amd", "libagenda_hip.so"))
+lib = C.CDLL(os.environ.get("AGD_LIB", os.path.join(ROOT, "agenda_amd", "libagenda_hip_exp.so")))
 import sys
 lib.agd_set_igemm_cfg(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 lib.agd_bench_conv.argtypes = [C.c_int] * 12 + [C.POINTER(C.c_double)]

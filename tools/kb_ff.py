@@ -2,7 +2,7 @@
 """GEGLU feed-forward of the C = 320 transformer blocks (M = 32768 rows at UNet batch 8): fused kernel against the two launches."""
 import ctypes as C, os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-lib = C.CDLL(os.environ.get("AGD_LIB", os.path.join(ROOT, "agenda_amd", "libagenda_hip.so")))
+lib = C.CDLL(os.environ.get("AGD_LIB", os.path.join(ROOT, "agenda_amd", "libagenda_hip_exp.so")))
 lib.agd_bench_ff.argtypes = [C.c_int] * 4 + [C.POINTER(C.c_double)]
 for M in (32768, 16384, 4096):
     row = []

@@ -3,7 +3,7 @@ Needs an experiments build of the library: make -C agenda_amd/csrc clean all EXT
 import ctypes as C, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if len(sys.argv) > 1 and sys.argv[1] == "--one":
-    lib = C.CDLL(os.path.join(ROOT, "agenda_amd", "libagenda_hip.so"))
+    lib = C.CDLL(os.environ.get("AGD_LIB", os.path.join(ROOT, "agenda_amd", "libagenda_hip_exp.so")))
     lib.agd_bench_conv.argtypes = [C.c_int] * 12 + [C.POINTER(C.c_double)]
     H, C0, Cout, k, res = map(int, sys.argv[2:7])
     ms = C.c_double()

@@ -3,7 +3,7 @@
 with the streaming rate (one read + one write of the activation).  python tools/kb_gn.py"""
 import ctypes as C, os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-lib = C.CDLL(os.environ.get("AGD_LIB", os.path.join(ROOT, "agenda_amd", "libagenda_hip.so")))
+lib = C.CDLL(os.environ.get("AGD_LIB", os.path.join(ROOT, "agenda_amd", "libagenda_hip_exp.so")))
 lib.agd_bench_groupnorm_ex.argtypes = [C.c_int] * 6 + [C.POINTER(C.c_double)]
 B = 8
 # (HW, C0, C1, launches per forward): resnet norm1 / norm2, transformer norm, conv_norm_out

@@ -2,7 +2,7 @@
 """3x3 stride-1 convs: general kernel against the row-halo kernel (igemm_halo.h), per shape.  python tools/kb_halo.py"""
 import ctypes as C, os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-lib = C.CDLL(os.environ.get("AGD_LIB", os.path.join(ROOT, "agenda_amd", "libagenda_hip.so")))
+lib = C.CDLL(os.environ.get("AGD_LIB", os.path.join(ROOT, "agenda_amd", "libagenda_hip_exp.so")))
 lib.agd_bench_conv.argtypes = [C.c_int] * 12 + [C.POINTER(C.c_double)]
 shapes = [("L0 320->320 +res", (8, 64, 320, 0, 320, 1)), ("L0 640->320 (concat)", (8, 64, 320, 320, 320, 0)), ("L0 960->320 (concat)", (8, 64, 640, 320, 320, 0)),
           ("L1 640->640 +res", (8, 32, 640, 0, 640, 1)), ("L1 1280->640 (concat)", (8, 32, 640, 640, 640, 0)), ("L1 320->640", (8, 32, 320, 0, 640, 0)),

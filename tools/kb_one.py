@@ -3,7 +3,7 @@
 rocprofv3 --pmc <counters> -d <dir> -- python3 tools/kb_one.py"""
 import ctypes as C, os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-lib = C.CDLL(os.environ.get("AGD_LIB", os.path.join(ROOT, "agenda_amd", "libagenda_hip.so")))
+lib = C.CDLL(os.environ.get("AGD_LIB", os.path.join(ROOT, "agenda_amd", "libagenda_hip_exp.so")))
 lib.agd_bench_conv.argtypes = [C.c_int] * 12 + [C.POINTER(C.c_double)]
 ms = C.c_double()
 for sh in ((8, 64, 640, 320, 3, 0, 0), (8, 64, 320, 320, 1, 0, 1), (8, 64, 320, 2560, 1, 1, 0)):

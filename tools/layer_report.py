@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Join the per-launch igemm shape log (AGD_IGEMM_LOG=1, stderr) with a rocprofv3 kernel trace: per-layer in-situ
+"""Join the per-launch igemm shape log (experiments library, AGD_IGEMM_LOG=1, stderr) with a rocprofv3 kernel trace: per-layer in-situ
 time and TFLOP/s for ONE UNet forward.  Usage: layer_report.py <stderr log> <kernel_trace.csv> [forward index]"""
 import collections
 import csv
@@ -17,8 +17,11 @@ with open(trace) as f:
     for r in csv.DictReader(f):
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
 rows.sort()
-ig = [(i, r) for i, r in enumerate(rows) if r[2].startswith("void igemm_kernel")]
+# every igemm launch logs one line, whichever kernel family it dispatches to (4-wave general / row-halo / 8-phase); the log and the
+# trace are both in launch order on the one stream
+ig = [(i, r) for i, r in enumerate(rows) if r[2].startswith(("void igemm_kernel", "void igemm_halo_kernel", "void igemm8p_kernel"))]
 assert len(ig) == len(shapes), (len(ig), len(shapes))
+fam = {"void igemm_kernel": "4w", "void igemm_halo_kernel": "halo", "void igemm8p_kernel": "8p"}
 marks = [i for i, r in enumerate(rows) if "timestep_embed" in r[2] or "prep_latents" in r[2]]
 prep = [i for i, r in enumerate(rows) if "prep_latents" in r[2]]
 a, b = prep[fwd], prep[fwd + 1]
@@ -29,15 +32,16 @@ for (i, r), sh in zip(ig, shapes):
     us = (r[1] - r[0]) / 1e3
     if int(sh["splits"]) > 1 and i + 1 < len(rows) and "splitk_reduce" in rows[i + 1][2]:
         us += (rows[i + 1][1] - rows[i + 1][0]) / 1e3
-    key = (sh["ks"], sh["M"], sh["K"], sh["N"], sh["stride"], sh["up"], sh["geglu"], sh["res"], sh["tile"], sh["splits"])
+    kind = next(v for k, v in fam.items() if r[2].startswith(k))
+    key = (sh["ks"], sh["M"], sh["K"], sh["N"], sh["stride"], sh["up"], sh["geglu"], sh["res"], sh["tile"] + "/" + kind, sh["splits"])
     e = agg.setdefault(key, [0, 0.0])
     e[0] += 1
     e[1] += us
 tot = 0.0
-print(f"{'ks':>2} {'M':>6} {'K':>6} {'N':>6} s u g r {'tile':>8} sp   n   us/launch   TF/s   total_us")
+print(f"{'ks':>2} {'M':>6} {'K':>6} {'N':>6} s u g r {'tile/kernel':>12} sp   n   us/launch   TF/s   total_us")
 for key, (n, us) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
     ks, M, K, N, st, up, gg, res, tile, sp = key
     fl = 2.0 * int(M) * int(K) * int(N)
     tot += us
-    print(f"{ks:>2} {M:>6} {K:>6} {N:>6} {st} {up} {gg} {res} {tile:>8} {sp:>2} {n:>3} {us / n:>10.1f} {fl * n / us / 1e6:>7.0f} {us:>10.1f}")
+    print(f"{ks:>2} {M:>6} {K:>6} {N:>6} {st} {up} {gg} {res} {tile:>12} {sp:>2} {n:>3} {us / n:>10.1f} {fl * n / us / 1e6:>7.0f} {us:>10.1f}")
 print(f"igemm total {tot:.0f} us per forward")

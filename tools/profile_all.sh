@@ -2,7 +2,7 @@
 # Round profile set on the GPU box (one gpurun call): kernel stats of the bench command, FETCH/WRITE PMC passes (separate
 # runs, no trace domains mixed with --pmc), MFMA-busy PMC pass, per-layer report.  Outputs under gpurun_out/prof_$1/.
 set -e
-R=${1:-r02}
+R=${1:-r03}
 OUT=gpurun_out/prof_$R
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
@@ -26,7 +26,8 @@ python3 tools/pmc_traffic.py $FE $WR $KT > $OUT/${R}_pmc_traffic_summary.csv
 python3 tools/pmc_mfma.py $MF > $OUT/${R}_pmc_mfma_util.csv
 tail -1 $OUT/bench_stats.log > $OUT/${R}_bench_line_profiled.json
 # per-layer report: one short run with the shape log
-AGD_IGEMM_LOG=1 rocprofv3 --kernel-trace --output-format csv -d $OUT/layers -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-profile > $OUT/bench_layers.log 2> $OUT/layers.err || true
+# (the shape log exists only in the experiments library: agenda_amd/libagenda_hip_exp.so, `make -C agenda_amd/csrc exp`)
+AGD_LIB=$GRAFT_REPO_ROOT/agenda_amd/libagenda_hip_exp.so AGD_IGEMM_LOG=1 rocprofv3 --kernel-trace --output-format csv -d $OUT/layers -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-profile > $OUT/bench_layers.log 2> $OUT/layers.err || true
 LT=$(find $OUT/layers -name "*kernel_trace.csv" | head -1)
 python3 tools/layer_report.py $OUT/layers.err $LT 24 > $OUT/${R}_layer_report.txt 2>&1 || true
 # keep only the summaries (the raw traces are hundreds of MB)
