@@ -52,6 +52,7 @@ _SIGS = {
     "agd_text_encode": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P]),
     "agd_text_set_embedding_row": (C.c_int, [_P, C.c_int, _P]),
     "agd_unet_forward": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_float, _P, _P]),
+    "agd_unet_forward_ts": (C.c_int, [_P, _P, C.c_int, C.c_int, C.POINTER(C.c_float), _P, _P]),
     "agd_cfg_ddim_step": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, _P]),
     "agd_denoise": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float),
                               C.POINTER(C.c_float), C.c_float, _P]),

@@ -51,6 +51,7 @@ class SchedulerConfig:
     steps_offset: int = 1
     set_alpha_to_one: bool = False
     prediction_type: str = "epsilon"  # "v_prediction" for SD-2.1 768
+    skip_prk_steps: bool = True       # PNDM only: SD checkpoints set it (pure PLMS); False (Runge-Kutta warm-up) is refused, not ignored
 
 
 @dataclass

@@ -83,6 +83,7 @@ struct agd_ctx {
   // time embedding
   WMat tproj_all; float* tproj_bias = nullptr; float* tproj_out = nullptr; int tproj_total = 0;
   const float* tproj_cur = nullptr;                 // time_emb_proj outputs of the forward being walked
+  int tproj_cur_ld = 0;                             // 0: one timestep for every image; tproj_total: one row per image (agd_unet_forward_ts)
   float* tsteps_buf = nullptr; int tsteps_cap = 0;   // agd_denoise: embeddings of ALL steps, computed up front
   std::unordered_map<std::string, int> tproj_off;
   float* temb_buf = nullptr;   // [dim | 4dim | 4dim] fp32 scratch
@@ -271,7 +272,7 @@ static int resnet(agd_ctx* c, hipStream_t st, const std::string& pre, const Act&
   if (has_temb) {
     auto it = c->tproj_off.find(pre);
     if (it == c->tproj_off.end()) FAIL("no time_emb_proj for %s", pre.c_str());
-    o1.rowadd = c->tproj_cur + it->second; o1.rowadd_ld = 0;
+    o1.rowadd = c->tproj_cur + it->second; o1.rowadd_ld = c->tproj_cur_ld;
   }
   CK(run_conv(c, st, n1.p, Cin, nullptr, 0, B, H, Wd, *w1, 3, h.p, o1, c->zero_page));
   Act n2 = alloc_act(c, B, H, Wd, Cout); if (!n2.p) return -1;
@@ -494,12 +495,14 @@ static int time_embed(agd_ctx* c, hipStream_t st, const float* ts, int n, float*
 // x: [B2][L*L][64] bf16 (latent channels zero-padded) -> eps [B2][L*L][out_channels] fp32 NHWC
 // tproj_row: this timestep's time_emb_proj outputs when the caller computed them up front (agd_denoise), else nullptr
 // cfg_shared: rows [0,B2/2) and [B2/2,B2) of xin are identical (agd_denoise): share everything ahead of the first attn2
+// tproj_ld: 0 = tproj_row serves every image; tproj_total = tproj_row holds one row per image (per-sample timesteps, training)
 static int unet_walk(agd_ctx* c, hipStream_t st, const bf16_t* xin, int B2, int L, float t, float* eps_out,
-                     const float* tproj_row = nullptr, bool cfg_shared = false) {
+                     const float* tproj_row = nullptr, bool cfg_shared = false, int tproj_ld = 0) {
   const agd_config& g = c->cfg;
   const int nl = g.n_levels, G = g.norm_num_groups;
   const std::string u = "unet.";
   c->arena.release(0);
+  c->tproj_cur_ld = tproj_row ? tproj_ld : 0;
   if (tproj_row) c->tproj_cur = tproj_row;
   else { CK(time_embed(c, st, &t, 1, c->temb_buf, c->tproj_out)); c->tproj_cur = c->tproj_out; }
   std::vector<Act> skips;
@@ -892,6 +895,7 @@ static int ensure_lat(agd_ctx* c, int B2, int L) {
   return 0;
 }
 
+static int embed_all_timesteps(agd_ctx* c, hipStream_t st, const float* timesteps, int n, const float** out);
 AGD_API int agd_unet_forward(agd_ctx* c, const float* sample, int batch2, int L, float timestep, float* out, void* stream) {
   API_CK(c, need_final(c));
   hipStream_t st = S(stream);
@@ -899,6 +903,22 @@ AGD_API int agd_unet_forward(agd_ctx* c, const float* sample, int batch2, int L,
   const int Cl = c->cfg.in_channels;
   { ProfScope ps(c, st, PC_ELEM, 0); API_CK(c, launch_prep_latents(sample, c->lat_bf16, batch2, Cl, L * L, 64, 1, 1.0f, st)); }
   API_CK(c, unet_walk(c, st, c->lat_bf16, batch2, L, timestep, c->eps_nhwc));
+  { ProfScope ps(c, st, PC_ELEM, 0); API_CK(c, launch_nchw_from_nhwc_f32(c->eps_nhwc, c->cfg.out_channels, out, batch2, c->cfg.out_channels, L * L, st)); }
+  return 0;
+}
+
+// the training call `unet(noisy, timesteps[bsz], encoder_hidden_states)` (finetune_sd_token.py:1027): one timestep PER IMAGE
+// (host array of batch2 floats): every image gets its own time-embedding row in the resnets' row add
+AGD_API int agd_unet_forward_ts(agd_ctx* c, const float* sample, int batch2, int L, const float* timesteps, float* out, void* stream) {
+  API_CK(c, need_final(c));
+  if (!timesteps || batch2 < 1) { agd_set_error("unet_forward_ts: bad arguments"); return fail_ctx(c); }
+  hipStream_t st = S(stream);
+  API_CK(c, ensure_lat(c, batch2, L));
+  const int Cl = c->cfg.in_channels;
+  const float* tp_all = nullptr;
+  API_CK(c, embed_all_timesteps(c, st, timesteps, batch2, &tp_all));
+  { ProfScope ps(c, st, PC_ELEM, 0); API_CK(c, launch_prep_latents(sample, c->lat_bf16, batch2, Cl, L * L, 64, 1, 1.0f, st)); }
+  API_CK(c, unet_walk(c, st, c->lat_bf16, batch2, L, timesteps[0], c->eps_nhwc, tp_all, false, c->tproj_total));
   { ProfScope ps(c, st, PC_ELEM, 0); API_CK(c, launch_nchw_from_nhwc_f32(c->eps_nhwc, c->cfg.out_channels, out, batch2, c->cfg.out_channels, L * L, st)); }
   return 0;
 }

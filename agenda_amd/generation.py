@@ -112,17 +112,20 @@ def gather_outputs(images: torch.Tensor, heatmaps: torch.Tensor, seeds: Optional
             return t
         return torch.cat([t, t.new_zeros((mb - t.shape[0],) + tuple(t.shape[1:]))])
 
+    # the collective form is chosen up front, identically on every rank (never retry a collective after one failed: the other
+    # ranks would not join the second one): RCCL takes the flat form, other backends (gloo rehearsals) the list form
+    flat = dist.get_backend() == "nccl"
+
     def gather(t):
-        """one collective per tensor into a single [world * mb, ...] buffer (no per-rank list copies)"""
+        """one collective per tensor; RCCL: into a single [world * mb, ...] buffer (no per-rank list copies)"""
         t = pad(t)
-        out = t.new_empty((w * mb,) + tuple(t.shape[1:]))
-        try:
+        if flat:
+            out = t.new_empty((w * mb,) + tuple(t.shape[1:]))
             dist.all_gather_into_tensor(out, t)
-        except (RuntimeError, NotImplementedError):           # a backend without the flat form
-            parts = [torch.empty_like(t) for _ in range(w)]
-            dist.all_gather(parts, t)
-            out = torch.cat(parts)
-        return out
+            return out
+        parts = [torch.empty_like(t) for _ in range(w)]
+        dist.all_gather(parts, t)
+        return torch.cat(parts)
 
     ids = torch.full((mb,), -1, dtype=torch.int64, device=images.device)
     if seeds is not None and b:

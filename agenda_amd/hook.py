@@ -74,8 +74,11 @@ class UNetCrossAttentionHooker:
         self._pipe = pipe
 
     def _on_generate(self, batch: int, latent_side: int, tokens: int):
+        """pipe(...) reset the device recorder (agd_record_reset): the Python-side views of the old store go with it, so that
+        `cross_attn_maps[k]` can never return the autograd map of an earlier seam call for a freshly recorded index k."""
         self._bp = 2 * batch if self.is_train else batch
         self._tokens, self._side = tokens, latent_side
+        self._seam_maps.clear(); self._grad_maps.clear(); self._cache = (-1, [])
 
     def _ensure(self, rows: int, side: int, tokens: int):
         """(Re)size the device recorder when the kept batch rows / latent side / token count change; otherwise maps keep
@@ -165,6 +168,13 @@ class UNetCrossAttentionHooker:
         if idx.ndim != 2 or idx.shape[0] != maps[0].shape[0]:
             raise ValueError(f"new_tokens_start_indices must be [B={maps[0].shape[0]}, n_tokens], got {tuple(idx.shape)}")
         has = idx[:, 0] > 0                                                        # :1048 "whether there is a car in the image"
+        T = maps[0].shape[1]
+        # the reference indexes sample_attn_map[obj_index] (:1049-1060) and raises IndexError on a token row the map does not have
+        # (a mis-set n_object_embedding, a truncated prompt); only "no object in this sample" is a silent skip
+        worst = int(torch.where(has, idx[:, 0] + n_object_embedding, torch.zeros_like(idx[:, 0])).max()) if bool(has.any()) else 0
+        worst = max(worst, int(idx[has].max()) if bool(has.any()) else 0)
+        if worst >= T:
+            raise IndexError(f"index {worst} is out of bounds for dimension 0 with size {T}")
         obj = torch.where(has, idx[:, 0] + n_object_embedding, torch.full_like(idx[:, 0], -1))          # :1049
         fg = torch.where(has, idx[:, 0], torch.full_like(idx[:, 0], -1))                                 # :1055
         last = torch.tensor([int(r[r > -1][-1]) if bool((r > -1).any()) else -1 for r in idx])          # :1059

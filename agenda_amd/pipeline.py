@@ -30,6 +30,12 @@ from .text import SimpleTokenizer, SyntheticTextEncoder
 
 
 @dataclass
+class UNetOutput:
+    """diffusers' UNet2DConditionOutput: `unet(...).sample`."""
+    sample: torch.Tensor
+
+
+@dataclass
 class PipelineOutput:
     images: list
     latents: Optional[torch.Tensor] = None
@@ -127,12 +133,20 @@ class Engine:
         row = row.detach().to(torch.float32).contiguous()
         self._ck(self.lib.agd_text_set_embedding_row(self.ctx, int(token_id), C.c_void_p(row.data_ptr())), "agd_text_set_embedding_row")
 
-    def unet_forward(self, sample: torch.Tensor, timestep: float) -> torch.Tensor:
+    def unet_forward(self, sample: torch.Tensor, timestep) -> torch.Tensor:
+        """`timestep`: a number (one timestep for the batch) or a [B] tensor / sequence (one per image, the training call)."""
         sample = sample.to(device=f"cuda:{self.device}", dtype=torch.float32).contiguous()
         out = torch.empty_like(sample)
         b2, _, L, _ = sample.shape
-        self._ck(self.lib.agd_unet_forward(self.ctx, _lib.ptr(sample), b2, L, float(timestep), _lib.ptr(out), self._stream()),
-                 "agd_unet_forward")
+        ts = timestep.detach().flatten().tolist() if torch.is_tensor(timestep) else (list(timestep) if isinstance(timestep, (list, tuple)) else [timestep])
+        if len(ts) == 1:
+            self._ck(self.lib.agd_unet_forward(self.ctx, _lib.ptr(sample), b2, L, float(ts[0]), _lib.ptr(out), self._stream()),
+                     "agd_unet_forward")
+        else:
+            if len(ts) != b2:
+                raise ValueError(f"timestep has {len(ts)} entries for a batch of {b2}")
+            arr = (C.c_float * b2)(*[float(t) for t in ts])
+            self._ck(self.lib.agd_unet_forward_ts(self.ctx, _lib.ptr(sample), b2, L, arr, _lib.ptr(out), self._stream()), "agd_unet_forward_ts")
         return out
 
     def denoise(self, latents: torch.Tensor, timesteps, a_t, a_p, guidance: float):
@@ -355,16 +369,28 @@ class UNetHandle:
         """The `Attention` module handle (attn1 = self-, attn2 = cross-attention) the processor is called with."""
         return self._attn2[name] if name in self._attn2 else self._attn1[name]
 
-    def __call__(self, sample, timestep, encoder_hidden_states=None):
-        """`unet(sample, t, encoder_hidden_states)` (finetune_sd_token.py:1027 calls it like this, without CFG): one fused forward;
-        an installed hooker records its attn2 calls (train mode keeps the 16 per-call maps, hook.py:110-112)."""
+    def __call__(self, sample, timestep, encoder_hidden_states=None, class_labels=None, return_dict: bool = True, **unused):
+        """`unet(sample, t, encoder_hidden_states)`: one fused forward; an installed hooker records its attn2 calls (train mode keeps
+        the 16 per-call maps, hook.py:110-112).  finetune_sd_token.py:1027 calls it as
+        `unet(noisy_latents, timesteps, encoder_hidden_states, class_labels=None, return_dict=False)[0]` with a per-sample
+        [bsz] timestep tensor and without CFG: `timestep` may be a number or a [B] tensor, the result is `UNetOutput(sample=...)`
+        (diffusers' UNet2DConditionOutput) or, with return_dict=False, the tuple `(sample,)`.  The maps recorded by this fused
+        call are detached (no UNet backward here -- INTEGRATION.md); gradients flow only through direct seam calls."""
+        if class_labels is not None:
+            raise NotImplementedError("class-conditional UNets (class_labels) are not part of this path")
+        if unused:
+            raise TypeError(f"unsupported unet() arguments: {sorted(unused)}")
+        out = self._forward(sample, timestep, encoder_hidden_states)
+        return UNetOutput(sample=out) if return_dict else (out,)
+
+    def _forward(self, sample, timestep, encoder_hidden_states=None):
         if encoder_hidden_states is not None:
             self._pipe.engine.set_context(encoder_hidden_states)
         hk = self._pipe._hooker
         if hk is not None and self._pipe._trace is None:
             hk._ensure(sample.shape[0] if hk.is_train else sample.shape[0] // 2, sample.shape[-1],
                        encoder_hidden_states.shape[1] if encoder_hidden_states is not None else self._pipe.cfg.max_tokens)
-        out = self._pipe.engine.unet_forward(sample, float(timestep))
+        out = self._pipe.engine.unet_forward(sample, timestep)
         if hk is not None:
             hk._cache = (-1, [])
         return out
@@ -461,7 +487,9 @@ class StableDiffusionPipeline:
                     raise _lib.AgendaHipError(f"{sp}: scheduler '{sched_name}' is not implemented (have: {sorted(SCHEDULERS)}); "
                                               "pass from_pretrained(..., scheduler='DDIMScheduler') to override")
             sc = SchedulerConfig(sj.get("num_train_timesteps", 1000), sj.get("beta_start", 0.00085), sj.get("beta_end", 0.012),
-                                 sj.get("steps_offset", 1), sj.get("set_alpha_to_one", False), sj.get("prediction_type", "epsilon"))
+                                 sj.get("steps_offset", 1), sj.get("set_alpha_to_one", False), sj.get("prediction_type", "epsilon"),
+                                 # diffusers' PNDMScheduler defaults skip_prk_steps to False; SD checkpoints store True
+                                 bool(sj.get("skip_prk_steps", False)) if sched_name == "PNDMScheduler" else True)
         cfg = SDConfig(name=os.path.basename(path.rstrip("/")), unet=ucfg, vae=vcfg, sched=sc,
                        default_sample_size=uc.get("sample_size", 64))
 
@@ -605,8 +633,10 @@ class StableDiffusionPipeline:
                 noise_enc: Optional[torch.Tensor] = None, noise: Optional[torch.Tensor] = None, output_type: str = "pil"):
         """image: float [B,3,S,S] in [-1,1] (or uint8 [B,S,S,3]).  Noise draws come from a CPU generator (or are passed
         explicitly) for the same host-reproducibility reason as the txt2img latents."""
-        if not isinstance(self.scheduler, DDIMScheduler):
-            raise NotImplementedError("img2img runs the strength-truncated DDIM schedule; build the pipeline with scheduler='DDIMScheduler'")
+        # img2img runs the strength-truncated DDIM schedule.  A checkpoint whose own scheduler is PNDM (SD-1.x) gets a DDIM scheduler
+        # built from the same scheduler config for this call (the reference has no img2img call site; strength-truncated PLMS is not
+        # implemented)
+        sched = self.scheduler if isinstance(self.scheduler, DDIMScheduler) else DDIMScheduler.from_config(self.cfg.sched)
         if image.dtype == torch.uint8:
             image = image.permute(0, 3, 1, 2).float() / 127.5 - 1.0
         B, _, S, _ = image.shape
@@ -619,14 +649,14 @@ class StableDiffusionPipeline:
             raise ValueError("use a CPU torch.Generator")
         noise_enc = noise_enc if noise_enc is not None else torch.randn(shape, generator=generator)
         noise = noise if noise is not None else torch.randn(shape, generator=generator)
-        ts = self.scheduler.set_timesteps(num_inference_steps)
-        a_t, a_p = self.scheduler.step_coeffs()
+        ts = sched.set_timesteps(num_inference_steps)
+        a_t, a_p = sched.step_coeffs()
         init = min(int(num_inference_steps * strength), num_inference_steps)
         t0 = max(num_inference_steps - init, 0)
         ts, a_t, a_p = ts[t0:], a_t[t0:], a_p[t0:]
         mean, logvar = self.engine.vae_encode(image)
         x0 = (mean + torch.exp(0.5 * logvar) * noise_enc.to(mean.device)) * self.cfg.vae.scaling_factor
-        a = float(self.scheduler.alphas_cumprod[int(ts[0])])
+        a = float(sched.alphas_cumprod[int(ts[0])])
         lat = (a ** 0.5 * x0 + (1 - a) ** 0.5 * noise.to(mean.device)).contiguous()
         self.engine.set_context(prompt_embeds)
         self._apply_record_mode()

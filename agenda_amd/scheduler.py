@@ -73,7 +73,8 @@ class PNDMScheduler:
 
     @classmethod
     def from_config(cls, sc):
-        return cls(sc.num_train_timesteps, sc.beta_start, sc.beta_end, sc.steps_offset, sc.set_alpha_to_one, sc.prediction_type)
+        return cls(sc.num_train_timesteps, sc.beta_start, sc.beta_end, sc.steps_offset, sc.set_alpha_to_one, sc.prediction_type,
+                   getattr(sc, "skip_prk_steps", True))
 
     def set_timesteps(self, num_inference_steps: int):
         if num_inference_steps < 2 or num_inference_steps > self.num_train_timesteps:

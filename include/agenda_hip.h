@@ -71,6 +71,9 @@ int agd_text_set_embedding_row(agd_ctx* ctx, int token_id, const float* row);
 /* ---- `unet(sample, t, encoder_hidden_states).sample`: sample/out fp32 NCHW [B2,4,L,L] */
 int agd_unet_forward(agd_ctx* ctx, const float* sample, int batch2, int latent_side, float timestep, float* out,
                      void* stream);
+/* the same with one timestep PER IMAGE (host array of batch2 floats): the training call `unet(noisy_latents, timesteps, ehs)` of
+ * finetune_sd_token.py:1027, where `timesteps` is a [bsz] tensor */
+int agd_unet_forward_ts(agd_ctx* ctx, const float* sample, int batch2, int latent_side, const float* timesteps, float* out, void* stream);
 
 /* ---- CFG combine + DDIM (eta 0) step on fp32 NCHW latents [B,4,L,L] in place;
  * eps is [2B,4,L,L] NCHW.  (`scheduler.step` inside pipeline.__call__) */

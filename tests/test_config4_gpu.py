@@ -57,3 +57,68 @@ def test_config4_learned_token_heatmaps_to_stacked_rgb(tmp_path):
     a = np.asarray(Image.open(out / "daam_new_token_v0_heatmaps" / "0.png")).astype(int)
     b = np.asarray(Image.open(out2 / "daam_new_token_v0_heatmaps" / "0.png")).astype(int)
     assert np.abs(a - b).max() > 0
+
+
+def test_config4_learned_token_heatmaps_match_the_oracle(tmp_path):
+    """The same flow with an ORACLE leg: the PNG payloads the HIP driver writes for the learned tokens and for
+    a plain word are compared with what the reference's own stack would produce from the same checkpoint files --
+    `transformers.CLIPTokenizer` + `transformers.CLIPTextModel` (the classes data_generation.py runs through the pipeline) with
+    the learned rows injected as data_generation.py:45-52 does, then the CPU oracle: PNDM loop with the daam recorder
+    (data_generation.py:56-64), `compute_word_heat_map` (:74), min-max -> uint8 -> PIL resize (:82-85)."""
+    from PIL import Image
+    from transformers import CLIPTokenizer
+    from _util import write_tiny_checkpoint
+    from test_text_gpu import _hf_model
+    from agenda_amd import config, generation, synthetic
+    from oracle import sd_oracle as O
+    cfg = config.tiny()
+    cfg.text = config.TextConfig(hidden_size=64, num_hidden_layers=1, num_attention_heads=1, intermediate_size=128, vocab_size=514)
+    u, v = synthetic.make_unet_weights(cfg, 11, bias_std=0.05), synthetic.make_vae_weights(cfg, 12, bias_std=0.05, with_encoder=True)
+    tsd = synthetic.make_text_weights(cfg, 3)
+    ck = tmp_path / "ckpt"
+    write_tiny_checkpoint(str(ck), cfg, u, v, tsd)
+    g = torch.Generator().manual_seed(0)
+    embeds = {f"new_token_v{i}": torch.randn(64, generator=g) * 0.02 for i in range(3)}
+    torch.save(embeds, tmp_path / "learned_embeds.bin")
+    template, init = "An aerial view image with {} cars in {} New Zealand", ["cars", "Utah", "New Zealand"]
+    steps, S, n_img = 3, 56, 3
+    out = tmp_path / "Synthetic"
+    generation.main(["--save-dir", str(out), "--pretrained-model-path", str(ck), "--learnable-tokens-embedding-path", str(tmp_path / "learned_embeds.bin"),
+                     "--prompt", template, "--initialize_token", *init, "--store_learnable_token_heatmaps", "--word_token_heatmaps", "view",
+                     "--num-images", str(n_img), "--batch-size", "2", "--num-inference-steps", str(steps), "--image-size", str(S)])
+
+    # ---- oracle leg
+    new_tokens, words, prompt = O.select_learned_tokens(template, init, list(embeds.keys()), ["view"], True)
+    assert new_tokens == ["new_token_v0", "new_token_v2"] and words == ["view", "new_token_v0", "new_token_v2"]
+    tok = CLIPTokenizer.from_pretrained(str(ck / "tokenizer"))
+    tok.add_tokens(new_tokens)
+    ids = tok.convert_tokens_to_ids(new_tokens)
+    assert ids == [514, 515]
+    sd2 = dict(tsd)
+    sd2["embeddings.token_embedding.weight"] = torch.cat([tsd["embeddings.token_embedding.weight"], torch.stack([embeds[t] for t in new_tokens])])
+    tc = config.TextConfig(hidden_size=64, num_hidden_layers=1, num_attention_heads=1, intermediate_size=128, vocab_size=516)
+    enc = _hf_model(tc, sd2)
+
+    def encode(text):
+        tid = tok([text], padding="max_length", max_length=77, truncation=True, return_tensors="pt").input_ids
+        with torch.no_grad():
+            return enc(input_ids=tid).last_hidden_state
+    ctx = torch.cat([encode("").repeat(n_img, 1, 1), encode(prompt).repeat(n_img, 1, 1)])
+    L = cfg.default_sample_size
+    lat = synthetic.make_latents(cfg, list(range(n_img)), L)
+    rec = O.DaamRecorder(L * L, context_size=77)
+    O.generate(u, v, cfg, ctx, lat, steps, 7.5, recorder=rec, decode=False, scheduler="pndm")
+    n_rows = len(tok.tokenize(prompt)) + 2
+    gmap = rec.compute_global_heat_map(n_rows)                        # [image, rows, L, L]
+    worst = 0
+    for w in words:
+        idx, _ = O.compute_token_merge_indices(tok.tokenize, prompt, w)
+        for i in range(n_img):
+            hm = O.word_heat_map(gmap[i], idx).numpy()
+            want = np.asarray(Image.fromarray(O.export_heatmap_u8(hm)).resize((S, S))).astype(int)
+            got = np.asarray(Image.open(out / f"daam_{w}_heatmaps" / f"{i}.png")).astype(int)
+            assert got.shape == want.shape == (S, S)
+            d = np.abs(got - want)
+            worst = max(worst, int(d.max()))
+            assert d.max() <= 12 and d.mean() < 3.0, (w, i, int(d.max()), float(d.mean()))      # bf16 path vs fp32 oracle (measured: worst 5)
+    print(f"config 4 learned-token heat maps vs oracle: worst |diff| {worst}/255")

@@ -285,15 +285,73 @@ def test_config1_sd15_256px_10_steps_end_to_end_vs_oracle():
     pipe.engine.close()
 
 
-def test_config5_sd21_768px_unet_forward_vs_oracle():
-    """BASELINE config 5 shapes: SD-2.1 (heads 5/10/20/20 -> d = 64, ctx 1024, linear proj_in/out), 768 px
-    (latent 96, 9216 tokens), CFG batch 2: one UNet forward + DAAM record against the CPU oracle."""
+@pytest.mark.parametrize("name,heads,side", [("down_blocks.0.attentions.0.transformer_blocks.0.attn2", 8, 64),     # C = 320, d = 40, N = 4096
+                                             ("mid_block.attentions.0.transformer_blocks.0.attn2", 8, 8)])          # C = 1280, d = 160, N = 64
+def test_seam_backward_at_sd15_shapes(sd15_host_weights, sd15_pipe, name, heads, side):
+    """SURVEY 8f-4 at SD-1.5's own shapes: the seam's backward (attn_bwd_kernel + the input-gradient GEMMs) with head
+    dims 40 / 160 and 4096 / 64 queries, against torch autograd of hook.py's restatement."""
+    from test_train_gpu import seam_backward_check
+    cfg, u, v = sd15_host_weights
+    seam_backward_check(sd15_pipe, cfg, u, name, heads, side, True, B2=2)
+
+
+@pytest.fixture(scope="module")
+def sd21():
     from agenda_amd import StableDiffusionPipeline, config, synthetic
-    from oracle import sd_oracle as O
     cfg = config.sd21()
     u = synthetic.make_unet_weights(cfg, 2100)
     v = synthetic.make_vae_weights(cfg, 2101)
     pipe = StableDiffusionPipeline(cfg, u, v, workspace_bytes=12 << 30)
+    yield cfg, u, v, pipe
+    pipe.engine.close()
+
+
+def test_config5_sd21_768px_vae_decode_vs_oracle(sd21):
+    """BASELINE config 5's decode: 768 px (latent 96 -> 9216-token mid-block attention, 768^2 convs) against the CPU oracle."""
+    from agenda_amd import synthetic
+    from oracle import sd_oracle as O
+    cfg, u, v, pipe = sd21
+    z = (synthetic.make_latents(cfg, [1], 96) * 0.18215).to(torch.bfloat16).float()
+    with torch.no_grad():
+        want = O.vae_decode(v, cfg.vae, z / cfg.vae.scaling_factor)
+    u8, f32 = pipe.engine.vae_decode(z, want_f32=True)
+    assert u8.shape == (1, 768, 768, 3) and torch.isfinite(f32).all()
+    err = _rms_rel(f32.permute(0, 3, 1, 2), want)
+    psnr = _psnr_u8(u8.cpu().numpy(), O.postprocess_image(want))
+    print(f"config5 vae decode 768 px: rms rel {err:.5f}, PSNR {psnr:.1f} dB")
+    assert err < 2.0 ** -6, err
+    assert psnr > 40.0, psnr
+
+
+def test_config5_sd21_768px_v_prediction_denoise_vs_oracle(sd21):
+    """BASELINE config 5's loop at size: three DDIM steps with v-prediction (SD-2.1's scheduler config) at 768 px, CFG 7.5, DAAM
+    recording on, against the oracle's loop (DDIM.step with prediction_type = v_prediction)."""
+    from agenda_amd import synthetic, trace
+    from oracle import sd_oracle as O
+    cfg, u, v, pipe = sd21
+    assert cfg.sched.prediction_type == "v_prediction"
+    L, steps = 96, 3
+    ctx = synthetic.make_context(cfg, 1, seed=9)
+    lat = synthetic.make_latents(cfg, [4], L)
+    rec = O.DaamRecorder(L * L, 77)
+    _, want = O.generate(u, v, cfg, ctx, lat, steps, 7.5, recorder=rec, decode=False)
+    with trace(pipe) as trc:
+        out = pipe(prompt_embeds=ctx, latents=lat, num_inference_steps=steps, height=768, width=768, output_type="latent")
+        hm = trc.compute_global_heat_map(image_index=0).heat_maps.cpu()
+    err = _rms_rel(out.latents, want)
+    whm = rec.compute_global_heat_map()[0]
+    hm_err = float((hm - whm).abs().max() / whm.abs().max())
+    print(f"config5 v-prediction denoise (768 px, {steps} steps): latents rms rel {err:.5f}, heat map rel {hm_err:.4f}")
+    assert err < 0.05, err
+    assert hm_err < 0.03, hm_err
+
+
+def test_config5_sd21_768px_unet_forward_vs_oracle(sd21):
+    """BASELINE config 5 shapes: SD-2.1 (heads 5/10/20/20 -> d = 64, ctx 1024, linear proj_in/out), 768 px
+    (latent 96, 9216 tokens), CFG batch 2: one UNet forward + DAAM record against the CPU oracle."""
+    from agenda_amd import synthetic
+    from oracle import sd_oracle as O
+    cfg, u, v, pipe = sd21
     L = 96
     ctx = synthetic.make_context(cfg, 1, seed=7)
     lat = synthetic.make_latents(cfg, [0], L)
@@ -313,4 +371,3 @@ def test_config5_sd21_768px_unet_forward_vs_oracle():
     assert err < 0.02, err              # measured 0.0121 (the SD-1.5 256 px forward: < 2^-6); 9216-token softmax rows
     assert hm_err < 0.01, hm_err        # measured 0.0036
     pipe.engine.record_config(0)
-    pipe.engine.close()

@@ -287,3 +287,13 @@ def test_save_outputs_and_postprocess_roundtrip(tmp_path):
     o, f, b = (np.asarray(Image.open(tmp_path / f"daam_{w}_heatmaps" / "7.png")) for w in words)
     np.testing.assert_array_equal(rgb, np.stack([o, f, 255 - b], -1))
     np.testing.assert_array_equal(np.asarray(Image.open(tmp_path / "daam_inv_heatmaps" / "7.png")), 255 - b)
+
+
+def test_pndm_without_skip_prk_steps_is_refused_not_silently_plms(tmp_path):
+    """diffusers' PNDMScheduler defaults skip_prk_steps to False (Runge-Kutta warm-up steps); only the SD configuration (True = PLMS)
+    is implemented, and a scheduler config that says otherwise must not run PLMS silently."""
+    from agenda_amd.config import SchedulerConfig
+    from agenda_amd.scheduler import PNDMScheduler
+    PNDMScheduler.from_config(SchedulerConfig())                       # SD's own: skip_prk_steps = True
+    with pytest.raises(ValueError, match="skip_prk_steps"):
+        PNDMScheduler.from_config(SchedulerConfig(skip_prk_steps=False))

@@ -474,8 +474,18 @@ def test_pndm_generation_matches_oracle(tiny_pipe, tmp_path):
     whm = rec.compute_global_heat_map()
     assert float(hm.sum(1).mean()) == pytest.approx(steps + 1, rel=0.02)          # steps + 1 UNet evaluations were recorded
     assert _rel(hm, whm) < 0.06
-    with pytest.raises(NotImplementedError):
-        pipe.img2img(prompt_embeds=ctx, image=torch.zeros(B, 3, 128, 128), num_inference_steps=4)
+    # img2img on a PNDM pipeline (what from_pretrained builds for an SD-1.x checkpoint) runs the strength-truncated DDIM schedule on a
+    # DDIM scheduler made from the same config: identical to a DDIM pipeline's img2img
+    ve = synthetic.make_vae_weights(cfg, 12, bias_std=0.05, perturb_norm=0.1, with_encoder=True)
+    p_pndm = StableDiffusionPipeline(cfg, u, ve, workspace_bytes=1 << 30, scheduler="PNDMScheduler")
+    p_ddim = StableDiffusionPipeline(cfg, u, ve, workspace_bytes=1 << 30, scheduler="DDIMScheduler")
+    g = torch.Generator().manual_seed(3)
+    img = torch.rand(B, 3, 128, 128, generator=g) * 2 - 1
+    ne, nz = torch.randn(B, 4, 16, 16, generator=g), torch.randn(B, 4, 16, 16, generator=g)
+    a = p_pndm.img2img(prompt_embeds=ctx, image=img, num_inference_steps=4, noise_enc=ne, noise=nz, output_type="latent").latents
+    b = p_ddim.img2img(prompt_embeds=ctx, image=img, num_inference_steps=4, noise_enc=ne, noise=nz, output_type="latent").latents
+    assert torch.isfinite(a).all() and torch.equal(a, b)
+    p_pndm.engine.close(); p_ddim.engine.close()
     with pytest.raises(ValueError, match="not implemented"):
         StableDiffusionPipeline(cfg, u, v, workspace_bytes=1 << 28, scheduler="EulerDiscreteScheduler")
     pipe.engine.close()
