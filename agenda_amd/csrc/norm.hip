@@ -5,6 +5,7 @@
 // (per-block partials -> fp64 finalize), affine folded into per-(image,channel) scale/shift.
 #include "kernels.h"
 #include <cstdlib>
+typedef __attribute__((ext_vector_type(2))) float f32x2;
 
 // ws layout (floats): [0, B*nchunk*groups*2) block partials ; then B*C scale ; then B*C shift
 // Thread t owns channel vector (t % nvec) and pixel-row (t / nvec) of its block's pixel chunk, so no
@@ -163,12 +164,23 @@ __global__ __launch_bounds__(512) void gn_apply_part_kernel(const bf16_t* __rest
     const int nt0 = HW / bm0, nt1 = C1 ? HW / bm1 : 0;
     const int ntm = nt0 > nt1 ? nt0 : nt1;
     double a = 0.0, q = 0.0;
-    for (int idx = lane; idx < cpg * ntm; idx += 64) {
-      const int tile = idx / cpg, ch = g * cpg + (idx - tile * cpg);
-      const float* pp = nullptr;
-      if (ch < C0) { if (tile < nt0) pp = part0 + (((long long)b * nt0 + tile) * C0 + ch) * 2; }
-      else if (tile < nt1) pp = part1 + (((long long)b * nt1 + tile) * C1 + (ch - C0)) * 2;
-      if (pp) { a += (double)pp[0]; q += (double)pp[1]; }
+    // eight independent 8-byte loads in flight per lane and round: one at a time, a 64 x 64 map's 320 .. 960 partial sums per group
+    // cost the block 5 .. 15 dependent L2 round trips (3 - 10 us) before its first activation byte moved; same summation order
+    const int n = cpg * ntm;
+    for (int i0 = lane; i0 < n; i0 += 64 * 8) {
+      f32x2 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int idx = i0 + 64 * u;
+        v[u] = f32x2{0.f, 0.f};
+        if (idx < n) {
+          const int tile = idx / cpg, ch = g * cpg + (idx - tile * cpg);
+          if (ch < C0) { if (tile < nt0) v[u] = *(const f32x2*)(part0 + (((long long)b * nt0 + tile) * C0 + ch) * 2); }
+          else if (tile < nt1) v[u] = *(const f32x2*)(part1 + (((long long)b * nt1 + tile) * C1 + (ch - C0)) * 2);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { a += (double)v[u][0]; q += (double)v[u][1]; }
     }
     for (int o = 32; o >= 1; o >>= 1) { a += __shfl_xor(a, o); q += __shfl_xor(q, o); }
     if (lane == 0) {
@@ -204,15 +216,14 @@ __global__ __launch_bounds__(512) void gn_apply_part_kernel(const bf16_t* __rest
     pk[0] = pack_bf2(o[0], o[1]); pk[1] = pack_bf2(o[2], o[3]); pk[2] = pack_bf2(o[4], o[5]); pk[3] = pack_bf2(o[6], o[7]);
     *(u32x4*)(yb + (long long)px * C) = pk;
   };
-  int px = p0 + prow;
-  for (; px + 3 * PR < p1; px += 4 * PR) {
-    s16x8 v[4];
+  // up to eight 16-byte loads in flight per lane; the ragged end of the chunk is predicated, not a one-load-at-a-time tail loop
+  for (int px = p0 + prow; px < p1; px += 8 * PR) {
+    s16x8 v[8];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) v[u] = *(const s16x8*)(base + (long long)(px + u * PR) * Csrc);
+    for (int u = 0; u < 8; ++u) if (px + u * PR < p1) v[u] = *(const s16x8*)(base + (long long)(px + u * PR) * Csrc);
 #pragma unroll
-    for (int u = 0; u < 4; ++u) one(v[u], px + u * PR);
+    for (int u = 0; u < 8; ++u) if (px + u * PR < p1) one(v[u], px + u * PR);
   }
-  for (; px < p1; px += PR) one(*(const s16x8*)(base + (long long)px * Csrc), px);
 }
 
 // true when launch_groupnorm can use the producers' partial sums for this problem
