@@ -28,7 +28,6 @@
 #include "igemm_epilogue.h"
 #include "igemm_halo.h"
 #include "igemm8p.h"
-#include "ff_fused.h"
 #include <cstdlib>
 #define CK0(expr) do { if ((expr) != 0) return -1; } while (0)
 
@@ -628,27 +627,4 @@ int igemm_query(const IgemmP& p_in, int* cfg3) {
   IgemmP p = p_in;
   p.cfg_out = cfg3;
   return launch_igemm(p, nullptr);
-}
-
-// fused GEGLU feed-forward (ff_fused.h): C = 320 only (the 128 x C activation panel + two weight rings fit the 160 KB of LDS)
-bool ff_fused_supported(int C) { return C == 320; }
-int launch_ff_fused(const FfP& p, int C, hipStream_t st) {
-  if (!ff_fused_supported(C)) { agd_set_error("ff_fused: C = %d unsupported", C); return -1; }
-  if (p.M < 1 || !p.h || !p.out || !p.w1 || !p.w2p || !p.ln_stats || p.ln_slots < 1 || !p.ln_cs || !p.bias1 || !p.bias2) { agd_set_error("ff_fused: bad arguments"); return -1; }
-  if ((long long)p.M * C * 2 >= (1LL << 31)) { agd_set_error("ff_fused: activation beyond 32-bit byte offsets"); return -1; }
-  constexpr int lds = 3 * 16384 + 2 * 320 * 128 + 4 * 1280 * 4;   // GEMM1 weight ring + two GEMM2 chunk tiles + GEGLU constants
-  auto kfn = ff_fused_kernel<320>;
-  static bool attr[AGD_MAX_DEVICES] = {};
-  int dev = 0; HIP_CHECK_RET(hipGetDevice(&dev));
-  if (dev < 0 || dev >= AGD_MAX_DEVICES) { agd_set_error("ff_fused: device ordinal %d out of range", dev); return -1; }
-  if (!attr[dev]) { HIP_CHECK_RET(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); attr[dev] = true; }
-  hipLaunchKernelGGL(kfn, dim3((p.M + 127) / 128), dim3(256), lds, st, p);
-  HIP_CHECK_RET(hipGetLastError());
-  return 0;
-}
-int launch_ff_permute_w2(const bf16_t* w2, bf16_t* w2p, int rows, int hid, hipStream_t st) {
-  if (hid % 64) { agd_set_error("ff_permute_w2: hidden width %d not a multiple of 64", hid); return -1; }
-  hipLaunchKernelGGL(ff_permute_w2_kernel, dim3(512), dim3(256), 0, st, w2, w2p, rows, hid);
-  HIP_CHECK_RET(hipGetLastError());
-  return 0;
 }

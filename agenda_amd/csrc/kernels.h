@@ -47,19 +47,6 @@ struct IgemmP {
   int dbg;                          // timing experiments only (builds with -DAGD_EXPERIMENTS)
 };
 int launch_igemm(const IgemmP& p, hipStream_t st);
-// fused GEGLU feed-forward (ff_fused.h, launched from igemm.hip)
-struct FfP {
-  const bf16_t* h; bf16_t* out;            // [M][C]; out may alias h (each element is read, then written, by one lane)
-  const bf16_t* w1;                        // [8C][C] LayerNorm-folded GEGLU projection, rows in [8 values | 8 gates] groups
-  const bf16_t* w2p;                       // [C][4C] ff.net.2 weight, columns permuted per 64-chunk (see above)
-  const float* ln_stats; int ln_slots;     // [M][slots] float2 partial (sum, sum of squares) of h's rows
-  const float* ln_cs; const float* bias1;  // [8C]: values then gates (colsum of W1, folded bias)
-  const float* bias2;                      // [C]
-  int M; float ln_invC, ln_eps;
-};
-bool ff_fused_supported(int C);
-int launch_ff_fused(const FfP& p, int C, hipStream_t st);
-int launch_ff_permute_w2(const bf16_t* w2, bf16_t* w2p, int rows, int hid, hipStream_t st);
 int igemm_query(const IgemmP& p, int* cfg3);       // {BM, BN, K splits} launch_igemm would use; launches nothing
 
 // ---------------------------------------------------------------------------------------

@@ -106,7 +106,6 @@ struct agd_ctx {
   int opt_ln_fold = 1;                                // agd_set_option("ln_fold"): LayerNorm folded into the GEMMs around it
   int opt_gn_fused = 1;                               // agd_set_option("gn_fused_stats"): GroupNorm statistics from the producing igemm's epilogue
   int opt_warm = 3;                                   // agd_set_option("weight_warm"): in-kernel cold-weight warm-up: 1 = W-major launches (per-XCD slices), 3 = A-major launches too
-  int opt_ff_fused = 0;                               // agd_set_option("ff_fused"): GEGLU feed-forward of the C = 320 blocks as one kernel (ff_fused.h)
   int opt_p8 = 1;                                     // agd_set_option("igemm8p"): 256-row 8-wave / 8-phase igemm for launches with enough tiles (igemm8p.h)
   int opt_halo = 1;                                   // agd_set_option("conv_halo"): 3x3 stride-1 convs through the row-halo kernel (igemm_halo.h)
   int opt_touch = 3;                                  // agd_set_option("weight_touch"): n > 0 = stream 1x1 weight matrices of >= n MB through the caches right before their launch
@@ -456,15 +455,6 @@ static int transformer(agd_ctx* c, hipStream_t st, const std::string& pre, const
     GemmOpt oo; oo.bias = bo; oo.residual = h.p;
     CK(produce(att, C, *wo, oo, h.p)); }
   // --- GEGLU feed-forward ---
-  const bool fused_ff = fold && c->opt_ff_fused && ff_fused_supported(C) && c->W.count(t + "ff.net.2.weight.p64");
-  if (fused_ff) {
-    const std::string k = t + "ff.net.0.proj.weight.lnfold";
-    GETW(wf, k); GETV(cs, k + ".cs"); GETV(bf, k + ".bias"); GETW(w2p, t + "ff.net.2.weight.p64"); GETV(b2, t + "ff.net.2.bias");
-    FfP fp{}; fp.h = h.p; fp.out = h.p; fp.w1 = wf->w; fp.w2p = w2p->w; fp.ln_stats = stats; fp.ln_slots = slots; fp.ln_cs = cs; fp.bias1 = bf; fp.bias2 = b2;
-    fp.M = M; fp.ln_invC = 1.0f / (float)C; fp.ln_eps = lneps;
-    ProfScope ps(c, st, PC_GEMM, 2.0 * M * (double)C * 12.0 * C, 2.0 * (3.0 * M * C + 12.0 * C * C));
-    CK(launch_ff_fused(fp, C, st));
-  } else
   { bf16_t* ff = (bf16_t*)c->arena.alloc((size_t)M * 4 * C * 2); if (!ff) return -1;
     GETV(b1, t + "ff.net.0.proj.bias");
     CK(consume(t + "norm3", t + "ff.net.0.proj.weight", b1, 1, ff));
@@ -823,17 +813,6 @@ AGD_API int agd_finalize(agd_ctx* c) {
       const std::string k = t + f.w + ".lnfold";
       c->W[k] = wf; c->V[k + ".cs"] = cs; c->V[k + ".bias"] = bf; c->Vn[k + ".cs"] = w->N; c->Vn[k + ".bias"] = w->N;
     }
-    // fused feed-forward (ff_fused.h): ff.net.2's columns in the k order of the GEGLU epilogue's register fragments
-    if (ff_fused_supported(xl.C)) {
-      const WMat* w2 = getW(c, t + "ff.net.2.weight");
-      if (!w2) return fail_ctx(c);
-      if (w2->taps == 1 && w2->Cpad == w2->Cin && w2->N == xl.C && w2->Cin == 4 * xl.C) {
-        WMat wp = *w2; wp.w = dmalloc<bf16_t>(c, (size_t)w2->N * w2->Cpad);
-        if (!wp.w) return fail_ctx(c);
-        API_CK(c, launch_ff_permute_w2(w2->w, wp.w, w2->N, w2->Cpad, 0));
-        c->W[t + "ff.net.2.weight.p64"] = wp;
-      }
-    }
   }
   // ---- all time_emb_proj stacked into one [sum Cout][4*dim] matrix
   { std::vector<const WMat*> parts; std::vector<std::string> pres; int total = 0;
@@ -1056,7 +1035,6 @@ AGD_API int agd_set_option(agd_ctx* c, const char* name, int value) {
   if (!strcmp(name, "weight_warm")) { c->opt_warm = value; return 0; }
   if (!strcmp(name, "conv_halo")) { c->opt_halo = value != 0; return 0; }
   if (!strcmp(name, "igemm8p")) { c->opt_p8 = value < 0 ? 0 : value; return 0; }   // 0 off, 1 on (the launcher decides per launch); tests: 2 / 3 / 4 force the 256-wide / 160-wide / any legal tile
-  if (!strcmp(name, "ff_fused")) { c->opt_ff_fused = value != 0; return 0; }
   agd_set_error("set_option: unknown option '%s'", name);
   return fail_ctx(c);
 }
@@ -1608,44 +1586,6 @@ AGD_API int agd_bench_conv_cold(int B, int H, int W, int C0, int Cout, int ksize
   }
   *ms_out = tot / iters;
   hipEventDestroy(a); hipEventDestroy(b);
-  return 0;
-}
-
-// GEGLU feed-forward of a transformer block on M rows of C channels: fused = 1 the one-kernel form (ff_fused.h), 0 the two launches
-// (LayerNorm-folded GEGLU projection, then ff.net.2 + residual).  Random operands, unit row statistics.
-AGD_API int agd_bench_ff(int M, int C, int fused, int iters, double* ms_out) {
-  Tmp tmp;
-  if (M < 1 || C % 64 || iters < 1 || !ms_out) { agd_set_error("bench_ff: bad arguments"); return -1; }
-  bf16_t* h = tmp.get<bf16_t>((size_t)M * C); bf16_t* w1 = tmp.get<bf16_t>((size_t)8 * C * C); bf16_t* w2 = tmp.get<bf16_t>((size_t)4 * C * C);
-  bf16_t* w2p = tmp.get<bf16_t>((size_t)4 * C * C); bf16_t* ff = tmp.get<bf16_t>((size_t)M * 4 * C);
-  float* stats = tmp.get<float>((size_t)M * 2); float* cs = tmp.get<float>(8 * C); float* b1 = tmp.get<float>(8 * C); float* b2 = tmp.get<float>(C);
-  if (!h || !w1 || !w2 || !w2p || !ff || !stats || !cs || !b1 || !b2) return -1;
-  fill_rand(h, (long long)M * C, 1, 1.0f); fill_rand(w1, (long long)8 * C * C, 2, 0.05f); fill_rand(w2, (long long)4 * C * C, 3, 0.02f);
-  hipMemset(cs, 0, 8 * C * 4); hipMemset(b1, 0, 8 * C * 4); hipMemset(b2, 0, C * 4);
-  { std::vector<float> hs((size_t)M * 2); for (int i = 0; i < M; ++i) { hs[2 * i] = 0.f; hs[2 * i + 1] = (float)C; }    // mean 0, variance 1
-    hipMemcpy(stats, hs.data(), hs.size() * 4, hipMemcpyHostToDevice); }
-  CK(launch_ff_permute_w2(w2, w2p, C, 4 * C, 0));
-  WMat wm1; wm1.w = w1; wm1.N = 8 * C; wm1.Cin = C; wm1.Cpad = C; wm1.taps = 1;
-  WMat wm2; wm2.w = w2; wm2.N = C; wm2.Cin = 4 * C; wm2.Cpad = 4 * C; wm2.taps = 1;
-  auto once = [&]() -> int {
-    if (fused) {
-      FfP fp{}; fp.h = h; fp.out = h; fp.w1 = w1; fp.w2p = w2p; fp.ln_stats = stats; fp.ln_slots = 1; fp.ln_cs = cs; fp.bias1 = b1; fp.bias2 = b2;
-      fp.M = M; fp.ln_invC = 1.0f / (float)C; fp.ln_eps = 1e-5f;
-      return launch_ff_fused(fp, C, 0);
-    }
-    GemmOpt o; o.bias = b1; o.geglu = 1; o.ln_stats = stats; o.ln_slots = 1; o.ln_cs = cs; o.ln_invC = 1.0f / (float)C; o.ln_eps = 1e-5f;
-    CK(run_conv(nullptr, 0, h, C, nullptr, 0, 1, 1, M, wm1, 1, ff, o, op_zero_page()));
-    GemmOpt o2; o2.bias = b2; o2.residual = h;
-    return run_conv(nullptr, 0, ff, 4 * C, nullptr, 0, 1, 1, M, wm2, 1, h, o2, op_zero_page());
-  };
-  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-  for (int i = 0; i < 2; ++i) CK(once());
-  hipEventRecord(e0, 0);
-  for (int i = 0; i < iters; ++i) CK(once());
-  hipEventRecord(e1, 0); hipEventSynchronize(e1);
-  float t = 0; hipEventElapsedTime(&t, e0, e1);
-  *ms_out = t / iters;
-  hipEventDestroy(e0); hipEventDestroy(e1);
   return 0;
 }
 

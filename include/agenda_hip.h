@@ -109,11 +109,12 @@ int agd_vae_encode(agd_ctx* ctx, const float* image, int batch, int side, float*
  * kernel right in front of the launch that uses them (the UNet's 1.7 GB of weights never stay in the 256 MB Infinity Cache).
  * "conv_halo" (default 1): 3x3 stride-1 convolutions run the row-halo kernel (one LDS image of the tile's pixel rows serves the three
  * horizontal taps) where its geometry applies.
- * "ff_fused" (default 0): the GEGLU feed-forward of the C = 320 blocks as ONE kernel (the hidden activation stays in registers);
- * correct and parity-tested, but at one workgroup per CU its gelu no longer hides under another workgroup's MFMAs: 148 vs 151 us.
  * "weight_warm" (default 3; 0 off): the first workgroups of a launch stream its weight matrix through the caches before their main
  * loops -- 1: only launches whose weights outweigh their activations (each XCD its own slice, into its L2); 3: every launch with
- * >= 1 MB of weights and 1024 <= M <= 32768 (the touch launches then disappear). */
+ * >= 1 MB of weights and 1024 <= M <= 32768 (the touch launches then disappear).
+ * "igemm8p" (default 1): launches with enough 256-row tiles (wide 1x1 projections, 3x3 convs with N a multiple of 256, the
+ * upsampling convs) run the 8-wave / 8-phase implicit-GEMM kernel (igemm8p.h); 0 = the 4-wave kernels everywhere; tests: 2 / 3 / 4
+ * force its 256-wide / 160-wide / any legal tile. */
 int agd_set_option(agd_ctx* ctx, const char* name, int value);
 
 /* ---- heat-map recording (daam.trace / hook.py UNetCrossAttentionHooker state)
@@ -222,8 +223,6 @@ int agd_bench_attention(int B, int H, int D, int Nq, int Nk, int record, int ite
 /* one launch with cold weights (caches flushed per iteration); warm: 0 cold, 1 streaming touch of the weights timed with the launch, 2 weights hot */
 int agd_bench_conv_cold(int B, int H, int W, int C0, int Cout, int ksize, int geglu, int with_residual, int warm, int iters, double* ms_out);
 int agd_bench_groupnorm(int B, int HW, int C, int iters, double* ms_out);
-/* GEGLU feed-forward (M rows, C channels): fused = 1 one kernel (C = 320), 0 = GEGLU projection + ff.net.2 launches */
-int agd_bench_ff(int M, int C, int fused, int iters, double* ms_out);
 int agd_bench_groupnorm_ex(int B, int HW, int C0, int C1, int fused_stats, int iters, double* ms_out);
 #endif /* AGD_EXPERIMENTS */
 

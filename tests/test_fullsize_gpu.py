@@ -127,26 +127,6 @@ def test_cold_weight_warmup_options_do_not_change_results(sd15_cuda):
         assert torch.equal(o, outs[0])
 
 
-def test_fused_feed_forward_option_matches_the_two_launch_path(sd15_cuda):
-    """`ff_fused` (ff_fused.h, off by default): GEGLU projection, gelu gate and ff.net.2 of the C = 320 blocks in one kernel whose
-    second GEMM takes the GEGLU epilogue's registers as its pixel-side fragments.  Same bf16 rounding points as the two launches
-    (the hidden activation is rounded to bf16 either way), so the UNet output moves only by fp32 summation order + its
-    amplification through the network."""
-    from agenda_amd import synthetic
-    pipe = sd15_cuda
-    ctx = synthetic.make_context(pipe.cfg, 1, seed=11)
-    lat = synthetic.make_latents(pipe.cfg, [3], 64)
-    x = torch.cat([lat, lat]).to(torch.bfloat16).float()
-    pipe.engine.set_context(ctx)
-    pipe.engine.set_option("ff_fused", 0)
-    y0 = pipe.engine.unet_forward(x, 500.0).clone()
-    pipe.engine.set_option("ff_fused", 1)
-    y1 = pipe.engine.unet_forward(x, 500.0).clone()
-    pipe.engine.set_option("ff_fused", 0)
-    assert torch.isfinite(y1).all() and not torch.equal(y0, y1)
-    assert _rms_rel(y1, y0.cpu()) < 2.0 ** -5, _rms_rel(y1, y0.cpu())
-
-
 _ORACLE_CACHE = {}
 
 
