@@ -89,7 +89,23 @@ def generate_batch(pipe, seeds: Sequence[int], words: Sequence[str], prompt: Opt
     return out.images, torch.stack(hms)
 
 
-def gather_outputs(images: torch.Tensor, heatmaps: torch.Tensor, seeds: Optional[Sequence[int]] = None, max_batch: Optional[int] = None):
+class PendingGather:
+    """Handle of an all_gather posted with `gather_outputs(..., async_op=True)`: the collectives run on the backend's own stream
+    while the caller enqueues the next batch; `wait()` returns what the blocking call returns."""
+
+    def __init__(self, works, finish):
+        self._works, self._finish, self._out = works, finish, None
+
+    def wait(self):
+        if self._out is None:
+            for w in self._works:
+                w.wait()
+            self._out = self._finish()
+        return self._out
+
+
+def gather_outputs(images: torch.Tensor, heatmaps: torch.Tensor, seeds: Optional[Sequence[int]] = None, max_batch: Optional[int] = None,
+                   async_op: bool = False):
     """The final exchange step: ONE all_gather of images + heat maps (+ their seeds) across ranks.
 
     Ranks may hold different batch sizes (the last, ragged round of `shard_seeds`; even zero images): every rank pads its
@@ -99,7 +115,8 @@ def gather_outputs(images: torch.Tensor, heatmaps: torch.Tensor, seeds: Optional
     `shard_seeds`), else (seeds, images, heatmaps).  No-op for world size 1."""
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
-        return (images, heatmaps) if seeds is None else (list(seeds), images, heatmaps)
+        res = (images, heatmaps) if seeds is None else (list(seeds), images, heatmaps)
+        return PendingGather([], lambda: res) if async_op else res
     w = dist.get_world_size()
     b = images.shape[0]
     mb = int(max_batch) if max_batch is not None else b
@@ -116,28 +133,36 @@ def gather_outputs(images: torch.Tensor, heatmaps: torch.Tensor, seeds: Optional
     # ranks would not join the second one): RCCL takes the flat form, other backends (gloo rehearsals) the list form
     flat = dist.get_backend() == "nccl"
 
+    works = []
+
     def gather(t):
-        """one collective per tensor; RCCL: into a single [world * mb, ...] buffer (no per-rank list copies)"""
+        """one collective per tensor; RCCL: into a single [world * mb, ...] buffer (no per-rank list copies).  Returns a thunk."""
         t = pad(t)
         if flat:
             out = t.new_empty((w * mb,) + tuple(t.shape[1:]))
-            dist.all_gather_into_tensor(out, t)
-            return out
+            works.append(dist.all_gather_into_tensor(out, t, async_op=True))
+            return lambda: out
         parts = [torch.empty_like(t) for _ in range(w)]
-        dist.all_gather(parts, t)
-        return torch.cat(parts)
+        works.append(dist.all_gather(parts, t, async_op=True))
+        return lambda: torch.cat(parts)
 
     ids = torch.full((mb,), -1, dtype=torch.int64, device=images.device)
     if seeds is not None and b:
         ids[:b] = torch.as_tensor(list(seeds), dtype=torch.int64, device=images.device)
     elif b:
         ids[:b] = torch.arange(b, device=images.device) * w + dist.get_rank()     # seed = rank + world * local_index
-    gi, gh, gs = gather(images), gather(heatmaps), gather(ids)
-    keep = torch.nonzero(gs >= 0).flatten()
-    order = keep[torch.argsort(gs[keep])]
-    if seeds is None:
-        return gi[order], gh[order]
-    return gs[order].tolist(), gi[order], gh[order]
+    ti, th, ts = gather(images), gather(heatmaps), gather(ids)
+
+    def finish():
+        gi, gh, gs = ti(), th(), ts()
+        keep = torch.nonzero(gs >= 0).flatten()
+        order = keep[torch.argsort(gs[keep])]
+        if seeds is None:
+            return gi[order], gh[order]
+        return gs[order].tolist(), gi[order], gh[order]
+
+    pend = PendingGather(works, finish)
+    return pend if async_op else pend.wait()
 
 
 def save_outputs(save_dir: str, seeds, images_u8, heatmaps, words, image_size: int, stack_words=None, exported: bool = False):

@@ -438,6 +438,11 @@ class StableDiffusionPipeline:
         self._hooker = None
         self._last_prompt = None
         self._progress = {}
+        self._source_path = None          # from_pretrained: the checkpoint directory (save_pretrained re-exports from it)
+        # diffusers' `pipeline.safety_checker` slot: None (no checker weights ship with this repo) or a callable
+        # images uint8 [B,H,W,3] (cuda tensor) -> sequence of B bools; flagged images are returned black, which the generation
+        # driver then skips exactly as data_generation.py:61-62 does
+        self.safety_checker = None
 
     # ---- construction -------------------------------------------------------------------
     @classmethod
@@ -492,6 +497,7 @@ class StableDiffusionPipeline:
                                  bool(sj.get("skip_prk_steps", False)) if sched_name == "PNDMScheduler" else True)
         cfg = SDConfig(name=os.path.basename(path.rstrip("/")), unet=ucfg, vae=vcfg, sched=sc,
                        default_sample_size=uc.get("sample_size", 64))
+        src_path = path
 
         def wload(sub):
             for fn in ("diffusion_pytorch_model.safetensors", "model.safetensors"):
@@ -531,7 +537,51 @@ class StableDiffusionPipeline:
         elif tsd is not None:
             raise _lib.AgendaHipError(f"{path}: text_encoder/ weights found but no tokenizer/ directory; "
                                       "no silent fallback to the synthetic tokenizer")
-        return cls(cfg, usd, vsd, tokenizer=tok, device=device, workspace_bytes=workspace_bytes, text_sd=tsd, scheduler=sched_name)
+        pipe = cls(cfg, usd, vsd, tokenizer=tok, device=device, workspace_bytes=workspace_bytes, text_sd=tsd, scheduler=sched_name)
+        pipe._source_path = src_path
+        return pipe
+
+    def save_pretrained(self, save_directory: str):
+        """`pipeline.save_pretrained(dir)` (finetune_sd_token.py:164-187 writes its result this way): the diffusers layout
+        `from_pretrained` reads.  This pipeline is an inference engine -- UNet / VAE / scheduler are exactly what was loaded, so
+        their directories are re-exported from the source checkpoint; what CAN have changed is the prompt side
+        (`tokenizer.add_tokens` + rows written into `text_encoder.get_input_embeddings().weight`, data_generation.py:45-52): the
+        tokenizer is saved with its added tokens and the text encoder with its current (resized) embedding table."""
+        import shutil
+        from safetensors.torch import load_file, save_file
+        if self._source_path is None:
+            raise ValueError("save_pretrained: this pipeline was built from in-memory weights (no checkpoint directory to re-export)")
+        src, dst = self._source_path, save_directory
+        os.makedirs(dst, exist_ok=True)
+        for sub in ("unet", "vae", "scheduler"):
+            if os.path.isdir(os.path.join(src, sub)):
+                shutil.copytree(os.path.join(src, sub), os.path.join(dst, sub), dirs_exist_ok=True)
+        mi = os.path.join(src, "model_index.json")
+        if os.path.exists(mi):
+            shutil.copy(mi, os.path.join(dst, "model_index.json"))
+        else:
+            with open(os.path.join(dst, "model_index.json"), "w") as f:
+                json.dump({"_class_name": "StableDiffusionPipeline", "unet": ["diffusers", "UNet2DConditionModel"], "vae": ["diffusers", "AutoencoderKL"],
+                           "scheduler": ["diffusers", type(self.scheduler).__name__], "text_encoder": ["transformers", "CLIPTextModel"],
+                           "tokenizer": ["transformers", "CLIPTokenizer"], "safety_checker": [None, None]}, f, indent=2)
+        te = os.path.join(src, "text_encoder")
+        if os.path.isdir(te):
+            os.makedirs(os.path.join(dst, "text_encoder"), exist_ok=True)
+            fn = next(f for f in ("model.safetensors", "diffusion_pytorch_model.safetensors") if os.path.exists(os.path.join(te, f)))
+            tsd = load_file(os.path.join(te, fn))
+            key = next(k for k in tsd if k.endswith("embeddings.token_embedding.weight"))
+            w = self.text_encoder.get_input_embeddings().weight
+            tsd[key] = w.detach().to(tsd[key].dtype).contiguous().clone()
+            save_file(tsd, os.path.join(dst, "text_encoder", fn))
+            with open(os.path.join(te, "config.json")) as f:
+                tj = json.load(f)
+            tj["vocab_size"] = int(w.shape[0])
+            with open(os.path.join(dst, "text_encoder", "config.json"), "w") as f:
+                json.dump(tj, f, indent=2)
+        if hasattr(self.tokenizer, "save_pretrained"):
+            self.tokenizer.save_pretrained(os.path.join(dst, "tokenizer"))
+        elif os.path.isdir(os.path.join(src, "tokenizer")):
+            shutil.copytree(os.path.join(src, "tokenizer"), os.path.join(dst, "tokenizer"), dirs_exist_ok=True)
 
 
     def to(self, device):
@@ -585,9 +635,10 @@ class StableDiffusionPipeline:
             gens = generator if isinstance(generator, (list, tuple)) else [generator] * B
             parts = []
             for g in gens:
-                if g is not None and g.device.type != "cpu":
-                    raise ValueError("use a CPU torch.Generator (initial latents are an explicit, host-reproducible input)")
-                parts.append(torch.randn(1, self.cfg.unet.in_channels, L, L, generator=g))
+                # data_generation.py:58 seeds `torch.Generator(device="cuda")`: accepted (torch's device Philox stream; whether it is
+                # bit-identical to an NVIDIA run of the reference is not verifiable here).  CPU generators give host-reproducible latents.
+                dev_g = g.device if g is not None else "cpu"
+                parts.append(torch.randn(1, self.cfg.unet.in_channels, L, L, generator=g, device=dev_g).cpu())
             latents = torch.cat(parts, 0)
         expect = (B, self.cfg.unet.in_channels, L, L)
         if tuple(latents.shape) != expect:                 # diffusers prepare_latents raises the same way
@@ -618,13 +669,21 @@ class StableDiffusionPipeline:
 
     def _finish(self, lat, B, output_type):
         u8 = self.engine.vae_decode(lat)
+        flags = [False] * B
+        if self.safety_checker is not None:        # diffusers run_safety_checker: flagged images come back black
+            flags = [bool(f) for f in self.safety_checker(u8)]
+            if len(flags) != B:
+                raise ValueError(f"safety_checker returned {len(flags)} flags for {B} images")
+            if any(flags):
+                u8 = u8.clone()
+                u8[torch.tensor(flags, device=u8.device)] = 0
         if output_type == "pt":
-            return PipelineOutput(images=u8, latents=lat)
+            return PipelineOutput(images=u8, latents=lat, nsfw_content_detected=flags)
         arr = u8.cpu().numpy()
         if output_type == "np":
-            return PipelineOutput(images=arr, latents=lat, nsfw_content_detected=[False] * B)
+            return PipelineOutput(images=arr, latents=lat, nsfw_content_detected=flags)
         from PIL import Image
-        return PipelineOutput(images=[Image.fromarray(a) for a in arr], latents=lat, nsfw_content_detected=[False] * B)
+        return PipelineOutput(images=[Image.fromarray(a) for a in arr], latents=lat, nsfw_content_detected=flags)
 
     # ---- img2img (diffusers StableDiffusionImg2ImgPipeline semantics, parity-unpinned) ------
     @torch.no_grad()

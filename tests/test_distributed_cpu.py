@@ -50,7 +50,10 @@ def _ragged_worker(rank, world, port, out_dir, num_images, batch):
         chunk = seeds[r * batch:(r + 1) * batch]              # may be shorter than `batch`, or empty
         imgs = torch.stack([torch.full((4, 4, 3), s, dtype=torch.uint8) for s in chunk]) if chunk else torch.zeros(0, 4, 4, 3, dtype=torch.uint8)
         hms = torch.stack([torch.full((2, 8, 8), float(s)) for s in chunk]) if chunk else torch.zeros(0, 2, 8, 8)
-        s_, i_, h_ = gather_outputs(imgs, hms, seeds=chunk, max_batch=batch)
+        if r % 2:                                             # both forms: blocking, and posted-then-waited (bench.py's overlap)
+            s_, i_, h_ = gather_outputs(imgs, hms, seeds=chunk, max_batch=batch, async_op=True).wait()
+        else:
+            s_, i_, h_ = gather_outputs(imgs, hms, seeds=chunk, max_batch=batch)
         got_s += s_; got_i.append(i_); got_h.append(h_)
     np.save(os.path.join(out_dir, f"s{rank}.npy"), np.array(got_s))
     np.save(os.path.join(out_dir, f"i{rank}.npy"), torch.cat(got_i).numpy())
@@ -59,7 +62,7 @@ def _ragged_worker(rank, world, port, out_dir, num_images, batch):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,num_images,batch", [(2, 7, 2), (3, 4, 2), (2, 1, 4)])
+@pytest.mark.parametrize("world,num_images,batch", [(2, 7, 2), (3, 4, 2), (2, 1, 4), (8, 19, 2)])      # last: a full node, ragged + empty tail
 def test_gather_handles_ragged_and_empty_last_batches(tmp_path, world, num_images, batch):
     """The last round of `shard_seeds` leaves ranks with fewer (or zero) images: the collective count and the tensor
     shapes must still match on every rank, and every seed must come back exactly once with its own payload."""

@@ -40,8 +40,11 @@ def test_call_order_and_argument_errors():
     with pytest.raises(_lib.AgendaHipError, match="text encoder not configured"):
         pipe.engine.cfg.text = config.TextConfig(hidden_size=64)          # python-side only; the ctx has none
         pipe.engine.text_encode(torch.zeros(1, 77, dtype=torch.int32))
-    with pytest.raises(ValueError, match="CPU torch.Generator"):
-        pipe(prompt_embeds=ctx, generator=torch.Generator(device="cuda").manual_seed(0), num_inference_steps=1)
+    # data_generation.py:58: `generator = torch.Generator(device="cuda").manual_seed(i)` is accepted as the reference passes it
+    a = pipe(prompt_embeds=ctx, generator=torch.Generator(device="cuda").manual_seed(3), num_inference_steps=1, output_type="latent").latents
+    b = pipe(prompt_embeds=ctx, generator=torch.Generator(device="cuda").manual_seed(3), num_inference_steps=1, output_type="latent").latents
+    c = pipe(prompt_embeds=ctx, generator=torch.Generator(device="cuda").manual_seed(4), num_inference_steps=1, output_type="latent").latents
+    assert torch.equal(a, b) and not torch.equal(a, c)
     with pytest.raises(ValueError, match="not found in prompt"):
         with trace(pipe) as trc:
             pipe(["a photo of cars"], num_inference_steps=1, output_type="latent")

@@ -238,7 +238,25 @@ def test_from_pretrained_roundtrip(tmp_path, tiny_pipe):
     o2 = p2.img2img(prompt_embeds=ctx, image=img, strength=0.5, num_inference_steps=4, noise_enc=ne, noise=nz, output_type="pt")
     assert torch.equal(o1.images, o2.images)
     pw.engine.close()
+    # save_pretrained (finetune_sd_token.py:164-187 layout): the injected token survives the round trip -- tokenizer with the added
+    # token, text encoder with the resized embedding table -- and the reloaded pipeline produces the same context and images
+    prompt = "an aerial view image with new_token_v0 cars"
+    p2.save_pretrained(str(tmp_path / "resaved"))
+    p3 = StableDiffusionPipeline.from_pretrained(str(tmp_path / "resaved"), workspace_bytes=1 << 30, scheduler="DDIMScheduler")
+    assert len(p3.tokenizer) == n_vocab + 1 and p3.tokenizer.convert_tokens_to_ids("new_token_v0") == n_vocab
+    assert torch.equal(p3.text_encoder([prompt]), e2)
+    lat0 = synthetic.make_latents(cfg, [5], 16)
+    i2 = p2([prompt], latents=lat0, num_inference_steps=2, output_type="pt").images
+    i3 = p3([prompt], latents=lat0, num_inference_steps=2, output_type="pt").images
+    assert torch.equal(i2, i3)
+    # the safety-checker slot: flagged images come back black (and the generation driver then skips them, data_generation.py:61-62)
+    p3.safety_checker = lambda imgs: [True] * imgs.shape[0]
+    o = p3([prompt], latents=lat0, num_inference_steps=1, output_type="np")
+    assert o.nsfw_content_detected == [True] and int(o.images.max()) == 0
+    p3.engine.close()
     p2.engine.close()
+    with pytest.raises(ValueError, match="in-memory weights"):
+        StableDiffusionPipeline(cfg, u, v, workspace_bytes=1 << 28).save_pretrained(str(tmp_path / "nope"))
     # real CLIP weights without a loadable tokenizer must NOT fall back to the word-level stand-in
     import shutil
     from agenda_amd import _lib
