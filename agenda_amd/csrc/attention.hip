@@ -48,7 +48,12 @@ template <int D> struct AttnCfg {
 // probabilities into per-image rows once -- the DAAM layers at latent resolution, where the aggregation is linear in the heads
 // (bicubic to the same size is the identity and clamp(min=0) cannot fire), so 1/8 of the accumulator traffic.
 template <int D, int KB, int QB, int RECORD, int AMASK = 0>
-__global__ __launch_bounds__(256, (AMASK ? 1 : (QB == 1 && D <= 40 && !RECORD) ? 4 : (QB == 1 && D <= 64 && !RECORD) ? 3 : (QB == 1 && D <= 80) ? 2 : 1)) void attn_kernel(const AttnP p) {
+#if defined(AGD_EXPERIMENTS) && defined(EXP_ATTN_LB)      // tools/: occupancy experiments on the plain flash kernels
+#define ATTN_LB(def) ((!RECORD && !AMASK) ? EXP_ATTN_LB : (def))
+#else
+#define ATTN_LB(def) (def)
+#endif
+__global__ __launch_bounds__(256, ATTN_LB((AMASK ? 1 : (QB == 1 && D <= 40 && !RECORD) ? 4 : (QB == 1 && D <= 64 && !RECORD) ? 3 : (QB == 1 && D <= 80) ? 2 : 1))) void attn_kernel(const AttnP p) {
   using C = AttnCfg<D>;
   constexpr int KEYS = KB * 32;
   constexpr int KSTEPS = C::KSTEPS, DBLK = C::DBLK, KPITCH = C::KPITCH, VPITCH = C::VPITCH, CH = C::CH;
@@ -525,6 +530,9 @@ static int launch_attn_d(const AttnP& p, hipStream_t st) {
   }
   if (p.Nk <= 96 && p.Nk > 64) return launch_attn_t<D, 3, 1, 0>(p, st);
   if constexpr (D <= 80) { if (p.Nq >= 1024 && g_attn_qb == 2) return launch_attn_t<D, 2, 2, 0>(p, st); }
+#if defined(AGD_EXPERIMENTS) && defined(EXP_ATTN_KB)
+  if (p.Nk >= 1024) return launch_attn_t<D, EXP_ATTN_KB, 1, 0>(p, st);
+#endif
   return launch_attn_t<D, 2, 1, 0>(p, st);
 }
 
