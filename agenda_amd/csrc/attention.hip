@@ -53,7 +53,7 @@ template <int D, int KB, int QB, int RECORD, int AMASK = 0>
 #else
 #define ATTN_LB(def) (def)
 #endif
-__global__ __launch_bounds__(256, ATTN_LB((AMASK ? 1 : (QB == 1 && D <= 40 && !RECORD) ? 4 : (QB == 1 && D <= 64 && !RECORD) ? 3 : (QB == 1 && D <= 80) ? 2 : 1))) void attn_kernel(const AttnP p) {
+__global__ __launch_bounds__(256, ATTN_LB((AMASK ? 1 : (QB == 1 && D <= 64 && !RECORD) ? 3 : (QB == 1 && D <= 80) ? 2 : 1))) void attn_kernel(const AttnP p) {
   using C = AttnCfg<D>;
   constexpr int KEYS = KB * 32;
   constexpr int KSTEPS = C::KSTEPS, DBLK = C::DBLK, KPITCH = C::KPITCH, VPITCH = C::VPITCH, CH = C::CH;

@@ -476,7 +476,7 @@ static int launch_8p(const IgemmP& p, hipStream_t st) {
 // tiles, and the share of MFMA slots doing useful work (tile padding in M and N x the last, partial wave of tiles) decides.
 static int pick_8p(const IgemmP& p) {
   const bool lin = p.ksize == 1 && p.stride == 1 && p.up == 1 && p.pad == 0 && p.Hin == p.Hout && p.Win == p.Wout;
-  if (!(p.ksize == 3 || lin) || p.batch > 1) return 0;
+  if (!(p.ksize == 3 || lin) || p.batch > 1 || p.rowstat_out) return 0;      // (the 8-phase epilogue carries no LayerNorm row-statistics producer)
   if (p.M >= (1 << 24) || (long long)p.N * p.K * 2 >= (1LL << 31)) return 0;
   const long long amax = (long long)p.Hin * p.Win * (p.C0 > p.C1 ? p.C0 : p.C1) * 2;       // bytes of one image of the wider source
   if (amax * ((long long)p.M / (p.Hout * p.Wout) + 1) >= (1LL << 31)) return 0;                // 32-bit byte offsets per source

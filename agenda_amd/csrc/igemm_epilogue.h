@@ -190,9 +190,11 @@ AGD_DEV void igemm_epilogue(const IgemmP& p, f32x4 (&acc)[BM / WM / 16][BN / WN 
 #pragma unroll
           for (int e = 0; e < CW; ++e) v[e] = gelu_erf_f(v[e]);
         }
-        if (p.rowstat_out) {
+        if constexpr (!FAST_ONLY) {      // the 8-phase kernels are never LayerNorm-statistics producers (their launcher refuses): 16 registers less
+          if (p.rowstat_out) {
 #pragma unroll
-          for (int e = 0; e < CW; ++e) { const float r = bf2f(f2bf(v[e])); rs[i] += r; rq[i] += r * r; }
+            for (int e = 0; e < CW; ++e) { const float r = bf2f(f2bf(v[e])); rs[i] += r; rq[i] += r * r; }
+          }
         }
         if (p.out_f32) {
           float* op = (float*)p.out + bz * p.sO + (long long)m * p.ldo + no;
@@ -274,7 +276,7 @@ AGD_DEV void igemm_epilogue(const IgemmP& p, f32x4 (&acc)[BM / WM / 16][BN / WN 
         }
       }
     }
-    if (p.rowstat_out) {          // wave-uniform (kernel argument)
+    if (!FAST_ONLY && p.rowstat_out) {          // wave-uniform (kernel argument)
       constexpr int NT = WM * WN * 64;
 #pragma unroll
       for (int i = 0; i < MI; ++i) {                   // the 4 lanes (q) that share a pixel row

@@ -163,6 +163,7 @@ struct GemmOpt {
   const float* ln_stats = nullptr; int ln_slots = 0; const float* ln_cs = nullptr; float ln_invC = 0.f, ln_eps = 0.f;   // consumer side
   int warm = 0;                 // benches: request the in-kernel cold-weight warm-up (the walk sets it through the ctx option)
   int halo = 0;                 // benches: allow the row-halo 3x3 kernel (the walk sets it through the ctx option)
+  int want_rowstat = 0;         // igemm_query only: the launch will be a LayerNorm row-statistics producer (changes the kernel family)
   int p8 = 0;                   // benches: 1 = allow the 8-phase kernel, 2 / 3 = force its 256- / 160-wide tile (the walk sets it through the ctx option)
   int pad = -1;                 // -1: 1 for 3x3, 0 for 1x1
   int hout = 0, wout = 0;       // >0: override (asymmetric (0,1,0,1) padding of the VAE encoder's stride-2 convs)
@@ -191,7 +192,7 @@ static int run_conv(agd_ctx* c, hipStream_t st, const bf16_t* s0, int C0, const 
   p.ln_stats = o.ln_stats; p.ln_slots = o.ln_slots; p.ln_cs = o.ln_cs; p.ln_invC = o.ln_invC; p.ln_eps = o.ln_eps;
   p.halo = (c && c->opt_halo) || o.halo;
   p.p8 = o.p8 ? o.p8 : c ? c->opt_p8 : 0;          // before any igemm_query: the tile shape depends on it
-  if (o.query_cfg) return igemm_query(p, o.query_cfg);
+  if (o.query_cfg) { if (o.want_rowstat && !p.rowstat_out) { p.rowstat_out = (float*)16; p.rowstat_slots = 0; } return igemm_query(p, o.query_cfg); }   // (nothing is launched)
   if (o.out_act) {
     o.out_act->cpart_bm = 0;
     if (o.out_act->cpart && !o.out_f32 && !o.geglu) {
@@ -401,7 +402,7 @@ static int transformer(agd_ctx* c, hipStream_t st, const std::string& pre, const
   // h_out = A . W^T (+ bias, + residual): writes h and, when folding, its row statistics
   auto produce = [&](const bf16_t* A, int K, const WMat& w, GemmOpt o, bf16_t* hout) -> int {
     if (fold) {
-      int cfg[3] = {0, 0, 0}; GemmOpt qo = o; qo.query_cfg = cfg;
+      int cfg[3] = {0, 0, 0}; GemmOpt qo = o; qo.query_cfg = cfg; qo.want_rowstat = 1;
       CK(run_conv(c, st, A, K, nullptr, 0, 1, 1, M, w, 1, hout, qo, c->zero_page));
       slots = (w.N + cfg[1] - 1) / cfg[1];
       stats = (float*)c->arena.alloc((size_t)B * HW * slots * 2 * sizeof(float)); if (!stats) return -1;   // B*HW rows: room for the CFG duplicate
@@ -1523,7 +1524,7 @@ AGD_API int agd_bench_conv(int B, int H, int W, int C0, int C1, int Cout, int ks
   o.p8 = (mode & 32) ? 2 : (mode & 64) ? 3 : (mode & 16) ? 1 : 0;
   float* stats = nullptr; float* cs = nullptr;
   if (mode & 6) {
-    int cfg[3] = {0, 0, 0}; GemmOpt qo = o; qo.query_cfg = cfg;
+    int cfg[3] = {0, 0, 0}; GemmOpt qo = o; qo.query_cfg = cfg; qo.want_rowstat = (mode & 2) ? 1 : 0;
     CK(run_conv(nullptr, 0, x0, C0, x1, C1, B, H, W, wm, ksize, y, qo, op_zero_page()));
     const int slots = (mode & 2) ? (Cout + cfg[1] - 1) / cfg[1] : 2;
     stats = tmp.get<float>((size_t)M * slots * 2); cs = tmp.get<float>(Cout);

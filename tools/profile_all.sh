@@ -10,7 +10,7 @@ BENCH="python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline"
 # PMC passes: one batch of 10 DDIM steps (the per-launch counters do not depend on the step count; rocprofv3 --pmc crashed
 # in its dispatch interception on the full 3-batch x 50-step run, ~45k dispatches)
 PMCB="python3 bench.py --steps 1 --warmup 0 --ddim-steps 10 --no-cpu-baseline --no-profile"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- $BENCH > $OUT/bench_stats.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- $BENCH > $OUT/bench_stats.out 2> $OUT/bench_stats.log
 echo "stats done"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- $PMCB > $OUT/bench_fetch.log 2>&1
 echo "fetch done"
@@ -24,7 +24,7 @@ MF=$(find $OUT/mfma -name "*counter_collection.csv" | head -1)
 cp $ST $OUT/${R}_bench_kernel_stats.csv
 python3 tools/pmc_traffic.py $FE $WR $KT > $OUT/${R}_pmc_traffic_summary.csv
 python3 tools/pmc_mfma.py $MF > $OUT/${R}_pmc_mfma_util.csv
-tail -1 $OUT/bench_stats.log > $OUT/${R}_bench_line_profiled.json
+grep '"metric"' $OUT/bench_stats.out | tail -1 > $OUT/${R}_bench_line_profiled.json
 # per-layer report: one short run with the shape log
 # (the shape log exists only in the experiments library: agenda_amd/libagenda_hip_exp.so, `make -C agenda_amd/csrc exp`)
 AGD_LIB=$GRAFT_REPO_ROOT/agenda_amd/libagenda_hip_exp.so AGD_IGEMM_LOG=1 rocprofv3 --kernel-trace --output-format csv -d $OUT/layers -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-profile > $OUT/bench_layers.log 2> $OUT/layers.err || true
