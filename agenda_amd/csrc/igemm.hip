@@ -290,6 +290,17 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_kernel(const IgemmP p) 
     __builtin_amdgcn_sched_group_barrier(0x8, 2 * MI * NI - 2 * NG, 0);
   };
 
+  // LayerNorm-fold consumer: one thread per tile row sums the producer's partial sums while the prologue stages are in flight and
+  // leaves (mean, rstd) in LDS behind the ring (the epilogue then reads two floats per row instead of chasing `slots` loads)
+  float* const lnst = (float*)(smem + STAGES * STAGE + 4096);
+  if (!SPLITK && p.ln_stats && tid < BM) {
+    const int m = m0 + tid;
+    float S = 0.f, Q = 0.f;
+    if (m < p.M) for (int k = 0; k < p.ln_slots; ++k) { const f32x2 v = *(const f32x2*)(p.ln_stats + ((long long)m * p.ln_slots + k) * 2); S += v[0]; Q += v[1]; }
+    const float mu = S * p.ln_invC;
+    float var = Q * p.ln_invC - mu * mu; var = var < 0.f ? 0.f : var;
+    *(f32x2*)(lnst + tid * 2) = f32x2{mu, rsqrtf(var + p.ln_eps)};
+  }
   {
     // STAGES-deep ring: stages ks+1 .. ks+STAGES-2 stay in flight across the barrier (counted vmcnt), the stage
     // for step ks+STAGES-1 is issued inside step ks into the slot step ks-1 just released.  A deeper ring is what
@@ -325,7 +336,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_kernel(const IgemmP p) 
     return;
   }
 #endif
-  igemm_epilogue<BM, BN, WM, WN, GEGLU, SPLITK>(p, acc, smem, lane, wm, wn, m0, n0, tn, bz);
+  igemm_epilogue<BM, BN, WM, WN, GEGLU, SPLITK>(p, acc, smem, lane, wm, wn, m0, n0, tn, bz, (!SPLITK && p.ln_stats && nk > 0) ? lnst : nullptr);
 }
 
 // split-K second pass: out = epilogue(sum_s partial[s])   (deterministic slab sum, no atomics)
@@ -354,7 +365,7 @@ template <int BM, int BN, int WM, int WN, int KS, int STAGES, int GEGLU, int SPL
 static int launch_one(const IgemmP& p, int splits, hipStream_t st) {
   constexpr int NT = WM * WN * 64;
   constexpr int stage = (BM + BN) * 128;
-  constexpr int lds = STAGES * stage + 4096;             // + one scratch KiB per wave (cold-weight warm-up pieces)
+  constexpr int lds = STAGES * stage + 4096 + BM * 8;    // + one scratch KiB per wave (cold-weight warm-up pieces) + (mean, rstd) of the tile's rows
   const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
   dim3 grid(tiles, p.batch > 0 ? p.batch : 1, splits);
   auto kfn = igemm_kernel<BM, BN, WM, WN, KS, STAGES, GEGLU, SPLITK>;
