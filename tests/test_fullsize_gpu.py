@@ -168,6 +168,37 @@ def test_sd15_unet_forward_512px_matches_oracle(sd15_host_weights, sd15_pipe, p8
     assert hm_err < 0.02, hm_err
 
 
+def test_sd15_unet_forward_512px_batch4_matches_oracle(sd15_host_weights, sd15_pipe):
+    """BASELINE config 2 at the bench's OWN batch: four images (UNet batch 8, M = 32768 at 64 x 64), one forward with the DAAM
+    recorder on, against the fp32 CPU oracle.  At this batch the launcher's choices differ from the CFG-pair test above (the
+    8-phase igemm on qkv / GEGLU / the upsampling convs, other tile and split-K choices), so this is the oracle check of the
+    kernels the benchmark actually runs."""
+    from agenda_amd import synthetic
+    from oracle import sd_oracle as O
+    cfg, u, v = sd15_host_weights
+    pipe, L, B = sd15_pipe, 64, 4
+    ctx = synthetic.make_context(cfg, B, seed=21)
+    lat = synthetic.make_latents(cfg, [30, 31, 32, 33], L)
+    x = torch.cat([lat, lat]).to(torch.bfloat16).float()
+    rec = O.DaamRecorder(L * L, 77)
+    with torch.no_grad():
+        want = O.unet_forward(u, cfg.unet, x, torch.tensor(601), ctx, rec)
+    whm = rec.compute_global_heat_map()
+    pipe.engine.set_context(ctx)
+    pipe.engine.record_config(1, False, 77)
+    pipe.engine.record_reset(B, L)
+    try:
+        got = pipe.engine.unet_forward(x, 601.0)
+        hm = torch.stack([pipe.engine.daam_global(i, 77, L).cpu() for i in range(B)])
+    finally:
+        pipe.engine.record_config(0)
+    err = _rms_rel(got, want)
+    hm_err = float((hm - whm).abs().max() / whm.abs().max())
+    print(f"config2 forward at batch 4 (UNet batch 8, 512 px): rms rel {err:.5f}, heat map rel {hm_err:.4f}")
+    assert err < 2.0 ** -6, err
+    assert hm_err < 0.02, hm_err
+
+
 @pytest.mark.parametrize("p8", [1, 4])
 def test_sd15_vae_decode_512_matches_oracle(sd15_host_weights, sd15_pipe, p8):
     """`vae.decode` at 512 px (the decode bench.py times) against the CPU oracle, plus the uint8 post-process rule
