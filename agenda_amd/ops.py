@@ -119,7 +119,15 @@ def attn_reg_loss(attn_map: torch.Tensor, obj_idx, fg_idx, bg_idx, coef: float, 
     assert m.is_cuda and m.ndim == 4
     B, T = m.shape[:2]
     P = m.shape[2] * m.shape[3]
-    idx = [torch.as_tensor(list(map(int, i)) if not torch.is_tensor(i) else i, dtype=torch.int32).to(m.device).contiguous() for i in (obj_idx, fg_idx, bg_idx)]
+    host = [torch.as_tensor(list(map(int, i)) if not torch.is_tensor(i) else i.detach().cpu(), dtype=torch.int32) for i in (obj_idx, fg_idx, bg_idx)]
+    has = host[0] >= 0
+    # the reference indexes the map's token rows directly (finetune_sd_token.py:1049-1060): a row the map does not have is an
+    # IndexError there, never a silently skipped sample (only obj < 0 means "no object in this sample")
+    if bool(has.any()):
+        worst = max(int(h[has].max()) for h in host)
+        if worst >= T:
+            raise IndexError(f"index {worst} is out of bounds for dimension 0 with size {T}")
+    idx = [h.to(m.device).contiguous() for h in host]
     loss = torch.empty(B, 2, device=m.device, dtype=torch.float32)
     dmap = torch.empty_like(m) if want_grad else None
     _lib.check(lib.agd_op_attn_reg_loss(_lib.ptr(m), B, T, P, _lib.ptr(idx[0]), _lib.ptr(idx[1]), _lib.ptr(idx[2]), float(coef), _lib.ptr(loss),
