@@ -56,6 +56,9 @@ __global__ __launch_bounds__(512, 2) void igemm8p_kernel(const IgemmP p) {
   constexpr unsigned OOB = 0x80000000u, LIVE = 0x7FFFFFF0u;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
+#ifdef AGD_EXPERIMENTS
+  if (p.dbg & 32) return;                          // timing experiment (agd_set_igemm_cfg(512)): dispatch cost of this grid only
+#endif
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int grp = wid >> 2;                           // waves 4..7 share the SIMDs of waves 0..3: they run one barrier behind
@@ -260,5 +263,16 @@ __global__ __launch_bounds__(512, 2) void igemm8p_kernel(const IgemmP p) {
   if (grp == 0) P8_BAR();
   p8_wait_vm<0>();                                   // dead tail pieces still write zeros into LDS: let them land before the epilogue reuses it
 
+#ifdef AGD_EXPERIMENTS
+  if (p.dbg & 64) {                                // timing experiment (agd_set_igemm_cfg(1024)): no epilogue (keeps acc live)
+    float sacc = 0.f;
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NI; ++j) sacc += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+    if (sacc == 1.2345e-30f) ((float*)p.out)[0] = sacc;
+    return;
+  }
+#endif
   igemm_epilogue<BM, BN, WM, WN, GEGLU, 0, 1>(p, acc, smem, lane, wm, wn, m0, n0, tn, 0, p.ln_stats ? (const float*)(smem + G::STATS_OFF) : nullptr);
 }
