@@ -93,6 +93,16 @@ def cpu_baseline(cfg, usd, vsd, ctx, threads):
                       f"extrapolated x50 steps; fp32 PyTorch restatement of the reference path (diffusers absent)"}
 
 
+def rccl_version():
+    """RCCL's version as torch reports it (torch.cuda.nccl is RCCL on ROCm); never lets a reporting detail fail a multi-GPU run."""
+    try:
+        import torch
+        v = torch.cuda.nccl.version()
+        return ".".join(str(x) for x in v) if isinstance(v, (tuple, list)) else str(v)
+    except Exception as e:                                      # pragma: no cover
+        return f"unavailable ({type(e).__name__})"
+
+
 def class_table(classes, step_ms):
     """Per kernel class: time, achieved TFLOP/s and GB/s (algorithmic work / time), the fraction of each roof, and `frac`
     against the BINDING roof of each launch (max(flop / 2.5 PF, bytes / 8 TB/s) summed over the class's launches).
@@ -259,7 +269,7 @@ def main():
                 "config": {"workload": f"SD-1.5 512x512 batch={B}/GPU, {args.ddim_steps} DDIM steps (eta 0, CFG 7.5), DAAM heat maps on (77 rows recorded, 2 word maps), VAE decode",
                            "global_batch": world * B, "ddim_steps": args.ddim_steps, "parallelism": f"seed-sharded x{world} + all_gather",
                            "collective_backend": backend, "world_size": dist.get_world_size() if world > 1 else 1,
-                           "rccl_version": ".".join(str(x) for x in torch.cuda.nccl.version()) if backend == "nccl" else None},
+                           "rccl_version": rccl_version() if backend == "nccl" else None},
                 "roofline": roof, "cpu_baseline": cpu}
         if daam:
             line["daam_accumulate"] = daam
