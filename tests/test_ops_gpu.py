@@ -151,6 +151,7 @@ def _attn_ref(q, k, v, heads):
     (2, 8, 40, 256, 256), (1, 8, 80, 64, 64), (1, 8, 160, 64, 64), (2, 2, 64, 128, 128),
     (1, 2, 32, 256, 256), (1, 4, 40, 144, 144),   # ragged query/key tails (768-px mid block)
     (1, 8, 40, 1024, 1024), (1, 2, 128, 64, 64),
+    (1, 8, 80, 256, 256), (1, 4, 40, 96, 192), (1, 2, 64, 200, 320),   # several whole 64-key tiles with ragged query tiles
 ])
 def test_self_attention(ops, B, H, D, Nq, Nk):
     g = torch.Generator().manual_seed(D + Nq)
