@@ -571,6 +571,8 @@ int launch_igemm(const IgemmP& p_in, hipStream_t st) {
       int S = f_s; if (S > nk / 2) S = nk / 2; if (S < 1) S = 1;
       if (S >= 2) CK0(ensure_splitk(p, S));
       if (f_bn == 64) return f_st == 4 ? launch_cfg<64, 64, 2, 2, 4>(p, S, st) : launch_cfg<64, 64, 2, 2>(p, S, st);
+      if (f_bn == 1064) return f_st == 4 ? launch_cfg<64, 160, 2, 2, 4>(p, S, st) : launch_cfg<64, 160, 2, 2>(p, S, st);
+      if (f_bn == 2064) return f_st == 4 ? launch_cfg<64, 128, 2, 2, 4>(p, S, st) : launch_cfg<64, 128, 2, 2>(p, S, st);
       if (f_bn == 160) return f_st == 4 ? launch_cfg<128, 160, 2, 2, 4>(p, S, st) : launch_cfg<128, 160, 2, 2>(p, S, st);
       return f_st == 4 ? launch_cfg<128, 128, 2, 2, 4>(p, S, st) : launch_cfg<128, 128, 2, 2>(p, S, st);
     }
@@ -578,6 +580,18 @@ int launch_igemm(const IgemmP& p_in, hipStream_t st) {
 #endif
   if (p.p8) { const int c8 = pick_8p(p); if (c8 == 1) return launch_8p<2, 4, 8, 2, 2>(p, st); if (c8 == 2) return launch_8p<4, 2, 4, 3, 2>(p, st); }
   if (p.geglu) return launch_cfg<128, 128, 2, 2>(p, 1, st);
+  // 1x1 launches of the 16x16 / 8x8 maps with N a multiple of 160: 64 x 160 tiles on the 4-stage ring give exactly (or, with K slices,
+  // up to) 256 workgroups where the 128-row tiles give 160 or need a K split -- M = 2048, N = 1280 (tools/kb_force64.py, hot operands):
+  // K = 1280 17.5 -> 16.1 us, K = 2560 25.4 -> 23.3, K = 5120 45.5 (128 x 160, 2 slices) -> 39.4 unsplit; M = 512, K = 5120: 26.6 (8 slices) ->
+  // 21.9 (4 slices).  3x3 launches and every other shape tried are better off on the 128-row tiles.
+  if (!KNOB(14) && batch == 1 && p.ksize == 1 && (p.N % 160) == 0 && (p.M % 64) == 0 && nk >= 16) {
+    const long long t64 = (long long)(p.M / 64) * (p.N / 160);
+    if (t64 >= 192 && t64 <= 256) return launch_cfg<64, 160, 2, 2, 4>(p, 1, st);
+    if (t64 <= 64 && nk >= 64) {
+      int S = (int)(256 / t64); if (S > nk / 16) S = nk / 16;
+      if (S >= 2) { CK0(ensure_splitk(p, S)); return launch_cfg<64, 160, 2, 2, 4>(p, S, st); }
+    }
+  }
   // Small-M launches (8x8 / 16x16 feature maps): ONE workgroup per CU on the 4-stage ring, tile width and K split
   // chosen so that the launch has as close to 256 workgroups as possible.  These launches are a load-latency chain:
   // two more stages in flight hide more of it than a second co-resident workgroup on a 2-stage ring does
