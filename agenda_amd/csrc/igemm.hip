@@ -583,7 +583,8 @@ int launch_igemm(const IgemmP& p_in, hipStream_t st) {
   // 1x1 launches of the 16x16 / 8x8 maps with N a multiple of 160: 64 x 160 tiles on the 4-stage ring give exactly (or, with K slices,
   // up to) 256 workgroups where the 128-row tiles give 160 or need a K split -- M = 2048, N = 1280 (tools/kb_force64.py, hot operands):
   // K = 1280 17.5 -> 16.1 us, K = 2560 25.4 -> 23.3, K = 5120 45.5 (128 x 160, 2 slices) -> 39.4 unsplit; M = 512, K = 5120: 26.6 (8 slices) ->
-  // 21.9 (4 slices).  3x3 launches and every other shape tried are better off on the 128-row tiles.
+  // 21.9 (4 slices).  In situ (tools/ab_bench_libs.sh): 548.3 -> 539.8 ms per batch.  3x3 launches and every other shape tried are better off on
+  // the 128-row tiles; in situ also: 512 tiles of 64 x 160 for the 32x32 maps' C->C launches (+0.5 .. 8 ms) and 64 x 128 GEGLU tiles for M <= 2048 (+0.3 ms).
   if (!KNOB(14) && batch == 1 && p.ksize == 1 && (p.N % 160) == 0 && (p.M % 64) == 0 && nk >= 16) {
     const long long t64 = (long long)(p.M / 64) * (p.N / 160);
     if (t64 >= 192 && t64 <= 256) return launch_cfg<64, 160, 2, 2, 4>(p, 1, st);
