@@ -1562,6 +1562,7 @@ AGD_API int agd_bench_conv_cold(int B, int H, int W, int C0, int Cout, int ksize
   hipMemset(bias, 0, Cout * 4);
   WMat wm; wm.w = w; wm.N = Cout; wm.Cin = C0; wm.Cpad = C0; wm.taps = taps;
   GemmOpt o; o.bias = bias; o.geglu = geglu; o.residual = r; o.warm = warm == 3 ? 3 : 0;      // warm 3: cold weights, in-kernel warm-up
+  o.halo = 1; o.p8 = 1;                                                                         // the walk's dispatch options (ctx defaults)
   // the intervening layer (warm >= 4): conv3x3 640 -> 640 on 8 x 32 x 32
   bf16_t* ix = tmp.get<bf16_t>((size_t)8 * 1024 * 640); bf16_t* iy = tmp.get<bf16_t>((size_t)8 * 1024 * 640); bf16_t* iw = tmp.get<bf16_t>((size_t)640 * 9 * 640);
   if (!ix || !iy || !iw) return -1;
