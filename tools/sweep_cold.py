@@ -16,7 +16,11 @@ shapes = [(32, 640, 640, 1, 1), (32, 640, 1920, 1, 0), (32, 2560, 640, 1, 1), (3
           (16, 1280, 1280, 1, 1), (16, 1280, 3840, 1, 0), (16, 5120, 1280, 1, 1), (16, 2560, 1280, 1, 0), (16, 1920, 1280, 1, 0), (16, 640, 1280, 1, 0),
           (16, 1280, 1280, 3, 1), (16, 2560, 1280, 3, 0), (16, 1920, 1280, 3, 0), (16, 640, 1280, 3, 0),
           (8, 1280, 1280, 1, 1), (8, 1280, 3840, 1, 0), (8, 5120, 1280, 1, 1), (8, 2560, 1280, 1, 0), (8, 1280, 1280, 3, 1), (8, 2560, 1280, 3, 0)]
+if len(sys.argv) > 1 and sys.argv[1] == "l0":      # the 64x64 maps (M = 32768): no K slices
+    shapes = [(64, 320, 320, 1, 1), (64, 320, 320, 1, 0), (64, 320, 960, 1, 0), (64, 1280, 320, 1, 1), (64, 960, 320, 1, 0), (64, 640, 320, 1, 0),
+              (64, 320, 320, 3, 1), (64, 640, 320, 3, 0), (64, 960, 320, 3, 0)]
 cfgs = ["", "128:1:2", "128:1:4", "160:1:2", "160:1:4", "64:1:4", "1064:1:4", "1064:1:2", "2064:1:4", "128:2:4", "160:2:4", "1064:2:4", "128:4:4", "160:4:4", "1064:4:4", "160:8:4", "128:8:4"]
+if len(sys.argv) > 1 and sys.argv[1] == "l0": cfgs = ["", "128:1:2", "128:1:4", "160:1:2", "160:1:4", "64:1:2", "64:1:4", "1064:1:2", "1064:1:4", "2064:1:2", "2064:1:4"]
 print(f"{'shape (H Cin Cout k res)':28s}" + "".join(f"{(c or 'default'):>10s}" for c in cfgs), flush=True)
 for sh in shapes:
     row = []
