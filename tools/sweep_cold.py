@@ -7,8 +7,9 @@ if len(sys.argv) > 1 and sys.argv[1] == "--one":
     lib = C.CDLL(os.environ.get("AGD_LIB", os.path.join(ROOT, "agenda_amd", "libagenda_hip_exp.so")))
     lib.agd_bench_conv_cold.argtypes = [C.c_int] * 10 + [C.POINTER(C.c_double)]
     H, C0, Cout, k, res = map(int, sys.argv[2:7])
+    geglu = int(sys.argv[7]) if len(sys.argv) > 7 else 0
     ms = C.c_double()
-    rc = lib.agd_bench_conv_cold(8, H, H, C0, Cout, k, 0, res, 3, 8, C.byref(ms))
+    rc = lib.agd_bench_conv_cold(8, H, H, C0, Cout, k, geglu, res, 3, 8, C.byref(ms))
     print(f"{ms.value * 1e3:.1f}" if rc == 0 else "nan")
     sys.exit(0)
 shapes = [(32, 640, 640, 1, 1), (32, 640, 1920, 1, 0), (32, 2560, 640, 1, 1), (32, 1280, 640, 1, 0), (32, 1920, 640, 1, 0), (32, 960, 640, 1, 0),
@@ -19,8 +20,12 @@ shapes = [(32, 640, 640, 1, 1), (32, 640, 1920, 1, 0), (32, 2560, 640, 1, 1), (3
 if len(sys.argv) > 1 and sys.argv[1] == "l0":      # the 64x64 maps (M = 32768): no K slices
     shapes = [(64, 320, 320, 1, 1), (64, 320, 320, 1, 0), (64, 320, 960, 1, 0), (64, 1280, 320, 1, 1), (64, 960, 320, 1, 0), (64, 640, 320, 1, 0),
               (64, 320, 320, 3, 1), (64, 640, 320, 3, 0), (64, 960, 320, 3, 0)]
+if len(sys.argv) > 1 and sys.argv[1] == "geglu":   # GEGLU launches (sixth field 1): 128x128 on the 2- / 4-stage ring; default = the launcher (8-phase kernel where it applies)
+    shapes = [(64, 320, 2560, 1, 0, 1), (32, 640, 5120, 1, 0, 1), (16, 1280, 10240, 1, 0, 1), (8, 1280, 10240, 1, 0, 1)]
+mode = sys.argv[1] if len(sys.argv) > 1 else ""
 cfgs = ["", "128:1:2", "128:1:4", "160:1:2", "160:1:4", "64:1:4", "1064:1:4", "1064:1:2", "2064:1:4", "128:2:4", "160:2:4", "1064:2:4", "128:4:4", "160:4:4", "1064:4:4", "160:8:4", "128:8:4"]
-if len(sys.argv) > 1 and sys.argv[1] == "l0": cfgs = ["", "128:1:2", "128:1:4", "160:1:2", "160:1:4", "64:1:2", "64:1:4", "1064:1:2", "1064:1:4", "2064:1:2", "2064:1:4"]
+if mode == "l0": cfgs = ["", "128:1:2", "128:1:4", "160:1:2", "160:1:4", "64:1:2", "64:1:4", "1064:1:2", "1064:1:4", "2064:1:2", "2064:1:4"]
+if mode == "geglu": cfgs = ["", "128:1:2", "128:1:4"]
 print(f"{'shape (H Cin Cout k res)':28s}" + "".join(f"{(c or 'default'):>10s}" for c in cfgs), flush=True)
 for sh in shapes:
     row = []
