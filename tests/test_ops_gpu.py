@@ -62,8 +62,11 @@ def test_conv2d(ops, B, Cin, H, Cout, k, stride, up):
     (4096, 1280, 320, False, True),
     (8192, 320, 320, False, True),       # BN=160 tile path
     (8192, 320, 960, False, False),      # BN=160, fused qkv width
-    (512, 5120, 1280, False, True),      # split-K linear
-    (2048, 1280, 1280, False, True),     # 160 tiles of 128x128 on the deep ring (one workgroup per CU)
+    (512, 5120, 1280, False, True),      # split-K linear: 64 tiles of 64x160 x 4 K slices
+    (2048, 1280, 1280, False, True),     # 256 tiles of 64x160 on the deep ring (one workgroup per CU)
+    (2048, 5120, 1280, False, True),     # the same tile, 80 K steps, unsplit
+    (1984, 1280, 1280, False, False),    # M % 64 == 0 but not % 128: 248 tiles of 64x160
+    (2048, 1280, 1120, False, True),     # N = 7 x 160
     (2048, 1280, 3840, False, False),    # weights outweigh activations: W-major tile walk
     (2048, 1280, 10240, True, False),    # W-major + GEGLU ([8 values | 8 gates] row groups)
     (8192, 2560, 640, False, True),      # long-K 1x1 -> 256 tiles of 128x160
