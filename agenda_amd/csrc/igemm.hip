@@ -80,7 +80,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_kernel(const IgemmP p) 
   // wave-uniform buffer descriptors (kernel args + blockIdx only)
   const bf16_t* base0 = p.src0 + bz * p.sA0;
   const bf16_t* base1 = p.src1 ? p.src1 + bz * p.sA1 : p.src0;
-  const bf16_t* baseW = p.W + bz * p.sW;
+  const bf16_t* baseW = p.W + bz * p.sW + (p.w_per_image ? (long long)(m0 / (p.Hout * p.Wout)) * p.sW : 0);   // per-image matrices: GroupNorm folded into W
 #ifdef AGD_EXPERIMENTS   // timing experiments only (p.dbg): zero-record descriptors drop the loads but keep the instruction stream
   const unsigned nrecA = (p.dbg & 1) ? 0u : 0x7FFFFFF0u, nrecB = (p.dbg & 2) ? 0u : 0x7FFFFFF0u;
 #else
@@ -539,6 +539,11 @@ int launch_igemm(const IgemmP& p_in, hipStream_t st) {
   if ((p.rowstat_out || p.colstat_out) && (p.geglu || p.out_f32 || p.batch > 1)) { agd_set_error("igemm: row / column statistics only for plain bf16 launches"); return -1; }
   if (p.ln_stats && (!p.ln_cs || p.ln_slots < 1 || p.batch > 1)) { agd_set_error("igemm: LayerNorm fold needs colsum + slots"); return -1; }
   const int batch = p.batch > 0 ? p.batch : 1;
+  if (p.w_per_image) {           // image i's rows multiply with W + i * sW: plain 1x1 launches whose 128-row tiles stay inside one image, general kernel only
+    const int hw = p.Hout * p.Wout;
+    if (p.ksize != 1 || batch != 1 || p.geglu || hw % 128 || p.M % hw || p.sW < (long long)p.N * p.K) { agd_set_error("igemm: per-image weights need a plain 1x1 launch with Hout*Wout %% 128 == 0"); return -1; }
+    p.p8 = 0; p.warm = 0;
+  }
   {  // tile walk order: W-major when the weight matrix is the larger operand (bytes fetched once per XCD either way)
     const double a_bytes = 2.0 * p.M * (double)(p.C0 + p.C1);   // ~ the input pixels (each fetched once from the fabric per XCD)
     const double w_bytes = 2.0 * p.N * (double)p.K;

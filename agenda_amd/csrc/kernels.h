@@ -39,6 +39,8 @@ struct IgemmP {
   float* rowstat_out; int rowstat_slots;
   const float* ln_stats; int ln_slots; const float* ln_cs; float ln_invC, ln_eps;
   int* cfg_out;                     // host pointer: igemm_query() -- report {BM, BN, splits} instead of launching
+  int w_per_image;                  // 1x1 launches only: image i (= m / (Hout*Wout)) multiplies with W + i * sW (GroupNorm folded into the weights, model.hip transformer());
+                                    // M tiles must not straddle images
   int wmajor;                       // set by the launcher: 1 = consecutive tiles share the weight panel (W-major walk), else the A panel
   int warm;                         // caller: 1 = cold weights expected; the launcher keeps it only for W-major launches (in-kernel warm-up of the XCD's W slice)
   int halo;                         // caller: 1 = 3x3 stride-1 launches may take the row-halo kernel (igemm_halo.h)
@@ -85,6 +87,10 @@ struct GroupNormP {
   const float* part0; const float* part1; int bm0, bm1;
 };
 int launch_groupnorm(const GroupNormP& p, hipStream_t st);
+// GroupNorm (no activation) folded into the 1x1 projection that follows it: per image, Wb = W . diag(rstd_g gamma) (bf16) and
+// rowadd = bias + W beta - Wb mu (fp32), statistics from the producer's per-(tile, channel) partial sums [HW / bm tiles][C] float2
+int launch_gn_fold_weight(const float* part, int bm, int B, int HW, int C, int groups, float eps, const float* gamma, const float* beta,
+                          const bf16_t* W, const float* bias, int N, bf16_t* Wb, float* rowadd, hipStream_t st);
 long long groupnorm_ws_floats(int B, int C, int HW, int groups);   // workspace floats a launch_groupnorm call needs
 int launch_layernorm(const bf16_t* x, bf16_t* y, const float* g, const float* b, int rows, int C, float eps, hipStream_t st);
 

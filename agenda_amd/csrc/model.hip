@@ -106,6 +106,7 @@ struct agd_ctx {
   int opt_ln_fold = 1;                                // agd_set_option("ln_fold"): LayerNorm folded into the GEMMs around it
   int opt_gn_fused = 1;                               // agd_set_option("gn_fused_stats"): GroupNorm statistics from the producing igemm's epilogue
   int opt_warm = 3;                                   // agd_set_option("weight_warm"): in-kernel cold-weight warm-up: 1 = W-major launches (per-XCD slices), 3 = A-major launches too
+  int opt_gn_proj_fold = 1;                           // agd_set_option("gn_proj_fold"): the transformers' GroupNorm folded into per-image proj_in matrices (1: C <= 320, 2: C <= 640)
   int opt_p8 = 1;                                     // agd_set_option("igemm8p"): 256-row 8-wave / 8-phase igemm for launches with enough tiles (igemm8p.h)
   int opt_halo = 1;                                   // agd_set_option("conv_halo"): 3x3 stride-1 convs through the row-halo kernel (igemm_halo.h)
   int opt_touch = 3;                                  // agd_set_option("weight_touch"): n > 0 = stream 1x1 weight matrices of >= n MB through the caches right before their launch
@@ -165,6 +166,7 @@ struct GemmOpt {
   int halo = 0;                 // benches: allow the row-halo 3x3 kernel (the walk sets it through the ctx option)
   int want_rowstat = 0;         // igemm_query only: the launch will be a LayerNorm row-statistics producer (changes the kernel family)
   int p8 = 0;                   // benches: 1 = allow the 8-phase kernel, 2 / 3 = force its 256- / 160-wide tile (the walk sets it through the ctx option)
+  int w_per_image = 0;          // 1x1 launches: image i multiplies with w.w + i * N * K (GroupNorm folded into per-image matrices)
   int pad = -1;                 // -1: 1 for 3x3, 0 for 1x1
   int hout = 0, wout = 0;       // >0: override (asymmetric (0,1,0,1) padding of the VAE encoder's stride-2 convs)
 };
@@ -190,6 +192,7 @@ static int run_conv(agd_ctx* c, hipStream_t st, const bf16_t* s0, int C0, const 
   p.alpha = o.alpha; p.geglu = o.geglu; p.act = o.act; p.batch = 1; p.zero_page = zero_page; p.ws = c ? &c->splitk : nullptr;
   p.rowstat_out = o.rowstat_out; p.rowstat_slots = o.rowstat_slots;
   p.ln_stats = o.ln_stats; p.ln_slots = o.ln_slots; p.ln_cs = o.ln_cs; p.ln_invC = o.ln_invC; p.ln_eps = o.ln_eps;
+  if (o.w_per_image) { p.w_per_image = 1; p.sW = (long long)w.N * w.taps * w.Cpad; }
   p.halo = (c && c->opt_halo) || o.halo;
   p.p8 = o.p8 ? o.p8 : c ? c->opt_p8 : 0;          // before any igemm_query: the tile shape depends on it
   if (o.query_cfg) { if (o.want_rowstat && !p.rowstat_out) { p.rowstat_out = (float*)16; p.rowstat_slots = 0; } return igemm_query(p, o.query_cfg); }   // (nothing is launched)
@@ -386,7 +389,12 @@ static int transformer(agd_ctx* c, hipStream_t st, const std::string& pre, const
   const std::string t = pre + "transformer_blocks.0.";
   Act n = alloc_act(c, B, x.H, x.W, C); if (!n.p) return -1;
   GETV(gg, pre + "norm.weight"); GETV(gb, pre + "norm.bias");
-  CK(run_gn(c, st, x.p, C, nullptr, 0, Bs, HW, gg, gb, groups, 1e-6f, 0, n.p, &x));
+  // The transformer's GroupNorm has no activation behind it: where the producer of x left its per-tile channel sums, the norm is folded
+  // into per-image proj_in matrices (norm.hip gn_fold_weight_kernel) and proj_in reads the raw x -- no read + write of the activation by
+  // a GroupNorm kernel.  Default C <= 320 (the 64 x 64 maps: the fold launch takes 8.5 us against the 17 us apply pass; in situ 522.4 -> 521.3 ms
+  // per batch, tools/ab_option.py); at C = 640 the fold (16.8 us, 6.5 MB of matrices) costs more than the 10.8 us pass it replaces.
+  const bool gfold = c->opt_gn_proj_fold && c->opt_gn_fused && C <= (c->opt_gn_proj_fold >= 2 ? 640 : 320) && x.cpart && x.cpart_bm > 0 && HW % 128 == 0 && HW % x.cpart_bm == 0;
+  if (!gfold) CK(run_gn(c, st, x.p, C, nullptr, 0, Bs, HW, gg, gb, groups, 1e-6f, 0, n.p, &x));
   Act h = alloc_act(c, B, x.H, x.W, C); if (!h.p) return -1;
   Act ln = n;  // reuse (only the unfolded path normalises into it)
   bf16_t* qkv = (bf16_t*)c->arena.alloc((size_t)B * HW * 3 * C * 2); if (!qkv) return -1;
@@ -400,15 +408,17 @@ static int transformer(agd_ctx* c, hipStream_t st, const std::string& pre, const
   const float lneps = 1e-5f;
   float* stats = nullptr; int slots = 0;               // row statistics of the current h
   // h_out = A . W^T (+ bias, + residual): writes h and, when folding, its row statistics
-  auto produce = [&](const bf16_t* A, int K, const WMat& w, GemmOpt o, bf16_t* hout) -> int {
+  // (shaped: launched as [images][H][W] instead of one row of M pixels -- the per-image forms of the epilogue need the image of a row)
+  auto produce = [&](const bf16_t* A, int K, const WMat& w, GemmOpt o, bf16_t* hout, bool shaped = false) -> int {
+    const int gb_ = shaped ? M / HW : 1, gh_ = shaped ? x.H : 1, gw_ = shaped ? x.W : M;
     if (fold) {
       int cfg[3] = {0, 0, 0}; GemmOpt qo = o; qo.query_cfg = cfg; qo.want_rowstat = 1;
-      CK(run_conv(c, st, A, K, nullptr, 0, 1, 1, M, w, 1, hout, qo, c->zero_page));
+      CK(run_conv(c, st, A, K, nullptr, 0, gb_, gh_, gw_, w, 1, hout, qo, c->zero_page));
       slots = (w.N + cfg[1] - 1) / cfg[1];
       stats = (float*)c->arena.alloc((size_t)B * HW * slots * 2 * sizeof(float)); if (!stats) return -1;   // B*HW rows: room for the CFG duplicate
       o.rowstat_out = stats; o.rowstat_slots = slots;
     }
-    return run_conv(c, st, A, K, nullptr, 0, 1, 1, M, w, 1, hout, o, c->zero_page);
+    return run_conv(c, st, A, K, nullptr, 0, gb_, gh_, gw_, w, 1, hout, o, c->zero_page);
   };
   // out = LayerNorm(h) . W^T (+ bias) [GEGLU]: folded, or the LayerNorm kernel followed by the plain GEMM
   auto consume = [&](const std::string& lnkey, const std::string& wkey, const float* bias, int geglu, bf16_t* outp) -> int {
@@ -423,8 +433,22 @@ static int transformer(agd_ctx* c, hipStream_t st, const std::string& pre, const
     GETW(w, wkey); GemmOpt o; o.bias = bias; o.geglu = geglu;
     return run_conv(c, st, ln.p, C, nullptr, 0, 1, 1, M, *w, 1, outp, o, c->zero_page);
   };
-  { GETW(w, pre + "proj_in.weight"); GETV(b, pre + "proj_in.bias"); GemmOpt o; o.bias = b;
-    CK(produce(n.p, C, *w, o, h.p)); }
+  { GETW(w, pre + "proj_in.weight"); GETV(b, pre + "proj_in.bias");
+    if (gfold) {
+      if (w->taps != 1 || w->Cpad != C) FAIL("gn_proj_fold: proj_in weight [N=%d taps=%d Cpad=%d] is not a 1x1 over %d channels", w->N, w->taps, w->Cpad, C);
+      bf16_t* wb = (bf16_t*)c->arena.alloc((size_t)Bs * w->N * C * 2);
+      float* radd = (float*)c->arena.alloc((size_t)Bs * w->N * sizeof(float));
+      if (!wb || !radd) return -1;
+      { ProfScope ps(c, st, PC_GN, 0, 2.0 * Bs * (double)w->N * C * 2);
+        CK(launch_gn_fold_weight(x.cpart, x.cpart_bm, Bs, HW, C, groups, 1e-6f, gg, gb, w->w, b, w->N, wb, radd, st)); }
+      WMat wi = *w; wi.w = wb;
+      GemmOpt o; o.rowadd = radd; o.rowadd_ld = w->N; o.w_per_image = 1;
+      CK(produce(x.p, C, wi, o, h.p, true));
+    } else {
+      GemmOpt o; o.bias = b;
+      CK(produce(n.p, C, *w, o, h.p));
+    }
+  }
   // --- self attention ---
   { CK(consume(t + "norm1", t + "attn1.qkv", nullptr, 0, qkv));
     AttnP a{}; a.q = qkv; a.k = qkv + C; a.v = qkv + 2 * C; a.o = att;
@@ -1035,6 +1059,7 @@ AGD_API int agd_set_option(agd_ctx* c, const char* name, int value) {
   if (!strcmp(name, "weight_touch")) { c->opt_touch = value < 0 ? 0 : value; return 0; }
   if (!strcmp(name, "weight_warm")) { c->opt_warm = value; return 0; }
   if (!strcmp(name, "conv_halo")) { c->opt_halo = value != 0; return 0; }
+  if (!strcmp(name, "gn_proj_fold")) { c->opt_gn_proj_fold = value < 0 ? 0 : value; return 0; }   // 0 off, 1: blocks with C <= 320, 2: C <= 640 (A/B)
   if (!strcmp(name, "igemm8p")) { c->opt_p8 = value < 0 ? 0 : value; return 0; }   // 0 off, 1 on (the launcher decides per launch); tests: 2 / 3 / 4 force the 256-wide / 160-wide / any legal tile
   agd_set_error("set_option: unknown option '%s'", name);
   return fail_ctx(c);

@@ -337,3 +337,106 @@ int launch_layernorm(const bf16_t* x, bf16_t* y, const float* g, const float* b,
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }
+
+// ---------------------------------------------------------------------------------------
+// GroupNorm folded into the projection behind it (Transformer2DModel: norm -> proj_in, no activation in between).
+//   proj_in(GN(x))[n] = sum_c W[n][c] (gamma_c rstd_g (x_c - mu_g) + beta_c) + bias[n]
+//                     = sum_c Wb[n][c] x_c  +  (bias[n] + sum_c W[n][c] beta_c - sum_c Wb[n][c] mu_g(c)),   Wb = bf16(W gamma rstd)
+// per IMAGE (the statistics are per image and group): the GEMM then reads the RAW activation with image i's matrix and adds image i's
+// row -- the separate read + write of the activation by gn_apply_part disappears.  The mean term uses the ROUNDED Wb, so what is
+// rounded once to bf16 is W gamma rstd and nothing is amplified by |mu| / sigma.  grid (N / 32, B): a block first reduces the
+// image's 32 group statistics from the producer's partial sums (fp64, fixed order), then 8 waves x 4 rows each.
+// ---------------------------------------------------------------------------------------
+#define GNF_ROWS 16
+__global__ __launch_bounds__(512) void gn_fold_weight_kernel(const float* __restrict__ part, int bm, int HW, int C, int groups, float eps,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             const bf16_t* __restrict__ W, const float* __restrict__ bias, int N,
+                                                             bf16_t* __restrict__ Wb, float* __restrict__ rowadd) {
+  extern __shared__ float gsm[];                   // [groups] mean, [groups] rstd, [C] scale, [C] mean per channel, [C] beta
+  float* smean = gsm; float* srstd = gsm + groups; float* sa = gsm + 2 * groups; float* smu = sa + C; float* sbeta = smu + C;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.y, cpg = C / groups, nt = HW / bm;
+  // every launch of this kernel is a chain of dependent L2 round trips: all loads of a phase are issued before the first is used.
+  // The rows' weight vectors first (their latency runs under the statistics phase): wave w owns rows w and w + 8 of the block's 16
+  const int nvec = C >> 3;
+  constexpr int VPL = 2;                           // vectors per lane and row (C <= 1024)
+  s16x8 w8[2][VPL];
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    const int n = blockIdx.x * GNF_ROWS + wave + 8 * r;
+#pragma unroll
+    for (int k = 0; k < VPL; ++k) {
+      const int v = lane + 64 * k;
+      w8[r][k] = s16x8{0, 0, 0, 0, 0, 0, 0, 0};
+      if (n < N && v < nvec) w8[r][k] = *(const s16x8*)(W + (long long)n * C + v * 8);
+    }
+  }
+  // statistics: a 16-lane quarter of a wave per group (group = 8 * round + ... below), its cpg * nt partial sums in one batch of loads
+  const int qd = lane >> 4, ql = lane & 15;
+  const float inv_cpg = 1.0f / (float)cpg;
+  for (int g0 = 0; g0 < groups; g0 += 32) {
+    const int g = g0 + wave * 4 + qd;
+    const int n = cpg * nt;
+    double a = 0.0, q = 0.0;
+    for (int i0 = ql; i0 < n; i0 += 16 * 24) {
+      f32x2 v[24];
+#pragma unroll
+      for (int u = 0; u < 24; ++u) {
+        const int idx = i0 + 16 * u;
+        v[u] = f32x2{0.f, 0.f};
+        if (g < groups && idx < n) { const int tile = fast_udiv(idx, cpg, inv_cpg), ch = g * cpg + (idx - tile * cpg); v[u] = *(const f32x2*)(part + (((long long)b * nt + tile) * C + ch) * 2); }
+      }
+#pragma unroll
+      for (int u = 0; u < 24; ++u) { a += (double)v[u][0]; q += (double)v[u][1]; }
+    }
+    for (int o = 8; o >= 1; o >>= 1) { a += __shfl_xor(a, o); q += __shfl_xor(q, o); }
+    if (ql == 0 && g < groups) {
+      const double cnt = (double)HW * cpg;
+      const double mean = a / cnt;
+      double var = q / cnt - mean * mean;
+      if (var < 0) var = 0;
+      smean[g] = (float)mean; srstd[g] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+  }
+  __syncthreads();
+  for (int c = tid; c < C; c += 512) { const int g = fast_udiv(c, cpg, inv_cpg); sa[c] = srstd[g] * gamma[c]; smu[c] = smean[g]; sbeta[c] = beta[c]; }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    const int n = blockIdx.x * GNF_ROWS + wave + 8 * r;
+    if (n >= N) break;                               // wave-uniform
+    bf16_t* wo = Wb + ((long long)b * N + n) * C;
+    float accb = 0.f, accm = 0.f;
+#pragma unroll
+    for (int k = 0; k < VPL; ++k) {
+      const int v = lane + 64 * k;
+      if (v < nvec) {
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int c = v * 8 + e;
+          const float w = bf2f((bf16_t)w8[r][k][e]);
+          const float wb = bf2f(f2bf(w * sa[c]));
+          o[e] = wb;
+          accb += w * sbeta[c];
+          accm += wb * smu[c];
+        }
+        u32x4 pk;
+        pk[0] = pack_bf2(o[0], o[1]); pk[1] = pack_bf2(o[2], o[3]); pk[2] = pack_bf2(o[4], o[5]); pk[3] = pack_bf2(o[6], o[7]);
+        *(u32x4*)(wo + v * 8) = pk;
+      }
+    }
+    for (int o = 32; o >= 1; o >>= 1) { accb += __shfl_xor(accb, o); accm += __shfl_xor(accm, o); }
+    if (lane == 0) rowadd[(long long)b * N + n] = (bias ? bias[n] : 0.f) + accb - accm;
+  }
+}
+
+int launch_gn_fold_weight(const float* part, int bm, int B, int HW, int C, int groups, float eps, const float* gamma, const float* beta,
+                          const bf16_t* W, const float* bias, int N, bf16_t* Wb, float* rowadd, hipStream_t st) {
+  if (!part || bm < 1 || HW % bm || C % groups || (C & 7) || B < 1 || N < 1) { agd_set_error("gn_fold_weight: bad shape (HW %d bm %d C %d groups %d)", HW, bm, C, groups); return -1; }
+  const size_t lds = (size_t)(2 * groups + 3 * C) * sizeof(float);
+  if (C > 1024 || lds > 48 * 1024) { agd_set_error("gn_fold_weight: C = %d too wide", C); return -1; }
+  hipLaunchKernelGGL(gn_fold_weight_kernel, dim3((N + GNF_ROWS - 1) / GNF_ROWS, B), dim3(512), lds, st, part, bm, HW, C, groups, eps, gamma, beta, W, bias, N, Wb, rowadd);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}

@@ -105,6 +105,8 @@ int agd_vae_encode(agd_ctx* ctx, const float* image, int batch, int side, float*
 /* ---- per-ctx options (no environment variables steer the library).  "cfg_shared_prefix" (default 1): agd_denoise runs the
  * layers ahead of the first cross-attention once for the identical unconditional / conditional halves (bit-identical to 0).
  * "ln_fold", "gn_fused_stats" (default 1): LayerNorm / GroupNorm statistics produced by the GEMM that writes the activation.
+ * "gn_proj_fold" (default 1; 0 off, 2: also C = 640): the GroupNorm in front of a transformer's proj_in (no activation in between) is
+ * folded into per-image proj_in matrices where C <= 320 and the producer left its statistics; proj_in then reads the un-normalised activation.
  * "weight_touch" (default 3; 0 off): 1x1 weight matrices of at least that many MB are streamed through the caches by a read-only
  * kernel right in front of the launch that uses them (the UNet's 1.7 GB of weights never stay in the 256 MB Infinity Cache).
  * "conv_halo" (default 1): 3x3 stride-1 convolutions run the row-halo kernel (one LDS image of the tile's pixel rows serves the three

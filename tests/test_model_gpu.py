@@ -538,6 +538,37 @@ def test_layernorm_fold_matches_the_separate_layernorm_kernels(cfgname):
     pipe.engine.close()
 
 
+@pytest.mark.parametrize("cfgname", ["tiny", "tiny40"])
+def test_groupnorm_fold_into_proj_in_matches_the_groupnorm_kernel(cfgname):
+    """opt "gn_proj_fold" (default on): the transformer's GroupNorm (no activation behind it) folded into per-image proj_in matrices
+    (norm.hip gn_fold_weight_kernel: Wb = W diag(rstd gamma), the mean and beta terms in a per-image row added in the epilogue)
+    vs the GroupNorm kernel + the plain proj_in, and both vs the oracle.  What is rounded to bf16 differs (W gamma rstd instead of the
+    normalised activation), so the two agree to bf16 noise, not bitwise; both are deterministic.  perturb_norm: gamma / beta are not
+    1 / 0, bias_std: every bias term of the identity is exercised."""
+    from agenda_amd import StableDiffusionPipeline, config, synthetic
+    from oracle import sd_oracle as O
+    cfg = config.CONFIGS[cfgname]()
+    u = synthetic.make_unet_weights(cfg, 31, bias_std=0.05, perturb_norm=0.1)
+    v = synthetic.make_vae_weights(cfg, 32)
+    pipe = StableDiffusionPipeline(cfg, u, v, workspace_bytes=1 << 30)
+    ctx = synthetic.make_context(cfg, 2, seed=3)
+    x = synthetic.make_latents(cfg, [0, 1, 2, 3], 32).to(torch.bfloat16).float() + 0.3      # 32x32 and 16x16 maps fold (HW % 128 == 0); a mean to subtract
+    with torch.no_grad():
+        want = O.unet_forward(u, cfg.unet, x, torch.tensor(501), ctx)
+    pipe.engine.set_context(ctx)
+    a = pipe.engine.unet_forward(x, 501.0).clone()
+    a2 = pipe.engine.unet_forward(x, 501.0).clone()
+    pipe.engine.set_option("gn_proj_fold", 0)
+    b = pipe.engine.unet_forward(x, 501.0).clone()
+    pipe.engine.set_option("gn_proj_fold", 1)
+    assert torch.equal(a, a2)
+    assert not torch.equal(a, b)                               # the option really switches the path
+    e_a, e_b, e_ab = _rms_rel(a, want), _rms_rel(b, want), _rms_rel(a, b.cpu())
+    print(f"gn_proj_fold {cfgname}: folded vs oracle {e_a:.5f}, unfolded vs oracle {e_b:.5f}, folded vs unfolded {e_ab:.5f}")
+    assert e_a < 2.0 ** -6 and e_b < 2.0 ** -6 and e_ab < 2.0 ** -5
+    pipe.engine.close()
+
+
 def test_groupnorm_statistics_from_producer_epilogues(tiny_pipe):
     """opt "gn_fused_stats" (default on): the igemm launch that writes an activation also leaves per-(M tile, channel) partial
     sums, and the GroupNorm that reads it skips its statistics pass (one kernel instead of two).  The statistics are sums of
