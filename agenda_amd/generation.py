@@ -81,7 +81,9 @@ def generate_batch(pipe, seeds: Sequence[int], words: Sequence[str], prompt: Opt
         for i in range(B):
             g = trc.compute_global_heat_map(prompt=prompt, image_index=i)
             if word_rows is not None:
-                hms.append(torch.stack([g.heat_maps[list(r)].mean(0) for r in word_rows]))
+                # integer (view) indexing: a python list index makes torch upload an index tensor with a BLOCKING pageable copy, i.e. a host
+                # sync at the end of every batch
+                hms.append(torch.stack([torch.stack([g.heat_maps[int(i)] for i in r]).mean(0) for r in word_rows]))
             elif words:
                 hms.append(torch.stack([g.compute_word_heat_map(w).heatmap for w in words]))
             else:

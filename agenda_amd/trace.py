@@ -44,7 +44,8 @@ class GlobalHeatMap:
         merge_idxs, _ = compute_token_merge_indices(self.tokenizer, self.prompt, word, word_idx, offset_idx)
         if max(merge_idxs) >= self.heat_maps.shape[0]:
             raise ValueError(f"token index {max(merge_idxs)} beyond the {self.heat_maps.shape[0]} recorded rows")
-        return WordHeatMap(self.heat_maps[merge_idxs].mean(0), word)
+        # (integer indexing: views, no index tensor uploaded through a blocking copy)
+        return WordHeatMap(torch.stack([self.heat_maps[int(i)] for i in merge_idxs]).mean(0), word)
 
 
 class trace:
