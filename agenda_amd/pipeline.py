@@ -124,13 +124,14 @@ class Engine:
         if t.device.type != "cpu":
             return t.to(device=f"cuda:{self.device}").contiguous()
         pool = self.__dict__.setdefault("_stage", {})
-        slot = pool.setdefault(tuple(t.shape), {"bufs": [], "evs": [], "next": 0})
-        if len(slot["bufs"]) < 2:
-            slot["bufs"].append(torch.empty(t.shape, dtype=torch.float32).pin_memory()); slot["evs"].append(torch.cuda.Event())
-            k = len(slot["bufs"]) - 1
-        else:
-            k = slot["next"]; slot["next"] = (k + 1) % 2
-            slot["evs"][k].synchronize()
+        slot = pool.get(tuple(t.shape))
+        if slot is None:                                   # both buffers at the first use of a shape (a warm-up batch): pinning stalls for tens of ms
+            slot = pool[tuple(t.shape)] = {"bufs": [torch.empty(t.shape, dtype=torch.float32).pin_memory() for _ in range(2)],
+                                           "evs": [torch.cuda.Event() for _ in range(2)], "next": 0}
+            for e in slot["evs"]:
+                e.record()
+        k = slot["next"]; slot["next"] = (k + 1) % 2
+        slot["evs"][k].synchronize()
         slot["bufs"][k].copy_(t)
         out = slot["bufs"][k].to(device=f"cuda:{self.device}", non_blocking=True)
         slot["evs"][k].record()
