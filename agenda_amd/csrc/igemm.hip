@@ -361,6 +361,96 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const IgemmP p, int 
   }
 }
 
+// split-K second pass fused with the GroupNorm(+SiLU) that reads the result (IgemmP::gn_y): one workgroup per (image, group) owns the
+// [HW][C / groups] block of the output -- sums its slab rows in slice order (deterministic), applies the conv epilogue, rounds to bf16,
+// takes the group's mean / variance from the ROUNDED values it holds in registers (what the separate statistics kernel would read back)
+// and writes silu?((x - mean) rstd gamma + beta).  Replaces three launches (slab sum, gn_stats, gn_apply) that each re-read the last
+// one's output; MAXQ = float4 quads per thread.
+template <int MAXQ>
+__global__ __launch_bounds__(256) void splitk_reduce_gn_kernel(const IgemmP p, int S) {
+  __shared__ float red[2][4];
+  const int HWo = p.Hout * p.Wout, cpg = p.N / p.gn_groups, nq = cpg >> 2;
+  const int grp = blockIdx.x, img = blockIdx.y, tid = threadIdx.x;
+  const int total = HWo * nq;
+  const int n0 = grp * cpg;
+  const long long slab = (long long)p.M * p.N;
+  // every load of a pass is issued before the first use (indices of the tail quads are clamped, only their stores are predicated):
+  // a branch around each load would make the compiler wait for every one of them in turn
+  long long off[MAXQ]; int nn[MAXQ]; bool ok[MAXQ];
+#pragma unroll
+  for (int k = 0; k < MAXQ; ++k) {
+    const int qi0 = tid + k * 256;
+    ok[k] = qi0 < total;
+    const int qi = ok[k] ? qi0 : total - 1;
+    const int px = qi / nq;
+    nn[k] = n0 + 4 * (qi - px * nq);
+    off[k] = ((long long)img * HWo + px) * p.N + nn[k];
+  }
+  f32x4 a[MAXQ];
+#pragma unroll
+  for (int k = 0; k < MAXQ; ++k) a[k] = *(const f32x4*)(p.splitk_ws + off[k]);
+  for (int s = 1; s < S; ++s) {
+    f32x4 t[MAXQ];
+#pragma unroll
+    for (int k = 0; k < MAXQ; ++k) t[k] = *(const f32x4*)(p.splitk_ws + s * slab + off[k]);
+#pragma unroll
+    for (int k = 0; k < MAXQ; ++k) a[k] += t[k];
+  }
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int k = 0; k < MAXQ; ++k) {
+    const int n = nn[k];
+    const long long m = (off[k] - n) / p.N;
+    if (p.bias_mode == 1) a[k] += *(const f32x4*)(p.bias + n); else if (p.bias_mode == 2) a[k] += p.bias[m];
+    if (p.rowadd) a[k] += *(const f32x4*)(p.rowadd + (long long)img * p.rowadd_ld + n);
+    if (p.residual) {
+      const u32x2 r = *(const u32x2*)(p.residual + m * p.ldr + n);
+      a[k] += f32x4{__uint_as_float(r[0] << 16), __uint_as_float(r[0] & 0xFFFF0000u), __uint_as_float(r[1] << 16), __uint_as_float(r[1] & 0xFFFF0000u)};
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float x = a[k][e];
+      if (p.act == 1) x = silu_f(x);
+      x = bf2f(f2bf(x));                                  // the stored activation: statistics and normalisation see the rounded value
+      a[k][e] = x;
+      if (ok[k]) { s1 += x; s2 += x * x; }
+    }
+    if (p.gn_keep_out && ok[k]) {
+      u32x2 pk; pk[0] = pack_bf2(a[k][0], a[k][1]); pk[1] = pack_bf2(a[k][2], a[k][3]);
+      *(u32x2*)((bf16_t*)p.out + m * p.ldo + n) = pk;
+    }
+  }
+  for (int o = 32; o >= 1; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+  if ((tid & 63) == 0) { red[0][tid >> 6] = s1; red[1][tid >> 6] = s2; }
+  __syncthreads();
+  const double cnt = (double)HWo * cpg;
+  const double S1 = (double)red[0][0] + (double)red[0][1] + (double)red[0][2] + (double)red[0][3];
+  const double S2 = (double)red[1][0] + (double)red[1][1] + (double)red[1][2] + (double)red[1][3];
+  const double mean = S1 / cnt;
+  double var = S2 / cnt - mean * mean; if (var < 0) var = 0;
+  const float mu = (float)mean, rstd = (float)(1.0 / sqrt(var + (double)p.gn_eps));
+#pragma unroll
+  for (int k = 0; k < MAXQ; ++k) {
+    const int n = nn[k];
+    const f32x4 ga = *(const f32x4*)(p.gn_gamma + n), be = *(const f32x4*)(p.gn_beta + n);
+    float o[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float sc = rstd * ga[e];                      // same affine form as gn_apply: x * scale + shift
+      const float r = fmaf(a[k][e], sc, be[e] - mu * sc);
+      o[e] = p.gn_silu ? silu_f(r) : r;
+    }
+    if (ok[k]) { u32x2 pk; pk[0] = pack_bf2(o[0], o[1]); pk[1] = pack_bf2(o[2], o[3]); *(u32x2*)(p.gn_y + off[k]) = pk; }
+  }
+}
+// the shapes the fused slab-sum + GroupNorm pass takes (else the caller's separate GroupNorm launches run)
+static bool reduce_gn_ok(const IgemmP& p) {
+  if (!p.gn_y || !p.gn_gamma || !p.gn_beta || p.gn_groups < 1 || p.out_f32 || p.geglu || p.batch > 1) return false;
+  const int HWo = p.Hout * p.Wout;
+  if (p.N % p.gn_groups || (p.N / p.gn_groups) % 4 || p.M % HWo || p.ldo != p.N || (p.residual && p.ldr % 4)) return false;
+  return (long long)HWo * (p.N / p.gn_groups / 4) <= 256 * 10 && p.act <= 1;
+}
+
 template <int BM, int BN, int WM, int WN, int KS, int STAGES, int GEGLU, int SPLITK>
 static int launch_one(const IgemmP& p, int splits, hipStream_t st) {
   constexpr int NT = WM * WN * 64;
@@ -418,6 +508,16 @@ static int launch_cfg(const IgemmP& p, int splits, hipStream_t st) {
     if constexpr (HALO_TILE) { rc = halo_ok(p) ? launch_halo<BN, 1, STAGES == 4 ? 4 : 2>(p, splits, st) : (p.ksize == 3) ? launch_one<BM, BN, WM, WN, 3, STAGES, 0, 1>(p, splits, st) : launch_one<BM, BN, WM, WN, 1, STAGES, 0, 1>(p, splits, st); }
     else rc = (p.ksize == 3) ? launch_one<BM, BN, WM, WN, 3, STAGES, 0, 1>(p, splits, st) : launch_one<BM, BN, WM, WN, 1, STAGES, 0, 1>(p, splits, st);
     if (rc) return rc;
+    if (reduce_gn_ok(p)) {
+      const long long quads = (long long)p.Hout * p.Wout * (p.N / p.gn_groups / 4);
+      const dim3 g(p.gn_groups, p.M / (p.Hout * p.Wout));
+      if (quads <= 256 * 3) hipLaunchKernelGGL(splitk_reduce_gn_kernel<3>, g, dim3(256), 0, st, p, splits);
+      else if (quads <= 256 * 5) hipLaunchKernelGGL(splitk_reduce_gn_kernel<5>, g, dim3(256), 0, st, p, splits);
+      else hipLaunchKernelGGL(splitk_reduce_gn_kernel<10>, g, dim3(256), 0, st, p, splits);
+      HIP_CHECK_RET(hipGetLastError());
+      if (p.gn_fused) *p.gn_fused = 1;
+      return 0;
+    }
     const long long total = (long long)p.M * (p.N >> 2);
     const int grid = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid), dim3(256), 0, st, p, splits);
@@ -566,6 +666,9 @@ int launch_igemm(const IgemmP& p_in, hipStream_t st) {
   }
   const long long t128 = (long long)((p.M + 127) / 128) * ((p.N + 127) / 128) * batch;
   const int nk = p.K >> 6;
+  // LayerNorm-fold producers / consumers and GroupNorm-statistics producers finish in the tile's own epilogue: they never take a split-K
+  // configuration (a transformer wider than SD's -- K >= 4096 at M <= 512 -- falls through to an unsplit tile instead of failing the forward)
+  const bool nosplit = p.rowstat_out || p.ln_stats || p.colstat_out;
 #ifdef AGD_EXPERIMENTS
   {  // exploration only: AGD_IGEMM_FORCE="<bn>:<splits>:<stages>" forces one configuration for every non-GEGLU launch
     static int f_bn = -1, f_s = 1, f_st = 2;
@@ -593,7 +696,7 @@ int launch_igemm(const IgemmP& p_in, hipStream_t st) {
   if (!KNOB(14) && batch == 1 && p.ksize == 1 && (p.N % 160) == 0 && (p.M % 64) == 0 && nk >= 16) {
     const long long t64 = (long long)(p.M / 64) * (p.N / 160);
     if (t64 >= 192 && t64 <= 256) return launch_cfg<64, 160, 2, 2, 4>(p, 1, st);
-    if (t64 <= 64 && nk >= 64) {
+    if (t64 <= 64 && nk >= 64 && !nosplit) {
       int S = (int)(256 / t64); if (S > nk / 16) S = nk / 16;
       if (S >= 2) { CK0(ensure_splitk(p, S)); return launch_cfg<64, 160, 2, 2, 4>(p, S, st); }
     }
@@ -603,7 +706,7 @@ int launch_igemm(const IgemmP& p_in, hipStream_t st) {
   // two more stages in flight hide more of it than a second co-resident workgroup on a 2-stage ring does
   // (8x8 1280->1280: 35 -> 30 us).  16x16 maps (M = 2048, N = 1280) get 128 tiles of 128x160 x 2 K slices = 256.
   if (!KNOB(6) && batch == 1 && t128 <= 160 && nk >= 64 && p.M >= 128 && (p.N & 3) == 0) {
-    auto splits = [&](long long tt) { int S = (int)(256 / tt); if (S > 8) S = 8; if (S > nk / 8) S = nk / 8; return S < 1 ? 1 : S; };
+    auto splits = [&](long long tt) { if (nosplit) return 1; int S = (int)(256 / tt); if (S > 8) S = 8; if (S > nk / 8) S = nk / 8; return S < 1 ? 1 : S; };
     const long long mt = (p.M + 127) / 128;
     const int S8 = splits(t128);
     long long T8 = t128 * S8, T0 = 0; int S0 = 1;
@@ -617,7 +720,7 @@ int launch_igemm(const IgemmP& p_in, hipStream_t st) {
     }
   }
   // split-K for small-M problems (8x8 / 16x16 feature maps): fill the 256 CUs with K slices
-  if (batch == 1 && t128 <= 160 && nk >= 64 && (p.N & 3) == 0 && p.M >= 128) {
+  if (batch == 1 && t128 <= 160 && nk >= 64 && (p.N & 3) == 0 && p.M >= 128 && !nosplit) {
     int S = (int)((384 + t128 - 1) / t128);
     if (S > 8) S = 8;
     if (S > nk / 8) S = nk / 8;

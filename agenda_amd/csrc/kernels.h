@@ -45,6 +45,11 @@ struct IgemmP {
   int warm;                         // caller: 1 = cold weights expected; the launcher keeps it only for W-major launches (in-kernel warm-up of the XCD's W slice)
   int halo;                         // caller: 1 = 3x3 stride-1 launches may take the row-halo kernel (igemm_halo.h)
   int p8;                           // caller: 1 = launches with enough 256-row tiles take the 8-wave / 8-phase kernel (igemm8p.h); 2 / 3 force its 256- / 160-wide tile, 4 = any legal tile (benches, tests)
+  // split-K launches whose output a GroupNorm(+SiLU) reads next (resnet conv1 -> norm2): the slab-sum pass normalises as well -- one
+  // workgroup per (image, group) sums the slabs, applies the epilogue, takes the group's statistics from the bf16-rounded values it
+  // holds in registers and writes gn_y = silu?(gn(out)); `out` itself is written only with gn_keep_out.  The launcher sets *gn_fused
+  // (host) to 1 when it took this form; otherwise the caller runs the GroupNorm kernels as before.
+  const float* gn_gamma; const float* gn_beta; bf16_t* gn_y; int gn_groups; float gn_eps; int gn_silu; int gn_keep_out; int* gn_fused;
   int stagger;                      // timing experiments only: start delay of the CU's second workgroup, x1024 cycles
   int dbg;                          // timing experiments only (builds with -DAGD_EXPERIMENTS)
 };
@@ -72,6 +77,35 @@ struct AttnP {
   const float* mask;                // additive fp32 [B][Nk] (broadcast over heads and queries) or NULL
 };
 int launch_attention(const AttnP& p, hipStream_t st);
+
+// ---------------------------------------------------------------------------------------
+// Fused row-panel kernels of the transformer blocks at C = 320 (tblock.hip)
+// ---------------------------------------------------------------------------------------
+// norm3 -> GEGLU projection -> ff.net.2 + residual in one launch; the LayerNorm is folded (W1 = W diag(gamma), cs1 = its column sums,
+// b1 = bias + W beta: values then gates, un-permuted hidden index), its row statistics are taken from the rows themselves
+struct FFusedP {
+  const bf16_t* h; bf16_t* out;     // [M][C] residual stream in / out (may alias: a workgroup reads its 128 rows before it writes them)
+  const bf16_t* w1f;                // GEGLU projection in fragment order (launch_frag_order_w1)
+  const float* cs1; const float* b1;
+  const bf16_t* w2f;                // ff.net.2 [C][4C] in fragment order (launch_frag_order_w, NI = C / 64, KC = 128)
+  const float* b2;                  // [C]
+  int M; float ln_eps;
+};
+int launch_ff_fused(const FFusedP& p, int C, hipStream_t st);
+// norm2 -> to_q -> cross-attention (77 keys, recorder optional) -> to_out + bias + residual in one launch; 8 heads of 40
+struct AttnChainP {
+  const bf16_t* h; bf16_t* out;     // [M][C] residual stream in / out (may alias)
+  const float* gamma; const float* beta; float ln_eps;     // norm2
+  const bf16_t* wqf;                // attn2.to_q [C][C] in fragment order (launch_frag_order_w, NI = C / 64, KC = C)
+  const bf16_t* wof; const float* bo;                      // attn2.to_out.0
+  const bf16_t* kv; int ldkv; long long skv;               // projected context [B][T][ldkv]: K at column 0, V at column C
+  int M, HW, T; float scale;
+  int record; float* rec; long long rec_img_stride, rec_head_stride; int rec_T, rec_b0, rec_hpb;   // as AttnP record_mode 3 (rec_hpb in {1, 2, 4, 8})
+  float* rowstat_out;               // optional: [M] float2 (sum, sum of squares) of the bf16 outputs (LayerNorm-fold producer, one slot)
+};
+int launch_attn_chain(const AttnChainP& p, int C, int heads, hipStream_t st);
+int launch_frag_order_w1(const bf16_t* src, bf16_t* dst, int C, int HID, hipStream_t st);
+int launch_frag_order_w(const bf16_t* src, bf16_t* dst, int N, int K, int NI, int KC, hipStream_t st);
 
 // ---------------------------------------------------------------------------------------
 // Norms

@@ -109,6 +109,8 @@ struct agd_ctx {
   int opt_gn_proj_fold = 1;                           // agd_set_option("gn_proj_fold"): the transformers' GroupNorm folded into per-image proj_in matrices (1: C <= 320, 2: C <= 640)
   int opt_p8 = 1;                                     // agd_set_option("igemm8p"): 256-row 8-wave / 8-phase igemm for launches with enough tiles (igemm8p.h)
   int opt_halo = 1;                                   // agd_set_option("conv_halo"): 3x3 stride-1 convs through the row-halo kernel (igemm_halo.h)
+  int opt_tb_fuse = 3;                                // agd_set_option("tblock_fuse"): fused row-panel kernels of the C = 320 transformer blocks (tblock.hip): bit 0 = feed-forward, bit 1 = attn2 chain
+  int opt_reduce_gn = 1;                              // agd_set_option("reduce_gn"): split-K slab sum + the GroupNorm that reads it as one launch (igemm.hip splitk_reduce_gn_kernel)
   int opt_touch = 3;                                  // agd_set_option("weight_touch"): n > 0 = stream 1x1 weight matrices of >= n MB through the caches right before their launch
   unsigned* touch_sink = nullptr;
   // profiling
@@ -167,6 +169,8 @@ struct GemmOpt {
   int want_rowstat = 0;         // igemm_query only: the launch will be a LayerNorm row-statistics producer (changes the kernel family)
   int p8 = 0;                   // benches: 1 = allow the 8-phase kernel, 2 / 3 = force its 256- / 160-wide tile (the walk sets it through the ctx option)
   int w_per_image = 0;          // 1x1 launches: image i multiplies with w.w + i * N * K (GroupNorm folded into per-image matrices)
+  // the GroupNorm(+SiLU) that reads this launch's output next, for split-K launches (IgemmP::gn_y): *gn_fused = 1 when the slab-sum pass did it
+  const float* gn_gamma = nullptr; const float* gn_beta = nullptr; bf16_t* gn_y = nullptr; int gn_groups = 0; float gn_eps = 0.f; int gn_silu = 0, gn_keep_out = 0; int* gn_fused = nullptr;
   int pad = -1;                 // -1: 1 for 3x3, 0 for 1x1
   int hout = 0, wout = 0;       // >0: override (asymmetric (0,1,0,1) padding of the VAE encoder's stride-2 convs)
 };
@@ -193,6 +197,8 @@ static int run_conv(agd_ctx* c, hipStream_t st, const bf16_t* s0, int C0, const 
   p.rowstat_out = o.rowstat_out; p.rowstat_slots = o.rowstat_slots;
   p.ln_stats = o.ln_stats; p.ln_slots = o.ln_slots; p.ln_cs = o.ln_cs; p.ln_invC = o.ln_invC; p.ln_eps = o.ln_eps;
   if (o.w_per_image) { p.w_per_image = 1; p.sW = (long long)w.N * w.taps * w.Cpad; }
+  if (o.gn_y && c && c->opt_reduce_gn) { p.gn_gamma = o.gn_gamma; p.gn_beta = o.gn_beta; p.gn_y = o.gn_y; p.gn_groups = o.gn_groups; p.gn_eps = o.gn_eps; p.gn_silu = o.gn_silu;
+                                         p.gn_keep_out = o.gn_keep_out; p.gn_fused = o.gn_fused; }
   p.halo = (c && c->opt_halo) || o.halo;
   p.p8 = o.p8 ? o.p8 : c ? c->opt_p8 : 0;          // before any igemm_query: the tile shape depends on it
   if (o.query_cfg) { if (o.want_rowstat && !p.rowstat_out) { p.rowstat_out = (float*)16; p.rowstat_slots = 0; } return igemm_query(p, o.query_cfg); }   // (nothing is launched)
@@ -277,10 +283,13 @@ static int resnet(agd_ctx* c, hipStream_t st, const std::string& pre, const Act&
     if (it == c->tproj_off.end()) FAIL("no time_emb_proj for %s", pre.c_str());
     o1.rowadd = c->tproj_cur + it->second; o1.rowadd_ld = c->tproj_cur_ld;
   }
-  CK(run_conv(c, st, n1.p, Cin, nullptr, 0, B, H, Wd, *w1, 3, h.p, o1, c->zero_page));
   Act n2 = alloc_act(c, B, H, Wd, Cout); if (!n2.p) return -1;
   GETV(g2, pre + "norm2.weight"); GETV(b2, pre + "norm2.bias");
-  CK(run_gn(c, st, h.p, Cout, nullptr, 0, B, HW, g2, b2, groups, eps, 1, n2.p, &h));
+  // conv1's output is read by norm2 and by nothing else: a split-K launch's slab-sum pass normalises straight into n2 (h is not written)
+  int gn_done = 0;
+  o1.gn_gamma = g2; o1.gn_beta = b2; o1.gn_y = n2.p; o1.gn_groups = groups; o1.gn_eps = eps; o1.gn_silu = 1; o1.gn_keep_out = 0; o1.gn_fused = &gn_done;
+  CK(run_conv(c, st, n1.p, Cin, nullptr, 0, B, H, Wd, *w1, 3, h.p, o1, c->zero_page));
+  if (!gn_done) CK(run_gn(c, st, h.p, Cout, nullptr, 0, B, HW, g2, b2, groups, eps, 1, n2.p, &h));
   const bf16_t* res = x0.p;
   if (c->W.count(pre + "conv_shortcut.weight")) {
     GETW(ws, pre + "conv_shortcut.weight"); GETV(bs, pre + "conv_shortcut.bias");
@@ -409,9 +418,10 @@ static int transformer(agd_ctx* c, hipStream_t st, const std::string& pre, const
   float* stats = nullptr; int slots = 0;               // row statistics of the current h
   // h_out = A . W^T (+ bias, + residual): writes h and, when folding, its row statistics
   // (shaped: launched as [images][H][W] instead of one row of M pixels -- the per-image forms of the epilogue need the image of a row)
-  auto produce = [&](const bf16_t* A, int K, const WMat& w, GemmOpt o, bf16_t* hout, bool shaped = false) -> int {
+  auto produce = [&](const bf16_t* A, int K, const WMat& w, GemmOpt o, bf16_t* hout, bool shaped = false, bool want_stats = true) -> int {
     const int gb_ = shaped ? M / HW : 1, gh_ = shaped ? x.H : 1, gw_ = shaped ? x.W : M;
-    if (fold) {
+    stats = nullptr; slots = 0;
+    if (fold && want_stats) {
       int cfg[3] = {0, 0, 0}; GemmOpt qo = o; qo.query_cfg = cfg; qo.want_rowstat = 1;
       CK(run_conv(c, st, A, K, nullptr, 0, gb_, gh_, gw_, w, 1, hout, qo, c->zero_page));
       slots = (w.N + cfg[1] - 1) / cfg[1];
@@ -449,6 +459,10 @@ static int transformer(agd_ctx* c, hipStream_t st, const std::string& pre, const
       CK(produce(n.p, C, *w, o, h.p));
     }
   }
+  // fused row-panel kernels of this block (tblock.hip), where their shape is built: C = 320, 8 heads, <= 96 keys, whole 128-row tiles per
+  // image; the hook.py recorder (per-head maps of every call) keeps the kernel chain
+  const bool ff_fused = (c->opt_tb_fuse & 1) && fold && C == 320 && c->W.count(t + "ff.w1.frag");
+  const bool chain_fuse = (c->opt_tb_fuse & 2) && C == 320 && heads == 8 && HW % 128 == 0 && c->ctx_T <= 96 && c->rec_mode != 2 && c->W.count(t + "attn2.to_q.frag");
   // --- self attention ---
   { CK(consume(t + "norm1", t + "attn1.qkv", nullptr, 0, qkv));
     AttnP a{}; a.q = qkv; a.k = qkv + C; a.v = qkv + 2 * C; a.o = att;
@@ -457,10 +471,10 @@ static int transformer(agd_ctx* c, hipStream_t st, const std::string& pre, const
     CK(run_attention(c, st, PC_ATTN_SELF, a));
     GETW(wo, t + "attn1.to_out.0.weight"); GETV(bo, t + "attn1.to_out.0.bias");
     GemmOpt oo; oo.bias = bo; oo.residual = h.p;
-    CK(produce(att, C, *wo, oo, h.p)); }
+    CK(produce(att, C, *wo, oo, h.p, false, !chain_fuse)); }      // (the fused attn2 chain takes norm2's statistics from the rows themselves)
   if (dup) {                                           // the halves diverge from here on (text context)
     CK(dup_half(c, st, h.p, (long long)M * C));
-    if (fold) { ProfScope ps(c, st, PC_ELEM, 0);
+    if (fold && stats) { ProfScope ps(c, st, PC_ELEM, 0);
       if (hipMemcpyAsync(stats + (size_t)M * slots * 2, stats, (size_t)M * slots * 2 * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) FAIL("dup stats copy failed"); }
     Act x2 = alloc_act(c, B, x.H, x.W, C); if (!x2.p) return -1;
     { ProfScope ps(c, st, PC_ELEM, 0);
@@ -470,16 +484,52 @@ static int transformer(agd_ctx* c, hipStream_t st, const std::string& pre, const
     M = B * HW;
   }
   // --- cross attention (the processor seam) ---
+  bool chain_done = false;
+  { auto it = c->xl_idx.find(t + "attn2");
+    if (it == c->xl_idx.end()) FAIL("cross-attn layer %s not registered", (t + "attn2").c_str());
+    if (c->ctx_B2 != B) FAIL("context batch %d != unet batch %d (call agd_set_context)", c->ctx_B2, B);
+    XLayer& xl = c->xl[it->second];
+    // one launch for norm2 -> to_q -> attention (+ DAAM record) -> to_out + residual (tblock.hip)
+    if (chain_fuse) {
+      GETW(fq, t + "attn2.to_q.frag"); GETW(fo, t + "attn2.to_out.frag");
+      GETV(g2, t + "norm2.weight"); GETV(b2_, t + "norm2.bias"); GETV(bo, t + "attn2.to_out.0.bias");
+      const int T = c->ctx_T, D = C / heads;
+      AttnChainP ap{}; ap.h = h.p; ap.out = h.p; ap.gamma = g2; ap.beta = b2_; ap.ln_eps = lneps; ap.wqf = fq->w; ap.wof = fo->w; ap.bo = bo;
+      ap.kv = xl.kv; ap.ldkv = 2 * C; ap.skv = (long long)T * 2 * C; ap.M = M; ap.HW = HW; ap.T = T; ap.scale = 1.0f / sqrtf((float)D);
+      double rec_bytes = 0;
+      if (c->rec_mode == 1 && !xl.mid && xl.acc && c->rec_L / x.H != 8 && x.H == xl.acc_side && x.W == x.H && B / 2 == c->rec_B) {   // daam's rule, as cross_attention()
+        ap.record = 1; ap.rec = xl.acc; ap.rec_b0 = B / 2; ap.rec_T = c->rec_T; ap.rec_hpb = heads / xl.acc_heads;
+        ap.rec_head_stride = (long long)c->rec_T * HW; ap.rec_img_stride = ap.rec_head_stride * xl.acc_heads;
+        rec_bytes = 8.0 * (B - ap.rec_b0) * xl.acc_heads * (double)c->rec_T * HW;
+      }
+      if (fold && !ff_fused) {                           // the GEGLU consumer of the LayerNorm fold reads one slot of row statistics
+        slots = 1; stats = (float*)c->arena.alloc((size_t)M * 2 * sizeof(float)); if (!stats) return -1;
+        ap.rowstat_out = stats;
+      }
+      ProfScope ps(c, st, PC_ATTN_CROSS, 4.0 * M * (double)C * C + 4.0 * B * heads * (double)HW * T * D,
+                   4.0 * M * (double)C + 4.0 * C * (double)C + 4.0 * B * (double)T * C + rec_bytes);
+      CK(launch_attn_chain(ap, C, heads, st));
+      chain_done = true;
+    }
+  }
+  if (!chain_done)
   { bf16_t* q = qkv;
     CK(consume(t + "norm2", t + "attn2.to_q.weight", nullptr, 0, q));
     auto it = c->xl_idx.find(t + "attn2");
-    if (it == c->xl_idx.end()) FAIL("cross-attn layer %s not registered", (t + "attn2").c_str());
-    if (c->ctx_B2 != B) FAIL("context batch %d != unet batch %d (call agd_set_context)", c->ctx_B2, B);
     CK(cross_attention(c, st, c->xl[it->second], q, B, HW, att, true));
     GETW(wo, t + "attn2.to_out.0.weight"); GETV(bo, t + "attn2.to_out.0.bias");
     GemmOpt oo; oo.bias = bo; oo.residual = h.p;
-    CK(produce(att, C, *wo, oo, h.p)); }
+    CK(produce(att, C, *wo, oo, h.p, false, !ff_fused)); }
   // --- GEGLU feed-forward ---
+  if (ff_fused) {
+    // one launch: norm3 (folded) -> GEGLU -> ff.net.2 + residual; the 4C-wide hidden activation stays in LDS (tblock.hip)
+    GETW(f1, t + "ff.w1.frag"); GETW(f2, t + "ff.w2.frag");
+    const std::string k = t + "ff.net.0.proj.weight.lnfold";
+    GETV(cs, k + ".cs"); GETV(bf, k + ".bias"); GETV(b2, t + "ff.net.2.bias");
+    FFusedP fp{}; fp.h = h.p; fp.out = h.p; fp.w1f = f1->w; fp.cs1 = cs; fp.b1 = bf; fp.w2f = f2->w; fp.b2 = b2; fp.M = M; fp.ln_eps = lneps;
+    ProfScope ps(c, st, PC_GEMM, 2.0 * M * (double)C * 12.0 * C, 4.0 * M * (double)C + 2.0 * 12.0 * C * (double)C);
+    CK(launch_ff_fused(fp, C, st));
+  } else
   { bf16_t* ff = (bf16_t*)c->arena.alloc((size_t)M * 4 * C * 2); if (!ff) return -1;
     GETV(b1, t + "ff.net.0.proj.bias");
     CK(consume(t + "norm3", t + "ff.net.0.proj.weight", b1, 1, ff));
@@ -838,6 +888,30 @@ AGD_API int agd_finalize(agd_ctx* c) {
       const std::string k = t + f.w + ".lnfold";
       c->W[k] = wf; c->V[k + ".cs"] = cs; c->V[k + ".bias"] = bf; c->Vn[k + ".cs"] = w->N; c->Vn[k + ".bias"] = w->N;
     }
+    // fused row-panel kernels (tblock.hip, C = 320 blocks): the matrices once more in MFMA fragment order
+    if (q->N == 320) {
+      const int C = q->N;
+      const WMat* w1 = getW(c, t + "ff.net.0.proj.weight.lnfold"); const WMat* w2 = getW(c, t + "ff.net.2.weight");
+      if (!w1 || !w2) return fail_ctx(c);
+      if (w1->N == 8 * C && w1->Cpad == C && w2->N == C && w2->Cpad == 4 * C && w2->taps == 1) {
+        WMat f1 = *w1, f2 = *w2;
+        f1.w = dmalloc<bf16_t>(c, (size_t)w1->N * C); f2.w = dmalloc<bf16_t>(c, (size_t)C * 4 * C);
+        if (!f1.w || !f2.w) return fail_ctx(c);
+        API_CK(c, launch_frag_order_w1(w1->w, f1.w, C, 4 * C, 0));
+        API_CK(c, launch_frag_order_w(w2->w, f2.w, C, 4 * C, C / 64, 128, 0));
+        c->W[t + "ff.w1.frag"] = f1; c->W[t + "ff.w2.frag"] = f2;
+      }
+      const WMat* wq = getW(c, t + "attn2.to_q.weight"); const WMat* wo = getW(c, t + "attn2.to_out.0.weight");
+      if (!wq || !wo) return fail_ctx(c);
+      if (wq->N == C && wq->Cpad == C && wq->taps == 1 && wo->N == C && wo->Cpad == C && wo->taps == 1 && xl.heads == 8) {
+        WMat fq = *wq, fo = *wo;
+        fq.w = dmalloc<bf16_t>(c, (size_t)C * C); fo.w = dmalloc<bf16_t>(c, (size_t)C * C);
+        if (!fq.w || !fo.w) return fail_ctx(c);
+        API_CK(c, launch_frag_order_w(wq->w, fq.w, C, C, C / 64, C, 0));
+        API_CK(c, launch_frag_order_w(wo->w, fo.w, C, C, C / 64, C, 0));
+        c->W[t + "attn2.to_q.frag"] = fq; c->W[t + "attn2.to_out.frag"] = fo;
+      }
+    }
   }
   // ---- all time_emb_proj stacked into one [sum Cout][4*dim] matrix
   { std::vector<const WMat*> parts; std::vector<std::string> pres; int total = 0;
@@ -1060,6 +1134,8 @@ AGD_API int agd_set_option(agd_ctx* c, const char* name, int value) {
   if (!strcmp(name, "weight_warm")) { c->opt_warm = value; return 0; }
   if (!strcmp(name, "conv_halo")) { c->opt_halo = value != 0; return 0; }
   if (!strcmp(name, "gn_proj_fold")) { c->opt_gn_proj_fold = value < 0 ? 0 : value; return 0; }   // 0 off, 1: blocks with C <= 320, 2: C <= 640 (A/B)
+  if (!strcmp(name, "tblock_fuse")) { c->opt_tb_fuse = value < 0 ? 0 : value; return 0; }   // bit 0: fused feed-forward, bit 1: fused attn2 chain (C = 320 blocks)
+  if (!strcmp(name, "reduce_gn")) { c->opt_reduce_gn = value != 0; return 0; }
   if (!strcmp(name, "igemm8p")) { c->opt_p8 = value < 0 ? 0 : value; return 0; }   // 0 off, 1 on (the launcher decides per launch); tests: 2 / 3 / 4 force the 256-wide / 160-wide / any legal tile
   agd_set_error("set_option: unknown option '%s'", name);
   return fail_ctx(c);
@@ -1457,6 +1533,59 @@ AGD_API int agd_op_layernorm(const float* x, const float* gamma, const float* be
   return 0;
 }
 
+// y = x + ff.net.2(GEGLU(ff.net.0(LayerNorm(x)))) through the fused row-panel kernel (tblock.hip); w1 [8C][C] (values then gates),
+// b1 [8C], w2 [C][4C], b2 [C], x / y [M][C] fp32 (x is rounded to bf16 first, as the residual stream is stored)
+AGD_API int agd_op_ff_fused(const float* x, const float* gamma, const float* beta, const float* w1, const float* b1, const float* w2,
+                            const float* b2, float* y, int M, int C, float eps, void* stream) {
+  hipStream_t st = S(stream); Tmp tmp;
+  if (C != 320) { agd_set_error("op_ff_fused: C = %d (320 only)", C); return -1; }
+  const int H8 = 8 * C, H4 = 4 * C;
+  bf16_t* xb = tmp.get<bf16_t>((size_t)M * C); bf16_t* yb = tmp.get<bf16_t>((size_t)M * C);
+  bf16_t* w1b = tmp.get<bf16_t>((size_t)H8 * C); bf16_t* w1l = tmp.get<bf16_t>((size_t)H8 * C); bf16_t* w1f = tmp.get<bf16_t>((size_t)H8 * C);
+  bf16_t* w2b = tmp.get<bf16_t>((size_t)C * H4); bf16_t* w2f = tmp.get<bf16_t>((size_t)C * H4);
+  float* cs = tmp.get<float>(H8); float* bf = tmp.get<float>(H8);
+  if (!xb || !yb || !w1b || !w1l || !w1f || !w2b || !w2f || !cs || !bf) return -1;
+  CK(launch_f32_to_bf16(x, xb, (long long)M * C, st));
+  CK(launch_convert_weight(w1, w1b, H8, C, 1, C, 16, st));
+  CK(launch_ln_fold_weight(w1b, gamma, beta, b1, H8, C, 16, w1l, cs, bf, st));
+  CK(launch_frag_order_w1(w1l, w1f, C, H4, st));
+  CK(launch_convert_weight(w2, w2b, C, H4, 1, H4, 0, st));
+  CK(launch_frag_order_w(w2b, w2f, C, H4, C / 64, 128, st));
+  FFusedP fp{}; fp.h = xb; fp.out = yb; fp.w1f = w1f; fp.cs1 = cs; fp.b1 = bf; fp.w2f = w2f; fp.b2 = b2; fp.M = M; fp.ln_eps = eps;
+  CK(launch_ff_fused(fp, C, st));
+  CK(launch_bf16_to_f32(yb, y, (long long)M * C, st));
+  hipStreamSynchronize(st);
+  return 0;
+}
+
+// y = x + to_out(attention(to_q(LayerNorm(x)), k, v)) through the fused row-panel kernel (tblock.hip): x / y [B * HW][C] fp32, wq / wo
+// [C][C], bo [C], kv [B][T][2C] (projected context: K columns then V columns); probs_sum (optional) [B][T][HW] = probabilities summed
+// over the heads (the recorder's head-group form, all images recording)
+AGD_API int agd_op_attn_chain(const float* x, const float* gamma, const float* beta, const float* wq, const float* kv, const float* wo,
+                              const float* bo, float* y, float* probs_sum, int B, int HW, int T, int C, int heads, float eps, void* stream) {
+  hipStream_t st = S(stream); Tmp tmp;
+  const long long M = (long long)B * HW;
+  bf16_t* xb = tmp.get<bf16_t>((size_t)M * C); bf16_t* yb = tmp.get<bf16_t>((size_t)M * C); bf16_t* kvb = tmp.get<bf16_t>((size_t)B * T * 2 * C);
+  bf16_t* wqb = tmp.get<bf16_t>((size_t)C * C); bf16_t* wqf = tmp.get<bf16_t>((size_t)C * C);
+  bf16_t* wob = tmp.get<bf16_t>((size_t)C * C); bf16_t* wof = tmp.get<bf16_t>((size_t)C * C);
+  if (!xb || !yb || !kvb || !wqb || !wqf || !wob || !wof) return -1;
+  if (C % 64) { agd_set_error("op_attn_chain: C %d", C); return -1; }
+  CK(launch_f32_to_bf16(x, xb, M * C, st));
+  CK(launch_f32_to_bf16(kv, kvb, (long long)B * T * 2 * C, st));
+  CK(launch_convert_weight(wq, wqb, C, C, 1, C, 0, st)); CK(launch_frag_order_w(wqb, wqf, C, C, C / 64, C, st));
+  CK(launch_convert_weight(wo, wob, C, C, 1, C, 0, st)); CK(launch_frag_order_w(wob, wof, C, C, C / 64, C, st));
+  AttnChainP ap{}; ap.h = xb; ap.out = yb; ap.gamma = gamma; ap.beta = beta; ap.ln_eps = eps; ap.wqf = wqf; ap.wof = wof; ap.bo = bo;
+  ap.kv = kvb; ap.ldkv = 2 * C; ap.skv = (long long)T * 2 * C; ap.M = (int)M; ap.HW = HW; ap.T = T; ap.scale = 1.0f / sqrtf((float)(C / heads));
+  if (probs_sum) {
+    if (hipMemsetAsync(probs_sum, 0, (size_t)B * T * HW * 4, st) != hipSuccess) { agd_set_error("memset probs"); return -1; }
+    ap.record = 1; ap.rec = probs_sum; ap.rec_b0 = 0; ap.rec_T = T; ap.rec_hpb = heads; ap.rec_head_stride = (long long)T * HW; ap.rec_img_stride = (long long)T * HW;
+  }
+  CK(launch_attn_chain(ap, C, heads, st));
+  CK(launch_bf16_to_f32(yb, y, M * C, st));
+  hipStreamSynchronize(st);
+  return 0;
+}
+
 AGD_API int agd_op_attention(const float* q, const float* k, const float* v, float* o, int B, int H, int D, int Nq, int Nk,
                                 float scale, float* probs_out, void* stream) {
   hipStream_t st = S(stream); Tmp tmp;
@@ -1612,6 +1741,41 @@ AGD_API int agd_bench_conv_cold(int B, int H, int W, int C0, int Cout, int ksize
     if (i > 0) tot += t;
   }
   *ms_out = tot / iters;
+  hipEventDestroy(a); hipEventDestroy(b);
+  return 0;
+}
+
+// fused row-panel kernels (tblock.hip) at C = 320: kind 0 = feed-forward, 1 = attn2 chain (B images of HW tokens, 77 keys, the upper half of the
+// images recording head-summed probabilities, as in a CFG forward)
+AGD_API int agd_bench_tblock(int kind, int B, int HW, int iters, double* ms_out) {
+  Tmp tmp;
+  const int C = 320, T = 77; const long long M = (long long)B * HW;
+  bf16_t* h = tmp.get<bf16_t>((size_t)M * C); bf16_t* o = tmp.get<bf16_t>((size_t)M * C);
+  bf16_t* w1 = tmp.get<bf16_t>((size_t)8 * C * C); bf16_t* w1f = tmp.get<bf16_t>((size_t)8 * C * C);
+  bf16_t* w2 = tmp.get<bf16_t>((size_t)4 * C * C); bf16_t* w2f = tmp.get<bf16_t>((size_t)4 * C * C);
+  bf16_t* kv = tmp.get<bf16_t>((size_t)B * T * 2 * C);
+  float* vec = tmp.get<float>((size_t)16 * C + 64); float* rec = tmp.get<float>((size_t)B * T * HW);
+  if (!h || !o || !w1 || !w1f || !w2 || !w2f || !kv || !vec || !rec) return -1;
+  fill_rand(h, M * C, 1, 1.0f); fill_rand(w1, 8LL * C * C, 2, 0.05f); fill_rand(w2, 4LL * C * C, 3, 0.03f); fill_rand(kv, (long long)B * T * 2 * C, 4, 1.0f);
+  hipMemset(vec, 0, ((size_t)16 * C + 64) * 4); hipMemset(rec, 0, (size_t)B * T * HW * 4);
+  FFusedP fp{}; AttnChainP ap{};
+  if (kind == 0) {
+    CK(launch_frag_order_w1(w1, w1f, C, 4 * C, 0)); CK(launch_frag_order_w(w2, w2f, C, 4 * C, C / 64, 128, 0));
+    fp.h = h; fp.out = o; fp.w1f = w1f; fp.cs1 = vec; fp.b1 = vec + 8 * C; fp.w2f = w2f; fp.b2 = vec; fp.M = (int)M; fp.ln_eps = 1e-5f;
+  } else {
+    CK(launch_frag_order_w(w1, w1f, C, C, C / 64, C, 0)); CK(launch_frag_order_w(w2, w2f, C, C, C / 64, C, 0));
+    ap.h = h; ap.out = o; ap.gamma = vec; ap.beta = vec; ap.ln_eps = 1e-5f; ap.wqf = w1f; ap.wof = w2f; ap.bo = vec; ap.kv = kv; ap.ldkv = 2 * C; ap.skv = (long long)T * 2 * C;
+    ap.M = (int)M; ap.HW = HW; ap.T = T; ap.scale = 1.0f / sqrtf(40.f);
+    ap.record = 1; ap.rec = rec; ap.rec_b0 = B / 2; ap.rec_T = T; ap.rec_hpb = 8; ap.rec_head_stride = (long long)T * HW; ap.rec_img_stride = (long long)T * HW;
+  }
+  auto run = [&]() { return kind == 0 ? launch_ff_fused(fp, C, 0) : launch_attn_chain(ap, C, 8, 0); };
+  hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+  for (int i = 0; i < 2; ++i) CK(run());
+  hipEventRecord(a, 0);
+  for (int i = 0; i < iters; ++i) CK(run());
+  hipEventRecord(b, 0); hipEventSynchronize(b);
+  float t = 0; hipEventElapsedTime(&t, a, b);
+  *ms_out = t / iters;
   hipEventDestroy(a); hipEventDestroy(b);
   return 0;
 }

@@ -1,0 +1,704 @@
+// Fused row-panel kernels for the transformer blocks of the 64 x 64 maps (C = 320) -- round 4, VERDICT r3 items 1 and 4.
+//
+// Replaces, on the reference path (BasicTransformerBlock reached through diffusers from data_generation/data_generation.py:59; the
+// attention-processor body is restated by data_generation/hook.py:91-120):
+//   ff_fused_kernel:   norm3 -> ff.net.0 (GEGLU: Linear C -> 8C, value * gelu(gate)) -> ff.net.2 (Linear 4C -> C) + residual
+// as ONE launch per block.  The 4C-wide hidden activation (168 MB written + re-read per block at 64 x 64, UNet batch 8) never leaves
+// the CU: a workgroup owns 128 token rows, keeps the raw residual rows in LDS (80 KB), and walks the hidden dimension in chunks of
+// 128 columns: GEMM1 chunk (K = C) -> LayerNorm-fold + bias + GEGLU in registers -> bf16 chunk in LDS (32 KB, double-buffered)
+// -> GEMM2 accumulates the chunk (K = 128) into the 128 x C output panel held in accumulator registers for the whole kernel.
+//
+// Structure (MI355X-first):
+//  * 8 waves = 2 row halves x 4 column quarters; a wave owns 64 rows x 80 output columns (20 accumulator tiles of 16 x 16) and, per
+//    chunk, 64 rows x (32 value + 32 gate) GEGLU columns (16 tiles).  MFMA operand roles are swapped (D = W_tile . X_tile^T, as in
+//    igemm_epilogue.h) so a lane owns consecutive channels of one row: every epilogue is lane-local;
+//  * weights are re-laid at load time in FRAGMENT ORDER (frag_order_*_kernel): the 1 KB a wave's MFMA A-operand needs is one
+//    contiguous, fully coalesced 16-B-per-lane global load, streamed straight into registers (L2-resident: 2.4 MB per block) --
+//    no LDS staging, no barrier and no counted vmcnt for the weight stream; activations (the shared operand) are the ones in LDS;
+//  * the two row halves run the chunk pipeline STAGGERED by the GEGLU epilogue: within a barrier interval half 0 issues
+//    {GEMM2(k-1), GEMM1(k), GEGLU(k)} and half 1 {GEGLU(k-1), GEMM2(k-2), GEMM1(k)}.  Each SIMD hosts one wave of each half, so one
+//    wave's gelu VALU work runs beside the other's MFMAs (MI355X_MICROARCH.md 'Two waves per SIMD', item 9) at no register cost:
+//    a half's GEGLU only feeds its own rows of GEMM2, the workgroup barrier per interval is the only synchronisation;
+//  * LDS images are XOR-swizzled for conflict-free ds_read_b128 fragment reads (640-B rows: key (row >> 1) & 7 on the low three
+//    chunk bits; 256-B rows: key row & 15).
+#include "kernels.h"
+
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+#ifdef AGD_EXPERIMENTS
+int g_tb_variant = 0;   // timing variants of the fused kernels (tools/ only)
+extern "C" __attribute__((visibility("default"))) void agd_set_tb_variant(int v) { g_tb_variant = v; }
+#endif
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// weight re-layout: fragment order.  One thread = one lane's 16 bytes of one MFMA A-operand fragment.
+// lane l of a fragment: weight row rho = l & 15 of the 16-row tile, k-group g = l >> 4 (8 consecutive k).  Within a wave's column
+// range, tile j row 4q' + r' <-> wave-local column q' * 4NI + 4j + r' (so that lane q owns 4 NI consecutive columns of its pixel).
+// ---------------------------------------------------------------------------------------------------------------------------
+// GEGLU projection: src = the stored (LayerNorm-folded) matrix [2 HID][C] whose rows are permuted in groups of 16 = [8 values | 8 gates]
+__global__ __launch_bounds__(256) void frag_order_w1_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst, int C, int HID) {
+  const int KS1 = C / 32, NCH = HID / 128;
+  const long long total = (long long)NCH * 4 * KS1 * 4 * 64;
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    const int l = (int)(idx & 63); long long f = idx >> 6;
+    const int j = (int)(f & 3); f >>= 2;
+    const int ks = (int)(f % KS1); f /= KS1;
+    const int nq = (int)(f & 3); const int c = (int)(f >> 2);
+    const int rho = l & 15, g = l >> 4, qp = rho >> 2, rp = rho & 3;
+    const int gate = j >> 1, jj = j & 1;
+    const int hcol = 128 * c + 32 * nq + 8 * qp + 4 * jj + rp;
+    const long long row = 16LL * (hcol >> 3) + 8 * gate + (hcol & 7);
+    *(u32x4*)(dst + idx * 8) = *(const u32x4*)(src + row * C + 32 * ks + 8 * g);
+  }
+}
+// plain [N][K] matrix, wave column ranges of NI * 16 columns each (NQ ranges), K walked in chunks of KC (k-steps of 32 inside a chunk):
+// dst index = ((((chunk * NQ + nq) * (KC / 32) + ks) * NI + j) * 64 + lane) * 8
+__global__ __launch_bounds__(256) void frag_order_w_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst, int N, int K, int NI, int KC) {
+  const int NQ = N / (NI * 16), KSC = KC / 32, NCH = K / KC;
+  const long long total = (long long)NCH * NQ * KSC * NI * 64;
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    const int l = (int)(idx & 63); long long f = idx >> 6;
+    const int j = (int)(f % NI); f /= NI;
+    const int ks = (int)(f % KSC); f /= KSC;
+    const int nq = (int)(f % NQ); const int c = (int)(f / NQ);
+    const int rho = l & 15, g = l >> 4, qp = rho >> 2, rp = rho & 3;
+    const long long n = (long long)nq * NI * 16 + qp * 4 * NI + 4 * j + rp;
+    *(u32x4*)(dst + idx * 8) = *(const u32x4*)(src + n * K + (long long)c * KC + 32 * ks + 8 * g);
+  }
+}
+int launch_frag_order_w1(const bf16_t* src, bf16_t* dst, int C, int HID, hipStream_t st) {
+  if (C % 32 || HID % 128) { agd_set_error("frag_order_w1: C %d / hidden %d", C, HID); return -1; }
+  hipLaunchKernelGGL(frag_order_w1_kernel, dim3(1024), dim3(256), 0, st, src, dst, C, HID);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+int launch_frag_order_w(const bf16_t* src, bf16_t* dst, int N, int K, int NI, int KC, hipStream_t st) {
+  if (N % (NI * 16) || K % KC || KC % 32) { agd_set_error("frag_order_w: N %d K %d NI %d KC %d", N, K, NI, KC); return -1; }
+  hipLaunchKernelGGL(frag_order_w_kernel, dim3(1024), dim3(256), 0, st, src, dst, N, K, NI, KC);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// shared pieces
+// ---------------------------------------------------------------------------------------------------------------------------
+#define TB_OOB 0x80000000u
+// physical 16-B chunk of logical chunk `ch` in row `row` of a panel with C / 8 chunks per row (C / 8 a multiple of 8)
+AGD_DEV int panel_swz(int ch, int row) { return (ch & ~7) | ((ch & 7) ^ ((row >> 1) & 7)); }
+
+// [128][C] bf16 rows m0 .. m0+127 of `src` -> LDS panel (swizzled), by LDS-DMA; 8 waves, 1 KiB pieces.  Caller waits (vmcnt(0) + barrier).
+template <int C>
+AGD_DEV void panel_load_dma(const bf16_t* src, int m0, int M, char* panel, int wid, int lane) {
+  constexpr int CHR = C / 8, PIECES = 128 * CHR / 64;
+  static_assert(PIECES % 8 == 0, "pieces split evenly over 8 waves");
+#pragma unroll
+  for (int i = 0; i < PIECES / 8; ++i) {
+    const int piece = i * 8 + wid, pos = piece * 64 + lane;
+    const int row = pos / CHR, pc = pos - row * CHR;
+    const int lc = panel_swz(pc, row);                 // the swizzle is an involution on the low three chunk bits
+    const int m = m0 + row;
+    const unsigned voff = m < M ? (unsigned)(((long long)m * C + lc * 8) * 2) : TB_OOB;
+    bufdma16(src, panel + piece * 1024, voff, 0u);
+  }
+}
+
+// per-row LayerNorm statistics of the panel's 128 rows (bf16 values as stored): 4 threads per row, (mean, rstd) -> lnst[row]
+template <int C>
+AGD_DEV void panel_row_stats(const char* panel, float* lnst, int tid, float eps) {
+  constexpr int CHR = C / 8, PER = CHR / 4;
+  static_assert(CHR % 4 == 0, "chunks per row split over 4 threads");
+  const int row = tid >> 2, part = tid & 3;
+  float S = 0.f, Q = 0.f;
+#pragma unroll
+  for (int cc = 0; cc < PER; ++cc) {
+    const u32x4 v = *(const u32x4*)(panel + row * (C * 2) + panel_swz(part * PER + cc, row) * 16);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float a = __uint_as_float(v[e] << 16), b = __uint_as_float(v[e] & 0xFFFF0000u);
+      S += a + b; Q += a * a + b * b;
+    }
+  }
+  S += __shfl_xor(S, 1); Q += __shfl_xor(Q, 1);
+  S += __shfl_xor(S, 2); Q += __shfl_xor(Q, 2);
+  if (part == 0) {
+    const float mu = S * (1.0f / C);
+    float var = Q * (1.0f / C) - mu * mu; var = var < 0.f ? 0.f : var;
+    *(f32x2_t*)(lnst + row * 2) = f32x2_t{mu, rsqrtf(var + eps)};
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// fused GEGLU feed-forward
+// ---------------------------------------------------------------------------------------------------------------------------
+// VAR: timing experiments only (experiments library; results are garbage): bit 0 = no gelu arithmetic, bit 1 = the weight ring is loaded once,
+// bit 2 = activation fragments are read once, bit 3 = no GEGLU epilogue at all
+template <int C, int VAR = 0>
+__global__ __launch_bounds__(512, 2) void ff_fused_kernel(const FFusedP p) {
+  constexpr int BM = 128, HID = 4 * C, HC = 128, NCH = HID / HC, KS1 = C / 32, KS2 = HC / 32, NI2 = C / 64;   // NI2: 16-col tiles per wave (C / 4 / 16)
+  constexpr int PITCH = C * 2;
+  static_assert(C % 64 == 0 && (C / 8) % 8 == 0 && KS1 % 2 == 0, "panel geometry");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* panel = smem;                                   // [BM][C] bf16, swizzled: the raw residual rows (GEMM1 operand AND residual)
+  char* hbuf = smem + BM * PITCH;                       // 2 x [BM][HC] bf16, swizzled: GEGLU output chunks
+  float* lnst = (float*)(hbuf + 2 * BM * HC * 2);       // [BM] (mean, rstd)
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int mh = wid >> 2, nq = wid & 3;
+  const int q = lane >> 4, px = lane & 15;
+  const int m0 = blockIdx.x * BM;
+
+  panel_load_dma<C>(p.h, m0, p.M, panel, wid, lane);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  panel_row_stats<C>(panel, lnst, tid, p.ln_eps);
+  __syncthreads();
+
+  const int rbase = 64 * mh + px;                       // + 16 i: this lane's row in row tile i
+  float mu[4], rs[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { const f32x2_t v = *(const f32x2_t*)(lnst + (rbase + 16 * i) * 2); mu[i] = v[0]; rs[i] = v[1]; }
+
+  // X fragment (MFMA B operand) addresses in the panel: row rbase + 16 i, logical chunk 4 ks + q
+  const int sx = (px >> 1) & 7;
+  const int xoff0 = ((q ^ sx) << 4), xoff1 = (((4 + q) ^ sx) << 4);
+  const char* xrow = panel + rbase * PITCH;
+
+  f32x4 acc2[4][NI2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < NI2; ++j) acc2[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 acc1[4][4];
+
+  // weight fragments through buffer loads: per-lane offset lane * 16 (one VGPR for the whole kernel), the fragment's byte offset in an SGPR
+  const auto w1rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.w1f, 0, (unsigned)(2 * HID * C * 2), 0x00020000);
+  const auto w2rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.w2f, 0, (unsigned)(HID * C * 2), 0x00020000);
+  const unsigned lane16 = (unsigned)lane * 16u;
+  auto ldw1 = [&](unsigned sbase, int f) { return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(w1rs, lane16, sbase + (unsigned)f * 1024u, 0)); };
+  auto ldw2 = [&](unsigned sbase, int f) { return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(w2rs, lane16, sbase + (unsigned)f * 1024u, 0)); };
+  constexpr bool NOW = (VAR & 2) != 0, NOX = (VAR & 4) != 0;
+
+  // The weight stream: a ring of F fragment registers, filled D fragments ahead of use with plain 16-byte-per-lane global loads (one
+  // coalesced KiB per wave instruction).  Inside a barrier interval the consumption order is fixed -- GEMM2's KS2 x NI2 = 20 fragments
+  // (ring positions 0 .. 19), then GEMM1's KS1 x 4 = 40 (positions 20 .. 59) -- and 60 is a multiple of F, so every fragment has a
+  // compile-time ring slot.  The loads for the next phase's first D fragments are issued under the current phase's last MFMAs (also
+  // across the interval barrier and the GEGLU epilogue), so no phase starts on a cold stream; a phase whose predecessor did not run
+  // (first / last intervals) issues them itself.  sched_barrier pins each load ahead of the MFMAs it is meant to run under: left alone,
+  // hipcc sinks every load to just in front of its first use (measured: 108 us per launch against 127 for the two kernels it replaces).
+  constexpr int F = 12, D = 10, DX = 4, N2 = KS2 * NI2, N1 = KS1 * 4;     // DX: fragments of the next interval's GEMM2 kept in flight across the GEGLU epilogue (register budget)
+  static_assert((N1 + N2) % F == 0 && D < F && D <= N2 && DX <= D, "ring geometry");
+  u32x4 ring[F];
+
+  auto gemm2 = [&](int c, bool pre, bool has_next, unsigned nexts) {       // nexts: GEMM1's stream of this interval (if has_next)
+    const char* hb = hbuf + (c & 1) * (BM * HC * 2) + rbase * (HC * 2);
+    const unsigned wp = __builtin_amdgcn_readfirstlane((unsigned)(((c * 4 + nq) * KS2) * NI2) * 1024u);
+    if (!pre && !NOW) {
+#pragma unroll
+      for (int f = 0; f < DX; ++f) ring[f % F] = ldw2(wp, f);
+    }
+    if constexpr (!NOW) {
+#pragma unroll
+      for (int f = DX; f < D; ++f) ring[f % F] = ldw2(wp, f);
+    }
+    bf16x8 hf[4];
+#pragma unroll
+    for (int f = 0; f < N2; ++f) {
+      const int tgt = f + D;
+      if constexpr (!NOW) {
+        if (tgt < N2) ring[tgt % F] = ldw2(wp, tgt);
+        else if (has_next) ring[tgt % F] = ldw1(nexts, tgt - N2);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (f % NI2 == 0 && (!NOX || f == 0)) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) hf[i] = *(const bf16x8*)(hb + i * 16 * (HC * 2) + (((4 * (f / NI2) + q) ^ px) << 4));
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        acc2[i][f % NI2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ring[f % F]), hf[i], acc2[i][f % NI2], 0, 0, 0);
+    }
+  };
+
+  auto gemm1 = [&](int c, bool pre, bool has_next, unsigned nexts) {       // nexts: the NEXT interval's GEMM2 stream (if has_next)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc1[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const unsigned wp = __builtin_amdgcn_readfirstlane((unsigned)(((c * 4 + nq) * KS1) * 4) * 1024u);
+    if (!pre && !NOW) {
+#pragma unroll
+      for (int f = 0; f < D; ++f) ring[(N2 + f) % F] = ldw1(wp, f);
+    }
+    bf16x8 xf[4];
+#pragma unroll
+    for (int f = 0; f < N1; ++f) {
+      const int tgt = f + D;
+      if constexpr (!NOW) {
+        if (tgt < N1) ring[(N2 + tgt) % F] = ldw1(wp, tgt);
+        else if (has_next && tgt - N1 < DX) ring[(N2 + tgt) % F] = ldw2(nexts, tgt - N1);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (f % 4 == 0 && (!NOX || f == 0)) {
+        const int ks = f / 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) xf[i] = *(const bf16x8*)(xrow + i * 16 * PITCH + (ks >> 1) * 128 + ((ks & 1) ? xoff1 : xoff0));
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        acc1[i][f % 4] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ring[(N2 + f) % F]), xf[i], acc1[i][f % 4], 0, 0, 0);
+    }
+  };
+
+  // LayerNorm fold + bias + value * gelu(gate) of chunk c -> hbuf[c & 1]; lane (q, px) owns hidden columns 128 c + 32 nq + 8 q .. + 8
+  auto geglu = [&](int c) {
+    const int hcol0 = HC * c + 32 * nq + 8 * q;
+    char* hb = hbuf + (c & 1) * (BM * HC * 2);
+    u32x2 pk[4][2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {                      // four columns at a time: 16 epilogue constants live instead of 32
+      const f32x4 csv = *(const f32x4*)(p.cs1 + hcol0 + 4 * t), csg = *(const f32x4*)(p.cs1 + HID + hcol0 + 4 * t);
+      const f32x4 bv = *(const f32x4*)(p.b1 + hcol0 + 4 * t), bg = *(const f32x4*)(p.b1 + HID + hcol0 + 4 * t);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float o[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float v = rs[i] * (acc1[i][t][r] - mu[i] * csv[r]) + bv[r];
+          const float g = rs[i] * (acc1[i][2 + t][r] - mu[i] * csg[r]) + bg[r];
+          o[r] = (VAR & 1) ? v + g : v * gelu_erf_f(g);
+        }
+        pk[i][t][0] = pack_bf2(o[0], o[1]); pk[i][t][1] = pack_bf2(o[2], o[3]);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      *(u32x4*)(hb + (rbase + 16 * i) * (HC * 2) + (((4 * nq + q) ^ px) << 4)) = u32x4{pk[i][0][0], pk[i][0][1], pk[i][1][0], pk[i][1][1]};
+  };
+
+  // staggered chunk pipeline: interval k, half 0: GEMM2(k-1), GEMM1(k), GEGLU(k); half 1: GEGLU(k-1), GEMM2(k-2), GEMM1(k).
+  // Every GEGLU(c) of a half is separated from that half's GEMM2(c) by exactly one workgroup barrier; hbuf[c & 1] is rewritten two
+  // intervals after GEMM2(c-2) read it.  All branches are wave-uniform.
+  bool pre2 = false;                                    // this interval's GEMM2 stream head is already in flight
+  if constexpr (NOW) {
+#pragma unroll
+    for (int f = 0; f < F; ++f) ring[f] = ldw1(0u, f);
+  }
+  for (int k = 0; k <= NCH + 1; ++k) {
+    if (!(VAR & 8) && mh == 1 && k >= 1 && k <= NCH) geglu(k - 1);
+    const int c2 = k - 1 - mh, c2n = k - mh;
+    const bool v2 = c2 >= 0 && c2 < NCH, v1 = k < NCH, v2n = c2n >= 0 && c2n < NCH;
+    const unsigned w1s = __builtin_amdgcn_readfirstlane((unsigned)(((k * 4 + nq) * KS1) * 4) * 1024u);
+    const unsigned w2ns = __builtin_amdgcn_readfirstlane((unsigned)(((c2n * 4 + nq) * KS2) * NI2) * 1024u);
+    if (v2) gemm2(c2, pre2, v1, w1s);
+    if (v1) gemm1(k, v2, v2n, w2ns);
+    pre2 = v1 && v2n;
+    if (!(VAR & 8) && mh == 0 && k < NCH) geglu(k);
+    if (k <= NCH) __syncthreads();
+  }
+
+  // epilogue: + bias + residual (the raw rows are still in the panel), one rounding to bf16, 8-byte row chunks
+  float b2v[NI2 * 4];
+#pragma unroll
+  for (int t = 0; t < NI2; ++t) *(f32x4*)&b2v[4 * t] = *(const f32x4*)(p.b2 + (C / 4) * nq + 4 * NI2 * q + 4 * t);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = rbase + 16 * i, m = m0 + row;
+    if (m >= p.M) continue;
+    bf16_t* op = p.out + (long long)m * C;
+#pragma unroll
+    for (int t = 0; t < NI2; ++t) {
+      const int n = (C / 4) * nq + 4 * NI2 * q + 4 * t;
+      const u32x2 r = *(const u32x2*)(panel + row * PITCH + panel_swz(n >> 3, row) * 16 + (n & 7) * 2);
+      u32x2 pk;
+      pk[0] = pack_bf2(acc2[i][t][0] + b2v[4 * t] + __uint_as_float(r[0] << 16), acc2[i][t][1] + b2v[4 * t + 1] + __uint_as_float(r[0] & 0xFFFF0000u));
+      pk[1] = pack_bf2(acc2[i][t][2] + b2v[4 * t + 2] + __uint_as_float(r[1] << 16), acc2[i][t][3] + b2v[4 * t + 3] + __uint_as_float(r[1] & 0xFFFF0000u));
+      *(u32x2*)(op + n) = pk;
+    }
+  }
+}
+
+int launch_ff_fused(const FFusedP& p, int C, hipStream_t st) {
+  if (C != 320) { agd_set_error("ff_fused: C = %d is not built (320 only)", C); return -1; }
+  if (p.M < 1 || !p.h || !p.out || !p.w1f || !p.w2f || !p.cs1 || !p.b1 || !p.b2) { agd_set_error("ff_fused: bad arguments"); return -1; }
+  if ((long long)p.M * C * 2 >= (1LL << 31)) { agd_set_error("ff_fused: activation too large for 32-bit offsets"); return -1; }
+  constexpr int lds = 128 * 320 * 2 + 2 * 128 * 128 * 2 + 128 * 8;
+  const void* kfn = (const void*)ff_fused_kernel<320>;
+#ifdef AGD_EXPERIMENTS
+  static const void* const vars[16] = {(const void*)ff_fused_kernel<320, 0>, (const void*)ff_fused_kernel<320, 1>, (const void*)ff_fused_kernel<320, 2>, (const void*)ff_fused_kernel<320, 3>,
+                                       (const void*)ff_fused_kernel<320, 4>, nullptr, (const void*)ff_fused_kernel<320, 6>, (const void*)ff_fused_kernel<320, 7>,
+                                       (const void*)ff_fused_kernel<320, 8>, nullptr, (const void*)ff_fused_kernel<320, 10>, nullptr, nullptr, nullptr, (const void*)ff_fused_kernel<320, 14>, nullptr};
+  if (g_tb_variant > 0 && g_tb_variant < 16 && vars[g_tb_variant]) kfn = vars[g_tb_variant];
+#endif
+  int dev = 0; HIP_CHECK_RET(hipGetDevice(&dev));
+  if (dev < 0 || dev >= AGD_MAX_DEVICES) { agd_set_error("ff_fused: device ordinal %d out of range", dev); return -1; }
+  HIP_CHECK_RET(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  FFusedP pp = p;
+  void* args[] = {&pp};
+  HIP_CHECK_RET(hipLaunchKernel(kfn, dim3((p.M + 127) / 128), dim3(512), args, lds, st));
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// fused attn2 chain:  norm2 -> to_q -> cross-attention (+ DAAM recorder) -> to_out + bias + residual (+ norm3 row statistics)
+//
+// Reference op sequence: data_generation/hook.py:91-120 (q = to_q(hidden); P = softmax(scale q k^T); out = P v; to_out[0]) between
+// BasicTransformerBlock's norm2 and the residual add; the recorder side channel is daam's per-(layer, head) time sums (SURVEY 8a
+// D2), here the head-group sums of attention.hip RECORD 2.  One workgroup = 128 token rows of ONE image, 8 waves:
+//   * GEMM stages (to_q, to_out): waves = 2 row halves x 4 column quarters, wave tile 64 rows x 80 columns, weights streamed in
+//     fragment order from L2 (as the feed-forward kernel above), activations from the LDS panel;
+//   * attention stage: waves = 4 query blocks of 32 x 2 head halves (heads 4 hh .. 4 hh + 3); Q fragments come from the panel,
+//     K / V of one head per half are staged in LDS (register-prefetched), S^T = K Q^T and O^T += V^T P^T on 32x32x16 MFMAs exactly as
+//     attn_kernel<RECORD = 2>; every head's O overwrites that head's Q columns of the wave's own 32 rows in place;
+//   * the panel is used three times: normalised rows (A of to_q) -> Q / O -> (A of to_out).  Q, O, the 21 MB activations that the
+//     three launches this replaces exchange through HBM, never leave the CU.
+// ---------------------------------------------------------------------------------------------------------------------------
+template <int C>
+__global__ __launch_bounds__(512, 2) void attn_chain_kernel(const AttnChainP p) {
+  constexpr int BM = 128, H = 8, D = C / H, KS = C / 32, NI = C / 64, PITCH = C * 2, CHR = C / 8;
+  static_assert(C == 320, "head dim 40 layout");
+  constexpr int KB = 3, KEYS = 96, KSTEPS = 3, DBLK = 2, CH = D / 8;       // 96 keys, d padded 40 -> 48 (QK^T) / 64 (PV)
+  constexpr int KPITCH = 7 * 16, VPITCH = 3 * 64;                          // odd chunk counts: conflict-free b128 / tr reads (attention.hip)
+  constexpr int KVSTAGE = KEYS * (KPITCH + VPITCH);                        // one head: 29184 B
+  constexpr int NCHUNK = KEYS * CH, LD_IT = (NCHUNK + 255) / 256;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* panel = smem;
+  char* kvs = smem + BM * PITCH;                        // 2 x KVSTAGE (one head per head half); later: probability hand-off / statistics staging
+  float* lnst = (float*)(kvs + 2 * KVSTAGE);
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int mh = wid >> 2, nq = wid & 3;                // GEMM roles
+  const int q = lane >> 4, px = lane & 15;
+  const int qb = wid & 3, hhalf = wid >> 2;             // attention roles
+  const int c = lane & 31, hh = lane >> 5;
+  const int m0 = blockIdx.x * BM;
+  const int b = m0 / p.HW, pix0 = m0 - b * p.HW;        // tiles stay inside one image (HW % 128 == 0)
+
+  panel_load_dma<C>(p.h, m0, p.M, panel, wid, lane);
+
+  // K / V staging of this wave's head half: pad chunks once, then head `h` through registers
+  char* sK = kvs + hhalf * KVSTAGE;
+  char* sV = sK + KEYS * KPITCH;
+  const int t4 = tid & 255;
+  for (int i = t4; i < KEYS * 2; i += 256) { const int r = i >> 1, cc = CH + (i & 1); *(u32x4*)(sK + r * KPITCH + cc * 16) = u32x4{0, 0, 0, 0}; }
+  for (int i = t4; i < KEYS * 7; i += 256) { const int r = i / 7, cc = CH + i % 7; *(u32x4*)(sV + r * VPITCH + cc * 16) = u32x4{0, 0, 0, 0}; }
+  u32x4 kreg[LD_IT], vreg[LD_IT];
+  unsigned kvoff[LD_IT];
+#pragma unroll
+  for (int it = 0; it < LD_IT; ++it) {
+    const int idx = t4 + it * 256, r = idx / CH, cc = idx - r * CH;
+    kvoff[it] = idx < NCHUNK ? (unsigned)((r * p.ldkv + cc * 8) * 2) : TB_OOB;
+  }
+  const unsigned kv_bytes = (unsigned)(((long long)(p.T - 1) * p.ldkv + D) * 2);
+  const bf16_t* kvb = p.kv + (long long)b * p.skv;
+  auto kv_load = [&](int h) {
+    const auto krs = __builtin_amdgcn_make_buffer_rsrc((void*)(kvb + h * D), 0, kv_bytes, 0x00020000);
+    const auto vrs = __builtin_amdgcn_make_buffer_rsrc((void*)(kvb + C + h * D), 0, kv_bytes, 0x00020000);
+#pragma unroll
+    for (int it = 0; it < LD_IT; ++it) {
+      kreg[it] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(krs, kvoff[it], 0, 0));
+      vreg[it] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(vrs, kvoff[it], 0, 0));
+    }
+  };
+  auto kv_store = [&]() {
+#pragma unroll
+    for (int it = 0; it < LD_IT; ++it) {
+      const int idx = t4 + it * 256, r = idx / CH, cc = idx - r * CH;
+      if (idx < NCHUNK) { *(u32x4*)(sK + r * KPITCH + cc * 16) = kreg[it]; *(u32x4*)(sV + r * VPITCH + cc * 16) = vreg[it]; }
+    }
+  };
+  kv_load(4 * hhalf);
+
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  kv_store();
+  panel_row_stats<C>(panel, lnst, tid, p.ln_eps);
+  __syncthreads();
+
+  // ---- GEMM stage: acc[4][NI] = W[80 nq .. +80][:] . panel[64 mh .. +64][:]^T ----
+  const int rbase = 64 * mh + px;
+  const int sx = (px >> 1) & 7;
+  const int xoff0 = ((q ^ sx) << 4), xoff1 = (((4 + q) ^ sx) << 4);
+  const char* xrow = panel + rbase * PITCH;
+  f32x4 acc[4][NI];
+  // weight stream as in ff_fused_kernel: a ring of F fragment registers filled D fragments ahead by buffer loads (per-lane offset lane * 16,
+  // fragment offset in an SGPR), pinned ahead of the MFMAs they run under; `head` issues the first D fragments (early: under the phase in
+  // front of the GEMM), `body` consumes the KS x NI fragments
+  constexpr int F = 12, PD = 10, NFR = KS * NI;
+  u32x4 ring[F];
+  const unsigned lane16 = (unsigned)lane * 16u;
+  const unsigned wbase = __builtin_amdgcn_readfirstlane((unsigned)(nq * NFR) * 1024u);
+  auto gemm_head = [&](const bf16_t* wf) {
+    const auto wrs = __builtin_amdgcn_make_buffer_rsrc((void*)wf, 0, (unsigned)(C * C * 2), 0x00020000);
+#pragma unroll
+    for (int f = 0; f < PD; ++f) ring[f % F] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, lane16, wbase + (unsigned)f * 1024u, 0));
+  };
+  auto gemm_body = [&](const bf16_t* wf) {
+    const auto wrs = __builtin_amdgcn_make_buffer_rsrc((void*)wf, 0, (unsigned)(C * C * 2), 0x00020000);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bf16x8 xf[4];
+#pragma unroll
+    for (int f = 0; f < NFR; ++f) {
+      if (f + PD < NFR) ring[(f + PD) % F] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, lane16, wbase + (unsigned)(f + PD) * 1024u, 0));
+      __builtin_amdgcn_sched_barrier(0);
+      if (f % NI == 0) {
+        const int ks = f / NI;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) xf[i] = *(const bf16x8*)(xrow + i * 16 * PITCH + (ks >> 1) * 128 + ((ks & 1) ? xoff1 : xoff0));
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        acc[i][f % NI] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ring[f % F]), xf[i], acc[i][f % NI], 0, 0, 0);
+    }
+  };
+
+  gemm_head(p.wqf);                                   // the first to_q weight fragments fly under the normalisation pass
+
+  // ---- norm2 in place: x^ = (h - mu) rstd gamma + beta, rounded to bf16 (what the LayerNorm kernel stores) ----
+#pragma unroll 2
+  for (int i = 0; i < BM * CHR / 512; ++i) {
+    const int pos = i * 512 + tid, row = pos / CHR, pc = pos - row * CHR, lc = panel_swz(pc, row);
+    u32x4 v = *(u32x4*)(panel + row * PITCH + pc * 16);
+    const f32x2_t st = *(const f32x2_t*)(lnst + row * 2);
+    const f32x4 g0 = *(const f32x4*)(p.gamma + lc * 8), g1 = *(const f32x4*)(p.gamma + lc * 8 + 4);
+    const f32x4 b0 = *(const f32x4*)(p.beta + lc * 8), b1 = *(const f32x4*)(p.beta + lc * 8 + 4);
+    float x[8];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { x[2 * e] = __uint_as_float(v[e] << 16); x[2 * e + 1] = __uint_as_float(v[e] & 0xFFFF0000u); }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { x[e] = (x[e] - st[0]) * st[1] * g0[e] + b0[e]; x[4 + e] = (x[4 + e] - st[0]) * st[1] * g1[e] + b1[e]; }
+    v[0] = pack_bf2(x[0], x[1]); v[1] = pack_bf2(x[2], x[3]); v[2] = pack_bf2(x[4], x[5]); v[3] = pack_bf2(x[6], x[7]);
+    *(u32x4*)(panel + row * PITCH + pc * 16) = v;
+  }
+  __syncthreads();
+
+  // ---- to_q: Q over the normalised rows (every wave has finished reading them before anyone overwrites) ----
+  gemm_body(p.wqf);
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = rbase + 16 * i;
+#pragma unroll
+    for (int t = 0; t < NI; ++t) {
+      const int n = (C / 4) * nq + 4 * NI * q + 4 * t;
+      u32x2 pk; pk[0] = pack_bf2(acc[i][t][0], acc[i][t][1]); pk[1] = pack_bf2(acc[i][t][2], acc[i][t][3]);
+      *(u32x2*)(panel + row * PITCH + panel_swz(n >> 3, row) * 16 + (n & 7) * 2) = pk;
+    }
+  }
+  __syncthreads();
+
+  // ---- attention: wave = query block qb (32 rows) x heads 4 hhalf .. 4 hhalf + 3 ----
+  {
+    const int qr = 32 * qb + c;
+    char* prow = panel + qr * PITCH;
+    const float sc = p.scale * 1.44269504088896340736f;
+    const bool recb = p.record && b >= p.rec_b0;
+    const int hpb = p.rec_hpb;
+    f32x16 pacc[KB];
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) pacc[kb][j] = 0.f;
+    const int gi = lane & 15;
+    const int tr_row = (gi >> 2) + 4 * hh;
+    const int tr_col = ((lane >> 4) & 1) * 16 + (gi & 3) * 4;
+    // one read-modify-write of the recorder rows [slice][T][HW] with the probabilities summed over a head group
+    auto rec_rmw = [&](int slice, const f32x16 (&pa)[KB]) {
+      float* base = p.rec + (long long)(b - p.rec_b0) * p.rec_img_stride + (long long)slice * p.rec_head_stride;
+      const unsigned nbytes = (unsigned)p.rec_T * (unsigned)p.HW * 4u;          // token rows >= rec_T are dropped by the range check
+      const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(base, 0, nbytes, 0x00020000);
+      const unsigned rowb = (unsigned)p.HW * 4u;
+      const unsigned voff0 = (unsigned)(pix0 + qr) * 4u + (unsigned)(4 * hh) * rowb;
+      float old[KB][16];
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+          old[kb][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff0 + (unsigned)(kb * 32 + (i & 3) + 8 * (i >> 2)) * rowb, 0, 0));
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, old[kb][i] + pa[kb][i]), rsrc,
+                                                voff0 + (unsigned)(kb * 32 + (i & 3) + 8 * (i >> 2)) * rowb, 0, 0);
+    };
+
+    for (int hi = 0; hi < 4; ++hi) {
+      const int h = 4 * hhalf + hi;
+      if (hi + 1 < 4) kv_load(h + 1);                  // next head's K / V under this head's work
+      bf16x8 qf[KSTEPS];
+#pragma unroll
+      for (int s = 0; s < KSTEPS; ++s) {
+        const int d0 = 16 * s + 8 * hh;
+        u32x4 v = u32x4{0, 0, 0, 0};
+        if (d0 < D) v = *(const u32x4*)(prow + panel_swz(CH * h + 2 * s + hh, qr) * 16);
+        qf[s] = __builtin_bit_cast(bf16x8, v);
+      }
+      f32x16 sacc[KB];
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s) {
+          const bf16x8 a = *(const bf16x8*)(sK + (kb * 32 + c) * KPITCH + (2 * s + hh) * 16);
+          if (s == 0) { const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                        sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[s], z, 0, 0, 0); }
+          else sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[s], sacc[kb], 0, 0, 0);
+        }
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int key = kb * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+          if (key >= p.T) sacc[kb][i] = -INFINITY;
+        }
+      float mx = sacc[0][0];
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) mx = fmaxf(mx, sacc[kb][i]);
+      mx = xhalf_max(mx) * sc;
+      float rsum = 0.f;
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { const float pv = __builtin_amdgcn_exp2f(fmaf(sacc[kb][i], sc, -mx)); sacc[kb][i] = pv; rsum += pv; }
+      const float inv = 1.0f / xhalf_sum(rsum);
+      if (recb) {
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) pacc[kb][i] += sacc[kb][i] * inv;
+      }
+      f32x16 oacc[DBLK];
+#pragma unroll
+      for (int db = 0; db < DBLK; ++db)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) oacc[db][j] = 0.f;
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          bf16x8 pf;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) pf[j] = (__bf16)sacc[kb][8 * s + j];
+          const char* vb = sV + (kb * 32 + 16 * s + tr_row) * VPITCH + tr_col * 2;
+#pragma unroll
+          for (int db = 0; db < DBLK; ++db) {
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vb + db * 64));
+            const s16x4 hi2 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vb + 8 * VPITCH + db * 64));
+            const u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi2);
+            const u32x4 a4 = u32x4{l2[0], l2[1], h2[0], h2[1]};
+            oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a4), pf, oacc[db], 0, 0, 0);
+          }
+        }
+      // O of this head over its Q columns (this wave's own rows; nobody else reads or writes them)
+#pragma unroll
+      for (int db = 0; db < DBLK; ++db)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int d0 = db * 32 + 8 * g + 4 * hh;
+          if (d0 < D) {
+            u32x2 pk;
+            pk[0] = pack_bf2(oacc[db][4 * g + 0] * inv, oacc[db][4 * g + 1] * inv);
+            pk[1] = pack_bf2(oacc[db][4 * g + 2] * inv, oacc[db][4 * g + 3] * inv);
+            *(u32x2*)(prow + panel_swz(CH * h + (d0 >> 3), qr) * 16 + (d0 & 7) * 2) = pk;
+          }
+        }
+      // recorder: head groups smaller than a head half are flushed by the wave that owns them
+      if (recb && hpb < H && ((hi + 1) % hpb) == 0) {
+        rec_rmw(h / hpb, pacc);
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+          for (int j = 0; j < 16; ++j) pacc[kb][j] = 0.f;
+      }
+      __syncthreads();                                 // every wave is done with this head's K / V
+      if (hi + 1 < 4) { kv_store(); __syncthreads(); }
+    }
+    gemm_head(p.wof);                                   // to_out's first weight fragments fly under the recorder hand-off
+    // all heads in one recorder slice: the upper head half hands its sum to the lower one through LDS (the K / V stage is free now)
+    if (p.record && hpb == H) {
+      float* xch = (float*)kvs + (qb * 48) * 64 + lane;
+      if (hhalf == 1 && recb) {
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) xch[(kb * 16 + i) * 64] = pacc[kb][i];
+      }
+      __syncthreads();
+      if (hhalf == 0 && recb) {
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) pacc[kb][i] += xch[(kb * 16 + i) * 64];
+        rec_rmw(0, pacc);
+      }
+    }
+  }
+  __syncthreads();                                       // O complete in the panel (and the exchange buffer is free)
+
+  // ---- to_out + bias + residual, one rounding; optional norm3 row statistics of the rounded outputs ----
+  gemm_body(p.wof);
+  float bv[NI * 4];
+#pragma unroll
+  for (int t = 0; t < NI; ++t) *(f32x4*)&bv[4 * t] = *(const f32x4*)(p.bo + (C / 4) * nq + 4 * NI * q + 4 * t);
+  float rs[4], rq[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = m0 + rbase + 16 * i;
+    rs[i] = 0.f; rq[i] = 0.f;
+    const bf16_t* rp = p.h + (long long)m * C + (C / 4) * nq + 4 * NI * q;
+    bf16_t* op = p.out + (long long)m * C + (C / 4) * nq + 4 * NI * q;
+    u32x2 r[NI];
+#pragma unroll
+    for (int t = 0; t < NI; ++t) r[t] = *(const u32x2*)(rp + 4 * t);
+#pragma unroll
+    for (int t = 0; t < NI; ++t) {
+      const float v0 = acc[i][t][0] + bv[4 * t] + __uint_as_float(r[t][0] << 16), v1 = acc[i][t][1] + bv[4 * t + 1] + __uint_as_float(r[t][0] & 0xFFFF0000u);
+      const float v2 = acc[i][t][2] + bv[4 * t + 2] + __uint_as_float(r[t][1] << 16), v3 = acc[i][t][3] + bv[4 * t + 3] + __uint_as_float(r[t][1] & 0xFFFF0000u);
+      u32x2 pk; pk[0] = pack_bf2(v0, v1); pk[1] = pack_bf2(v2, v3);
+      *(u32x2*)(op + 4 * t) = pk;
+      const float a0 = __uint_as_float(pk[0] << 16), a1 = __uint_as_float(pk[0] & 0xFFFF0000u), a2 = __uint_as_float(pk[1] << 16), a3 = __uint_as_float(pk[1] & 0xFFFF0000u);
+      rs[i] += (a0 + a1) + (a2 + a3); rq[i] += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+    }
+  }
+  if (p.rowstat_out) {                                  // wave-uniform (kernel argument); fixed summation order: reproducible
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      rs[i] += __shfl_xor(rs[i], 16); rs[i] += __shfl_xor(rs[i], 32);
+      rq[i] += __shfl_xor(rq[i], 16); rq[i] += __shfl_xor(rq[i], 32);
+    }
+    float* stg = (float*)kvs;                            // [4 nq][BM][2]
+    if (q == 0) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { stg[(nq * BM + rbase + 16 * i) * 2] = rs[i]; stg[(nq * BM + rbase + 16 * i) * 2 + 1] = rq[i]; }
+    }
+    __syncthreads();
+    if (tid < BM) {
+      float S = 0.f, Q = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) { S += stg[(w * BM + tid) * 2]; Q += stg[(w * BM + tid) * 2 + 1]; }
+      *(f32x2_t*)(p.rowstat_out + (long long)(m0 + tid) * 2) = f32x2_t{S, Q};
+    }
+  }
+}
+
+int launch_attn_chain(const AttnChainP& p, int C, int heads, hipStream_t st) {
+  if (C != 320 || heads != 8) { agd_set_error("attn_chain: C = %d / heads = %d is not built (320 / 8 only)", C, heads); return -1; }
+  if (p.M < 128 || p.M % 128 || p.HW % 128 || p.M % p.HW) { agd_set_error("attn_chain: M %d / HW %d must be multiples of 128 (whole images)", p.M, p.HW); return -1; }
+  if (p.T < 1 || p.T > 96) { agd_set_error("attn_chain: %d keys (1..96)", p.T); return -1; }
+  if ((long long)p.M * C * 2 >= (1LL << 31)) { agd_set_error("attn_chain: activation too large for 32-bit offsets"); return -1; }
+  if (p.record && (p.rec_hpb < 1 || 8 % p.rec_hpb || !p.rec)) { agd_set_error("attn_chain: recorder head group %d", p.rec_hpb); return -1; }
+  constexpr int lds = 128 * 320 * 2 + 2 * 96 * (7 * 16 + 3 * 64) + 128 * 8;
+  auto kfn = attn_chain_kernel<320>;
+  static bool attr[AGD_MAX_DEVICES] = {};
+  int dev = 0; HIP_CHECK_RET(hipGetDevice(&dev));
+  if (dev < 0 || dev >= AGD_MAX_DEVICES) { agd_set_error("attn_chain: device ordinal %d out of range", dev); return -1; }
+  if (!attr[dev]) { HIP_CHECK_RET(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); attr[dev] = true; }
+  hipLaunchKernelGGL(kfn, dim3(p.M / 128), dim3(512), lds, st, p);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}

@@ -107,14 +107,19 @@ class PendingGather:
 
 
 def gather_outputs(images: torch.Tensor, heatmaps: torch.Tensor, seeds: Optional[Sequence[int]] = None, max_batch: Optional[int] = None,
-                   async_op: bool = False):
-    """The final exchange step: ONE all_gather of images + heat maps (+ their seeds) across ranks.
+                   async_op: bool = False, global_seeds: Optional[Sequence[int]] = None):
+    """The final exchange step: literally ONE all_gather per batch.  Every rank packs its seed ids, images and
+    heat maps into one byte buffer ([ids int64 | images | heat maps], sections 16-byte aligned); one collective moves it; the
+    result is unpacked as views of the gathered buffer.
 
     Ranks may hold different batch sizes (the last, ragged round of `shard_seeds`; even zero images): every rank pads its
-    tensors to `max_batch` rows, the padding is dropped after the collective, and rows come back ordered by seed.
+    sections to `max_batch` rows (id -1), the padding is dropped after the collective, and rows come back ordered by seed.
     `max_batch` must be the same on every rank (defaults to the local batch: the equal-batch case of bench.py).
-    Returns (images, heatmaps) when `seeds` is None (equal batches, rank-interleaved = global seed order of
-    `shard_seeds`), else (seeds, images, heatmaps).  No-op for world size 1."""
+    Returns (images, heatmaps) when `seeds` is None (equal full batches: rank-interleaved = the global seed order of
+    `shard_seeds`, a pure view permutation), else (seeds, images, heatmaps).  With `global_seeds` (the sorted seeds of ALL ranks in
+    this round, which callers of `shard_seeds` know on the host) nothing here synchronises with the host: rows are ordered by a
+    masked argsort on the device and sliced by len(global_seeds); without it the seed list is read back from the gathered ids
+    (one device -> host copy).  No-op for world size 1."""
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         res = (images, heatmaps) if seeds is None else (list(seeds), images, heatmaps)
@@ -124,44 +129,53 @@ def gather_outputs(images: torch.Tensor, heatmaps: torch.Tensor, seeds: Optional
     mb = int(max_batch) if max_batch is not None else b
     if b > mb:
         raise ValueError(f"local batch {b} > max_batch {mb}")
-
-    def pad(t):
-        t = t.contiguous()
-        if t.shape[0] == mb:
-            return t
-        return torch.cat([t, t.new_zeros((mb - t.shape[0],) + tuple(t.shape[1:]))])
-
+    if seeds is None and b != mb:
+        raise ValueError("gather_outputs without seeds is the equal-batch form: pass seeds (and max_batch) for ragged rounds")
+    dev = images.device
+    ishape, hshape = tuple(images.shape[1:]), tuple(heatmaps.shape[1:])
+    ib = images[:0].new_empty((1,) + ishape).numel() * images.element_size()        # bytes per image row
+    hb = heatmaps[:0].new_empty((1,) + hshape).numel() * heatmaps.element_size()
+    a16 = lambda n: (n + 15) & ~15
+    o_img = a16(mb * 8)
+    o_hm = o_img + a16(mb * ib)
+    total = o_hm + a16(mb * hb)
+    buf = torch.zeros(total, dtype=torch.uint8, device=dev)
+    ids = buf[:mb * 8].view(torch.int64)
+    ids.fill_(-1)
+    if b:
+        if seeds is not None:
+            ids[:b] = torch.as_tensor(list(seeds), dtype=torch.int64).to(dev, non_blocking=True)
+        else:
+            ids[:b] = torch.arange(b, device=dev) * w + dist.get_rank()             # seed = rank + world * local_index
+        buf[o_img:o_img + b * ib] = images.contiguous().view(torch.uint8).reshape(-1)
+        buf[o_hm:o_hm + b * hb] = heatmaps.contiguous().view(torch.uint8).reshape(-1)
     # the collective form is chosen up front, identically on every rank (never retry a collective after one failed: the other
     # ranks would not join the second one): RCCL takes the flat form, other backends (gloo rehearsals) the list form
-    flat = dist.get_backend() == "nccl"
-
-    works = []
-
-    def gather(t):
-        """one collective per tensor; RCCL: into a single [world * mb, ...] buffer (no per-rank list copies).  Returns a thunk."""
-        t = pad(t)
-        if flat:
-            out = t.new_empty((w * mb,) + tuple(t.shape[1:]))
-            works.append(dist.all_gather_into_tensor(out, t, async_op=True))
-            return lambda: out
-        parts = [torch.empty_like(t) for _ in range(w)]
-        works.append(dist.all_gather(parts, t, async_op=True))
-        return lambda: torch.cat(parts)
-
-    ids = torch.full((mb,), -1, dtype=torch.int64, device=images.device)
-    if seeds is not None and b:
-        ids[:b] = torch.as_tensor(list(seeds), dtype=torch.int64, device=images.device)
-    elif b:
-        ids[:b] = torch.arange(b, device=images.device) * w + dist.get_rank()     # seed = rank + world * local_index
-    ti, th, ts = gather(images), gather(heatmaps), gather(ids)
+    if dist.get_backend() == "nccl":
+        out = torch.empty(w * total, dtype=torch.uint8, device=dev)
+        works = [dist.all_gather_into_tensor(out, buf, async_op=True)]
+        gathered = lambda: out.view(w, total)
+    else:
+        parts = [torch.empty_like(buf) for _ in range(w)]
+        works = [dist.all_gather(parts, buf, async_op=True)]
+        gathered = lambda: torch.stack(parts)
 
     def finish():
-        gi, gh, gs = ti(), th(), ts()
-        keep = torch.nonzero(gs >= 0).flatten()
-        order = keep[torch.argsort(gs[keep])]
-        if seeds is None:
-            return gi[order], gh[order]
-        return gs[order].tolist(), gi[order], gh[order]
+        g = gathered()                                                              # [world][total] bytes
+        gs = g[:, :mb * 8].contiguous().view(torch.int64).reshape(w * mb)
+        gi = g[:, o_img:o_img + mb * ib].contiguous().view(images.dtype).reshape((w, mb) + ishape)
+        gh = g[:, o_hm:o_hm + mb * hb].contiguous().view(heatmaps.dtype).reshape((w, mb) + hshape)
+        if seeds is None:                       # equal full batches: seed = rank + world * local index -> transpose, no sort, no sync
+            return gi.transpose(0, 1).reshape((w * mb,) + ishape), gh.transpose(0, 1).reshape((w * mb,) + hshape)
+        gi, gh = gi.reshape((w * mb,) + ishape), gh.reshape((w * mb,) + hshape)
+        key = torch.where(gs >= 0, gs, torch.full_like(gs, torch.iinfo(torch.int64).max))
+        order = torch.argsort(key)
+        if global_seeds is not None:            # the caller knows every rank's seeds of this round: no host sync at all
+            n = len(global_seeds)
+            return list(global_seeds), gi[order[:n]], gh[order[:n]]
+        srt = key[order].tolist()               # (device -> host: the seed list is part of the result)
+        n = sum(1 for s_ in srt if s_ != torch.iinfo(torch.int64).max)
+        return srt[:n], gi[order[:n]], gh[order[:n]]
 
     pend = PendingGather(works, finish)
     return pend if async_op else pend.wait()
@@ -275,7 +289,8 @@ def main(argv=None):
             hm8 = torch.zeros(0, len(words), S, S, dtype=torch.uint8, device=dev)
         if dist.get_backend() == "gloo":
             small, hm8 = small.cpu(), hm8.cpu()
-        all_seeds, small, hm8 = gather_outputs(small, hm8, seeds=chunk, max_batch=args.batch_size)
+        round_seeds = sorted(s_ for rk in range(world) for s_ in shard_seeds(args.num_images, rk, world)[r * args.batch_size:(r + 1) * args.batch_size])
+        all_seeds, small, hm8 = gather_outputs(small, hm8, seeds=chunk, max_batch=args.batch_size, global_seeds=round_seeds)
         if rank == 0:
             save_outputs(args.save_dir, all_seeds, small, hm8, words, S, stack_words=args.stack, exported=True)
     if world > 1:

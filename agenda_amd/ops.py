@@ -69,6 +69,33 @@ def layer_norm(x, gamma, beta, eps=1e-5):
     return y
 
 
+def ff_fused(x, gamma, beta, w1, b1, w2, b2, eps=1e-5):
+    """x + ff.net.2(GEGLU(ff.net.0(LayerNorm(x)))) as ONE launch (tblock.hip); x [..., C], w1 [8C, C] (value rows then gate rows), w2 [C, 4C]."""
+    lib = _lib.load()
+    Cc = x.shape[-1]
+    x2 = _f32c(x).reshape(-1, Cc)
+    y = torch.empty_like(x2)
+    _lib.check(lib.agd_op_ff_fused(_lib.ptr(x2), _lib.ptr(_f32c(gamma)), _lib.ptr(_f32c(beta)), _lib.ptr(_f32c(w1)), _lib.ptr(_f32c(b1)),
+                                   _lib.ptr(_f32c(w2)), _lib.ptr(_f32c(b2)), _lib.ptr(y), x2.shape[0], Cc, float(eps),
+                                   _lib.current_stream_ptr()), None, "agd_op_ff_fused")
+    return y.reshape(x.shape)
+
+
+def attn_chain(x, gamma, beta, wq, kv, wo, bo, heads=8, eps=1e-5, return_probs=False):
+    """x + to_out(attention(to_q(LayerNorm(x)), k, v)) as ONE launch (tblock.hip); x [B, HW, C], kv [B, T, 2C] (K columns then V columns).
+    With return_probs: also the probabilities summed over the heads, [B, T, HW]."""
+    lib = _lib.load()
+    x, kv = _f32c(x), _f32c(kv)
+    B, HW, Cc = x.shape
+    T = kv.shape[1]
+    y = torch.empty_like(x)
+    pr = torch.empty(B, T, HW, device=x.device, dtype=torch.float32) if return_probs else None
+    _lib.check(lib.agd_op_attn_chain(_lib.ptr(x), _lib.ptr(_f32c(gamma)), _lib.ptr(_f32c(beta)), _lib.ptr(_f32c(wq)), _lib.ptr(kv), _lib.ptr(_f32c(wo)),
+                                     _lib.ptr(_f32c(bo)), _lib.ptr(y), _lib.ptr(pr), B, HW, T, Cc, heads, float(eps), _lib.current_stream_ptr()),
+               None, "agd_op_attn_chain")
+    return (y, pr) if return_probs else y
+
+
 def attention(q, k, v, heads, scale=None, return_probs=False):
     """q [B,Nq,H*D], k/v [B,Nk,H*D] -> o [B,Nq,H*D] (+ probs [B,H,Nk,Nq] token-major if asked, Nk<=96)."""
     lib = _lib.load()

@@ -517,7 +517,9 @@ class StableDiffusionPipeline:
             sc = SchedulerConfig(sj.get("num_train_timesteps", 1000), sj.get("beta_start", 0.00085), sj.get("beta_end", 0.012),
                                  sj.get("steps_offset", 1), sj.get("set_alpha_to_one", False), sj.get("prediction_type", "epsilon"),
                                  # diffusers' PNDMScheduler defaults skip_prk_steps to False; SD checkpoints store True
-                                 bool(sj.get("skip_prk_steps", False)) if sched_name == "PNDMScheduler" else True)
+                                 # (that default applies only when the JSON itself is a PNDMScheduler config: an explicit scheduler="PNDMScheduler"
+                                 # override on a DDIM checkpoint has no such key and means the SD form, skip_prk_steps=True)
+                                 bool(sj.get("skip_prk_steps", False)) if sj.get("_class_name") == "PNDMScheduler" else True)
         cfg = SDConfig(name=os.path.basename(path.rstrip("/")), unet=ucfg, vae=vcfg, sched=sc,
                        default_sample_size=uc.get("sample_size", 64))
         src_path = path
@@ -576,21 +578,47 @@ class StableDiffusionPipeline:
             raise ValueError("save_pretrained: this pipeline was built from in-memory weights (no checkpoint directory to re-export)")
         src, dst = self._source_path, save_directory
         os.makedirs(dst, exist_ok=True)
+        same = os.path.realpath(src) == os.path.realpath(dst)          # saving over the source: nothing to copy, only the rewritten files
         for sub in ("unet", "vae", "scheduler"):
-            if os.path.isdir(os.path.join(src, sub)):
+            if not same and os.path.isdir(os.path.join(src, sub)):
                 shutil.copytree(os.path.join(src, sub), os.path.join(dst, sub), dirs_exist_ok=True)
+        sched_cls = type(self.scheduler).__name__
+        sp = os.path.join(src, "scheduler", "scheduler_config.json")
+        sj = {}
+        if os.path.exists(sp):
+            with open(sp) as f:
+                sj = json.load(f)
+        if sj.get("_class_name") != sched_cls:
+            # the pipeline runs a different scheduler than the source directory names (from_pretrained(..., scheduler=...)): a reload
+            # must give the scheduler this pipeline ran, so its config is written from the live objects
+            sc = self.cfg.sched
+            sj = {"_class_name": sched_cls, "num_train_timesteps": sc.num_train_timesteps, "beta_start": sc.beta_start, "beta_end": sc.beta_end,
+                  "beta_schedule": "scaled_linear", "steps_offset": sc.steps_offset, "set_alpha_to_one": sc.set_alpha_to_one,
+                  "prediction_type": sc.prediction_type}
+            if sched_cls == "PNDMScheduler":
+                sj["skip_prk_steps"] = bool(sc.skip_prk_steps)
+            os.makedirs(os.path.join(dst, "scheduler"), exist_ok=True)
+            with open(os.path.join(dst, "scheduler", "scheduler_config.json"), "w") as f:
+                json.dump(sj, f, indent=2)
         mi = os.path.join(src, "model_index.json")
+        mj = None
         if os.path.exists(mi):
-            shutil.copy(mi, os.path.join(dst, "model_index.json"))
-        else:
-            with open(os.path.join(dst, "model_index.json"), "w") as f:
-                json.dump({"_class_name": "StableDiffusionPipeline", "unet": ["diffusers", "UNet2DConditionModel"], "vae": ["diffusers", "AutoencoderKL"],
-                           "scheduler": ["diffusers", type(self.scheduler).__name__], "text_encoder": ["transformers", "CLIPTextModel"],
-                           "tokenizer": ["transformers", "CLIPTokenizer"], "safety_checker": [None, None]}, f, indent=2)
+            with open(mi) as f:
+                mj = json.load(f)
+        if mj is None:
+            mj = {"_class_name": "StableDiffusionPipeline", "unet": ["diffusers", "UNet2DConditionModel"], "vae": ["diffusers", "AutoencoderKL"],
+                  "text_encoder": ["transformers", "CLIPTextModel"], "tokenizer": ["transformers", "CLIPTokenizer"], "safety_checker": [None, None]}
+        mj["scheduler"] = ["diffusers", sched_cls]
+        with open(os.path.join(dst, "model_index.json"), "w") as f:
+            json.dump(mj, f, indent=2)
         te = os.path.join(src, "text_encoder")
         if os.path.isdir(te):
             os.makedirs(os.path.join(dst, "text_encoder"), exist_ok=True)
-            fn = next(f for f in ("model.safetensors", "diffusion_pytorch_model.safetensors") if os.path.exists(os.path.join(te, f)))
+            cands = ("model.safetensors", "diffusion_pytorch_model.safetensors")
+            fn = next((f for f in cands if os.path.exists(os.path.join(te, f))), None)
+            if fn is None:
+                raise _lib.AgendaHipError(f"save_pretrained: no single-file safetensors text encoder under {te} (looked for {', '.join(cands)}; "
+                                          "pytorch_model.bin and sharded checkpoints are not re-exported)")
             tsd = load_file(os.path.join(te, fn))
             key = next(k for k in tsd if k.endswith("embeddings.token_embedding.weight"))
             w = self.text_encoder.get_input_embeddings().weight
@@ -655,14 +683,18 @@ class StableDiffusionPipeline:
             prompt_embeds = self.encode_prompt(prompts, negs)
         B = prompt_embeds.shape[0] // 2
         if latents is None:
-            gens = generator if isinstance(generator, (list, tuple)) else [generator] * B
-            parts = []
-            for g in gens:
-                # data_generation.py:58 seeds `torch.Generator(device="cuda")`: accepted (torch's device Philox stream; whether it is
-                # bit-identical to an NVIDIA run of the reference is not verifiable here).  CPU generators give host-reproducible latents.
-                dev_g = g.device if g is not None else "cpu"
-                parts.append(torch.randn(1, self.cfg.unet.in_channels, L, L, generator=g, device=dev_g).cpu())
-            latents = torch.cat(parts, 0)
+            # data_generation.py:58 seeds `torch.Generator(device="cuda")`: accepted (torch's device Philox stream; whether it is
+            # bit-identical to an NVIDIA run of the reference is not verifiable here).  CPU generators give host-reproducible latents.
+            Cl = self.cfg.unet.in_channels
+            if isinstance(generator, (list, tuple)):           # diffusers randn_tensor: one (1, C, L, L) draw per generator
+                if len(generator) != B:
+                    raise ValueError(f"You have passed a list of generators of length {len(generator)}, but requested an effective batch size of {B}.")
+                parts = [torch.randn(1, Cl, L, L, generator=g, device=g.device if g is not None else "cpu") for g in generator]
+                if len({p_.device for p_ in parts}) > 1:
+                    parts = [p_.cpu() for p_ in parts]
+                latents = torch.cat(parts, 0)
+            else:                                              # ONE (B, C, L, L) draw, kept on the generator's device (no host round trip)
+                latents = torch.randn(B, Cl, L, L, generator=generator, device=generator.device if generator is not None else "cpu")
         expect = (B, self.cfg.unet.in_channels, L, L)
         if tuple(latents.shape) != expect:                 # diffusers prepare_latents raises the same way
             raise ValueError(f"Unexpected latents shape, got {tuple(latents.shape)}, expected {expect}")

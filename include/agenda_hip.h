@@ -116,7 +116,9 @@ int agd_vae_encode(agd_ctx* ctx, const float* image, int batch, int side, float*
  * >= 1 MB of weights and 1024 <= M <= 32768 (the touch launches then disappear).
  * "igemm8p" (default 1): launches with enough 256-row tiles (wide 1x1 projections, 3x3 convs with N a multiple of 256, the
  * upsampling convs) run the 8-wave / 8-phase implicit-GEMM kernel (igemm8p.h); 0 = the 4-wave kernels everywhere; tests: 2 / 3 / 4
- * force its 256-wide / 160-wide / any legal tile. */
+ * force its 256-wide / 160-wide / any legal tile.
+ * "tblock_fuse" (default 3): fused row-panel kernels of the transformer blocks at C = 320 (tblock.hip) -- bit 0: norm3 -> GEGLU ->
+ * ff.net.2 + residual as one launch, bit 1: norm2 -> to_q -> cross-attention (+ recorder) -> to_out + residual as one launch. */
 int agd_set_option(agd_ctx* ctx, const char* name, int value);
 
 /* ---- heat-map recording (daam.trace / hook.py UNetCrossAttentionHooker state)
@@ -179,6 +181,17 @@ int agd_op_conv2d_ex(const float* x, const float* w, const float* bias, float* y
                      int ksize, int stride, int pad, int upsample, int flags, void* stream);
 int agd_op_linear(const float* x, const float* w, const float* bias, const float* residual, float* y, int M, int K,
                   int N, int geglu, void* stream);
+/* BasicTransformerBlock's feed-forward tail as ONE launch (tblock.hip): y = x + ff.net.2(GEGLU(ff.net.0(norm3(x)))), the op sequence
+ * diffusers runs behind reference data_generation/data_generation.py:59; x / y [M][C] fp32, w1 [8C][C] (value rows then gate rows),
+ * b1 [8C], w2 [C][4C], b2 [C]; C = 320 (the 64 x 64 maps' blocks) */
+int agd_op_ff_fused(const float* x, const float* gamma, const float* beta, const float* w1, const float* b1, const float* w2,
+                    const float* b2, float* y, int M, int C, float eps, void* stream);
+/* BasicTransformerBlock's attn2 section as ONE launch (tblock.hip): y = x + to_out(softmax(scale to_q(norm2(x)) k^T) v), the processor body of
+ * reference data_generation/hook.py:91-120 with the LayerNorm in front and the residual behind it; x / y [B * HW][C] fp32, kv [B][T][2C] =
+ * the projected context (to_k columns then to_v columns), probs_sum (optional) [B][T][HW] = the probabilities summed over the heads;
+ * C = 320, 8 heads, T <= 96, HW a multiple of 128 */
+int agd_op_attn_chain(const float* x, const float* gamma, const float* beta, const float* wq, const float* kv, const float* wo,
+                      const float* bo, float* y, float* probs_sum, int B, int HW, int T, int C, int heads, float eps, void* stream);
 int agd_op_groupnorm(const float* x_nchw, const float* gamma, const float* beta, float* y_nchw, int B, int C, int HW,
                      int groups, float eps, int silu, void* stream);
 /* conv3x3(+bias) -> GroupNorm(+SiLU), chained as the graph walk chains them; fused != 0: the conv launch emits the per-channel

@@ -11,6 +11,13 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the CPU oracle's thread pool: a 1-GPU box grants 16 host cores but reports the whole machine's count, and an oversubscribed
+    # pool runs the oracle ~3x slower (50 DDIM steps at 512 px: 596 s against ~220 s); same rule as bench.py's cpu_baseline leg
+    try:
+        import torch
+        torch.set_num_threads(int(os.environ.get("AGD_CPU_THREADS", min(os.cpu_count() or 1, 16))))
+    except Exception:
+        pass
 
 
 def pytest_collection_modifyitems(config, items):

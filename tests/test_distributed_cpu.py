@@ -46,15 +46,25 @@ def _ragged_worker(rank, world, port, out_dir, num_images, batch):
     per_rank = (num_images + world - 1) // world
     rounds = (per_rank + batch - 1) // batch                  # every rank joins every round (generation.main)
     got_s, got_i, got_h = [], [], []
+    calls = {"n": 0}
+    real_all_gather = dist.all_gather
+
+    def counted(*a, **k):
+        calls["n"] += 1
+        return real_all_gather(*a, **k)
+    dist.all_gather = counted                                 # gloo takes the list form; RCCL all_gather_into_tensor
     for r in range(rounds):
         chunk = seeds[r * batch:(r + 1) * batch]              # may be shorter than `batch`, or empty
         imgs = torch.stack([torch.full((4, 4, 3), s, dtype=torch.uint8) for s in chunk]) if chunk else torch.zeros(0, 4, 4, 3, dtype=torch.uint8)
         hms = torch.stack([torch.full((2, 8, 8), float(s)) for s in chunk]) if chunk else torch.zeros(0, 2, 8, 8)
         if r % 2:                                             # both forms: blocking, and posted-then-waited (bench.py's overlap)
             s_, i_, h_ = gather_outputs(imgs, hms, seeds=chunk, max_batch=batch, async_op=True).wait()
-        else:
-            s_, i_, h_ = gather_outputs(imgs, hms, seeds=chunk, max_batch=batch)
+        else:                                                 # generation.main's form: the round's seeds are known on the host -> no sync
+            gseeds = sorted(x for rk in range(world) for x in shard_seeds(num_images, rk, world)[r * batch:(r + 1) * batch])
+            s_, i_, h_ = gather_outputs(imgs, hms, seeds=chunk, max_batch=batch, global_seeds=gseeds)
         got_s += s_; got_i.append(i_); got_h.append(h_)
+    dist.all_gather = real_all_gather
+    assert calls["n"] == rounds, (calls, rounds)              # literally ONE collective per batch (ids + images + heat maps in one buffer)
     np.save(os.path.join(out_dir, f"s{rank}.npy"), np.array(got_s))
     np.save(os.path.join(out_dir, f"i{rank}.npy"), torch.cat(got_i).numpy())
     np.save(os.path.join(out_dir, f"h{rank}.npy"), torch.cat(got_h).numpy())

@@ -89,6 +89,58 @@ def test_linear(ops, M, K, N, geglu, res):
     assert rel_err(got, y) < 1e-4
 
 
+@pytest.mark.parametrize("M", [128, 1000, 4096 * 2])      # one tile; ragged tail (1000 = 7 x 128 + 104); many tiles
+def test_ff_fused_matches_torch_and_the_unfused_kernels(ops, M):
+    """tblock.hip ff_fused_kernel (norm3 -> GEGLU -> ff.net.2 + residual in one launch, the hidden activation never in HBM) vs fp32 torch
+    on bf16-exact inputs, and vs the chain of kernels it replaces (layer_norm -> linear GEGLU -> linear + residual).  The fused path
+    rounds the hidden activation to bf16 once (as the unfused path does when it stores it) and the output once."""
+    C = 320
+    g = torch.Generator().manual_seed(M)
+    x = bfr(torch.randn(M, C, generator=g) * 1.5 + 0.3)
+    ga, be = torch.randn(C, generator=g) * 0.2 + 1, torch.randn(C, generator=g) * 0.2
+    w1 = bfr(torch.randn(8 * C, C, generator=g) / math.sqrt(C)); b1 = torch.randn(8 * C, generator=g) * 0.1
+    w2 = bfr(torch.randn(C, 4 * C, generator=g) / math.sqrt(4 * C)); b2 = torch.randn(C, generator=g) * 0.1
+    val, gate = F.linear(F.layer_norm(x, (C,), ga, be, 1e-5), w1, b1).chunk(2, dim=-1)
+    want = x + F.linear(val * F.gelu(gate), w2, b2)
+    cu = lambda t: t.cuda()
+    got = ops.ff_fused(cu(x), cu(ga), cu(be), cu(w1), cu(b1), cu(w2), cu(b2))
+    hid = ops.linear(ops.layer_norm(cu(x), cu(ga), cu(be)), cu(w1), cu(b1), geglu=True)
+    unf = ops.linear(hid, cu(w2), cu(b2), cu(x))
+    e_t, e_u = rel_err(got, want), rel_err(got, unf.cpu())
+    print(f"ff_fused M={M}: vs torch {e_t:.5f}, vs unfused kernels {e_u:.5f}")
+    assert e_t < REL, e_t                # bf16 hidden activation + bf16 output against fp32 torch
+    assert e_u < REL, e_u
+    assert torch.equal(got, ops.ff_fused(cu(x), cu(ga), cu(be), cu(w1), cu(b1), cu(w2), cu(b2)))      # run-to-run identical
+
+
+@pytest.mark.parametrize("B,HW,T", [(1, 128, 77), (2, 256, 77), (2, 4096, 77), (1, 1024, 96), (1, 384, 33)])
+def test_attn_chain_fused_matches_torch(ops, B, HW, T):
+    """tblock.hip attn_chain_kernel (norm2 -> to_q -> cross-attention -> to_out + residual, with the head-summed probability side output
+    of the DAAM recorder) vs fp32 torch on bf16-exact inputs: the op sequence of data_generation/hook.py:91-120 (explicit softmax) behind
+    a LayerNorm, SD-1.5's 64 x 64 block shape (C = 320, 8 heads of 40)."""
+    C, H = 320, 8
+    D = C // H
+    g = torch.Generator().manual_seed(B * 1000 + HW + T)
+    x = bfr(torch.randn(B, HW, C, generator=g) * 1.2 + 0.2)
+    ga, be = torch.randn(C, generator=g) * 0.2 + 1, torch.randn(C, generator=g) * 0.2
+    wq = bfr(torch.randn(C, C, generator=g) / math.sqrt(C)); wo = bfr(torch.randn(C, C, generator=g) / math.sqrt(C))
+    bo = torch.randn(C, generator=g) * 0.1
+    kv = bfr(torch.randn(B, T, 2 * C, generator=g))
+    qh = F.linear(F.layer_norm(x, (C,), ga, be, 1e-5), wq).reshape(B, HW, H, D).permute(0, 2, 1, 3)
+    kh = kv[..., :C].reshape(B, T, H, D).permute(0, 2, 1, 3); vh = kv[..., C:].reshape(B, T, H, D).permute(0, 2, 1, 3)
+    P = torch.softmax(qh @ kh.transpose(-1, -2) / math.sqrt(D), dim=-1)                  # [B, H, HW, T]
+    want = x + F.linear((P @ vh).permute(0, 2, 1, 3).reshape(B, HW, C), wo, bo)
+    want_p = P.sum(1).transpose(1, 2)                                                    # [B, T, HW]
+    cu = lambda t: t.cuda()
+    got, pr = ops.attn_chain(cu(x), cu(ga), cu(be), cu(wq), cu(kv), cu(wo), cu(bo), heads=H, return_probs=True)
+    e_y, e_p = rel_err(got, want), float((pr.cpu() - want_p).abs().max())
+    print(f"attn_chain B={B} HW={HW} T={T}: out {e_y:.5f}, head-summed probabilities max abs {e_p:.5f}")
+    assert e_y < REL, e_y
+    assert e_p < 8 * 2e-3, e_p                             # sum of 8 heads' probabilities (2e-3 each: bf16 Q / K operands)
+    got2, pr2 = ops.attn_chain(cu(x), cu(ga), cu(be), cu(wq), cu(kv), cu(wo), cu(bo), heads=H, return_probs=True)
+    assert torch.equal(got, got2) and torch.equal(pr, pr2)                               # run-to-run identical (no atomics)
+
+
 @pytest.mark.parametrize("B,C,H,groups,silu,eps", [
     (2, 320, 16, 32, True, 1e-5), (1, 1920, 8, 32, True, 1e-5), (2, 2560, 4, 32, False, 1e-6),
     (1, 128, 64, 32, True, 1e-6), (2, 64, 8, 32, False, 1e-5), (1, 960, 16, 32, True, 1e-5),
