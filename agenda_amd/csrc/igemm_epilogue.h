@@ -18,6 +18,7 @@
 // Summation order per row is unchanged (slot 0, 1, ...).  lds_stats != nullptr: the kernel prologue already left (mean, rstd) of
 // the tile's rows in LDS (igemm8p.h).
 typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef u32x4 __attribute__((aligned(8))) u32x4_a8;      // 16-byte access at an 8-byte aligned address
 template <int MI>
 AGD_DEV void ln_row_stats(const IgemmP& p, int mrow0, int row0_tile, const float* lds_stats, float (&lmu)[MI], float (&lrs)[MI]) {
   if (lds_stats) {
@@ -100,10 +101,18 @@ AGD_DEV void igemm_epilogue(const IgemmP& p, f32x4 (&acc)[BM / WM / 16][BN / WN 
         const int m = mrow0 + i * 16;
         if (m < p.M) {
           const bf16_t* rp = p.residual + bz * p.sR + (long long)m * p.ldr + no;
+          if constexpr (SV == 4 && CW % 8 == 4) {
+            // the 160-wide tile's 20 channels per lane = 40 bytes, 8-byte aligned: 16 + 16 + 8-byte accesses instead of five 8-byte ones (the
+            // row-per-lane epilogue is load / store ISSUE bound, MI355X_MICROARCH.md 'attention epilogue store tail')
+#pragma unroll
+            for (int c = 0; c < CW / 8; ++c) { const u32x4 t = *(const u32x4_a8*)(rp + 8 * c); rres[slot][4 * c] = t[0]; rres[slot][4 * c + 1] = t[1]; rres[slot][4 * c + 2] = t[2]; rres[slot][4 * c + 3] = t[3]; }
+            const u32x2 t = *(const u32x2*)(rp + CW - 4); rres[slot][CW / 2 - 2] = t[0]; rres[slot][CW / 2 - 1] = t[1];
+          } else {
 #pragma unroll
           for (int c = 0; c < CW / SV; ++c) {
             if constexpr (SV == 8) { const u32x4 t = *(const u32x4*)(rp + 8 * c); rres[slot][4 * c] = t[0]; rres[slot][4 * c + 1] = t[1]; rres[slot][4 * c + 2] = t[2]; rres[slot][4 * c + 3] = t[3]; }
             else { const u32x2 t = *(const u32x2*)(rp + 4 * c); rres[slot][2 * c] = t[0]; rres[slot][2 * c + 1] = t[1]; }
+          }
           }
         }
       };
@@ -203,6 +212,19 @@ AGD_DEV void igemm_epilogue(const IgemmP& p, f32x4 (&acc)[BM / WM / 16][BN / WN 
         } else {
           bf16_t* op = (bf16_t*)p.out + bz * p.sO + (long long)m * p.ldo + no;
           bf16_t* lp = ctile ? ctile + (i * 16 + px) * WTN + q * CA : nullptr;
+          if constexpr (SV == 4 && CW % 8 == 4) {
+#pragma unroll
+            for (int c = 0; c < CW / 8; ++c) {
+              u32x4 pk;
+              pk[0] = pack_bf2(v[8 * c], v[8 * c + 1]); pk[1] = pack_bf2(v[8 * c + 2], v[8 * c + 3]);
+              pk[2] = pack_bf2(v[8 * c + 4], v[8 * c + 5]); pk[3] = pack_bf2(v[8 * c + 6], v[8 * c + 7]);
+              *(u32x4_a8*)(op + 8 * c) = pk;
+              if (lp) *(u32x4_a8*)(lp + 8 * c) = pk;
+            }
+            u32x2 pk; pk[0] = pack_bf2(v[CW - 4], v[CW - 3]); pk[1] = pack_bf2(v[CW - 2], v[CW - 1]);
+            *(u32x2*)(op + CW - 4) = pk;
+            if (lp) *(u32x2*)(lp + CW - 4) = pk;
+          } else
 #pragma unroll
           for (int c = 0; c < CW / SV; ++c) {
             if constexpr (SV == 8) {

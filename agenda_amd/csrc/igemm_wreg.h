@@ -1,0 +1,114 @@
+// Weight-streaming 1x1 igemm for the small feature maps (round 4): W fragments straight to registers, activations through LDS.
+//
+// The 16 x 16 / 32 x 32 maps' linears (C -> C projections, qkv, ff.net.2) are INGEST bound in igemm_kernel:
+// both operands enter the CU through the LDS-DMA path (~30 B/clk/CU), and at M = 2048, K = N = 1280 a 64 x 160 tile moves 573 KB through it
+// for 26 MFLOP (16.7 us per launch against a 3 us MFMA floor).  Here the weight matrix -- the larger operand of these launches -- is
+// re-laid at load time in MFMA FRAGMENT ORDER (tblock.hip, launch_frag_order_w), so that the 1 KiB a wave's A-operand needs is one
+// coalesced 16-byte-per-lane global load: it goes straight to registers through the vector-memory path (64 B/clk/CU), in parallel with
+// the activation tile, which alone still goes through LDS (register-staged: plain loads + ds_write, so that every load of the loop is
+// of ONE kind and hipcc's counted waits stay counted -- cdna_hip_programming.md, 'Three .s-level traps' (b)).
+//   tile 64 rows x (4 waves x NI x 16) columns, waves 1 x 4: every weight fragment is fetched by exactly one wave of the workgroup and
+//   feeds four MFMAs (the four 16-row tiles); operand roles swapped as in igemm_kernel, so igemm_epilogue.h runs unchanged behind it.
+#pragma once
+#include "igemm_epilogue.h"
+
+#define WR_F 8      // weight-fragment ring (registers), filled WR_D fragments ahead
+#define WR_D 6
+template <int NI, int GEGLU>
+__global__ __launch_bounds__(256, 2) void igemm_wreg_kernel(const IgemmP p) {
+  constexpr int BM = 64, WN = 4, BN = WN * NI * 16, WTN = NI * 16, MI = 4;
+  constexpr int STG = 3, A_BYTES = BM * 128;           // activation ring: 3 stages of [64 rows][64 k] bf16, 128-byte rows, chunk ^ (row & 7)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tiles_n = p.N / BN, tiles_m = (p.M + BM - 1) / BM;
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  int tn, tm;
+  if (p.wmajor) { tm = bid % tiles_m; tn = bid / tiles_m; } else { tn = bid % tiles_n; tm = bid / tiles_n; }
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int nk = p.K >> 6;                              // stages of 64 k
+
+  // activation staging: thread t fetches chunks (row = t / 8 + 32 u, chunk t % 8), u = 0, 1, of every stage
+  const int arow = tid >> 3, ach = tid & 7;
+  const bf16_t* ap[2]; bool aok[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) { const int m = m0 + arow + 32 * u; aok[u] = m < p.M; ap[u] = p.src0 + (long long)(aok[u] ? m : 0) * p.K + ach * 8; }
+  const int awoff[2] = {(arow) * 128 + ((ach ^ (arow & 7)) << 4), (arow + 32) * 128 + ((ach ^ (arow & 7)) << 4)};
+  u32x4 areg[2][2];                                     // two stages in flight
+  auto a_load = [&](int slot, int s) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) areg[slot][u] = aok[u] ? *(const u32x4*)(ap[u] + s * 64) : u32x4{0, 0, 0, 0};
+  };
+  auto a_store = [&](int slot, int stg) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) *(u32x4*)(smem + stg * A_BYTES + awoff[u]) = areg[slot][u];
+  };
+
+  // weight stream of this wave: fragments (k-step of 32, tile j) in consumption order, (n0 / 16 / NI + wid) is the wave's column range
+  const auto wrs = __builtin_amdgcn_make_buffer_rsrc((void*)p.Wfrag, 0, (unsigned)((long long)p.N * p.K * 2), 0x00020000);
+  const unsigned lane16 = (unsigned)lane * 16u;
+  const int KS = p.K >> 5, NFR = KS * NI;
+  const unsigned wbase = __builtin_amdgcn_readfirstlane((unsigned)(((n0 / WTN + wid) * KS) * NI) * 1024u);
+  u32x4 ring[WR_F];
+  auto ldw = [&](int f) { return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, lane16, wbase + (unsigned)f * 1024u, 0)); };
+
+  f32x4 acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // prologue: activation stages 0, 1 requested, the ring's head in flight, stage 0 into LDS
+  a_load(0, 0);
+  if (nk > 1) a_load(1, 1);
+#pragma unroll
+  for (int f = 0; f < WR_D; ++f) ring[f] = ldw(f < NFR ? f : 0);
+  a_store(0, 0);
+  __syncthreads();
+
+  const int frow = lane & 15, fq = lane >> 4;
+  const int foff[2] = {frow * 128 + (((0 + fq) ^ (lane & 7)) << 4), frow * 128 + (((4 + fq) ^ (lane & 7)) << 4)};
+  // per stage: {store stage s+1 (requested two stages ago) | request stage s+2 | 2 k-steps of (NI weight fragments, 4 activation fragments,
+  // 4 NI MFMAs)} | barrier.  Fragment f = 2 NI s + NI kk + j sits in ring slot f % WR_F: the stage loop is unrolled by WR_F / gcd so that
+  // slots are compile-time -- 2 NI fragments per stage and WR_F = 8 give a period of 2 (NI = 2) or 1 (NI = 4) stages.
+  constexpr int FPS = 2 * NI, PER = WR_F / FPS > 0 ? WR_F / FPS : 1;
+  static_assert(WR_F % FPS == 0 || FPS % WR_F == 0, "ring period");
+  auto stage = [&](int s, auto ph_tag) {
+    constexpr int PH = decltype(ph_tag)::value;         // s % PER
+    const int cur = s % STG;
+    if (s + 1 < nk) a_store((s + 1) & 1, (s + 1) % STG);
+    if (s + 2 < nk) a_load(s & 1, s + 2);
+    const char* sA = smem + cur * A_BYTES;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      bf16x8 xf[MI];
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        constexpr int dummy = 0; (void)dummy;
+        const int fl = (PH * FPS + kk * NI + j);          // fragment index within the period
+        const int f = s * FPS + kk * NI + j;
+        const int tgt = f + WR_D;
+        ring[(fl + WR_D) % WR_F] = ldw(tgt < NFR ? tgt : NFR - 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (j == 0) {
+#pragma unroll
+          for (int i = 0; i < MI; ++i) xf[i] = *(const bf16x8*)(sA + i * 2048 + foff[kk]);
+        }
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ring[fl % WR_F]), xf[i], acc[i][j], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  };
+  {
+    using P0 = std::integral_constant<int, 0>; using P1 = std::integral_constant<int, 1 % PER>;
+    int s = 0;
+    for (; s + PER <= nk; s += PER) {
+      stage(s, P0{});
+      if constexpr (PER > 1) stage(s + 1, P1{});
+    }
+    if constexpr (PER > 1) { if (s < nk) stage(s, P0{}); }
+  }
+  igemm_epilogue<BM, BN, 1, WN, GEGLU, 0>(p, acc, smem, lane, 0, wid, m0, n0, tn, 0, nullptr);
+}

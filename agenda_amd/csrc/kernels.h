@@ -50,6 +50,7 @@ struct IgemmP {
   // holds in registers and writes gn_y = silu?(gn(out)); `out` itself is written only with gn_keep_out.  The launcher sets *gn_fused
   // (host) to 1 when it took this form; otherwise the caller runs the GroupNorm kernels as before.
   const float* gn_gamma; const float* gn_beta; bf16_t* gn_y; int gn_groups; float gn_eps; int gn_silu; int gn_keep_out; int* gn_fused;
+  const bf16_t* Wfrag; int wfrag_ni; // the same matrix in MFMA fragment order for the weight-streaming kernel (igemm_wreg.h): column ranges of wfrag_ni x 16, KC = K
   int stagger;                      // timing experiments only: start delay of the CU's second workgroup, x1024 cycles
   int dbg;                          // timing experiments only (builds with -DAGD_EXPERIMENTS)
 };
@@ -90,6 +91,9 @@ struct FFusedP {
   const bf16_t* w2f;                // ff.net.2 [C][4C] in fragment order (launch_frag_order_w, NI = C / 64, KC = 128)
   const float* b2;                  // [C]
   int M; float ln_eps;
+  // optional proj_out stage behind it (wpf != NULL): pout = (h + FF(h)) . Wp^T + bp + xres; `out` is then not written.
+  // colstat (optional): [M / 128][C] float2 per-(tile, channel) sums of the bf16 outputs for the GroupNorm that reads pout
+  const bf16_t* wpf; const float* bp; const bf16_t* xres; bf16_t* pout; float* colstat;
 };
 int launch_ff_fused(const FFusedP& p, int C, hipStream_t st);
 // norm2 -> to_q -> cross-attention (77 keys, recorder optional) -> to_out + bias + residual in one launch; 8 heads of 40
@@ -102,6 +106,8 @@ struct AttnChainP {
   int M, HW, T; float scale;
   int record; float* rec; long long rec_img_stride, rec_head_stride; int rec_T, rec_b0, rec_hpb;   // as AttnP record_mode 3 (rec_hpb in {1, 2, 4, 8})
   float* rowstat_out;               // optional: [M] float2 (sum, sum of squares) of the bf16 outputs (LayerNorm-fold producer, one slot)
+  // optional prologue (o1 != NULL): h1 = o1 . Wo1^T + bo1 + h first (attn1.to_out + residual); h1 goes to `out` (!= h) and is the chain's input
+  const bf16_t* o1; const bf16_t* wo1f; const float* bo1;
 };
 int launch_attn_chain(const AttnChainP& p, int C, int heads, hipStream_t st);
 int launch_frag_order_w1(const bf16_t* src, bf16_t* dst, int C, int HID, hipStream_t st);

@@ -109,7 +109,8 @@ struct agd_ctx {
   int opt_gn_proj_fold = 1;                           // agd_set_option("gn_proj_fold"): the transformers' GroupNorm folded into per-image proj_in matrices (1: C <= 320, 2: C <= 640)
   int opt_p8 = 1;                                     // agd_set_option("igemm8p"): 256-row 8-wave / 8-phase igemm for launches with enough tiles (igemm8p.h)
   int opt_halo = 1;                                   // agd_set_option("conv_halo"): 3x3 stride-1 convs through the row-halo kernel (igemm_halo.h)
-  int opt_tb_fuse = 3;                                // agd_set_option("tblock_fuse"): fused row-panel kernels of the C = 320 transformer blocks (tblock.hip): bit 0 = feed-forward, bit 1 = attn2 chain
+  int opt_tb_fuse = 15;                               // agd_set_option("tblock_fuse"): fused row-panel kernels of the C = 320 transformer blocks (tblock.hip): bit 0 = feed-forward (bit 3: + proj_out),
+                                                      // bit 1 = attn2 chain (bit 2: + attn1.to_out in front of it)
   int opt_reduce_gn = 1;                              // agd_set_option("reduce_gn"): split-K slab sum + the GroupNorm that reads it as one launch (igemm.hip splitk_reduce_gn_kernel)
   int opt_touch = 3;                                  // agd_set_option("weight_touch"): n > 0 = stream 1x1 weight matrices of >= n MB through the caches right before their launch
   unsigned* touch_sink = nullptr;
@@ -463,6 +464,7 @@ static int transformer(agd_ctx* c, hipStream_t st, const std::string& pre, const
   // image; the hook.py recorder (per-head maps of every call) keeps the kernel chain
   const bool ff_fused = (c->opt_tb_fuse & 1) && fold && C == 320 && c->W.count(t + "ff.w1.frag");
   const bool chain_fuse = (c->opt_tb_fuse & 2) && C == 320 && heads == 8 && HW % 128 == 0 && c->ctx_T <= 96 && c->rec_mode != 2 && c->W.count(t + "attn2.to_q.frag");
+  const bool chain_pre = chain_fuse && (c->opt_tb_fuse & 4) && !dup && c->W.count(t + "attn1.to_out.frag");     // attn1.to_out + residual inside the chain launch
   // --- self attention ---
   { CK(consume(t + "norm1", t + "attn1.qkv", nullptr, 0, qkv));
     AttnP a{}; a.q = qkv; a.k = qkv + C; a.v = qkv + 2 * C; a.o = att;
@@ -471,7 +473,8 @@ static int transformer(agd_ctx* c, hipStream_t st, const std::string& pre, const
     CK(run_attention(c, st, PC_ATTN_SELF, a));
     GETW(wo, t + "attn1.to_out.0.weight"); GETV(bo, t + "attn1.to_out.0.bias");
     GemmOpt oo; oo.bias = bo; oo.residual = h.p;
-    CK(produce(att, C, *wo, oo, h.p, false, !chain_fuse)); }      // (the fused attn2 chain takes norm2's statistics from the rows themselves)
+    // (the fused attn2 chain takes norm2's statistics from the rows themselves; with bit 2 it also starts at this very GEMM)
+    if (!chain_pre) CK(produce(att, C, *wo, oo, h.p, false, !chain_fuse)); }
   if (dup) {                                           // the halves diverge from here on (text context)
     CK(dup_half(c, st, h.p, (long long)M * C));
     if (fold && stats) { ProfScope ps(c, st, PC_ELEM, 0);
@@ -502,13 +505,19 @@ static int transformer(agd_ctx* c, hipStream_t st, const std::string& pre, const
         ap.rec_head_stride = (long long)c->rec_T * HW; ap.rec_img_stride = ap.rec_head_stride * xl.acc_heads;
         rec_bytes = 8.0 * (B - ap.rec_b0) * xl.acc_heads * (double)c->rec_T * HW;
       }
+      if (chain_pre) {                                   // h1 = attn1.to_out(att) + h is computed (and stored) by the chain itself: into a second buffer
+        GETW(f1o, t + "attn1.to_out.frag"); GETV(bo1, t + "attn1.to_out.0.bias");
+        bf16_t* h2 = (bf16_t*)c->arena.alloc((size_t)M * C * 2); if (!h2) return -1;
+        ap.o1 = att; ap.wo1f = f1o->w; ap.bo1 = bo1; ap.out = h2;
+      }
       if (fold && !ff_fused) {                           // the GEGLU consumer of the LayerNorm fold reads one slot of row statistics
         slots = 1; stats = (float*)c->arena.alloc((size_t)M * 2 * sizeof(float)); if (!stats) return -1;
         ap.rowstat_out = stats;
       }
-      ProfScope ps(c, st, PC_ATTN_CROSS, 4.0 * M * (double)C * C + 4.0 * B * heads * (double)HW * T * D,
-                   4.0 * M * (double)C + 4.0 * C * (double)C + 4.0 * B * (double)T * C + rec_bytes);
+      ProfScope ps(c, st, PC_ATTN_CROSS, (chain_pre ? 6.0 : 4.0) * M * (double)C * C + 4.0 * B * heads * (double)HW * T * D,
+                   (chain_pre ? 6.0 : 4.0) * M * (double)C + (chain_pre ? 6.0 : 4.0) * C * (double)C + 4.0 * B * (double)T * C + rec_bytes);
       CK(launch_attn_chain(ap, C, heads, st));
+      if (chain_pre) h.p = ap.out;                       // the residual stream continues in the second buffer
       chain_done = true;
     }
   }
@@ -521,13 +530,21 @@ static int transformer(agd_ctx* c, hipStream_t st, const std::string& pre, const
     GemmOpt oo; oo.bias = bo; oo.residual = h.p;
     CK(produce(att, C, *wo, oo, h.p, false, !ff_fused)); }
   // --- GEGLU feed-forward ---
+  bool proj_done = false;
   if (ff_fused) {
     // one launch: norm3 (folded) -> GEGLU -> ff.net.2 + residual; the 4C-wide hidden activation stays in LDS (tblock.hip)
     GETW(f1, t + "ff.w1.frag"); GETW(f2, t + "ff.w2.frag");
     const std::string k = t + "ff.net.0.proj.weight.lnfold";
     GETV(cs, k + ".cs"); GETV(bf, k + ".bias"); GETV(b2, t + "ff.net.2.bias");
     FFusedP fp{}; fp.h = h.p; fp.out = h.p; fp.w1f = f1->w; fp.cs1 = cs; fp.b1 = bf; fp.w2f = f2->w; fp.b2 = b2; fp.M = M; fp.ln_eps = lneps;
-    ProfScope ps(c, st, PC_GEMM, 2.0 * M * (double)C * 12.0 * C, 4.0 * M * (double)C + 2.0 * 12.0 * C * (double)C);
+    if ((c->opt_tb_fuse & 8) && c->W.count(pre + "proj_out.frag")) {      // proj_out + residual (+ the next GroupNorm's partial sums) behind it, same launch
+      GETW(fpw, pre + "proj_out.frag"); GETV(bp, pre + "proj_out.bias");
+      fp.wpf = fpw->w; fp.bp = bp; fp.xres = xres; fp.pout = out.p;
+      out.cpart_bm = 0;
+      if (out.cpart && c->opt_gn_fused && HW % 128 == 0) { fp.colstat = out.cpart; out.cpart_bm = 128; }
+      proj_done = true;
+    }
+    ProfScope ps(c, st, PC_GEMM, 2.0 * M * (double)C * (proj_done ? 13.0 : 12.0) * C, (proj_done ? 8.0 : 4.0) * M * (double)C + 2.0 * (proj_done ? 13.0 : 12.0) * C * (double)C);
     CK(launch_ff_fused(fp, C, st));
   } else
   { bf16_t* ff = (bf16_t*)c->arena.alloc((size_t)M * 4 * C * 2); if (!ff) return -1;
@@ -536,6 +553,7 @@ static int transformer(agd_ctx* c, hipStream_t st, const std::string& pre, const
     GETW(w2, t + "ff.net.2.weight"); GETV(b2, t + "ff.net.2.bias");
     GemmOpt o2; o2.bias = b2; o2.residual = h.p;
     CK(run_conv(c, st, ff, 4 * C, nullptr, 0, 1, 1, M, *w2, 1, h.p, o2, c->zero_page)); }
+  if (!proj_done)
   { GETW(w, pre + "proj_out.weight"); GETV(b, pre + "proj_out.bias"); GemmOpt o; o.bias = b; o.residual = xres; o.out_act = &out; o.rows_per_image = HW;
     CK(run_conv(c, st, h.p, C, nullptr, 0, 1, 1, M, *w, 1, out.p, o, c->zero_page)); }
   c->arena.release(mk);
@@ -900,6 +918,13 @@ AGD_API int agd_finalize(agd_ctx* c) {
         API_CK(c, launch_frag_order_w1(w1->w, f1.w, C, 4 * C, 0));
         API_CK(c, launch_frag_order_w(w2->w, f2.w, C, 4 * C, C / 64, 128, 0));
         c->W[t + "ff.w1.frag"] = f1; c->W[t + "ff.w2.frag"] = f2;
+        const WMat* wp = getW(c, pr.first + "proj_out.weight");
+        if (!wp) return fail_ctx(c);
+        if (wp->N == C && wp->Cpad == C && wp->taps == 1) {
+          WMat fp_ = *wp; fp_.w = dmalloc<bf16_t>(c, (size_t)C * C); if (!fp_.w) return fail_ctx(c);
+          API_CK(c, launch_frag_order_w(wp->w, fp_.w, C, C, C / 64, C, 0));
+          c->W[pr.first + "proj_out.frag"] = fp_;
+        }
       }
       const WMat* wq = getW(c, t + "attn2.to_q.weight"); const WMat* wo = getW(c, t + "attn2.to_out.0.weight");
       if (!wq || !wo) return fail_ctx(c);
@@ -910,6 +935,13 @@ AGD_API int agd_finalize(agd_ctx* c) {
         API_CK(c, launch_frag_order_w(wq->w, fq.w, C, C, C / 64, C, 0));
         API_CK(c, launch_frag_order_w(wo->w, fo.w, C, C, C / 64, C, 0));
         c->W[t + "attn2.to_q.frag"] = fq; c->W[t + "attn2.to_out.frag"] = fo;
+        const WMat* wo1 = getW(c, t + "attn1.to_out.0.weight");
+        if (!wo1) return fail_ctx(c);
+        if (wo1->N == C && wo1->Cpad == C && wo1->taps == 1) {
+          WMat f1o = *wo1; f1o.w = dmalloc<bf16_t>(c, (size_t)C * C); if (!f1o.w) return fail_ctx(c);
+          API_CK(c, launch_frag_order_w(wo1->w, f1o.w, C, C, C / 64, C, 0));
+          c->W[t + "attn1.to_out.frag"] = f1o;
+        }
       }
     }
   }
@@ -1768,7 +1800,22 @@ AGD_API int agd_bench_tblock(int kind, int B, int HW, int iters, double* ms_out)
     ap.M = (int)M; ap.HW = HW; ap.T = T; ap.scale = 1.0f / sqrtf(40.f);
     ap.record = 1; ap.rec = rec; ap.rec_b0 = B / 2; ap.rec_T = T; ap.rec_hpb = 8; ap.rec_head_stride = (long long)T * HW; ap.rec_img_stride = (long long)T * HW;
   }
-  auto run = [&]() { return kind == 0 ? launch_ff_fused(fp, C, 0) : launch_attn_chain(ap, C, 8, 0); };
+  bf16_t* o2 = nullptr; float* cst = nullptr;
+  if (kind == 2) {                                   // feed-forward + proj_out stage (+ column statistics)
+    o2 = tmp.get<bf16_t>((size_t)M * C); cst = tmp.get<float>((size_t)(M / 128 + 1) * C * 2); if (!o2 || !cst) return -1;
+    bf16_t* wpf = tmp.get<bf16_t>((size_t)C * C); if (!wpf) return -1;
+    CK(launch_frag_order_w(w2, wpf, C, C, C / 64, C, 0));          // (any matrix will do)
+    CK(launch_frag_order_w1(w1, w1f, C, 4 * C, 0)); CK(launch_frag_order_w(w2, w2f, C, 4 * C, C / 64, 128, 0));
+    fp.h = h; fp.out = o; fp.w1f = w1f; fp.cs1 = vec; fp.b1 = vec + 8 * C; fp.w2f = w2f; fp.b2 = vec; fp.M = (int)M; fp.ln_eps = 1e-5f;
+    fp.wpf = wpf; fp.bp = vec; fp.xres = o2; fp.pout = o; fp.colstat = cst;
+  }
+  if (kind == 3) {                                   // attn2 chain starting at attn1.to_out
+    o2 = tmp.get<bf16_t>((size_t)M * C); bf16_t* wo1f = tmp.get<bf16_t>((size_t)C * C); if (!o2 || !wo1f) return -1;
+    fill_rand(o2, M * C, 9, 1.0f);
+    CK(launch_frag_order_w(w2, wo1f, C, C, C / 64, C, 0));
+    ap.o1 = o2; ap.wo1f = wo1f; ap.bo1 = vec;
+  }
+  auto run = [&]() { return (kind == 0 || kind == 2) ? launch_ff_fused(fp, C, 0) : launch_attn_chain(ap, C, 8, 0); };
   hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
   for (int i = 0; i < 2; ++i) CK(run());
   hipEventRecord(a, 0);

@@ -126,12 +126,63 @@ AGD_DEV void panel_row_stats(const char* panel, float* lnst, int tid, float eps)
   }
 }
 
+// a lane's 4 NI consecutive bf16 channels of one row (NI = 5: 40 bytes, 8-byte aligned) as 16 + 16 + 8-byte accesses instead of five 8-byte
+// ones: the row-per-lane epilogues are store-ISSUE bound (MI355X_MICROARCH.md, 'attention epilogue store tail')
+typedef u32x4 __attribute__((aligned(8))) u32x4_a8;
+template <int NI> AGD_DEV void load_row_chunk(const bf16_t* p, u32x2 (&r)[NI]) {
+#pragma unroll
+  for (int t = 0; t + 1 < NI; t += 2) { const u32x4 v = *(const u32x4_a8*)(p + 4 * t); r[t] = u32x2{v[0], v[1]}; r[t + 1] = u32x2{v[2], v[3]}; }
+  if (NI & 1) r[NI - 1] = *(const u32x2*)(p + 4 * (NI - 1));
+}
+template <int NI> AGD_DEV void store_row_chunk(bf16_t* p, const u32x2 (&r)[NI]) {
+#pragma unroll
+  for (int t = 0; t + 1 < NI; t += 2) *(u32x4_a8*)(p + 4 * t) = u32x4{r[t][0], r[t][1], r[t + 1][0], r[t + 1][1]};
+  if (NI & 1) *(u32x2*)(p + 4 * (NI - 1)) = r[NI - 1];
+}
+
+// One C -> C GEMM stage over the LDS panel: acc[4][NI] = W[(C / 4) nq .. + C / 4][:] . panel[64 mh .. + 64][:]^T for wave (mh, nq).
+// The weight stream (fragment order, launch_frag_order_w with NI = C / 64, KC = C) runs through a ring of TB_F fragment registers
+// filled TB_D fragments ahead by buffer loads -- per-lane offset lane * 16, the fragment's offset in an SGPR -- each pinned ahead of the
+// MFMAs it is meant to run under (left alone, hipcc sinks every load to just in front of its first use).  `head` puts the first TB_D
+// fragments in flight (call it early: under whatever phase precedes the GEMM), `body` consumes the KS x NI fragments.
+#define TB_F 10
+#define TB_D 8
+template <int C>
+AGD_DEV void panel_gemm_head(u32x4 (&ring)[TB_F], const bf16_t* wf, unsigned wbase, unsigned lane16) {
+  const auto wrs = __builtin_amdgcn_make_buffer_rsrc((void*)wf, 0, (unsigned)(C * C * 2), 0x00020000);
+#pragma unroll
+  for (int f = 0; f < TB_D; ++f) ring[f % TB_F] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, lane16, wbase + (unsigned)f * 1024u, 0));
+}
+template <int C>
+AGD_DEV void panel_gemm_body(u32x4 (&ring)[TB_F], f32x4 (&acc)[4][C / 64], const bf16_t* wf, unsigned wbase, unsigned lane16, const char* xrow, int xoff0, int xoff1) {
+  constexpr int NI = C / 64, KS = C / 32, NFR = KS * NI, PITCH = C * 2;
+  const auto wrs = __builtin_amdgcn_make_buffer_rsrc((void*)wf, 0, (unsigned)(C * C * 2), 0x00020000);
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  bf16x8 xf[4];
+#pragma unroll
+  for (int f = 0; f < NFR; ++f) {
+    if (f + TB_D < NFR) ring[(f + TB_D) % TB_F] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, lane16, wbase + (unsigned)(f + TB_D) * 1024u, 0));
+    __builtin_amdgcn_sched_barrier(0);
+    if (f % NI == 0) {
+      const int ks = f / NI;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) xf[i] = *(const bf16x8*)(xrow + i * 16 * PITCH + (ks >> 1) * 128 + ((ks & 1) ? xoff1 : xoff0));
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      acc[i][f % NI] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ring[f % TB_F]), xf[i], acc[i][f % NI], 0, 0, 0);
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------------------------
 // fused GEGLU feed-forward
 // ---------------------------------------------------------------------------------------------------------------------------
 // VAR: timing experiments only (experiments library; results are garbage): bit 0 = no gelu arithmetic, bit 1 = the weight ring is loaded once,
 // bit 2 = activation fragments are read once, bit 3 = no GEGLU epilogue at all
-template <int C, int VAR = 0>
+template <int C, int VAR = 0, int POST = 0>
 __global__ __launch_bounds__(512, 2) void ff_fused_kernel(const FFusedP p) {
   constexpr int BM = 128, HID = 4 * C, HC = 128, NCH = HID / HC, KS1 = C / 32, KS2 = HC / 32, NI2 = C / 64;   // NI2: 16-col tiles per wave (C / 4 / 16)
   constexpr int PITCH = C * 2;
@@ -154,9 +205,6 @@ __global__ __launch_bounds__(512, 2) void ff_fused_kernel(const FFusedP p) {
   __syncthreads();
 
   const int rbase = 64 * mh + px;                       // + 16 i: this lane's row in row tile i
-  float mu[4], rs[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) { const f32x2_t v = *(const f32x2_t*)(lnst + (rbase + 16 * i) * 2); mu[i] = v[0]; rs[i] = v[1]; }
 
   // X fragment (MFMA B operand) addresses in the panel: row rbase + 16 i, logical chunk 4 ks + q
   const int sx = (px >> 1) & 7;
@@ -185,7 +233,7 @@ __global__ __launch_bounds__(512, 2) void ff_fused_kernel(const FFusedP p) {
   // across the interval barrier and the GEGLU epilogue), so no phase starts on a cold stream; a phase whose predecessor did not run
   // (first / last intervals) issues them itself.  sched_barrier pins each load ahead of the MFMAs it is meant to run under: left alone,
   // hipcc sinks every load to just in front of its first use (measured: 108 us per launch against 127 for the two kernels it replaces).
-  constexpr int F = 12, D = 10, DX = 4, N2 = KS2 * NI2, N1 = KS1 * 4;     // DX: fragments of the next interval's GEMM2 kept in flight across the GEGLU epilogue (register budget)
+  constexpr int F = TB_F, D = TB_D, DX = 2, N2 = KS2 * NI2, N1 = KS1 * 4;     // DX: fragments of the next interval's GEMM2 kept in flight across the GEGLU epilogue (register budget)
   static_assert((N1 + N2) % F == 0 && D < F && D <= N2 && DX <= D, "ring geometry");
   u32x4 ring[F];
 
@@ -254,6 +302,9 @@ __global__ __launch_bounds__(512, 2) void ff_fused_kernel(const FFusedP p) {
     const int hcol0 = HC * c + 32 * nq + 8 * q;
     char* hb = hbuf + (c & 1) * (BM * HC * 2);
     u32x2 pk[4][2];
+    float mu[4], rs[4];                                // (re-read per chunk: eight registers less across the MFMA phases)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { const f32x2_t v = *(const f32x2_t*)(lnst + (rbase + 16 * i) * 2); mu[i] = v[0]; rs[i] = v[1]; }
 #pragma unroll
     for (int t = 0; t < 2; ++t) {                      // four columns at a time: 16 epilogue constants live instead of 32
       const f32x4 csv = *(const f32x4*)(p.cs1 + hcol0 + 4 * t), csg = *(const f32x4*)(p.cs1 + HID + hcol0 + 4 * t);
@@ -296,24 +347,83 @@ __global__ __launch_bounds__(512, 2) void ff_fused_kernel(const FFusedP p) {
     if (k <= NCH) __syncthreads();
   }
 
-  // epilogue: + bias + residual (the raw rows are still in the panel), one rounding to bf16, 8-byte row chunks
+  // epilogue: + bias + residual (the raw rows are still in the panel), one rounding to bf16, 8-byte row chunks.
+  // With a proj_out stage behind it (p.wpf), the rounded rows go back into the panel instead of to HBM -- nothing else reads them --
+  // and one more C -> C GEMM runs over them: out = h3 . Wp^T + bp + xres, plus the per-(128-row tile, channel) sums the next
+  // GroupNorm reads (IgemmP::colstat_out's layout).
+  const int ncol0 = (C / 4) * nq + 4 * NI2 * q;
+  constexpr bool post = POST != 0;
+  static_assert(F == TB_F, "the proj_out stage reuses the weight ring");
+  const unsigned pwbase = __builtin_amdgcn_readfirstlane((unsigned)(nq * KS1 * NI2) * 1024u);
+  if (post) panel_gemm_head<C>(ring, p.wpf, pwbase, lane16);
   float b2v[NI2 * 4];
 #pragma unroll
-  for (int t = 0; t < NI2; ++t) *(f32x4*)&b2v[4 * t] = *(const f32x4*)(p.b2 + (C / 4) * nq + 4 * NI2 * q + 4 * t);
+  for (int t = 0; t < NI2; ++t) *(f32x4*)&b2v[4 * t] = *(const f32x4*)(p.b2 + ncol0 + 4 * t);
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int row = rbase + 16 * i, m = m0 + row;
-    if (m >= p.M) continue;
-    bf16_t* op = p.out + (long long)m * C;
+    if (!post && m >= p.M) continue;
+    u32x2 pk[NI2];
 #pragma unroll
     for (int t = 0; t < NI2; ++t) {
-      const int n = (C / 4) * nq + 4 * NI2 * q + 4 * t;
-      const u32x2 r = *(const u32x2*)(panel + row * PITCH + panel_swz(n >> 3, row) * 16 + (n & 7) * 2);
-      u32x2 pk;
-      pk[0] = pack_bf2(acc2[i][t][0] + b2v[4 * t] + __uint_as_float(r[0] << 16), acc2[i][t][1] + b2v[4 * t + 1] + __uint_as_float(r[0] & 0xFFFF0000u));
-      pk[1] = pack_bf2(acc2[i][t][2] + b2v[4 * t + 2] + __uint_as_float(r[1] << 16), acc2[i][t][3] + b2v[4 * t + 3] + __uint_as_float(r[1] & 0xFFFF0000u));
-      *(u32x2*)(op + n) = pk;
+      const int n = ncol0 + 4 * t;
+      char* pa = panel + row * PITCH + panel_swz(n >> 3, row) * 16 + (n & 7) * 2;
+      const u32x2 r = *(const u32x2*)pa;
+      pk[t][0] = pack_bf2(acc2[i][t][0] + b2v[4 * t] + __uint_as_float(r[0] << 16), acc2[i][t][1] + b2v[4 * t + 1] + __uint_as_float(r[0] & 0xFFFF0000u));
+      pk[t][1] = pack_bf2(acc2[i][t][2] + b2v[4 * t + 2] + __uint_as_float(r[1] << 16), acc2[i][t][3] + b2v[4 * t + 3] + __uint_as_float(r[1] & 0xFFFF0000u));
+      if (post) *(u32x2*)pa = pk[t];
     }
+    if (!post) store_row_chunk<NI2>(p.out + (long long)m * C + ncol0, pk);
+  }
+  if constexpr (post) {
+  __syncthreads();                                       // h3 complete in the panel (every GEMM1 read of the raw rows is long done)
+  u32x2 xr[4][NI2];                                      // the residual rows (HBM-cold) are requested ahead of the GEMM, not in its epilogue
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { const int m = m0 + rbase + 16 * i; load_row_chunk<NI2>(p.xres + (long long)(m < p.M ? m : 0) * C + ncol0, xr[i]); }
+  panel_gemm_body<C>(ring, acc2, p.wpf, pwbase, lane16, xrow, xoff0, xoff1);
+  float bpv[NI2 * 4];
+#pragma unroll
+  for (int t = 0; t < NI2; ++t) *(f32x4*)&bpv[4 * t] = *(const f32x4*)(p.bp + ncol0 + 4 * t);
+  float cs[NI2 * 4], cq[NI2 * 4];                        // this lane's channel sums over its 4 rows
+#pragma unroll
+  for (int e = 0; e < NI2 * 4; ++e) { cs[e] = 0.f; cq[e] = 0.f; }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = m0 + rbase + 16 * i;
+    const bool live = m < p.M;
+    const long long mo = (long long)(live ? m : 0) * C + ncol0;
+    u32x2 pkk[NI2];
+#pragma unroll
+    for (int t = 0; t < NI2; ++t) {
+      u32x2 pk;
+      pk[0] = pack_bf2(acc2[i][t][0] + bpv[4 * t] + __uint_as_float(xr[i][t][0] << 16), acc2[i][t][1] + bpv[4 * t + 1] + __uint_as_float(xr[i][t][0] & 0xFFFF0000u));
+      pk[1] = pack_bf2(acc2[i][t][2] + bpv[4 * t + 2] + __uint_as_float(xr[i][t][1] << 16), acc2[i][t][3] + bpv[4 * t + 3] + __uint_as_float(xr[i][t][1] & 0xFFFF0000u));
+      pkk[t] = pk;
+      if (live) {
+        const float a0 = __uint_as_float(pk[0] << 16), a1 = __uint_as_float(pk[0] & 0xFFFF0000u), a2 = __uint_as_float(pk[1] << 16), a3 = __uint_as_float(pk[1] & 0xFFFF0000u);
+        cs[4 * t] += a0; cs[4 * t + 1] += a1; cs[4 * t + 2] += a2; cs[4 * t + 3] += a3;
+        cq[4 * t] += a0 * a0; cq[4 * t + 1] += a1 * a1; cq[4 * t + 2] += a2 * a2; cq[4 * t + 3] += a3 * a3;
+      }
+    }
+    if (live) store_row_chunk<NI2>(p.pout + mo, pkk);
+  }
+  if (p.colstat) {                                      // wave-uniform; fixed reduction order: reproducible
+#pragma unroll
+    for (int e = 0; e < NI2 * 4; ++e) {                 // over the 16 pixel lanes of this (q, wave)
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) { cs[e] += __shfl_xor(cs[e], o); cq[e] += __shfl_xor(cq[e], o); }
+    }
+    float* stg = (float*)hbuf;                          // [2 row halves][C][2]; the GEGLU chunk buffers are free
+    if (px == 0) {
+#pragma unroll
+      for (int e = 0; e < NI2 * 4; ++e) { stg[(mh * C + ncol0 + e) * 2] = cs[e]; stg[(mh * C + ncol0 + e) * 2 + 1] = cq[e]; }
+    }
+    __syncthreads();
+    if (tid < C) {
+      float* op = p.colstat + ((long long)blockIdx.x * C + tid) * 2;
+      op[0] = stg[tid * 2] + stg[(C + tid) * 2]; op[1] = stg[tid * 2 + 1] + stg[(C + tid) * 2 + 1];
+    }
+  }
   }
 }
 
@@ -322,12 +432,13 @@ int launch_ff_fused(const FFusedP& p, int C, hipStream_t st) {
   if (p.M < 1 || !p.h || !p.out || !p.w1f || !p.w2f || !p.cs1 || !p.b1 || !p.b2) { agd_set_error("ff_fused: bad arguments"); return -1; }
   if ((long long)p.M * C * 2 >= (1LL << 31)) { agd_set_error("ff_fused: activation too large for 32-bit offsets"); return -1; }
   constexpr int lds = 128 * 320 * 2 + 2 * 128 * 128 * 2 + 128 * 8;
-  const void* kfn = (const void*)ff_fused_kernel<320>;
+  const void* kfn = p.wpf ? (const void*)ff_fused_kernel<320, 0, 1> : (const void*)ff_fused_kernel<320>;
+  if (p.wpf && (!p.bp || !p.xres || !p.pout)) { agd_set_error("ff_fused: the proj_out stage needs bias, residual and output"); return -1; }
 #ifdef AGD_EXPERIMENTS
   static const void* const vars[16] = {(const void*)ff_fused_kernel<320, 0>, (const void*)ff_fused_kernel<320, 1>, (const void*)ff_fused_kernel<320, 2>, (const void*)ff_fused_kernel<320, 3>,
                                        (const void*)ff_fused_kernel<320, 4>, nullptr, (const void*)ff_fused_kernel<320, 6>, (const void*)ff_fused_kernel<320, 7>,
                                        (const void*)ff_fused_kernel<320, 8>, nullptr, (const void*)ff_fused_kernel<320, 10>, nullptr, nullptr, nullptr, (const void*)ff_fused_kernel<320, 14>, nullptr};
-  if (g_tb_variant > 0 && g_tb_variant < 16 && vars[g_tb_variant]) kfn = vars[g_tb_variant];
+  if (!p.wpf && g_tb_variant > 0 && g_tb_variant < 16 && vars[g_tb_variant]) kfn = vars[g_tb_variant];
 #endif
   int dev = 0; HIP_CHECK_RET(hipGetDevice(&dev));
   if (dev < 0 || dev >= AGD_MAX_DEVICES) { agd_set_error("ff_fused: device ordinal %d out of range", dev); return -1; }
@@ -352,7 +463,9 @@ int launch_ff_fused(const FFusedP& p, int C, hipStream_t st) {
 //   * the panel is used three times: normalised rows (A of to_q) -> Q / O -> (A of to_out).  Q, O, the 21 MB activations that the
 //     three launches this replaces exchange through HBM, never leave the CU.
 // ---------------------------------------------------------------------------------------------------------------------------
-template <int C>
+// PRE = 1: the kernel starts one GEMM earlier, at attn1's to_out: h1 = o1 . Wo1^T + bo1 + h (written to `out`, the residual of the final
+// epilogue), norm2's statistics from the rounded h1 held in registers -- the launch between the self-attention and this chain disappears too
+template <int C, int PRE>
 __global__ __launch_bounds__(512, 2) void attn_chain_kernel(const AttnChainP p) {
   constexpr int BM = 128, H = 8, D = C / H, KS = C / 32, NI = C / 64, PITCH = C * 2, CHR = C / 8;
   static_assert(C == 320, "head dim 40 layout");
@@ -364,6 +477,7 @@ __global__ __launch_bounds__(512, 2) void attn_chain_kernel(const AttnChainP p) 
   char* panel = smem;
   char* kvs = smem + BM * PITCH;                        // 2 x KVSTAGE (one head per head half); later: probability hand-off / statistics staging
   float* lnst = (float*)(kvs + 2 * KVSTAGE);
+  float* pst = lnst + BM * 2;                           // PRE: [4 column quarters][BM] (sum, sum of squares) of h1
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -374,7 +488,7 @@ __global__ __launch_bounds__(512, 2) void attn_chain_kernel(const AttnChainP p) 
   const int m0 = blockIdx.x * BM;
   const int b = m0 / p.HW, pix0 = m0 - b * p.HW;        // tiles stay inside one image (HW % 128 == 0)
 
-  panel_load_dma<C>(p.h, m0, p.M, panel, wid, lane);
+  panel_load_dma<C>(PRE ? p.o1 : p.h, m0, p.M, panel, wid, lane);
 
   // K / V staging of this wave's head half: pad chunks once, then head `h` through registers
   char* sK = kvs + hhalf * KVSTAGE;
@@ -409,54 +523,85 @@ __global__ __launch_bounds__(512, 2) void attn_chain_kernel(const AttnChainP p) 
   };
   kv_load(4 * hhalf);
 
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  kv_store();
-  panel_row_stats<C>(panel, lnst, tid, p.ln_eps);
-  __syncthreads();
-
   // ---- GEMM stage: acc[4][NI] = W[80 nq .. +80][:] . panel[64 mh .. +64][:]^T ----
   const int rbase = 64 * mh + px;
   const int sx = (px >> 1) & 7;
   const int xoff0 = ((q ^ sx) << 4), xoff1 = (((4 + q) ^ sx) << 4);
   const char* xrow = panel + rbase * PITCH;
   f32x4 acc[4][NI];
-  // weight stream as in ff_fused_kernel: a ring of F fragment registers filled D fragments ahead by buffer loads (per-lane offset lane * 16,
-  // fragment offset in an SGPR), pinned ahead of the MFMAs they run under; `head` issues the first D fragments (early: under the phase in
-  // front of the GEMM), `body` consumes the KS x NI fragments
-  constexpr int F = 12, PD = 10, NFR = KS * NI;
-  u32x4 ring[F];
+  u32x4 ring[TB_F];
   const unsigned lane16 = (unsigned)lane * 16u;
-  const unsigned wbase = __builtin_amdgcn_readfirstlane((unsigned)(nq * NFR) * 1024u);
-  auto gemm_head = [&](const bf16_t* wf) {
-    const auto wrs = __builtin_amdgcn_make_buffer_rsrc((void*)wf, 0, (unsigned)(C * C * 2), 0x00020000);
+  const unsigned wbase = __builtin_amdgcn_readfirstlane((unsigned)(nq * KS * NI) * 1024u);
+  auto gemm_head = [&](const bf16_t* wf) { panel_gemm_head<C>(ring, wf, wbase, lane16); };
+  auto gemm_body = [&](const bf16_t* wf) { panel_gemm_body<C>(ring, acc, wf, wbase, lane16, xrow, xoff0, xoff1); };
+  const int ncol0 = (C / 4) * nq + 4 * NI * q;          // first of this lane's 4 NI consecutive channels (GEMM epilogues)
+
+  if constexpr (PRE) gemm_head(p.wo1f);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (also drains the ring's head: it is ten L2-resident KiB)
+  __syncthreads();
+  kv_store();
+  if constexpr (!PRE) {
+    panel_row_stats<C>(panel, lnst, tid, p.ln_eps);
+    __syncthreads();
+    gemm_head(p.wqf);                                   // the first to_q weight fragments fly under the normalisation pass
+  }
+
+  if constexpr (PRE) {
+    // ---- attn1.to_out + bias + residual -> h1 (rounded once, stored), its row statistics, norm2 from registers into the panel ----
+    u32x2 hr[4][NI];                                    // residual rows of h, requested ahead of the GEMM
 #pragma unroll
-    for (int f = 0; f < PD; ++f) ring[f % F] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, lane16, wbase + (unsigned)f * 1024u, 0));
-  };
-  auto gemm_body = [&](const bf16_t* wf) {
-    const auto wrs = __builtin_amdgcn_make_buffer_rsrc((void*)wf, 0, (unsigned)(C * C * 2), 0x00020000);
+    for (int i = 0; i < 4; ++i) load_row_chunk<NI>(p.h + (long long)(m0 + rbase + 16 * i) * C + ncol0, hr[i]);
+    gemm_body(p.wo1f);
+    gemm_head(p.wqf);
+    float bv1[NI * 4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int t = 0; t < NI; ++t) *(f32x4*)&bv1[4 * t] = *(const f32x4*)(p.bo1 + ncol0 + 4 * t);
+    float rs1[4], rq1[4];
 #pragma unroll
-      for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    bf16x8 xf[4];
+    for (int i = 0; i < 4; ++i) {
+      const int m = m0 + rbase + 16 * i;
+      bf16_t* op = p.out + (long long)m * C + ncol0;
+      u32x2 pkk[NI];
+      const u32x2 (&r)[NI] = hr[i];
+      rs1[i] = 0.f; rq1[i] = 0.f;
 #pragma unroll
-    for (int f = 0; f < NFR; ++f) {
-      if (f + PD < NFR) ring[(f + PD) % F] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, lane16, wbase + (unsigned)(f + PD) * 1024u, 0));
-      __builtin_amdgcn_sched_barrier(0);
-      if (f % NI == 0) {
-        const int ks = f / NI;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) xf[i] = *(const bf16x8*)(xrow + i * 16 * PITCH + (ks >> 1) * 128 + ((ks & 1) ? xoff1 : xoff0));
+      for (int t = 0; t < NI; ++t) {
+        u32x2 pk;
+        pk[0] = pack_bf2(acc[i][t][0] + bv1[4 * t] + __uint_as_float(r[t][0] << 16), acc[i][t][1] + bv1[4 * t + 1] + __uint_as_float(r[t][0] & 0xFFFF0000u));
+        pk[1] = pack_bf2(acc[i][t][2] + bv1[4 * t + 2] + __uint_as_float(r[t][1] << 16), acc[i][t][3] + bv1[4 * t + 3] + __uint_as_float(r[t][1] & 0xFFFF0000u));
+        pkk[t] = pk;
+        acc[i][t] = f32x4{__uint_as_float(pk[0] << 16), __uint_as_float(pk[0] & 0xFFFF0000u), __uint_as_float(pk[1] << 16), __uint_as_float(pk[1] & 0xFFFF0000u)};
+        rs1[i] += (acc[i][t][0] + acc[i][t][1]) + (acc[i][t][2] + acc[i][t][3]);
+        rq1[i] += (acc[i][t][0] * acc[i][t][0] + acc[i][t][1] * acc[i][t][1]) + (acc[i][t][2] * acc[i][t][2] + acc[i][t][3] * acc[i][t][3]);
       }
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-        acc[i][f % NI] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ring[f % F]), xf[i], acc[i][f % NI], 0, 0, 0);
+      store_row_chunk<NI>(op, pkk);
+      rs1[i] += __shfl_xor(rs1[i], 16); rs1[i] += __shfl_xor(rs1[i], 32);
+      rq1[i] += __shfl_xor(rq1[i], 16); rq1[i] += __shfl_xor(rq1[i], 32);
+      if (q == 0) *(f32x2_t*)(pst + (nq * BM + rbase + 16 * i) * 2) = f32x2_t{rs1[i], rq1[i]};
     }
-  };
-
-  gemm_head(p.wqf);                                   // the first to_q weight fragments fly under the normalisation pass
-
+    __syncthreads();                                    // partial sums staged AND every wave is done reading o1 from the panel
+    float g2[NI * 4], b2[NI * 4];
+#pragma unroll
+    for (int t = 0; t < NI; ++t) { *(f32x4*)&g2[4 * t] = *(const f32x4*)(p.gamma + ncol0 + 4 * t); *(f32x4*)&b2[4 * t] = *(const f32x4*)(p.beta + ncol0 + 4 * t); }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = rbase + 16 * i;
+      float S = 0.f, Q = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) { const f32x2_t v = *(const f32x2_t*)(pst + (w * BM + row) * 2); S += v[0]; Q += v[1]; }      // fixed order: reproducible
+      const float mu = S * (1.0f / C);
+      float var = Q * (1.0f / C) - mu * mu; var = var < 0.f ? 0.f : var;
+      const float rstd = rsqrtf(var + p.ln_eps);
+#pragma unroll
+      for (int t = 0; t < NI; ++t) {
+        const int n = ncol0 + 4 * t;
+        u32x2 pk;
+        pk[0] = pack_bf2((acc[i][t][0] - mu) * rstd * g2[4 * t] + b2[4 * t], (acc[i][t][1] - mu) * rstd * g2[4 * t + 1] + b2[4 * t + 1]);
+        pk[1] = pack_bf2((acc[i][t][2] - mu) * rstd * g2[4 * t + 2] + b2[4 * t + 2], (acc[i][t][3] - mu) * rstd * g2[4 * t + 3] + b2[4 * t + 3]);
+        *(u32x2*)(panel + row * PITCH + panel_swz(n >> 3, row) * 16 + (n & 7) * 2) = pk;
+      }
+    }
+  } else {
   // ---- norm2 in place: x^ = (h - mu) rstd gamma + beta, rounded to bf16 (what the LayerNorm kernel stores) ----
 #pragma unroll 2
   for (int i = 0; i < BM * CHR / 512; ++i) {
@@ -472,6 +617,7 @@ __global__ __launch_bounds__(512, 2) void attn_chain_kernel(const AttnChainP p) 
     for (int e = 0; e < 4; ++e) { x[e] = (x[e] - st[0]) * st[1] * g0[e] + b0[e]; x[4 + e] = (x[4 + e] - st[0]) * st[1] * g1[e] + b1[e]; }
     v[0] = pack_bf2(x[0], x[1]); v[1] = pack_bf2(x[2], x[3]); v[2] = pack_bf2(x[4], x[5]); v[3] = pack_bf2(x[6], x[7]);
     *(u32x4*)(panel + row * PITCH + pc * 16) = v;
+  }
   }
   __syncthreads();
 
@@ -641,6 +787,9 @@ __global__ __launch_bounds__(512, 2) void attn_chain_kernel(const AttnChainP p) 
   __syncthreads();                                       // O complete in the panel (and the exchange buffer is free)
 
   // ---- to_out + bias + residual, one rounding; optional norm3 row statistics of the rounded outputs ----
+  u32x2 fr[4][NI];                                      // residual rows, requested ahead of the GEMM (PRE: h1, stored by this very lane above)
+#pragma unroll
+  for (int i = 0; i < 4; ++i) load_row_chunk<NI>((PRE ? (const bf16_t*)p.out : p.h) + (long long)(m0 + rbase + 16 * i) * C + ncol0, fr[i]);
   gemm_body(p.wof);
   float bv[NI * 4];
 #pragma unroll
@@ -650,20 +799,19 @@ __global__ __launch_bounds__(512, 2) void attn_chain_kernel(const AttnChainP p) 
   for (int i = 0; i < 4; ++i) {
     const int m = m0 + rbase + 16 * i;
     rs[i] = 0.f; rq[i] = 0.f;
-    const bf16_t* rp = p.h + (long long)m * C + (C / 4) * nq + 4 * NI * q;
-    bf16_t* op = p.out + (long long)m * C + (C / 4) * nq + 4 * NI * q;
-    u32x2 r[NI];
-#pragma unroll
-    for (int t = 0; t < NI; ++t) r[t] = *(const u32x2*)(rp + 4 * t);
+    bf16_t* op = p.out + (long long)m * C + ncol0;
+    u32x2 pkk[NI];
+    const u32x2 (&r)[NI] = fr[i];
 #pragma unroll
     for (int t = 0; t < NI; ++t) {
       const float v0 = acc[i][t][0] + bv[4 * t] + __uint_as_float(r[t][0] << 16), v1 = acc[i][t][1] + bv[4 * t + 1] + __uint_as_float(r[t][0] & 0xFFFF0000u);
       const float v2 = acc[i][t][2] + bv[4 * t + 2] + __uint_as_float(r[t][1] << 16), v3 = acc[i][t][3] + bv[4 * t + 3] + __uint_as_float(r[t][1] & 0xFFFF0000u);
       u32x2 pk; pk[0] = pack_bf2(v0, v1); pk[1] = pack_bf2(v2, v3);
-      *(u32x2*)(op + 4 * t) = pk;
+      pkk[t] = pk;
       const float a0 = __uint_as_float(pk[0] << 16), a1 = __uint_as_float(pk[0] & 0xFFFF0000u), a2 = __uint_as_float(pk[1] << 16), a3 = __uint_as_float(pk[1] & 0xFFFF0000u);
       rs[i] += (a0 + a1) + (a2 + a3); rq[i] += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
     }
+    store_row_chunk<NI>(op, pkk);
   }
   if (p.rowstat_out) {                                  // wave-uniform (kernel argument); fixed summation order: reproducible
 #pragma unroll
@@ -692,13 +840,16 @@ int launch_attn_chain(const AttnChainP& p, int C, int heads, hipStream_t st) {
   if (p.T < 1 || p.T > 96) { agd_set_error("attn_chain: %d keys (1..96)", p.T); return -1; }
   if ((long long)p.M * C * 2 >= (1LL << 31)) { agd_set_error("attn_chain: activation too large for 32-bit offsets"); return -1; }
   if (p.record && (p.rec_hpb < 1 || 8 % p.rec_hpb || !p.rec)) { agd_set_error("attn_chain: recorder head group %d", p.rec_hpb); return -1; }
-  constexpr int lds = 128 * 320 * 2 + 2 * 96 * (7 * 16 + 3 * 64) + 128 * 8;
-  auto kfn = attn_chain_kernel<320>;
-  static bool attr[AGD_MAX_DEVICES] = {};
+  constexpr int lds = 128 * 320 * 2 + 2 * 96 * (7 * 16 + 3 * 64) + 128 * 8 + 4 * 128 * 8;
+  const bool pre = p.o1 != nullptr;
+  if (pre && (!p.wo1f || !p.bo1 || p.out == p.h)) { agd_set_error("attn_chain: the to_out prologue needs its weights and out != h"); return -1; }
+  const void* kfn = pre ? (const void*)attn_chain_kernel<320, 1> : (const void*)attn_chain_kernel<320, 0>;
+  static bool attr[AGD_MAX_DEVICES][2] = {};
   int dev = 0; HIP_CHECK_RET(hipGetDevice(&dev));
   if (dev < 0 || dev >= AGD_MAX_DEVICES) { agd_set_error("attn_chain: device ordinal %d out of range", dev); return -1; }
-  if (!attr[dev]) { HIP_CHECK_RET(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); attr[dev] = true; }
-  hipLaunchKernelGGL(kfn, dim3(p.M / 128), dim3(512), lds, st, p);
-  HIP_CHECK_RET(hipGetLastError());
+  if (!attr[dev][pre]) { HIP_CHECK_RET(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); attr[dev][pre] = true; }
+  AttnChainP pp = p;
+  void* args[] = {&pp};
+  HIP_CHECK_RET(hipLaunchKernel(kfn, dim3(p.M / 128), dim3(512), args, lds, st));
   return 0;
 }

@@ -168,6 +168,54 @@ def test_sd15_unet_forward_512px_matches_oracle(sd15_host_weights, sd15_pipe, p8
     assert hm_err < 0.02, hm_err
 
 
+def test_fused_transformer_block_kernels_match_the_kernel_chain_512px(sd15_host_weights, sd15_pipe):
+    """opt "tblock_fuse" (tblock.hip, the C = 320 blocks of the 64 x 64 maps): bit 0 norm3 -> GEGLU -> ff.net.2 + residual in one launch, bit 1
+    norm2 -> to_q -> cross-attention (+ DAAM record) -> to_out + residual in one launch, bit 2 that launch starting at attn1.to_out, bit 3 the
+    feed-forward launch ending with proj_out (+ the next GroupNorm's partial sums); opt "reduce_gn": split-K slab sum + GroupNorm in one launch.
+    Every combination against the fp32 oracle (UNet output and DAAM heat maps) and against the unfused kernel chain: the same fp32 function
+    with bf16 roundings at different points, so within bf16 noise of each other, each within the oracle bound."""
+    from agenda_amd import synthetic
+    from oracle import sd_oracle as O
+    cfg, u, v = sd15_host_weights
+    pipe, L = sd15_pipe, 64
+    ctx = synthetic.make_context(cfg, 1, seed=7)
+    lat = synthetic.make_latents(cfg, [0], L)
+    x = torch.cat([lat, lat]).to(torch.bfloat16).float()
+    if "unet512" not in _ORACLE_CACHE:
+        rec = O.DaamRecorder(L * L, 77)
+        with torch.no_grad():
+            want = O.unet_forward(u, cfg.unet, x, torch.tensor(981), ctx, rec)
+        _ORACLE_CACHE["unet512"] = (want, rec.compute_global_heat_map()[0], len(rec.acc))
+    want, whm, _ = _ORACLE_CACHE["unet512"]
+    outs = {}
+    try:
+        for fuse, rg in ((0, 0), (1, 1), (2, 1), (6, 1), (9, 1), (15, 1), (15, 0)):
+            pipe.engine.set_option("tblock_fuse", fuse)
+            pipe.engine.set_option("reduce_gn", rg)
+            pipe.engine.set_context(ctx)
+            pipe.engine.record_config(1, False, 77)
+            pipe.engine.record_reset(1, L)
+            got = pipe.engine.unet_forward(x, 981.0).clone()
+            hm = pipe.engine.daam_global(0, 77, L).cpu()
+            outs[(fuse, rg)] = (got, hm)
+            if (fuse, rg) == (15, 1):                                  # run-to-run identical (no atomics anywhere on the fused paths)
+                pipe.engine.record_reset(1, L)
+                again = pipe.engine.unet_forward(x, 981.0)
+                assert torch.equal(got, again) and torch.equal(hm, pipe.engine.daam_global(0, 77, L).cpu())
+    finally:
+        pipe.engine.set_option("tblock_fuse", 15)
+        pipe.engine.set_option("reduce_gn", 1)
+        pipe.engine.record_config(0)
+    base, bhm = outs[(0, 0)]
+    for key, (got, hm) in outs.items():
+        e_o, e_b = _rms_rel(got, want), _rms_rel(got, base.cpu())
+        h_o = float((hm - whm).abs().max() / whm.abs().max())
+        print(f"tblock_fuse={key[0]:2d} reduce_gn={key[1]}: vs oracle {e_o:.5f}, vs kernel chain {e_b:.5f}, heat map vs oracle {h_o:.4f}")
+        assert e_o < 2.0 ** -6, (key, e_o)
+        assert e_b < 2.0 ** -5, (key, e_b)
+        assert h_o < 0.02, (key, h_o)
+
+
 def test_sd15_unet_forward_512px_batch4_matches_oracle(sd15_host_weights, sd15_pipe):
     """BASELINE config 2 at the bench's OWN batch: four images (UNet batch 8, M = 32768 at 64 x 64), one forward with the DAAM
     recorder on, against the fp32 CPU oracle.  At this batch the launcher's choices differ from the CFG-pair test above (the

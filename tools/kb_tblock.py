@@ -45,3 +45,5 @@ for rnd in range(3):
     to = lin(Cc, Cc, geglu=2, res=1)             # to_out + residual as a row-statistics producer
     ms = C.c_double(); lib.agd_bench_attention(B, 8, 40, HW, 77, 2, 50, C.byref(ms)); at = ms.value * 1e3
     print(f"[{rnd}] attn_chain {ch:7.1f} us   vs to_q {tq:6.1f} + attention(record) {at:6.1f} + to_out {to:6.1f} = {tq + at + to:6.1f} us", flush=True)
+    po = lin(Cc, Cc, res=1)
+    print(f"[{rnd}] ff_fused + proj_out {tb(2):7.1f} us (vs {ff:6.1f} + C->C launch {po:5.1f});  chain from attn1.to_out {tb(3):7.1f} us (vs {ch:6.1f} + C->C launch {to:5.1f})", flush=True)
