@@ -28,6 +28,9 @@
 #include "igemm_epilogue.h"
 #include "igemm_halo.h"
 #include "igemm8p.h"
+#include "igemm_wreg.h"
+#include "igemm_smap.h"
+#include <type_traits>
 #include <cstdlib>
 #define CK0(expr) do { if ((expr) != 0) return -1; } while (0)
 
@@ -451,6 +454,25 @@ static bool reduce_gn_ok(const IgemmP& p) {
   return (long long)HWo * (p.N / p.gn_groups / 4) <= 256 * 10 && p.act <= 1;
 }
 
+// the slab pass of a split-K launch: out = epilogue(sum of the S slabs), fused with the GroupNorm that reads it where the caller asked for it
+static int launch_splitk_reduce(const IgemmP& p, int splits, hipStream_t st) {
+  if (reduce_gn_ok(p)) {
+    const long long quads = (long long)p.Hout * p.Wout * (p.N / p.gn_groups / 4);
+    const dim3 g(p.gn_groups, p.M / (p.Hout * p.Wout));
+    if (quads <= 256 * 3) hipLaunchKernelGGL(splitk_reduce_gn_kernel<3>, g, dim3(256), 0, st, p, splits);
+    else if (quads <= 256 * 5) hipLaunchKernelGGL(splitk_reduce_gn_kernel<5>, g, dim3(256), 0, st, p, splits);
+    else hipLaunchKernelGGL(splitk_reduce_gn_kernel<10>, g, dim3(256), 0, st, p, splits);
+    HIP_CHECK_RET(hipGetLastError());
+    if (p.gn_fused) *p.gn_fused = 1;
+    return 0;
+  }
+  const long long total = (long long)p.M * (p.N >> 2);
+  const int grid = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid), dim3(256), 0, st, p, splits);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+
 template <int BM, int BN, int WM, int WN, int KS, int STAGES, int GEGLU, int SPLITK>
 static int launch_one(const IgemmP& p, int splits, hipStream_t st) {
   constexpr int NT = WM * WN * 64;
@@ -508,21 +530,7 @@ static int launch_cfg(const IgemmP& p, int splits, hipStream_t st) {
     if constexpr (HALO_TILE) { rc = halo_ok(p) ? launch_halo<BN, 1, STAGES == 4 ? 4 : 2>(p, splits, st) : (p.ksize == 3) ? launch_one<BM, BN, WM, WN, 3, STAGES, 0, 1>(p, splits, st) : launch_one<BM, BN, WM, WN, 1, STAGES, 0, 1>(p, splits, st); }
     else rc = (p.ksize == 3) ? launch_one<BM, BN, WM, WN, 3, STAGES, 0, 1>(p, splits, st) : launch_one<BM, BN, WM, WN, 1, STAGES, 0, 1>(p, splits, st);
     if (rc) return rc;
-    if (reduce_gn_ok(p)) {
-      const long long quads = (long long)p.Hout * p.Wout * (p.N / p.gn_groups / 4);
-      const dim3 g(p.gn_groups, p.M / (p.Hout * p.Wout));
-      if (quads <= 256 * 3) hipLaunchKernelGGL(splitk_reduce_gn_kernel<3>, g, dim3(256), 0, st, p, splits);
-      else if (quads <= 256 * 5) hipLaunchKernelGGL(splitk_reduce_gn_kernel<5>, g, dim3(256), 0, st, p, splits);
-      else hipLaunchKernelGGL(splitk_reduce_gn_kernel<10>, g, dim3(256), 0, st, p, splits);
-      HIP_CHECK_RET(hipGetLastError());
-      if (p.gn_fused) *p.gn_fused = 1;
-      return 0;
-    }
-    const long long total = (long long)p.M * (p.N >> 2);
-    const int grid = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid), dim3(256), 0, st, p, splits);
-    HIP_CHECK_RET(hipGetLastError());
-    return 0;
+    return launch_splitk_reduce(p, splits, st);
   }
   if (p.geglu) {
     if constexpr (BN / WN == 64) { if (p.ksize == 1) return launch_one<BM, BN, WM, WN, 1, STAGES, 1, 0>(p, 1, st); }
@@ -622,6 +630,7 @@ extern "C" __attribute__((visibility("default"))) void agd_set_igemm_cfg(int v) 
 #define KNOB(n) false
 #endif
 
+static bool nosplit_early(const IgemmP& p) { return p.rowstat_out || p.ln_stats || p.colstat_out; }
 int launch_igemm(const IgemmP& p_in, hipStream_t st) {
   IgemmP p = p_in;
 #ifdef AGD_EXPERIMENTS
@@ -686,6 +695,51 @@ int launch_igemm(const IgemmP& p_in, hipStream_t st) {
     }
   }
 #endif
+  // 8 x 8 maps, 3x3 stride 1: whole images resident, every weight tile streamed once (igemm_smap.h)
+  if (p.smap && p.ksize == 3 && p.stride == 1 && p.pad == 1 && p.up == 1 && p.Hin == 8 && p.Win == 8 && p.Hout == 8 && p.Wout == 8 && batch == 1 && !p.geglu &&
+      !p.w_per_image && (p.N % 64) == 0 && (p.M % 64) == 0 && !nosplit_early(p) && (long long)p.N * p.K * 2 < (1LL << 32)) {
+    const int tiles = ((p.M + 511) / 512) * (p.N / 64), nch = (p.C0 + p.C1) >> 6;
+    int smax = 256 / tiles; if (smax < 1) smax = 1; if (smax > nch) smax = nch;
+    const int per = (nch + smax - 1) / smax, S = (nch + per - 1) / per;
+    if (p.cfg_out) { p.cfg_out[0] = 512; p.cfg_out[1] = 64; p.cfg_out[2] = S; return 0; }
+#ifdef AGD_EXPERIMENTS
+    { static const bool logit = getenv("AGD_IGEMM_LOG") != nullptr;
+      if (logit) fprintf(stderr, "IGEMM M=%d N=%d K=%d ks=3 stride=1 up=1 geglu=0 res=%d tile=512x64 splits=%d batch=1\n", p.M, p.N, p.K, p.residual ? 1 : 0, S); }
+#endif
+    constexpr int lds = 800 * 128 + 4 * 64 * 128 + 8192;
+    if (S >= 2) CK0(ensure_splitk(p, S));
+    const void* kfn = S >= 2 ? (const void*)igemm_smap_kernel<1> : (const void*)igemm_smap_kernel<0>;
+    static bool attr[AGD_MAX_DEVICES][2] = {};
+    int dev = 0; HIP_CHECK_RET(hipGetDevice(&dev));
+    if (dev < 0 || dev >= AGD_MAX_DEVICES) { agd_set_error("igemm_smap: device ordinal %d out of range", dev); return -1; }
+    if (!attr[dev][S >= 2]) { HIP_CHECK_RET(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); attr[dev][S >= 2] = true; }
+    IgemmP pp = p;
+    void* args[] = {&pp};
+    HIP_CHECK_RET(hipLaunchKernel(kfn, dim3((unsigned)tiles, 1, (unsigned)S), dim3(512), args, lds, st));
+    if (S >= 2) return launch_splitk_reduce(pp, S, st);
+    return 0;
+  }
+  // weight-streaming kernel (igemm_wreg.h): plain 1x1 launches of the small maps whose matrix exists in fragment order
+  if (p.Wfrag && p.wreg && p.ksize == 1 && batch == 1 && !p.w_per_image && p.C1 == 0 && p.C0 == p.K && p.stride == 1 && p.up == 1 && p.pad == 0 &&
+      p.Hin == p.Hout && p.Win == p.Wout && !p.out_f32 && p.M >= p.wreg_mmin && p.M <= p.wreg_mmax &&
+      (p.geglu ? (p.wfrag_ni == 4 && (p.wreg & 2) && p.N % 256 == 0) : (p.wfrag_ni == 2 && (p.wreg & 1) && p.N % 128 == 0))) {
+    const int bn = p.geglu ? 256 : 128;
+    const long long tiles = (long long)((p.M + 63) / 64) * (p.N / bn);
+    if (tiles >= 128) {
+      if (p.cfg_out) { p.cfg_out[0] = 64; p.cfg_out[1] = bn; p.cfg_out[2] = 1; return 0; }
+      if (p.colstat_out && (p.colstat_rows < 1 || p.colstat_rows % 64)) { agd_set_error("igemm_wreg: column statistics need M tiles inside one image"); return -1; }
+      if (p.rowstat_out && p.rowstat_slots != p.N / bn) { agd_set_error("igemm_wreg: rowstat_slots %d != N tiles %d", p.rowstat_slots, p.N / bn); return -1; }
+#ifdef AGD_EXPERIMENTS
+      { static const bool logit = getenv("AGD_IGEMM_LOG") != nullptr;
+        if (logit) fprintf(stderr, "IGEMM M=%d N=%d K=%d ks=1 stride=1 up=1 geglu=%d res=%d tile=64x%d splits=1 batch=1\n", p.M, p.N, p.K, p.geglu, p.residual ? 1 : 0, bn); }
+#endif
+      const void* kfn = p.geglu ? (const void*)igemm_wreg_kernel<4, 1> : (const void*)igemm_wreg_kernel<2, 0>;
+      IgemmP pp = p;
+      void* args[] = {&pp};
+      HIP_CHECK_RET(hipLaunchKernel(kfn, dim3((unsigned)tiles), dim3(256), args, 3 * 64 * 128, st));
+      return 0;
+    }
+  }
   if (p.p8) { const int c8 = pick_8p(p); if (c8 == 1) return launch_8p<2, 4, 8, 2, 2>(p, st); if (c8 == 2) return launch_8p<4, 2, 4, 3, 2>(p, st); }
   if (p.geglu) return launch_cfg<128, 128, 2, 2>(p, 1, st);
   // 1x1 launches of the 16x16 / 8x8 maps with N a multiple of 160: 64 x 160 tiles on the 4-stage ring give exactly (or, with K slices,

@@ -1,0 +1,141 @@
+// 3x3 / stride 1 / pad 1 implicit GEMM for the 8 x 8 feature maps: whole images resident, every weight byte streamed exactly once.
+// (included by igemm.hip; round 4)
+//
+// At 8 x 8 (UNet batch 8: M = 512 rows) the ResnetBlock2D convs are weight-streaming problems: 29.5 MB (1280 -> 1280) or 59 MB of bf16
+// weights against 1.3 MB of activations.  igemm_kernel tiles them 128 x 160 x 8 K-slices: every weight tile is fetched by four row
+// tiles and every im2col row by eight column tiles -- 828 KB through the LDS-DMA path per workgroup for 47 MFLOP (36 us + an 8 us slab
+// pass per launch, 0.15 of the binding roof).  Here a workgroup owns ALL 512 rows x 64 output channels x a slice of the input
+// channels:
+//   * the slice is walked in 64-channel chunks; ONE LDS image per chunk holds the eight images' pixels WITH their zero border
+//     (8 x 10 x 10 halo rows of 128 B, written by LDS-DMA: border rows get an out-of-range offset and the hardware writes zeros), and
+//     all nine taps read their MFMA fragments from it at a per-tap row offset -- 64 KB of activations per 9 x 64 k instead of 576 KB;
+//   * each weight tile (64 rows x 64 k of one tap) is fetched once by exactly one workgroup of the launch: the matrix crosses
+//     HBM -> L2 -> LDS once, through a 4-slot LDS-DMA ring;
+//   * 8 waves = 4 row groups x 2 column groups, wave tile 128 rows (two images) x 32 columns; operand roles swapped as everywhere,
+//     so igemm_epilogue.h runs behind it unchanged (split-K slabs; the slab pass -- fused with the GroupNorm that follows -- finishes).
+// LDS bank conflicts: the swizzle key of a halo row is its x coordinate (& 7): with it the 16 rows of every fragment read (two image
+// rows of eight pixels, any tap) fall on 16 distinct 16-byte slots (checked exhaustively for all tiles / taps / k-steps).
+#pragma once
+#include "kernels.h"
+#include "igemm_epilogue.h"
+#include <type_traits>
+
+template <int SPLITK>
+__global__ __launch_bounds__(512, 2) void igemm_smap_kernel(const IgemmP p) {
+  constexpr int BM = 512, BN = 64, WM = 4, WN = 2, NW = 8, WTN = 32, MI = 8, NI = 2;
+  constexpr int HS = 8, HP = HS + 2, IMG = HP * HP;               // 8 x 8 maps, halo pitch 10, 100 halo rows per image
+  constexpr int A_ROWS = 8 * IMG, A_BYTES = A_ROWS * 128;         // 800 rows = 100 pieces of 8 rows
+  constexpr int A_IT = (A_ROWS / 8 + NW - 1) / NW;                // 13 pieces per wave (the last four waves' 13th piece is dead)
+  constexpr int BST = 4, B_BYTES = BN * 128;                      // weight ring: 4 slots of [64 rows][64 k]
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const sA = smem;
+  char* const sBr = smem + A_BYTES;
+  char* const scr = sBr + BST * B_BYTES;                          // 8 KiB: dead-piece sink (one KiB per wave)
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wid >> 1, wn = wid & 1;
+  const int tiles_n = p.N / BN;
+  const int tn = blockIdx.x % tiles_n, tm = blockIdx.x / tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int img0 = m0 >> 6, nimg = (p.M >> 6) - img0;             // images of this tile (<= 8 are live)
+  const int Ct = p.C0 + p.C1, c0n = p.C0 >> 6, nch = Ct >> 6;
+
+  // chunk range of this K slice
+  int ch0 = 0, ch1 = nch;
+  if constexpr (SPLITK) {
+    const int per = (nch + (int)gridDim.z - 1) / (int)gridDim.z;
+    ch0 = (int)blockIdx.z * per; ch1 = ch0 + per < nch ? ch0 + per : nch;
+    if (ch1 < ch0) ch1 = ch0;
+  }
+
+  // ---- A image fill: piece (i * 8 + wid) covers halo rows 8 piece .. + 7; this lane: row lane >> 3, 16-byte chunk lane & 7 ----
+  const int lrow = lane >> 3;
+  int a_pix[A_IT]; unsigned a_live = 0; int a_key[A_IT];
+#pragma unroll
+  for (int i = 0; i < A_IT; ++i) {
+    const int piece = i * NW + wid, hr = piece * 8 + lrow;
+    const int im = hr / IMG, rem = hr - im * IMG, yy = rem / HP, xx = rem - yy * HP;
+    const bool ok = piece < A_ROWS / 8 && im < nimg && yy >= 1 && yy <= HS && xx >= 1 && xx <= HS;
+    a_pix[i] = ok ? ((img0 + im) * HS + (yy - 1)) * HS + (xx - 1) : 0;
+    a_key[i] = xx & 7;
+    a_live |= (ok ? 1u : 0u) << i;
+  }
+  auto a_issue = [&](int cc) {                                     // chunk cc of the concatenated channels
+    const bool s1 = cc >= c0n;
+    const int Cs = s1 ? p.C1 : p.C0;
+    const bf16_t* base = s1 ? p.src1 : p.src0;
+    const unsigned so = (unsigned)((s1 ? cc - c0n : cc) * 128);
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+      const int piece = i * NW + wid;
+      const unsigned voff = ((a_live >> i) & 1) ? (unsigned)(a_pix[i] * Cs + (((lane & 7) ^ a_key[i]) << 3)) * 2u : 0x80000000u;
+      char* dst = piece < A_ROWS / 8 ? sA + piece * 1024 : scr + wid * 1024;
+      bufdma16(base, dst, voff, so);
+    }
+  };
+
+  // ---- weight ring: stage t = (chunk, tap): rows n0 .. n0 + 63, k = tap * Ct + chunk * 64 .. + 63; one piece per wave ----
+  const int brow = wid * 8 + lrow;                                 // tile-local weight row this lane fetches
+  const int bqp = (brow % WTN) / (4 * NI);
+  const int bkey = (brow & 3) | ((bqp & 1) << 2);                  // permuted rows: fragment-row swizzle key (igemm.hip)
+  const unsigned bvoff = (unsigned)(((long long)(n0 + brow) * p.K + (((lane & 7) ^ bkey) << 3)) * 2);
+  const int nsteps = (ch1 - ch0) * 9;
+  auto b_issue = [&](int t, bool live) {
+    const int cc = ch0 + t / 9, tap = t - (t / 9) * 9;
+    const unsigned so = __builtin_amdgcn_readfirstlane((unsigned)((tap * Ct + cc * 64) * 2));
+    bufdma16(p.W, sBr + (t % BST) * B_BYTES + wid * 1024, bvoff, so, live ? 0x7FFFFFF0u : 0u);
+  };
+
+  f32x4 acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // ---- fragment addresses ----
+  const int frow = lane & 15, q = lane >> 4;
+  const int fx = frow & 7, fy = frow >> 3;                         // pixel of the row tile: (y0 + fy, fx); y0 = 2 (i & 3), image 2 wm + (i >> 2)
+  const int abase = ((2 * wm) * IMG + fy * HP + fx) * 128;         // + (i >> 2) * IMG * 128 + 2 (i & 3) * HP * 128 + (ky * HP + kx) * 128
+  int foffB[2];
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk) foffB[kk] = (frow >> 2) * (4 * NI * 128) + (frow & 3) * 128 + ((((kk << 2) + q) ^ (lane & 7)) << 4);
+
+  if (nsteps > 0) {
+    // prologue: the first three weight stages, then the first activation chunk
+#pragma unroll
+    for (int s = 0; s < BST - 1; ++s) b_issue(s, s < nsteps);
+    for (int t = 0; t < nsteps; ++t) {
+      const int tap = t % 9;
+      if (tap == 0) {
+        // chunk boundary: every wave has left the previous chunk's last tap -> refill the image, wait for everything in flight
+        asm volatile("s_barrier" ::: "memory");
+        a_issue(ch0 + t / 9);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"i"(BST - 2) : "memory");   // this step's weight stage has landed (two younger ones may fly)
+      }
+      asm volatile("s_barrier" ::: "memory");
+      b_issue(t + BST - 1, t + BST - 1 < nsteps);                  // into the slot step t - 1 released
+      const int ky = tap / 3, kx = tap - ky * 3;
+      const char* sB = sBr + (t % BST) * B_BYTES + wn * WTN * 128;
+      const int aoff = abase + (ky * HP + kx) * 128;
+      const int akey = (fx + kx) & 7;
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        bf16x8 b[NI], a[MI];
+#pragma unroll
+        for (int j = 0; j < NI; ++j) b[j] = *(const bf16x8*)(sB + j * 512 + foffB[kk]);
+        const int ach = (((kk << 2) + q) ^ akey) << 4;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) a[i] = *(const bf16x8*)(sA + aoff + ((i >> 2) * IMG + 2 * (i & 3) * HP) * 128 + ach);
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);   // D = W . X^T
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // dead tail pieces still write zeros to LDS: let them land
+  igemm_epilogue<BM, BN, WM, WN, 0, SPLITK>(p, acc, smem, lane, wm, wn, m0, n0, tn, 0, nullptr);
+}

@@ -50,6 +50,8 @@ struct IgemmP {
   // holds in registers and writes gn_y = silu?(gn(out)); `out` itself is written only with gn_keep_out.  The launcher sets *gn_fused
   // (host) to 1 when it took this form; otherwise the caller runs the GroupNorm kernels as before.
   const float* gn_gamma; const float* gn_beta; bf16_t* gn_y; int gn_groups; float gn_eps; int gn_silu; int gn_keep_out; int* gn_fused;
+  int smap;                         // caller: 1 = 3x3 stride-1 convs on 8 x 8 maps take the whole-images-resident kernel (igemm_smap.h)
+  int wreg, wreg_mmin, wreg_mmax;   // caller: bit 0 = plain / bit 1 = GEGLU 1x1 launches with wreg_mmin <= M <= wreg_mmax take the weight-streaming kernel when Wfrag is set
   const bf16_t* Wfrag; int wfrag_ni; // the same matrix in MFMA fragment order for the weight-streaming kernel (igemm_wreg.h): column ranges of wfrag_ni x 16, KC = K
   int stagger;                      // timing experiments only: start delay of the CU's second workgroup, x1024 cycles
   int dbg;                          // timing experiments only (builds with -DAGD_EXPERIMENTS)
@@ -110,6 +112,18 @@ struct AttnChainP {
   const bf16_t* o1; const bf16_t* wo1f; const float* bo1;
 };
 int launch_attn_chain(const AttnChainP& p, int C, int heads, hipStream_t st);
+// proj_in (GroupNorm folded into per-image matrices, launch_gn_fold_weight with frag_ni = C / 64) -> h (stored) -> norm1 -> fused q / k / v
+// projection in one launch; h [M][C], qkv [M][3C]
+struct QkvChainP {
+  const bf16_t* x;                  // [M][C] raw block input
+  const bf16_t* wbf; long long wb_stride; const float* rowadd;   // per-image proj_in matrices in fragment order (+ image * wb_stride elements), per-image rows [B][C]
+  bf16_t* h;                        // [M][C] residual stream out
+  const float* gamma; const float* beta; float ln_eps;           // norm1
+  const bf16_t* wqkvf;              // attn1 [3C][C] (q rows, k rows, v rows) in fragment order (NI = C / 64, KC = C)
+  bf16_t* qkv;                      // [M][3C]
+  int M, HW;
+};
+int launch_qkv_chain(const QkvChainP& p, int C, hipStream_t st);
 int launch_frag_order_w1(const bf16_t* src, bf16_t* dst, int C, int HID, hipStream_t st);
 int launch_frag_order_w(const bf16_t* src, bf16_t* dst, int N, int K, int NI, int KC, hipStream_t st);
 
@@ -130,7 +144,7 @@ int launch_groupnorm(const GroupNormP& p, hipStream_t st);
 // GroupNorm (no activation) folded into the 1x1 projection that follows it: per image, Wb = W . diag(rstd_g gamma) (bf16) and
 // rowadd = bias + W beta - Wb mu (fp32), statistics from the producer's per-(tile, channel) partial sums [HW / bm tiles][C] float2
 int launch_gn_fold_weight(const float* part, int bm, int B, int HW, int C, int groups, float eps, const float* gamma, const float* beta,
-                          const bf16_t* W, const float* bias, int N, bf16_t* Wb, float* rowadd, hipStream_t st);
+                          const bf16_t* W, const float* bias, int N, bf16_t* Wb, float* rowadd, hipStream_t st, int frag_ni = 0);   // frag_ni > 0: Wb in MFMA fragment order (tblock.hip)
 long long groupnorm_ws_floats(int B, int C, int HW, int groups);   // workspace floats a launch_groupnorm call needs
 int launch_layernorm(const bf16_t* x, bf16_t* y, const float* g, const float* b, int rows, int C, float eps, hipStream_t st);
 

@@ -25,7 +25,8 @@ extern "C" void agd_set_error(const char* fmt, ...) {
 #define CK(expr) do { if ((expr) != 0) return -1; } while (0)
 #define FAIL(...) do { agd_set_error(__VA_ARGS__); return -1; } while (0)
 
-struct WMat { bf16_t* w = nullptr; int N = 0, Cin = 0, Cpad = 0, taps = 0; };
+struct WMat { bf16_t* w = nullptr; int N = 0, Cin = 0, Cpad = 0, taps = 0;
+              bf16_t* wfrag = nullptr; int wfrag_ni = 0; };   // the matrix once more in MFMA fragment order (igemm_wreg.h), column ranges of wfrag_ni x 16
 // cpart: per-(M tile, channel) partial sums the producing igemm launch leaves for a following GroupNorm
 // ([B*H*W / cpart_bm][C] float2; cpart_bm = 0: none were produced -> the GroupNorm runs its own statistics pass)
 struct Act { bf16_t* p = nullptr; int B = 0, H = 0, W = 0, C = 0; float* cpart = nullptr; int cpart_bm = 0;
@@ -109,8 +110,9 @@ struct agd_ctx {
   int opt_gn_proj_fold = 1;                           // agd_set_option("gn_proj_fold"): the transformers' GroupNorm folded into per-image proj_in matrices (1: C <= 320, 2: C <= 640)
   int opt_p8 = 1;                                     // agd_set_option("igemm8p"): 256-row 8-wave / 8-phase igemm for launches with enough tiles (igemm8p.h)
   int opt_halo = 1;                                   // agd_set_option("conv_halo"): 3x3 stride-1 convs through the row-halo kernel (igemm_halo.h)
-  int opt_tb_fuse = 15;                               // agd_set_option("tblock_fuse"): fused row-panel kernels of the C = 320 transformer blocks (tblock.hip): bit 0 = feed-forward (bit 3: + proj_out),
-                                                      // bit 1 = attn2 chain (bit 2: + attn1.to_out in front of it)
+  int opt_tb_fuse = 31;                               // agd_set_option("tblock_fuse"): fused row-panel kernels of the C = 320 transformer blocks (tblock.hip): bit 0 = feed-forward (bit 3: + proj_out),
+                                                      // bit 1 = attn2 chain (bit 2: + attn1.to_out in front of it), bit 4 = proj_in -> norm1 -> qkv
+  int opt_smap = 1;                                   // agd_set_option("conv_smap"): 3x3 convs of the 8 x 8 maps through the whole-images-resident kernel (igemm_smap.h)
   int opt_reduce_gn = 1;                              // agd_set_option("reduce_gn"): split-K slab sum + the GroupNorm that reads it as one launch (igemm.hip splitk_reduce_gn_kernel)
   int opt_touch = 3;                                  // agd_set_option("weight_touch"): n > 0 = stream 1x1 weight matrices of >= n MB through the caches right before their launch
   unsigned* touch_sink = nullptr;
@@ -172,6 +174,8 @@ struct GemmOpt {
   int w_per_image = 0;          // 1x1 launches: image i multiplies with w.w + i * N * K (GroupNorm folded into per-image matrices)
   // the GroupNorm(+SiLU) that reads this launch's output next, for split-K launches (IgemmP::gn_y): *gn_fused = 1 when the slab-sum pass did it
   const float* gn_gamma = nullptr; const float* gn_beta = nullptr; bf16_t* gn_y = nullptr; int gn_groups = 0; float gn_eps = 0.f; int gn_silu = 0, gn_keep_out = 0; int* gn_fused = nullptr;
+  int smap = 0;                 // benches / tests: allow the 8 x 8 whole-images-resident 3x3 kernel (the walk sets it through the ctx option)
+  int wreg = 0;                 // benches / tests: weight-streaming kernel for this launch when the WMat carries a fragment-order copy (bit 0 plain, bit 1 GEGLU)
   int pad = -1;                 // -1: 1 for 3x3, 0 for 1x1
   int hout = 0, wout = 0;       // >0: override (asymmetric (0,1,0,1) padding of the VAE encoder's stride-2 convs)
 };
@@ -198,9 +202,11 @@ static int run_conv(agd_ctx* c, hipStream_t st, const bf16_t* s0, int C0, const 
   p.rowstat_out = o.rowstat_out; p.rowstat_slots = o.rowstat_slots;
   p.ln_stats = o.ln_stats; p.ln_slots = o.ln_slots; p.ln_cs = o.ln_cs; p.ln_invC = o.ln_invC; p.ln_eps = o.ln_eps;
   if (o.w_per_image) { p.w_per_image = 1; p.sW = (long long)w.N * w.taps * w.Cpad; }
+  if (o.wreg && w.wfrag) { p.Wfrag = w.wfrag; p.wfrag_ni = w.wfrag_ni; p.wreg = o.wreg; p.wreg_mmin = 1; p.wreg_mmax = 1 << 30; }
   if (o.gn_y && c && c->opt_reduce_gn) { p.gn_gamma = o.gn_gamma; p.gn_beta = o.gn_beta; p.gn_y = o.gn_y; p.gn_groups = o.gn_groups; p.gn_eps = o.gn_eps; p.gn_silu = o.gn_silu;
                                          p.gn_keep_out = o.gn_keep_out; p.gn_fused = o.gn_fused; }
   p.halo = (c && c->opt_halo) || o.halo;
+  p.smap = (c && c->opt_smap) || o.smap;
   p.p8 = o.p8 ? o.p8 : c ? c->opt_p8 : 0;          // before any igemm_query: the tile shape depends on it
   if (o.query_cfg) { if (o.want_rowstat && !p.rowstat_out) { p.rowstat_out = (float*)16; p.rowstat_slots = 0; } return igemm_query(p, o.query_cfg); }   // (nothing is launched)
   if (o.out_act) {
@@ -444,17 +450,29 @@ static int transformer(agd_ctx* c, hipStream_t st, const std::string& pre, const
     GETW(w, wkey); GemmOpt o; o.bias = bias; o.geglu = geglu;
     return run_conv(c, st, ln.p, C, nullptr, 0, 1, 1, M, *w, 1, outp, o, c->zero_page);
   };
+  bool qkv_done = false;
   { GETW(w, pre + "proj_in.weight"); GETV(b, pre + "proj_in.bias");
     if (gfold) {
       if (w->taps != 1 || w->Cpad != C) FAIL("gn_proj_fold: proj_in weight [N=%d taps=%d Cpad=%d] is not a 1x1 over %d channels", w->N, w->taps, w->Cpad, C);
       bf16_t* wb = (bf16_t*)c->arena.alloc((size_t)Bs * w->N * C * 2);
       float* radd = (float*)c->arena.alloc((size_t)Bs * w->N * sizeof(float));
       if (!wb || !radd) return -1;
+      const bool qkv_fuse = (c->opt_tb_fuse & 16) && C == 320 && w->N == C && c->W.count(t + "attn1.qkv.frag");
       { ProfScope ps(c, st, PC_GN, 0, 2.0 * Bs * (double)w->N * C * 2);
-        CK(launch_gn_fold_weight(x.cpart, x.cpart_bm, Bs, HW, C, groups, 1e-6f, gg, gb, w->w, b, w->N, wb, radd, st)); }
+        CK(launch_gn_fold_weight(x.cpart, x.cpart_bm, Bs, HW, C, groups, 1e-6f, gg, gb, w->w, b, w->N, wb, radd, st, qkv_fuse ? C / 64 : 0)); }
+      if (qkv_fuse) {      // proj_in -> h -> norm1 -> q / k / v in one launch (tblock.hip); norm1's statistics come from the rows themselves
+        GETW(fqkv, t + "attn1.qkv.frag"); GETV(g1, t + "norm1.weight"); GETV(b1_, t + "norm1.bias");
+        QkvChainP qp{}; qp.x = x.p; qp.wbf = wb; qp.wb_stride = (long long)w->N * C; qp.rowadd = radd; qp.h = h.p; qp.gamma = g1; qp.beta = b1_; qp.ln_eps = lneps;
+        qp.wqkvf = fqkv->w; qp.qkv = qkv; qp.M = M; qp.HW = HW;
+        stats = nullptr; slots = 0;
+        ProfScope ps(c, st, PC_GEMM, 8.0 * M * (double)C * C, 2.0 * M * (double)C * 5.0 + 2.0 * (Bs + 3.0) * C * (double)C);
+        CK(launch_qkv_chain(qp, C, st));
+        qkv_done = true;
+      } else {
       WMat wi = *w; wi.w = wb;
       GemmOpt o; o.rowadd = radd; o.rowadd_ld = w->N; o.w_per_image = 1;
       CK(produce(x.p, C, wi, o, h.p, true));
+      }
     } else {
       GemmOpt o; o.bias = b;
       CK(produce(n.p, C, *w, o, h.p));
@@ -466,7 +484,7 @@ static int transformer(agd_ctx* c, hipStream_t st, const std::string& pre, const
   const bool chain_fuse = (c->opt_tb_fuse & 2) && C == 320 && heads == 8 && HW % 128 == 0 && c->ctx_T <= 96 && c->rec_mode != 2 && c->W.count(t + "attn2.to_q.frag");
   const bool chain_pre = chain_fuse && (c->opt_tb_fuse & 4) && !dup && c->W.count(t + "attn1.to_out.frag");     // attn1.to_out + residual inside the chain launch
   // --- self attention ---
-  { CK(consume(t + "norm1", t + "attn1.qkv", nullptr, 0, qkv));
+  { if (!qkv_done) CK(consume(t + "norm1", t + "attn1.qkv", nullptr, 0, qkv));
     AttnP a{}; a.q = qkv; a.k = qkv + C; a.v = qkv + 2 * C; a.o = att;
     a.ldq = a.ldk = a.ldv = 3 * C; a.ldo = C; a.sq = a.sk = a.sv = (long long)HW * 3 * C; a.so = (long long)HW * C;
     a.B = Bs; a.H = heads; a.D = C / heads; a.Nq = HW; a.Nk = HW; a.scale = 1.0f / sqrtf((float)(C / heads));
@@ -935,6 +953,12 @@ AGD_API int agd_finalize(agd_ctx* c) {
         API_CK(c, launch_frag_order_w(wq->w, fq.w, C, C, C / 64, C, 0));
         API_CK(c, launch_frag_order_w(wo->w, fo.w, C, C, C / 64, C, 0));
         c->W[t + "attn2.to_q.frag"] = fq; c->W[t + "attn2.to_out.frag"] = fo;
+        { const WMat* wqkv = getW(c, t + "attn1.qkv"); if (!wqkv) return fail_ctx(c);
+          if (wqkv->N == 3 * C && wqkv->Cpad == C && wqkv->taps == 1) {
+            WMat fqkv = *wqkv; fqkv.w = dmalloc<bf16_t>(c, (size_t)3 * C * C); if (!fqkv.w) return fail_ctx(c);
+            API_CK(c, launch_frag_order_w(wqkv->w, fqkv.w, 3 * C, C, C / 64, C, 0));
+            c->W[t + "attn1.qkv.frag"] = fqkv;
+          } }
         const WMat* wo1 = getW(c, t + "attn1.to_out.0.weight");
         if (!wo1) return fail_ctx(c);
         if (wo1->N == C && wo1->Cpad == C && wo1->taps == 1) {
@@ -1168,6 +1192,7 @@ AGD_API int agd_set_option(agd_ctx* c, const char* name, int value) {
   if (!strcmp(name, "gn_proj_fold")) { c->opt_gn_proj_fold = value < 0 ? 0 : value; return 0; }   // 0 off, 1: blocks with C <= 320, 2: C <= 640 (A/B)
   if (!strcmp(name, "tblock_fuse")) { c->opt_tb_fuse = value < 0 ? 0 : value; return 0; }   // bit 0: fused feed-forward, bit 1: fused attn2 chain (C = 320 blocks)
   if (!strcmp(name, "reduce_gn")) { c->opt_reduce_gn = value != 0; return 0; }
+  if (!strcmp(name, "conv_smap")) { c->opt_smap = value != 0; return 0; }
   if (!strcmp(name, "igemm8p")) { c->opt_p8 = value < 0 ? 0 : value; return 0; }   // 0 off, 1 on (the launcher decides per launch); tests: 2 / 3 / 4 force the 256-wide / 160-wide / any legal tile
   agd_set_error("set_option: unknown option '%s'", name);
   return fail_ctx(c);
@@ -1477,6 +1502,7 @@ AGD_API int agd_op_conv2d_ex(const float* x, const float* w, const float* bias, 
   CK(launch_convert_weight(w, wb, Cout, Cin, taps, Cpad, 0, st));
   WMat wm; wm.w = wb; wm.N = Cout; wm.Cin = Cin; wm.Cpad = Cpad; wm.taps = taps;
   GemmOpt o; o.bias = bias; o.stride = stride; o.up = up; o.out_f32 = 1; o.halo = flags & 1; o.p8 = (flags & 4) ? 2 : (flags & 8) ? 3 : (flags & 2) ? 1 : 0;
+  o.smap = (flags & 16) ? 1 : 0;
   CK(run_conv(nullptr, st, xb, Cpad, nullptr, 0, B, H, W, wm, ksize, yn, o, op_zero_page()));
   CK(launch_nchw_from_nhwc_f32(yn, Cout, y, B, Cout, Ho * Wo, st));
   hipStreamSynchronize(st);
@@ -1497,6 +1523,17 @@ AGD_API int agd_op_linear(const float* x, const float* w, const float* bias, con
   if (residual) CK(launch_f32_to_bf16(residual, rb, (long long)M * Nout, st));
   WMat wm; wm.w = wb; wm.N = N; wm.Cin = K; wm.Cpad = K; wm.taps = 1;
   GemmOpt o; o.bias = bias; o.residual = rb; o.geglu = geglu; o.out_f32 = 1; o.p8 = (flags & 4) ? 2 : (flags & 8) ? 3 : (flags & 2) ? 1 : 0;
+  if (flags & 16) {                                  // the weight-streaming kernel (igemm_wreg.h); bf16 output (that kernel's only form), widened afterwards
+    const int ni = geglu ? 4 : 2;
+    if (N % (ni * 64)) { agd_set_error("op_linear: the weight-streaming kernel needs N %% %d == 0", ni * 64); return -1; }
+    wm.wfrag = tmp.get<bf16_t>((size_t)N * K); bf16_t* yb = tmp.get<bf16_t>((size_t)M * Nout); if (!wm.wfrag || !yb) return -1;
+    CK(launch_frag_order_w(wb, wm.wfrag, N, K, ni, K, st));
+    wm.wfrag_ni = ni; o.wreg = 3; o.out_f32 = 0;
+    CK(run_conv(nullptr, st, xb, K, nullptr, 0, 1, 1, M, wm, 1, yb, o, op_zero_page()));
+    CK(launch_bf16_to_f32(yb, y, (long long)M * Nout, st));
+    hipStreamSynchronize(st);
+    return 0;
+  }
   CK(run_conv(nullptr, st, xb, K, nullptr, 0, 1, 1, M, wm, 1, y, o, op_zero_page()));
   hipStreamSynchronize(st);
   return 0;
@@ -1708,6 +1745,14 @@ AGD_API int agd_bench_conv(int B, int H, int W, int C0, int C1, int Cout, int ks
   const int mode = geglu; geglu &= 1;
   GemmOpt o; o.bias = bias; o.stride = stride; o.up = up; o.geglu = geglu; o.residual = r; o.halo = (mode & 8) ? 1 : 0;
   o.p8 = (mode & 32) ? 2 : (mode & 64) ? 3 : (mode & 16) ? 1 : 0;
+  o.smap = (mode & 256) ? 1 : 0;
+  if (mode & 128) {                                  // weight-streaming kernel (igemm_wreg.h): the matrix once more in fragment order
+    const int ni = geglu ? 4 : 2;
+    wm.wfrag = tmp.get<bf16_t>((size_t)Cout * taps * Ctot); if (!wm.wfrag) return -1;
+    if (taps != 1 || C1) { agd_set_error("bench: wreg is for plain 1x1 launches"); return -1; }
+    CK(launch_frag_order_w(w, wm.wfrag, Cout, Ctot, ni, Ctot, 0));
+    wm.wfrag_ni = ni; o.wreg = 3;
+  }
   float* stats = nullptr; float* cs = nullptr;
   if (mode & 6) {
     int cfg[3] = {0, 0, 0}; GemmOpt qo = o; qo.query_cfg = cfg; qo.want_rowstat = (mode & 2) ? 1 : 0;

@@ -351,7 +351,7 @@ int launch_layernorm(const bf16_t* x, bf16_t* y, const float* g, const float* b,
 __global__ __launch_bounds__(512) void gn_fold_weight_kernel(const float* __restrict__ part, int bm, int HW, int C, int groups, float eps,
                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
                                                              const bf16_t* __restrict__ W, const float* __restrict__ bias, int N,
-                                                             bf16_t* __restrict__ Wb, float* __restrict__ rowadd) {
+                                                             bf16_t* __restrict__ Wb, float* __restrict__ rowadd, int frag_ni) {
   extern __shared__ float gsm[];                   // [groups] mean, [groups] rstd, [C] scale, [C] mean per channel, [C] beta
   float* smean = gsm; float* srstd = gsm + groups; float* sa = gsm + 2 * groups; float* smu = sa + C; float* sbeta = smu + C;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -423,7 +423,13 @@ __global__ __launch_bounds__(512) void gn_fold_weight_kernel(const float* __rest
         }
         u32x4 pk;
         pk[0] = pack_bf2(o[0], o[1]); pk[1] = pack_bf2(o[2], o[3]); pk[2] = pack_bf2(o[4], o[5]); pk[3] = pack_bf2(o[6], o[7]);
-        *(u32x4*)(wo + v * 8) = pk;
+        if (frag_ni > 0) {
+          // MFMA fragment order (tblock.hip launch_frag_order_w, KC = C): the 16 bytes (row n, k-vector v) are lane (v & 3) * 16 + rho of fragment
+          // (column range n / (16 NI), k-step v / 4, tile j), rho = 4 q' + r' with n % (16 NI) = q' * 4 NI + 4 j + r'
+          const int wr = frag_ni * 16, nqi = n / wr, cl = n - nqi * wr, qp = cl / (4 * frag_ni), rem = cl - qp * 4 * frag_ni, j = rem >> 2, rp = rem & 3;
+          const long long fi = (((long long)nqi * (C >> 5) + (v >> 2)) * frag_ni + j) * 64 + (v & 3) * 16 + 4 * qp + rp;
+          *(u32x4*)(Wb + (long long)b * N * C + fi * 8) = pk;
+        } else *(u32x4*)(wo + v * 8) = pk;
       }
     }
     for (int o = 32; o >= 1; o >>= 1) { accb += __shfl_xor(accb, o); accm += __shfl_xor(accm, o); }
@@ -432,11 +438,12 @@ __global__ __launch_bounds__(512) void gn_fold_weight_kernel(const float* __rest
 }
 
 int launch_gn_fold_weight(const float* part, int bm, int B, int HW, int C, int groups, float eps, const float* gamma, const float* beta,
-                          const bf16_t* W, const float* bias, int N, bf16_t* Wb, float* rowadd, hipStream_t st) {
+                          const bf16_t* W, const float* bias, int N, bf16_t* Wb, float* rowadd, hipStream_t st, int frag_ni) {
+  if (frag_ni > 0 && (N % (16 * frag_ni) || C % 32)) { agd_set_error("gn_fold_weight: fragment order needs N %% %d == 0 and C %% 32 == 0", 16 * frag_ni); return -1; }
   if (!part || bm < 1 || HW % bm || C % groups || (C & 7) || B < 1 || N < 1) { agd_set_error("gn_fold_weight: bad shape (HW %d bm %d C %d groups %d)", HW, bm, C, groups); return -1; }
   const size_t lds = (size_t)(2 * groups + 3 * C) * sizeof(float);
   if (C > 1024 || lds > 48 * 1024) { agd_set_error("gn_fold_weight: C = %d too wide", C); return -1; }
-  hipLaunchKernelGGL(gn_fold_weight_kernel, dim3((N + GNF_ROWS - 1) / GNF_ROWS, B), dim3(512), lds, st, part, bm, HW, C, groups, eps, gamma, beta, W, bias, N, Wb, rowadd);
+  hipLaunchKernelGGL(gn_fold_weight_kernel, dim3((N + GNF_ROWS - 1) / GNF_ROWS, B), dim3(512), lds, st, part, bm, HW, C, groups, eps, gamma, beta, W, bias, N, Wb, rowadd, frag_ni);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }

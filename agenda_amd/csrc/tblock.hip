@@ -148,15 +148,16 @@ template <int NI> AGD_DEV void store_row_chunk(bf16_t* p, const u32x2 (&r)[NI]) 
 #define TB_F 10
 #define TB_D 8
 template <int C>
-AGD_DEV void panel_gemm_head(u32x4 (&ring)[TB_F], const bf16_t* wf, unsigned wbase, unsigned lane16) {
-  const auto wrs = __builtin_amdgcn_make_buffer_rsrc((void*)wf, 0, (unsigned)(C * C * 2), 0x00020000);
+AGD_DEV void panel_gemm_head(u32x4 (&ring)[TB_F], const bf16_t* wf, unsigned wbase, unsigned lane16, unsigned wbytes = C * C * 2) {
+  const auto wrs = __builtin_amdgcn_make_buffer_rsrc((void*)wf, 0, wbytes, 0x00020000);
 #pragma unroll
   for (int f = 0; f < TB_D; ++f) ring[f % TB_F] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, lane16, wbase + (unsigned)f * 1024u, 0));
 }
 template <int C>
-AGD_DEV void panel_gemm_body(u32x4 (&ring)[TB_F], f32x4 (&acc)[4][C / 64], const bf16_t* wf, unsigned wbase, unsigned lane16, const char* xrow, int xoff0, int xoff1) {
+AGD_DEV void panel_gemm_body(u32x4 (&ring)[TB_F], f32x4 (&acc)[4][C / 64], const bf16_t* wf, unsigned wbase, unsigned lane16, const char* xrow, int xoff0, int xoff1,
+                             unsigned wbytes = C * C * 2) {
   constexpr int NI = C / 64, KS = C / 32, NFR = KS * NI, PITCH = C * 2;
-  const auto wrs = __builtin_amdgcn_make_buffer_rsrc((void*)wf, 0, (unsigned)(C * C * 2), 0x00020000);
+  const auto wrs = __builtin_amdgcn_make_buffer_rsrc((void*)wf, 0, wbytes, 0x00020000);
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -849,6 +850,131 @@ int launch_attn_chain(const AttnChainP& p, int C, int heads, hipStream_t st) {
   if (dev < 0 || dev >= AGD_MAX_DEVICES) { agd_set_error("attn_chain: device ordinal %d out of range", dev); return -1; }
   if (!attr[dev][pre]) { HIP_CHECK_RET(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); attr[dev][pre] = true; }
   AttnChainP pp = p;
+  void* args[] = {&pp};
+  HIP_CHECK_RET(hipLaunchKernel(kfn, dim3(p.M / 128), dim3(512), args, lds, st));
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// fused block head:  proj_in (the transformer's GroupNorm folded into per-image matrices) -> h -> norm1 -> q / k / v projections
+//
+// Transformer2DModel.proj_in and BasicTransformerBlock's norm1 + attn1.to_q / to_k / to_v (diffusers, behind data_generation.py:59).  One
+// workgroup = 128 token rows of one image: the raw rows in the LDS panel, GEMM with the image's folded matrix (+ its fp32 row), h rounded once
+// and stored (it is the residual of attn1.to_out), norm1 from the rounded values in registers back into the panel, then three C -> C GEMM
+// stages whose outputs go straight to the packed [M][3C] buffer the flash-attention kernel reads.  Replaces two launches and the 21 MB
+// write + re-read of h between them.
+// ---------------------------------------------------------------------------------------------------------------------------
+template <int C>
+__global__ __launch_bounds__(512, 2) void qkv_chain_kernel(const QkvChainP p) {
+  constexpr int BM = 128, KS = C / 32, NI = C / 64, PITCH = C * 2;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* panel = smem;
+  float* pst = (float*)(smem + BM * PITCH);            // [4 column quarters][BM] (sum, sum of squares) of h
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int mh = wid >> 2, nq = wid & 3;
+  const int q = lane >> 4, px = lane & 15;
+  const int m0 = blockIdx.x * BM;
+  const int img = m0 / p.HW;                           // tiles stay inside one image (HW % 128 == 0)
+
+  panel_load_dma<C>(p.x, m0, p.M, panel, wid, lane);
+  const int rbase = 64 * mh + px;
+  const int sx = (px >> 1) & 7;
+  const int xoff0 = ((q ^ sx) << 4), xoff1 = (((4 + q) ^ sx) << 4);
+  const char* xrow = panel + rbase * PITCH;
+  f32x4 acc[4][NI];
+  u32x4 ring[TB_F];
+  const unsigned lane16 = (unsigned)lane * 16u;
+  const int ncol0 = (C / 4) * nq + 4 * NI * q;
+  const unsigned wbase = __builtin_amdgcn_readfirstlane((unsigned)(nq * KS * NI) * 1024u);
+  const bf16_t* wimg = p.wbf + (long long)img * p.wb_stride;
+  panel_gemm_head<C>(ring, wimg, wbase, lane16);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  // ---- proj_in: h = x . Wb[img]^T + row[img], rounded once, stored; its row statistics ----
+  panel_gemm_body<C>(ring, acc, wimg, wbase, lane16, xrow, xoff0, xoff1);
+  panel_gemm_head<C>(ring, p.wqkvf, wbase, lane16, 3u * C * C * 2);
+  {
+    float rv[NI * 4];
+#pragma unroll
+    for (int t = 0; t < NI; ++t) *(f32x4*)&rv[4 * t] = *(const f32x4*)(p.rowadd + (long long)img * C + ncol0 + 4 * t);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = m0 + rbase + 16 * i;
+      u32x2 pkk[NI];
+      float rs1 = 0.f, rq1 = 0.f;
+#pragma unroll
+      for (int t = 0; t < NI; ++t) {
+        u32x2 pk;
+        pk[0] = pack_bf2(acc[i][t][0] + rv[4 * t], acc[i][t][1] + rv[4 * t + 1]);
+        pk[1] = pack_bf2(acc[i][t][2] + rv[4 * t + 2], acc[i][t][3] + rv[4 * t + 3]);
+        pkk[t] = pk;
+        acc[i][t] = f32x4{__uint_as_float(pk[0] << 16), __uint_as_float(pk[0] & 0xFFFF0000u), __uint_as_float(pk[1] << 16), __uint_as_float(pk[1] & 0xFFFF0000u)};
+        rs1 += (acc[i][t][0] + acc[i][t][1]) + (acc[i][t][2] + acc[i][t][3]);
+        rq1 += (acc[i][t][0] * acc[i][t][0] + acc[i][t][1] * acc[i][t][1]) + (acc[i][t][2] * acc[i][t][2] + acc[i][t][3] * acc[i][t][3]);
+      }
+      if (m < p.M) store_row_chunk<NI>(p.h + (long long)m * C + ncol0, pkk);
+      rs1 += __shfl_xor(rs1, 16); rs1 += __shfl_xor(rs1, 32);
+      rq1 += __shfl_xor(rq1, 16); rq1 += __shfl_xor(rq1, 32);
+      if (q == 0) *(f32x2_t*)(pst + (nq * BM + rbase + 16 * i) * 2) = f32x2_t{rs1, rq1};
+    }
+  }
+  __syncthreads();                                      // partial sums staged AND every wave is done reading x from the panel
+  {
+    float g1[NI * 4], b1[NI * 4];
+#pragma unroll
+    for (int t = 0; t < NI; ++t) { *(f32x4*)&g1[4 * t] = *(const f32x4*)(p.gamma + ncol0 + 4 * t); *(f32x4*)&b1[4 * t] = *(const f32x4*)(p.beta + ncol0 + 4 * t); }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = rbase + 16 * i;
+      float S = 0.f, Q = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) { const f32x2_t v = *(const f32x2_t*)(pst + (w * BM + row) * 2); S += v[0]; Q += v[1]; }
+      const float mu = S * (1.0f / C);
+      float var = Q * (1.0f / C) - mu * mu; var = var < 0.f ? 0.f : var;
+      const float rstd = rsqrtf(var + p.ln_eps);
+#pragma unroll
+      for (int t = 0; t < NI; ++t) {
+        const int n = ncol0 + 4 * t;
+        u32x2 pk;
+        pk[0] = pack_bf2((acc[i][t][0] - mu) * rstd * g1[4 * t] + b1[4 * t], (acc[i][t][1] - mu) * rstd * g1[4 * t + 1] + b1[4 * t + 1]);
+        pk[1] = pack_bf2((acc[i][t][2] - mu) * rstd * g1[4 * t + 2] + b1[4 * t + 2], (acc[i][t][3] - mu) * rstd * g1[4 * t + 3] + b1[4 * t + 3]);
+        *(u32x2*)(panel + row * PITCH + panel_swz(n >> 3, row) * 16 + (n & 7) * 2) = pk;
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- q, k, v: three C -> C stages over the normalised rows, each straight to its third of the packed row ----
+#pragma unroll
+  for (int s = 0; s < 3; ++s) {
+    const unsigned wb_s = __builtin_amdgcn_readfirstlane((unsigned)((4 * s + nq) * KS * NI) * 1024u);
+    if (s > 0) panel_gemm_head<C>(ring, p.wqkvf, wb_s, lane16, 3u * C * C * 2);
+    panel_gemm_body<C>(ring, acc, p.wqkvf, wb_s, lane16, xrow, xoff0, xoff1, 3u * C * C * 2);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = m0 + rbase + 16 * i;
+      u32x2 pkk[NI];
+#pragma unroll
+      for (int t = 0; t < NI; ++t) { pkk[t][0] = pack_bf2(acc[i][t][0], acc[i][t][1]); pkk[t][1] = pack_bf2(acc[i][t][2], acc[i][t][3]); }
+      if (m < p.M) store_row_chunk<NI>(p.qkv + (long long)m * 3 * C + s * C + ncol0, pkk);
+    }
+  }
+}
+
+int launch_qkv_chain(const QkvChainP& p, int C, hipStream_t st) {
+  if (C != 320) { agd_set_error("qkv_chain: C = %d is not built (320 only)", C); return -1; }
+  if (p.M < 128 || p.M % 128 || p.HW % 128 || p.M % p.HW) { agd_set_error("qkv_chain: M %d / HW %d must be multiples of 128 (whole images)", p.M, p.HW); return -1; }
+  if (!p.x || !p.wbf || !p.rowadd || !p.h || !p.gamma || !p.beta || !p.wqkvf || !p.qkv) { agd_set_error("qkv_chain: bad arguments"); return -1; }
+  if ((long long)p.M * C * 6 >= (1LL << 31)) { agd_set_error("qkv_chain: activation too large for 32-bit offsets"); return -1; }
+  constexpr int lds = 128 * 320 * 2 + 4 * 128 * 8;
+  const void* kfn = (const void*)qkv_chain_kernel<320>;
+  static bool attr[AGD_MAX_DEVICES] = {};
+  int dev = 0; HIP_CHECK_RET(hipGetDevice(&dev));
+  if (dev < 0 || dev >= AGD_MAX_DEVICES) { agd_set_error("qkv_chain: device ordinal %d out of range", dev); return -1; }
+  if (!attr[dev]) { HIP_CHECK_RET(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); attr[dev] = true; }
+  QkvChainP pp = p;
   void* args[] = {&pp};
   HIP_CHECK_RET(hipLaunchKernel(kfn, dim3(p.M / 128), dim3(512), args, lds, st));
   return 0;

@@ -117,9 +117,10 @@ int agd_vae_encode(agd_ctx* ctx, const float* image, int batch, int side, float*
  * "igemm8p" (default 1): launches with enough 256-row tiles (wide 1x1 projections, 3x3 convs with N a multiple of 256, the
  * upsampling convs) run the 8-wave / 8-phase implicit-GEMM kernel (igemm8p.h); 0 = the 4-wave kernels everywhere; tests: 2 / 3 / 4
  * force its 256-wide / 160-wide / any legal tile.
- * "tblock_fuse" (default 15): fused row-panel kernels of the transformer blocks at C = 320 (tblock.hip) -- bit 0: norm3 -> GEGLU ->
+ * "tblock_fuse" (default 31): fused row-panel kernels of the transformer blocks at C = 320 (tblock.hip) -- bit 0: norm3 -> GEGLU ->
  * ff.net.2 + residual as one launch, bit 1: norm2 -> to_q -> cross-attention (+ recorder) -> to_out + residual as one launch, bit 2: that
- * launch starts at attn1.to_out + residual, bit 3: the feed-forward launch ends with proj_out + residual (+ the next GroupNorm's sums). */
+ * launch starts at attn1.to_out + residual, bit 3: the feed-forward launch ends with proj_out + residual (+ the next GroupNorm's sums), bit 4: proj_in (GroupNorm folded) -> norm1 ->
+ * q / k / v projections as one launch. */
 int agd_set_option(agd_ctx* ctx, const char* name, int value);
 
 /* ---- heat-map recording (daam.trace / hook.py UNetCrossAttentionHooker state)
@@ -176,8 +177,10 @@ int agd_attn_processor_backward(agd_ctx* ctx, const char* layer, const float* hi
  * used by the parity tests, mirror torch.nn.functional signatures the oracle uses. */
 int agd_op_conv2d(const float* x_nchw, const float* w, const float* bias, float* y_nchw, int B, int Cin, int H, int W,
                   int Cout, int ksize, int stride, int pad, int upsample, void* stream);
-/* flags bit 0: 3x3 stride-1 launches take the row-halo kernel where it applies; bits 1..3: the 256-row 8-wave / 8-phase kernel --
-   2 = where the launcher would pick it, 4 / 8 = force its 256- / 160-wide tile (agd_op_linear: the same bits in `geglu`, bit 0 = GEGLU) */
+/* flags bit 0: 3x3 stride-1 launches take the row-halo kernel where it applies; bit 4: 8 x 8 maps take the whole-images-resident kernel
+   (igemm_smap.h); bits 1..3: the 256-row 8-wave / 8-phase kernel --
+   2 = where the launcher would pick it, 4 / 8 = force its 256- / 160-wide tile (agd_op_linear: the same bits in `geglu`, bit 0 = GEGLU,
+   bit 4 = the weight-streaming 1x1 kernel, igemm_wreg.h: the matrix in fragment order straight to registers, bf16 output) */
 int agd_op_conv2d_ex(const float* x, const float* w, const float* bias, float* y, int B, int Cin, int H, int W, int Cout,
                      int ksize, int stride, int pad, int upsample, int flags, void* stream);
 int agd_op_linear(const float* x, const float* w, const float* bias, const float* residual, float* y, int M, int K,

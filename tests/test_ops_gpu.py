@@ -89,6 +89,52 @@ def test_linear(ops, M, K, N, geglu, res):
     assert rel_err(got, y) < 1e-4
 
 
+@pytest.mark.parametrize("B,Cin,Cout", [(8, 1280, 1280), (8, 128, 64), (3, 320, 128), (16, 192, 192), (1, 64, 64)])
+def test_conv3x3_whole_images_resident_kernel_8x8(ops, B, Cin, Cout):
+    """igemm_smap.h: 3x3 / stride 1 / pad 1 on 8 x 8 maps -- all rows x 64 output channels x a slice of the input channels per workgroup,
+    the eight images with their zero border in one LDS image per 64-channel chunk, every weight tile streamed once (split-K slabs + the
+    ordered slab pass behind it).  vs F.conv2d fp32 and vs the default kernels: full tile (UNet batch 8), one chunk (no split), fewer
+    than eight images, two row tiles, a single image."""
+    g = torch.Generator().manual_seed(B * 7 + Cin + Cout)
+    x = bfr(torch.randn(B, Cin, 8, 8, generator=g))
+    w = bfr(torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(Cin * 9))
+    b = torch.randn(Cout, generator=g) * 0.1
+    want = F.conv2d(x, w, b, padding=1)
+    got = ops.conv2d(x.cuda(), w.cuda(), b.cuda(), smap=True)
+    ref = ops.conv2d(x.cuda(), w.cuda(), b.cuda())
+    assert rel_err(got, want) < 1e-4, rel_err(got, want)
+    assert rel_err(got, ref.cpu()) < 1e-4
+    assert torch.equal(got, ops.conv2d(x.cuda(), w.cuda(), b.cuda(), smap=True))        # ordered slab sum: run-to-run identical
+
+
+@pytest.mark.parametrize("M,K,N,geglu,res", [
+    (2048, 1280, 1280, False, True),     # 16 x 16 maps' C -> C projection + residual
+    (8192, 640, 1920, False, False),     # 32 x 32 qkv
+    (2048, 1280, 2560, True, False),     # GEGLU (256-wide tile, [8 values | 8 gates] row groups)
+    (1000, 192, 384, False, True),       # ragged M (1000 = 15 x 64 + 40), odd stage count (3 stages of 64)
+    (512, 5120, 1280, False, True),      # long K, few tiles
+])
+def test_linear_weight_streaming_kernel(ops, M, K, N, geglu, res):
+    """igemm_wreg.h: the weight matrix in MFMA fragment order straight to registers, activations register-staged through LDS; behind it the
+    same register epilogue as the other igemm kernels.  vs fp32 torch (bf16 output: 2^-7) and vs the launcher's default kernel."""
+    g = torch.Generator().manual_seed(M + K + N)
+    x = bfr(torch.randn(M, K, generator=g))
+    w = bfr(torch.randn(N, K, generator=g) / math.sqrt(K))
+    b = torch.randn(N, generator=g) * 0.1
+    y = F.linear(x, w, b)
+    if geglu:
+        val, gate = y.chunk(2, dim=-1)
+        y = val * F.gelu(gate)
+    r = bfr(torch.randn(M, y.shape[1], generator=g)) if res else None
+    if res:
+        y = y + r
+    got = ops.linear(x.cuda(), w.cuda(), b.cuda(), r.cuda() if res else None, geglu=geglu, wreg=True)
+    ref = ops.linear(x.cuda(), w.cuda(), b.cuda(), r.cuda() if res else None, geglu=geglu)
+    assert rel_err(got, y) < REL
+    assert rel_err(got, ref.cpu()) < REL
+    assert torch.equal(got, ops.linear(x.cuda(), w.cuda(), b.cuda(), r.cuda() if res else None, geglu=geglu, wreg=True))
+
+
 @pytest.mark.parametrize("M", [128, 1000, 4096 * 2])      # one tile; ragged tail (1000 = 7 x 128 + 104); many tiles
 def test_ff_fused_matches_torch_and_the_unfused_kernels(ops, M):
     """tblock.hip ff_fused_kernel (norm3 -> GEGLU -> ff.net.2 + residual in one launch, the hidden activation never in HBM) vs fp32 torch
