@@ -25,13 +25,17 @@ TFLOP_PER_IMAGE = {50: 82.84}          # 2*50*803.3 GF + 2514.5 
 UNET_GF, VAE_GF = 803.3, 2514.5
 MFMA_PEAK_TF = 2500.0                  # bf16 dense, MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0                  # HBM3E spec, MI355X_MICROARCH.md (6.3 TB/s is what a copy achieves)
-PMC_CSV = os.path.join("profiles", "r03_pmc_traffic_summary.csv")
+PMC_CSV = os.path.join("profiles", "r04_pmc_traffic_summary.csv")
+STATS_CSV = os.path.join("profiles", "r04_bench_kernel_stats.csv")
 
 # the kernel instantiations behind each class, as rocprofv3 names them: igemm_kernel<BM, BN, WM, WN, KS, ...>,
 # igemm_halo_kernel<BN, SPLITK, BST> (3x3 only), igemm8p_kernel<WM, WN, MI, NI0, NI1, KS, GEGLU>
-CLASS_KERNEL = {"igemm_conv3x3": [("igemm_kernel<", ", 3, "), ("igemm_halo_kernel<", ""), ("igemm8p_kernel<", ", 3, 0>")],
-                "igemm_linear_1x1": [("igemm_kernel<", ", 1, "), ("igemm8p_kernel<", ", 1, 0>"), ("igemm8p_kernel<", ", 1, 1>")],
-                "attn_self_flash": [("attn_kernel<", ", 0, 0>")], "attn_cross_daam": [("attn_kernel<", ", 1, 0>"), ("attn_kernel<", ", 2, 0>")],
+# round 4: the fused row-panel kernels of the C = 320 blocks (tblock.hip) are booked where the launches they replace were: ff_fused / qkv_chain
+# under the linears, attn_chain under cross-attention; igemm_smap_kernel (8 x 8 maps) and the split-K slab passes under the convs
+CLASS_KERNEL = {"igemm_conv3x3": [("igemm_kernel<", ", 3, "), ("igemm_halo_kernel<", ""), ("igemm8p_kernel<", ", 3, 0>"), ("igemm_smap_kernel<", "")],
+                "igemm_linear_1x1": [("igemm_kernel<", ", 1, "), ("igemm8p_kernel<", ", 1, 0>"), ("igemm8p_kernel<", ", 1, 1>"), ("ff_fused_kernel<", ""), ("qkv_chain_kernel<", "")],
+                "attn_self_flash": [("attn_kernel<", ", 0, 0>")],
+                "attn_cross_daam": [("attn_kernel<", ", 1, 0>"), ("attn_kernel<", ", 2, 0>"), ("attn_chain_kernel<", "")],
                 "groupnorm": [("gn_", "")], "layernorm": [("layernorm_kernel", "")]}
 
 
@@ -63,7 +67,30 @@ def pmc_traffic(cls):
             f = line.rsplit(",", 5)                            # kernel, launches, avg_us, fetch_MB, write_MB, total_MB
             if any(a in f[0] and b in f[0] for a, b in pats):
                 n += float(f[1]); mb += float(f[1]) * float(f[5])
-        return {"MB_per_launch": round(mb / n, 2), "launches_profiled": int(n), "source": PMC_CSV} if n else None
+        # (a committed rocprofv3 --pmc pass of the same command, NOT a measurement of this run: the counters cannot be sampled in-process)
+        return {"MB_per_launch": round(mb / n, 2), "launches_profiled": int(n), "source": PMC_CSV, "measured_in_this_run": False} if n else None
+    except Exception:
+        return None
+
+
+def heaviest_instantiation(cls):
+    """The single kernel instantiation of a class with the most total time in the committed `rocprofv3 --kernel-trace --stats` summary of
+    this command (so that the class-level fraction can be re-derived from one row of that file), or None."""
+    try:
+        pats = CLASS_KERNEL[cls]
+        best = None
+        import csv
+        with open(os.path.join(ROOT, STATS_CSV)) as f:
+            for r in csv.DictReader(f):
+                name = r.get("Name") or r.get("KernelName") or ""
+                if any(a in name and b in name for a, b in pats):
+                    tot = float(r.get("TotalDurationNs") or 0.0)
+                    if best is None or tot > best[0]:
+                        best = (tot, name, int(float(r.get("Calls") or 0)), float(r.get("AverageNs") or 0.0))
+        if best is None:
+            return None
+        return {"kernel": best[1].split("(")[0][:120], "calls": best[2], "avg_us": round(best[3] / 1e3, 1), "total_ms": round(best[0] / 1e6, 2),
+                "source": STATS_CSV, "measured_in_this_run": False}
     except Exception:
         return None
 
@@ -228,7 +255,7 @@ def main():
         roof = {"bound": "mfma" if mfma_bound else "hbm", "kernel": f"{CLASS_KERNEL.get(dom, [(dom, '')])[0][0].rstrip('<')} [{dom}]",
                 "achieved": d["TFLOPs"] if mfma_bound else d["GBs"], "peak": MFMA_PEAK_TF if mfma_bound else HBM_PEAK_GBS,
                 "unit": "TFLOP/s" if mfma_bound else "GB/s", "frac": d["frac_mfma"] if mfma_bound else d["frac_hbm"],
-                "frac_binding_roof": d["frac"], "traffic": pmc_traffic(dom),
+                "frac_binding_roof": d["frac"], "traffic": pmc_traffic(dom), "heaviest_instantiation": heaviest_instantiation(dom),
                 "launches": d["launches"], "avg_launch_us": round(d["ms"] * 1e3 / max(raw["launches"], 1), 1),
                 "algorithmic_per_launch": {"GFLOP": round(raw["flops"] / raw["launches"] / 1e9, 2), "MB": round(raw["bytes"] / raw["launches"] / 1e6, 2)},
                 "igemm_all_frac_mfma": round(ig_fl / (ig_ms * 1e-3) / 1e12 / MFMA_PEAK_TF, 4) if ig_ms else None,

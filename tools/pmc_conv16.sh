@@ -11,7 +11,7 @@ for form in halo gen:0 gen:1; do
     if [ -n "$w" ]; then export AGD_IGEMM_WMAJOR=$w; else unset AGD_IGEMM_WMAJOR; fi
     KB_FORM=$f rocprofv3 --pmc $set --output-format csv -d $O/p -- python3 tools/kb_conv16.py > $O/${form}_$i.log 2>&1 || echo "pass $form $i failed"
     c=$(find $O/p -name "*counter_collection.csv" | head -1)
-    if [ -n "$c" ]; then python3 tools/pmc_generic.py $c | grep -v "fill_random\|^kernel" | sed "s/^/$form,/" >> $O/table.csv; fi
+    if [ -n "$c" ]; then python3 tools/pmc_generic.py $c | grep -v "fill_random\|rocclr" | sed "s/^/$form,/" >> $O/table.csv; fi
     rm -rf $O/p
   done
 done
