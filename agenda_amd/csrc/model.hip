@@ -29,8 +29,13 @@ struct WMat { bf16_t* w = nullptr; int N = 0, Cin = 0, Cpad = 0, taps = 0;
               bf16_t* wfrag = nullptr; int wfrag_ni = 0; };   // the matrix once more in MFMA fragment order (igemm_wreg.h), column ranges of wfrag_ni x 16
 // cpart: per-(M tile, channel) partial sums the producing igemm launch leaves for a following GroupNorm
 // ([B*H*W / cpart_bm][C] float2; cpart_bm = 0: none were produced -> the GroupNorm runs its own statistics pass)
+// normed / normed_gamma: a GroupNorm of this activation that its producer already applied (split-K slab pass, igemm.hip splitk_reduce_gn_kernel):
+// the consumer whose norm weights are `normed_gamma` reads `normed` instead of running the GroupNorm kernels
 struct Act { bf16_t* p = nullptr; int B = 0, H = 0, W = 0, C = 0; float* cpart = nullptr; int cpart_bm = 0;
+             bf16_t* normed = nullptr; const float* normed_gamma = nullptr;
              long long n() const { return (long long)B * H * W * C; } };
+// the GroupNorm that will read a resnet's output next, when it reads that tensor alone (no concat): lets a split-K conv2 normalise in its slab pass
+struct NextGn { const float* gamma = nullptr; const float* beta = nullptr; float eps = 0.f; int silu = 0; };
 
 struct Arena {
   char* base = nullptr; size_t cap = 0, off = 0, peak = 0;
@@ -274,14 +279,18 @@ static const float* getV(agd_ctx* c, const std::string& k) {
 
 // ResnetBlock2D (norm1-silu-conv1 (+temb) - norm2-silu-conv2 + shortcut)
 static int resnet(agd_ctx* c, hipStream_t st, const std::string& pre, const Act& x0, const Act* x1, int Cout, float eps,
-                  bool has_temb, int groups, Act& out) {
+                  bool has_temb, int groups, Act& out, const NextGn* next = nullptr) {
   const int B = x0.B, H = x0.H, Wd = x0.W, HW = H * Wd;
   const int C1 = x1 ? x1->C : 0, Cin = x0.C + C1;
   out = alloc_act(c, B, H, Wd, Cout, true); if (!out.p) return -1;
+  bf16_t* out_normed = nullptr;
+  if (next && next->gamma && c->opt_reduce_gn) { out_normed = (bf16_t*)c->arena.alloc((size_t)out.n() * 2); if (!out_normed) return -1; }   // lives as long as `out`
   const size_t mk = c->arena.mark();
   Act n1 = alloc_act(c, B, H, Wd, Cin); if (!n1.p) return -1;
   GETV(g1, pre + "norm1.weight"); GETV(b1, pre + "norm1.bias");
-  CK(run_gn(c, st, x0.p, x0.C, x1 ? x1->p : nullptr, C1, B, HW, g1, b1, groups, eps, 1, n1.p, &x0, x1));
+  const bf16_t* n1p = n1.p;
+  if (!x1 && x0.normed && x0.normed_gamma == g1) n1p = x0.normed;      // the producer's slab pass already applied this very norm
+  else CK(run_gn(c, st, x0.p, x0.C, x1 ? x1->p : nullptr, C1, B, HW, g1, b1, groups, eps, 1, n1.p, &x0, x1));
   Act h = alloc_act(c, B, H, Wd, Cout, true); if (!h.p) return -1;
   GETW(w1, pre + "conv1.weight"); GETV(cb1, pre + "conv1.bias");
   GemmOpt o1; o1.bias = cb1; o1.out_act = &h;
@@ -295,7 +304,7 @@ static int resnet(agd_ctx* c, hipStream_t st, const std::string& pre, const Act&
   // conv1's output is read by norm2 and by nothing else: a split-K launch's slab-sum pass normalises straight into n2 (h is not written)
   int gn_done = 0;
   o1.gn_gamma = g2; o1.gn_beta = b2; o1.gn_y = n2.p; o1.gn_groups = groups; o1.gn_eps = eps; o1.gn_silu = 1; o1.gn_keep_out = 0; o1.gn_fused = &gn_done;
-  CK(run_conv(c, st, n1.p, Cin, nullptr, 0, B, H, Wd, *w1, 3, h.p, o1, c->zero_page));
+  CK(run_conv(c, st, n1p, Cin, nullptr, 0, B, H, Wd, *w1, 3, h.p, o1, c->zero_page));
   if (!gn_done) CK(run_gn(c, st, h.p, Cout, nullptr, 0, B, HW, g2, b2, groups, eps, 1, n2.p, &h));
   const bf16_t* res = x0.p;
   if (c->W.count(pre + "conv_shortcut.weight")) {
@@ -308,7 +317,13 @@ static int resnet(agd_ctx* c, hipStream_t st, const std::string& pre, const Act&
   }
   GETW(w2, pre + "conv2.weight"); GETV(cb2, pre + "conv2.bias");
   GemmOpt o2; o2.bias = cb2; o2.residual = res; o2.out_act = &out;
+  int gn2_done = 0;
+  if (out_normed) {      // the next GroupNorm reads this output alone: a split-K launch's slab pass writes the output AND its normalised copy
+    o2.gn_gamma = next->gamma; o2.gn_beta = next->beta; o2.gn_y = out_normed; o2.gn_groups = groups; o2.gn_eps = next->eps; o2.gn_silu = next->silu;
+    o2.gn_keep_out = 1; o2.gn_fused = &gn2_done;
+  }
   CK(run_conv(c, st, n2.p, Cout, nullptr, 0, B, H, Wd, *w2, 3, out.p, o2, c->zero_page));
+  if (gn2_done) { out.normed = out_normed; out.normed_gamma = next->gamma; }
   c->arena.release(mk);
   return 0;
 }
@@ -410,7 +425,10 @@ static int transformer(agd_ctx* c, hipStream_t st, const std::string& pre, const
   // a GroupNorm kernel.  Default C <= 320 (the 64 x 64 maps: the fold launch takes 8.5 us against the 17 us apply pass; in situ 522.4 -> 521.3 ms
   // per batch, tools/ab_option.py); at C = 640 the fold (16.8 us, 6.5 MB of matrices) costs more than the 10.8 us pass it replaces.
   const bool gfold = c->opt_gn_proj_fold && c->opt_gn_fused && C <= (c->opt_gn_proj_fold >= 2 ? 640 : 320) && x.cpart && x.cpart_bm > 0 && HW % 128 == 0 && HW % x.cpart_bm == 0;
-  if (!gfold) CK(run_gn(c, st, x.p, C, nullptr, 0, Bs, HW, gg, gb, groups, 1e-6f, 0, n.p, &x));
+  if (!gfold) {
+    if (x.normed && x.normed_gamma == gg) n.p = x.normed;          // the producing resnet's slab pass already applied this norm
+    else CK(run_gn(c, st, x.p, C, nullptr, 0, Bs, HW, gg, gb, groups, 1e-6f, 0, n.p, &x));
+  }
   Act h = alloc_act(c, B, x.H, x.W, C); if (!h.p) return -1;
   Act ln = n;  // reuse (only the unfolded path normalises into it)
   bf16_t* qkv = (bf16_t*)c->arena.alloc((size_t)B * HW * 3 * C * 2); if (!qkv) return -1;
@@ -625,7 +643,13 @@ static int unet_walk(agd_ctx* c, hipStream_t st, const bf16_t* xin, int B2, int 
     for (int j = 0; j < g.layers_per_block; ++j) {
       const bool first = shared && i == 0 && j == 0;
       Act hin = h; if (first) hin.B = Bh;
-      Act r; CK(resnet(c, st, u + "down_blocks." + std::to_string(i) + ".resnets." + std::to_string(j) + ".", hin, nullptr, co, 1e-5f, true, G, r));
+      // the GroupNorm that reads this resnet's output alone: the block's transformer, the next resnet of an attention-free level, or mid_block
+      NextGn ng; std::string nk; 
+      if (g.down_cross[i]) { nk = u + "down_blocks." + std::to_string(i) + ".attentions." + std::to_string(j) + ".norm."; ng.eps = 1e-6f; ng.silu = 0; }
+      else if (j + 1 < g.layers_per_block) { nk = u + "down_blocks." + std::to_string(i) + ".resnets." + std::to_string(j + 1) + ".norm1."; ng.eps = 1e-5f; ng.silu = 1; }
+      else if (i == nl - 1) { nk = u + "mid_block.resnets.0.norm1."; ng.eps = 1e-5f; ng.silu = 1; }
+      if (!nk.empty()) { auto ig = c->V.find(nk + "weight"), ib = c->V.find(nk + "bias"); if (ig != c->V.end() && ib != c->V.end()) { ng.gamma = ig->second; ng.beta = ib->second; } }
+      Act r; CK(resnet(c, st, u + "down_blocks." + std::to_string(i) + ".resnets." + std::to_string(j) + ".", hin, nullptr, co, 1e-5f, true, G, r, first ? nullptr : &ng));
       h = r;
       if (g.down_cross[i]) {
         Act a; CK(transformer(c, st, u + "down_blocks." + std::to_string(i) + ".attentions." + std::to_string(j) + ".", h, g.num_heads[i], G, a, first ? 1 : 0));
@@ -643,14 +667,19 @@ static int unet_walk(agd_ctx* c, hipStream_t st, const bf16_t* xin, int B2, int 
     }
   }
   { const int cm = g.block_out_channels[nl - 1];
-    Act r; CK(resnet(c, st, u + "mid_block.resnets.0.", h, nullptr, cm, 1e-5f, true, G, r)); h = r;
+    NextGn ngm; { auto ig = c->V.find(u + "mid_block.attentions.0.norm.weight"), ib = c->V.find(u + "mid_block.attentions.0.norm.bias");
+                  if (ig != c->V.end() && ib != c->V.end()) { ngm.gamma = ig->second; ngm.beta = ib->second; ngm.eps = 1e-6f; ngm.silu = 0; } }
+    Act r; CK(resnet(c, st, u + "mid_block.resnets.0.", h, nullptr, cm, 1e-5f, true, G, r, &ngm)); h = r;
     Act a; CK(transformer(c, st, u + "mid_block.attentions.0.", h, g.num_heads[nl - 1], G, a)); h = a;
     Act r2; CK(resnet(c, st, u + "mid_block.resnets.1.", h, nullptr, cm, 1e-5f, true, G, r2)); h = r2; }
   for (int i = 0; i < nl; ++i) {
     const int lvl = nl - 1 - i, co = g.block_out_channels[lvl];
     for (int j = 0; j < g.layers_per_block + 1; ++j) {
       Act sk = skips.back(); skips.pop_back();
-      Act r; CK(resnet(c, st, u + "up_blocks." + std::to_string(i) + ".resnets." + std::to_string(j) + ".", h, &sk, co, 1e-5f, true, G, r));
+      NextGn ngu;
+      if (g.down_cross[lvl]) { const std::string nk = u + "up_blocks." + std::to_string(i) + ".attentions." + std::to_string(j) + ".norm.";
+        auto ig = c->V.find(nk + "weight"), ib = c->V.find(nk + "bias"); if (ig != c->V.end() && ib != c->V.end()) { ngu.gamma = ig->second; ngu.beta = ib->second; ngu.eps = 1e-6f; ngu.silu = 0; } }
+      Act r; CK(resnet(c, st, u + "up_blocks." + std::to_string(i) + ".resnets." + std::to_string(j) + ".", h, &sk, co, 1e-5f, true, G, r, &ngu));
       h = r;
       if (g.down_cross[lvl]) {
         Act a; CK(transformer(c, st, u + "up_blocks." + std::to_string(i) + ".attentions." + std::to_string(j) + ".", h, g.num_heads[lvl], G, a));
