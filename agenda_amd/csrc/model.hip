@@ -115,8 +115,8 @@ struct agd_ctx {
   int opt_gn_proj_fold = 1;                           // agd_set_option("gn_proj_fold"): the transformers' GroupNorm folded into per-image proj_in matrices (1: C <= 320, 2: C <= 640)
   int opt_p8 = 1;                                     // agd_set_option("igemm8p"): 256-row 8-wave / 8-phase igemm for launches with enough tiles (igemm8p.h)
   int opt_halo = 1;                                   // agd_set_option("conv_halo"): 3x3 stride-1 convs through the row-halo kernel (igemm_halo.h)
-  int opt_tb_fuse = 31;                               // agd_set_option("tblock_fuse"): fused row-panel kernels of the C = 320 transformer blocks (tblock.hip): bit 0 = feed-forward (bit 3: + proj_out),
-                                                      // bit 1 = attn2 chain (bit 2: + attn1.to_out in front of it), bit 4 = proj_in -> norm1 -> qkv
+  int opt_tb_fuse = 63;                               // agd_set_option("tblock_fuse"): fused row-panel kernels of the C = 320 transformer blocks (tblock.hip): bit 0 = feed-forward (bit 3: + proj_out),
+                                                      // bit 1 = attn2 chain (bit 2: + attn1.to_out in front of it), bit 4 = proj_in -> norm1 -> qkv, bit 5 = the attn2 chain for the C = 640 blocks too
   int opt_smap = 1;                                   // agd_set_option("conv_smap"): 3x3 convs of the 8 x 8 maps through the whole-images-resident kernel (igemm_smap.h)
   int opt_reduce_gn = 1;                              // agd_set_option("reduce_gn"): split-K slab sum + the GroupNorm that reads it as one launch (igemm.hip splitk_reduce_gn_kernel)
   int opt_touch = 3;                                  // agd_set_option("weight_touch"): n > 0 = stream 1x1 weight matrices of >= n MB through the caches right before their launch
@@ -499,7 +499,8 @@ static int transformer(agd_ctx* c, hipStream_t st, const std::string& pre, const
   // fused row-panel kernels of this block (tblock.hip), where their shape is built: C = 320, 8 heads, <= 96 keys, whole 128-row tiles per
   // image; the hook.py recorder (per-head maps of every call) keeps the kernel chain
   const bool ff_fused = (c->opt_tb_fuse & 1) && fold && C == 320 && c->W.count(t + "ff.w1.frag");
-  const bool chain_fuse = (c->opt_tb_fuse & 2) && C == 320 && heads == 8 && HW % 128 == 0 && c->ctx_T <= 96 && c->rec_mode != 2 && c->W.count(t + "attn2.to_q.frag");
+  const bool chain_fuse = (c->opt_tb_fuse & 2) && (C == 320 || (C == 640 && (c->opt_tb_fuse & 32))) && heads == 8 && HW % (C == 320 ? 128 : 64) == 0 && c->ctx_T <= 96 &&
+                          c->rec_mode != 2 && c->W.count(t + "attn2.to_q.frag");
   const bool chain_pre = chain_fuse && (c->opt_tb_fuse & 4) && !dup && c->W.count(t + "attn1.to_out.frag");     // attn1.to_out + residual inside the chain launch
   // --- self attention ---
   { if (!qkv_done) CK(consume(t + "norm1", t + "attn1.qkv", nullptr, 0, qkv));
@@ -954,11 +955,11 @@ AGD_API int agd_finalize(agd_ctx* c) {
       c->W[k] = wf; c->V[k + ".cs"] = cs; c->V[k + ".bias"] = bf; c->Vn[k + ".cs"] = w->N; c->Vn[k + ".bias"] = w->N;
     }
     // fused row-panel kernels (tblock.hip, C = 320 blocks): the matrices once more in MFMA fragment order
-    if (q->N == 320) {
+    if (q->N == 320 || q->N == 640) {                 // (C = 640: the attn2 chain only -- a wave's GEMM tile is 80 columns whatever C: NI = 5)
       const int C = q->N;
       const WMat* w1 = getW(c, t + "ff.net.0.proj.weight.lnfold"); const WMat* w2 = getW(c, t + "ff.net.2.weight");
       if (!w1 || !w2) return fail_ctx(c);
-      if (w1->N == 8 * C && w1->Cpad == C && w2->N == C && w2->Cpad == 4 * C && w2->taps == 1) {
+      if (C == 320 && w1->N == 8 * C && w1->Cpad == C && w2->N == C && w2->Cpad == 4 * C && w2->taps == 1) {
         WMat f1 = *w1, f2 = *w2;
         f1.w = dmalloc<bf16_t>(c, (size_t)w1->N * C); f2.w = dmalloc<bf16_t>(c, (size_t)C * 4 * C);
         if (!f1.w || !f2.w) return fail_ctx(c);
@@ -979,11 +980,11 @@ AGD_API int agd_finalize(agd_ctx* c) {
         WMat fq = *wq, fo = *wo;
         fq.w = dmalloc<bf16_t>(c, (size_t)C * C); fo.w = dmalloc<bf16_t>(c, (size_t)C * C);
         if (!fq.w || !fo.w) return fail_ctx(c);
-        API_CK(c, launch_frag_order_w(wq->w, fq.w, C, C, C / 64, C, 0));
-        API_CK(c, launch_frag_order_w(wo->w, fo.w, C, C, C / 64, C, 0));
+        API_CK(c, launch_frag_order_w(wq->w, fq.w, C, C, 5, C, 0));
+        API_CK(c, launch_frag_order_w(wo->w, fo.w, C, C, 5, C, 0));
         c->W[t + "attn2.to_q.frag"] = fq; c->W[t + "attn2.to_out.frag"] = fo;
         { const WMat* wqkv = getW(c, t + "attn1.qkv"); if (!wqkv) return fail_ctx(c);
-          if (wqkv->N == 3 * C && wqkv->Cpad == C && wqkv->taps == 1) {
+          if (C == 320 && wqkv->N == 3 * C && wqkv->Cpad == C && wqkv->taps == 1) {
             WMat fqkv = *wqkv; fqkv.w = dmalloc<bf16_t>(c, (size_t)3 * C * C); if (!fqkv.w) return fail_ctx(c);
             API_CK(c, launch_frag_order_w(wqkv->w, fqkv.w, 3 * C, C, C / 64, C, 0));
             c->W[t + "attn1.qkv.frag"] = fqkv;
@@ -992,7 +993,7 @@ AGD_API int agd_finalize(agd_ctx* c) {
         if (!wo1) return fail_ctx(c);
         if (wo1->N == C && wo1->Cpad == C && wo1->taps == 1) {
           WMat f1o = *wo1; f1o.w = dmalloc<bf16_t>(c, (size_t)C * C); if (!f1o.w) return fail_ctx(c);
-          API_CK(c, launch_frag_order_w(wo1->w, f1o.w, C, C, C / 64, C, 0));
+          API_CK(c, launch_frag_order_w(wo1->w, f1o.w, C, C, 5, C, 0));
           c->W[t + "attn1.to_out.frag"] = f1o;
         }
       }
@@ -1667,11 +1668,11 @@ AGD_API int agd_op_attn_chain(const float* x, const float* gamma, const float* b
   bf16_t* wqb = tmp.get<bf16_t>((size_t)C * C); bf16_t* wqf = tmp.get<bf16_t>((size_t)C * C);
   bf16_t* wob = tmp.get<bf16_t>((size_t)C * C); bf16_t* wof = tmp.get<bf16_t>((size_t)C * C);
   if (!xb || !yb || !kvb || !wqb || !wqf || !wob || !wof) return -1;
-  if (C % 64) { agd_set_error("op_attn_chain: C %d", C); return -1; }
+  if (C != 320 && C != 640) { agd_set_error("op_attn_chain: C %d", C); return -1; }
   CK(launch_f32_to_bf16(x, xb, M * C, st));
   CK(launch_f32_to_bf16(kv, kvb, (long long)B * T * 2 * C, st));
-  CK(launch_convert_weight(wq, wqb, C, C, 1, C, 0, st)); CK(launch_frag_order_w(wqb, wqf, C, C, C / 64, C, st));
-  CK(launch_convert_weight(wo, wob, C, C, 1, C, 0, st)); CK(launch_frag_order_w(wob, wof, C, C, C / 64, C, st));
+  CK(launch_convert_weight(wq, wqb, C, C, 1, C, 0, st)); CK(launch_frag_order_w(wqb, wqf, C, C, 5, C, st));
+  CK(launch_convert_weight(wo, wob, C, C, 1, C, 0, st)); CK(launch_frag_order_w(wob, wof, C, C, 5, C, st));
   AttnChainP ap{}; ap.h = xb; ap.out = yb; ap.gamma = gamma; ap.beta = beta; ap.ln_eps = eps; ap.wqf = wqf; ap.wof = wof; ap.bo = bo;
   ap.kv = kvb; ap.ldkv = 2 * C; ap.skv = (long long)T * 2 * C; ap.M = (int)M; ap.HW = HW; ap.T = T; ap.scale = 1.0f / sqrtf((float)(C / heads));
   if (probs_sum) {
@@ -1855,24 +1856,26 @@ AGD_API int agd_bench_conv_cold(int B, int H, int W, int C0, int Cout, int ksize
 // images recording head-summed probabilities, as in a CFG forward)
 AGD_API int agd_bench_tblock(int kind, int B, int HW, int iters, double* ms_out) {
   Tmp tmp;
-  const int C = 320, T = 77; const long long M = (long long)B * HW;
+  const int C = kind >= 4 ? 640 : 320, T = 77; const long long M = (long long)B * HW;      // kind 4 / 5: the attn2 chain at C = 640 (plain / from attn1.to_out)
+  if (kind >= 4) kind = kind == 4 ? 1 : 3;
   bf16_t* h = tmp.get<bf16_t>((size_t)M * C); bf16_t* o = tmp.get<bf16_t>((size_t)M * C);
   bf16_t* w1 = tmp.get<bf16_t>((size_t)8 * C * C); bf16_t* w1f = tmp.get<bf16_t>((size_t)8 * C * C);
   bf16_t* w2 = tmp.get<bf16_t>((size_t)4 * C * C); bf16_t* w2f = tmp.get<bf16_t>((size_t)4 * C * C);
   bf16_t* kv = tmp.get<bf16_t>((size_t)B * T * 2 * C);
-  float* vec = tmp.get<float>((size_t)16 * C + 64); float* rec = tmp.get<float>((size_t)B * T * HW);
+  const int rslices = C == 640 ? 8 : 1;                 // recorder slices per image: per-head rows below latent resolution, one head-summed slice at it
+  float* vec = tmp.get<float>((size_t)16 * C + 64); float* rec = tmp.get<float>((size_t)B * rslices * T * HW);
   if (!h || !o || !w1 || !w1f || !w2 || !w2f || !kv || !vec || !rec) return -1;
   fill_rand(h, M * C, 1, 1.0f); fill_rand(w1, 8LL * C * C, 2, 0.05f); fill_rand(w2, 4LL * C * C, 3, 0.03f); fill_rand(kv, (long long)B * T * 2 * C, 4, 1.0f);
-  hipMemset(vec, 0, ((size_t)16 * C + 64) * 4); hipMemset(rec, 0, (size_t)B * T * HW * 4);
+  hipMemset(vec, 0, ((size_t)16 * C + 64) * 4); hipMemset(rec, 0, (size_t)B * rslices * T * HW * 4);
   FFusedP fp{}; AttnChainP ap{};
   if (kind == 0) {
     CK(launch_frag_order_w1(w1, w1f, C, 4 * C, 0)); CK(launch_frag_order_w(w2, w2f, C, 4 * C, C / 64, 128, 0));
     fp.h = h; fp.out = o; fp.w1f = w1f; fp.cs1 = vec; fp.b1 = vec + 8 * C; fp.w2f = w2f; fp.b2 = vec; fp.M = (int)M; fp.ln_eps = 1e-5f;
   } else {
-    CK(launch_frag_order_w(w1, w1f, C, C, C / 64, C, 0)); CK(launch_frag_order_w(w2, w2f, C, C, C / 64, C, 0));
+    CK(launch_frag_order_w(w1, w1f, C, C, 5, C, 0)); CK(launch_frag_order_w(w2, w2f, C, C, 5, C, 0));
     ap.h = h; ap.out = o; ap.gamma = vec; ap.beta = vec; ap.ln_eps = 1e-5f; ap.wqf = w1f; ap.wof = w2f; ap.bo = vec; ap.kv = kv; ap.ldkv = 2 * C; ap.skv = (long long)T * 2 * C;
-    ap.M = (int)M; ap.HW = HW; ap.T = T; ap.scale = 1.0f / sqrtf(40.f);
-    ap.record = 1; ap.rec = rec; ap.rec_b0 = B / 2; ap.rec_T = T; ap.rec_hpb = 8; ap.rec_head_stride = (long long)T * HW; ap.rec_img_stride = (long long)T * HW;
+    ap.M = (int)M; ap.HW = HW; ap.T = T; ap.scale = 1.0f / sqrtf((float)(C / 8));
+    ap.record = 1; ap.rec = rec; ap.rec_b0 = B / 2; ap.rec_T = T; ap.rec_hpb = 8 / rslices; ap.rec_head_stride = (long long)T * HW; ap.rec_img_stride = (long long)rslices * T * HW;
   }
   bf16_t* o2 = nullptr; float* cst = nullptr;
   if (kind == 2) {                                   // feed-forward + proj_out stage (+ column statistics)
@@ -1886,7 +1889,7 @@ AGD_API int agd_bench_tblock(int kind, int B, int HW, int iters, double* ms_out)
   if (kind == 3) {                                   // attn2 chain starting at attn1.to_out
     o2 = tmp.get<bf16_t>((size_t)M * C); bf16_t* wo1f = tmp.get<bf16_t>((size_t)C * C); if (!o2 || !wo1f) return -1;
     fill_rand(o2, M * C, 9, 1.0f);
-    CK(launch_frag_order_w(w2, wo1f, C, C, C / 64, C, 0));
+    CK(launch_frag_order_w(w2, wo1f, C, C, 5, C, 0));
     ap.o1 = o2; ap.wo1f = wo1f; ap.bo1 = vec;
   }
   auto run = [&]() { return (kind == 0 || kind == 2) ? launch_ff_fused(fp, C, 0) : launch_attn_chain(ap, C, 8, 0); };

@@ -82,43 +82,58 @@ int launch_frag_order_w(const bf16_t* src, bf16_t* dst, int N, int K, int NI, in
 // shared pieces
 // ---------------------------------------------------------------------------------------------------------------------------
 #define TB_OOB 0x80000000u
-// physical 16-B chunk of logical chunk `ch` in row `row` of a panel with C / 8 chunks per row (C / 8 a multiple of 8)
-AGD_DEV int panel_swz(int ch, int row) { return (ch & ~7) | ((ch & 7) ^ ((row >> 1) & 7)); }
+// physical 16-B chunk of logical chunk `ch` in row `row` of a panel of 2 C-byte rows.  C = 320: 640-byte rows alternate between the two halves
+// of the 256-byte bank row, key (row >> 1) & 7 on the low three chunk bits; C = 640: 1280-byte rows all start on the same bank, key row & 15 on
+// the low four (both checked by enumeration over the ds_read_b128 lane groups: conflict-free for the 16-row x 4 k-group fragment reads)
+template <int C> AGD_DEV int panel_swz(int ch, int row) {
+  if constexpr ((C * 2) % 256 == 128) return (ch & ~7) | ((ch & 7) ^ ((row >> 1) & 7));
+  else return (ch & ~15) | ((ch & 15) ^ (row & 15));
+}
+// per-lane byte offsets of the activation fragments inside a row for k-step ks: (ks / XG) * XG * 64 + xo[ks % XG]
+template <int C> struct XOff {
+  static constexpr int XG = ((C * 2) % 256 == 128) ? 2 : 4;
+  int xo[4];
+  AGD_DEV XOff(int q, int px) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) xo[t] = ((C * 2) % 256 == 128) ? (((4 * (t & 1) + q) ^ ((px >> 1) & 7)) << 4) : (((4 * t + q) ^ px) << 4);
+  }
+  AGD_DEV int at(int ks) const { return (ks / XG) * (XG * 64) + xo[ks % XG]; }
+};
 
 // [128][C] bf16 rows m0 .. m0+127 of `src` -> LDS panel (swizzled), by LDS-DMA; 8 waves, 1 KiB pieces.  Caller waits (vmcnt(0) + barrier).
-template <int C>
+template <int C, int BM = 128>
 AGD_DEV void panel_load_dma(const bf16_t* src, int m0, int M, char* panel, int wid, int lane) {
-  constexpr int CHR = C / 8, PIECES = 128 * CHR / 64;
+  constexpr int CHR = C / 8, PIECES = BM * CHR / 64;
   static_assert(PIECES % 8 == 0, "pieces split evenly over 8 waves");
 #pragma unroll
   for (int i = 0; i < PIECES / 8; ++i) {
     const int piece = i * 8 + wid, pos = piece * 64 + lane;
     const int row = pos / CHR, pc = pos - row * CHR;
-    const int lc = panel_swz(pc, row);                 // the swizzle is an involution on the low three chunk bits
+    const int lc = panel_swz<C>(pc, row);                 // the swizzle is an involution on the low three chunk bits
     const int m = m0 + row;
     const unsigned voff = m < M ? (unsigned)(((long long)m * C + lc * 8) * 2) : TB_OOB;
     bufdma16(src, panel + piece * 1024, voff, 0u);
   }
 }
 
-// per-row LayerNorm statistics of the panel's 128 rows (bf16 values as stored): 4 threads per row, (mean, rstd) -> lnst[row]
-template <int C>
+// per-row LayerNorm statistics of the panel's BM rows (bf16 values as stored): 512 / BM threads per row, (mean, rstd) -> lnst[row]
+template <int C, int BM = 128>
 AGD_DEV void panel_row_stats(const char* panel, float* lnst, int tid, float eps) {
-  constexpr int CHR = C / 8, PER = CHR / 4;
-  static_assert(CHR % 4 == 0, "chunks per row split over 4 threads");
-  const int row = tid >> 2, part = tid & 3;
+  constexpr int CHR = C / 8, TPR = 512 / BM, PER = CHR / TPR;
+  static_assert(CHR % TPR == 0, "chunks per row split over the row's threads");
+  const int row = tid / TPR, part = tid % TPR;
   float S = 0.f, Q = 0.f;
 #pragma unroll
   for (int cc = 0; cc < PER; ++cc) {
-    const u32x4 v = *(const u32x4*)(panel + row * (C * 2) + panel_swz(part * PER + cc, row) * 16);
+    const u32x4 v = *(const u32x4*)(panel + row * (C * 2) + panel_swz<C>(part * PER + cc, row) * 16);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const float a = __uint_as_float(v[e] << 16), b = __uint_as_float(v[e] & 0xFFFF0000u);
       S += a + b; Q += a * a + b * b;
     }
   }
-  S += __shfl_xor(S, 1); Q += __shfl_xor(Q, 1);
-  S += __shfl_xor(S, 2); Q += __shfl_xor(Q, 2);
+#pragma unroll
+  for (int o = 1; o < TPR; o <<= 1) { S += __shfl_xor(S, o); Q += __shfl_xor(Q, o); }
   if (part == 0) {
     const float mu = S * (1.0f / C);
     float var = Q * (1.0f / C) - mu * mu; var = var < 0.f ? 0.f : var;
@@ -154,9 +169,9 @@ AGD_DEV void panel_gemm_head(u32x4 (&ring)[TB_F], const bf16_t* wf, unsigned wba
   for (int f = 0; f < TB_D; ++f) ring[f % TB_F] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, lane16, wbase + (unsigned)f * 1024u, 0));
 }
 template <int C>
-AGD_DEV void panel_gemm_body(u32x4 (&ring)[TB_F], f32x4 (&acc)[4][C / 64], const bf16_t* wf, unsigned wbase, unsigned lane16, const char* xrow, int xoff0, int xoff1,
+AGD_DEV void panel_gemm_body(u32x4 (&ring)[TB_F], f32x4 (&acc)[4][5], const bf16_t* wf, unsigned wbase, unsigned lane16, const char* xrow, const XOff<C>& xo,
                              unsigned wbytes = C * C * 2) {
-  constexpr int NI = C / 64, KS = C / 32, NFR = KS * NI, PITCH = C * 2;
+  constexpr int NI = 5, KS = C / 32, NFR = KS * NI, PITCH = C * 2;       // a wave's tile is 64 rows x 80 columns whatever C
   const auto wrs = __builtin_amdgcn_make_buffer_rsrc((void*)wf, 0, wbytes, 0x00020000);
 #pragma unroll
   for (int i = 0; i < 4; ++i)
@@ -170,7 +185,7 @@ AGD_DEV void panel_gemm_body(u32x4 (&ring)[TB_F], f32x4 (&acc)[4][C / 64], const
     if (f % NI == 0) {
       const int ks = f / NI;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) xf[i] = *(const bf16x8*)(xrow + i * 16 * PITCH + (ks >> 1) * 128 + ((ks & 1) ? xoff1 : xoff0));
+      for (int i = 0; i < 4; ++i) xf[i] = *(const bf16x8*)(xrow + i * 16 * PITCH + xo.at(ks));
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -368,7 +383,7 @@ __global__ __launch_bounds__(512, 2) void ff_fused_kernel(const FFusedP p) {
 #pragma unroll
     for (int t = 0; t < NI2; ++t) {
       const int n = ncol0 + 4 * t;
-      char* pa = panel + row * PITCH + panel_swz(n >> 3, row) * 16 + (n & 7) * 2;
+      char* pa = panel + row * PITCH + panel_swz<C>(n >> 3, row) * 16 + (n & 7) * 2;
       const u32x2 r = *(const u32x2*)pa;
       pk[t][0] = pack_bf2(acc2[i][t][0] + b2v[4 * t] + __uint_as_float(r[0] << 16), acc2[i][t][1] + b2v[4 * t + 1] + __uint_as_float(r[0] & 0xFFFF0000u));
       pk[t][1] = pack_bf2(acc2[i][t][2] + b2v[4 * t + 2] + __uint_as_float(r[1] << 16), acc2[i][t][3] + b2v[4 * t + 3] + __uint_as_float(r[1] & 0xFFFF0000u));
@@ -381,7 +396,7 @@ __global__ __launch_bounds__(512, 2) void ff_fused_kernel(const FFusedP p) {
   u32x2 xr[4][NI2];                                      // the residual rows (HBM-cold) are requested ahead of the GEMM, not in its epilogue
 #pragma unroll
   for (int i = 0; i < 4; ++i) { const int m = m0 + rbase + 16 * i; load_row_chunk<NI2>(p.xres + (long long)(m < p.M ? m : 0) * C + ncol0, xr[i]); }
-  panel_gemm_body<C>(ring, acc2, p.wpf, pwbase, lane16, xrow, xoff0, xoff1);
+  panel_gemm_body<C>(ring, acc2, p.wpf, pwbase, lane16, xrow, XOff<C>(q, px));
   float bpv[NI2 * 4];
 #pragma unroll
   for (int t = 0; t < NI2; ++t) *(f32x4*)&bpv[4 * t] = *(const f32x4*)(p.bp + ncol0 + 4 * t);
@@ -468,35 +483,41 @@ int launch_ff_fused(const FFusedP& p, int C, hipStream_t st) {
 // epilogue), norm2's statistics from the rounded h1 held in registers -- the launch between the self-attention and this chain disappears too
 template <int C, int PRE>
 __global__ __launch_bounds__(512, 2) void attn_chain_kernel(const AttnChainP p) {
-  constexpr int BM = 128, H = 8, D = C / H, KS = C / 32, NI = C / 64, PITCH = C * 2, CHR = C / 8;
-  static_assert(C == 320, "head dim 40 layout");
-  constexpr int KB = 3, KEYS = 96, KSTEPS = 3, DBLK = 2, CH = D / 8;       // 96 keys, d padded 40 -> 48 (QK^T) / 64 (PV)
-  constexpr int KPITCH = 7 * 16, VPITCH = 3 * 64;                          // odd chunk counts: conflict-free b128 / tr reads (attention.hip)
-  constexpr int KVSTAGE = KEYS * (KPITCH + VPITCH);                        // one head: 29184 B
+  // geometry: a wave's GEMM tile is always 64 rows x 80 columns, so C / 80 column ranges x (8 waves / that) row halves: C = 320: 128 rows per
+  // workgroup, 2 x 4 waves; C = 640 (the 32 x 32 maps): 64 rows, 1 x 8 waves -- the panel is 80 KB either way.  Attention: BM / 32 query blocks x 2
+  // head slots of four heads; at C = 640 (two query blocks) waves 2, 3, 6, 7 only help loading K / V.
+  constexpr int NQ = C / 80, MH = 8 / NQ, BM = 64 * MH, QBN = BM / 32;
+  constexpr int H = 8, D = C / H, KS = C / 32, NI = 5, PITCH = C * 2, CHR = C / 8;
+  static_assert(C == 320 || C == 640, "8 heads of 40 / 80");
+  constexpr int KB = 3, KEYS = 96, KSTEPS = (D + 15) / 16, DBLK = (D + 31) / 32, CH = D / 8;   // 96 keys; d = 40: 48 (QK^T) / 64 (PV); d = 80: 80 / 96
+  constexpr int KPITCH = ((2 * KSTEPS) | 1) * 16, VPITCH = (DBLK | 1) * 64;                    // odd chunk counts: conflict-free b128 / tr reads (attention.hip)
+  constexpr int KVSTAGE = KEYS * (KPITCH + VPITCH);                        // one head: 29184 B (d = 40), 35328 B (d = 80)
   constexpr int NCHUNK = KEYS * CH, LD_IT = (NCHUNK + 255) / 256;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* panel = smem;
   char* kvs = smem + BM * PITCH;                        // 2 x KVSTAGE (one head per head half); later: probability hand-off / statistics staging
   float* lnst = (float*)(kvs + 2 * KVSTAGE);
-  float* pst = lnst + BM * 2;                           // PRE: [4 column quarters][BM] (sum, sum of squares) of h1
+  float* pst = lnst + BM * 2;                           // PRE: [NQ column ranges][BM] (sum, sum of squares) of h1
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int mh = wid >> 2, nq = wid & 3;                // GEMM roles
+  const int mh = wid / NQ, nq = wid % NQ;               // GEMM roles
   const int q = lane >> 4, px = lane & 15;
-  const int qb = wid & 3, hhalf = wid >> 2;             // attention roles
+  const int qb = wid & (QBN - 1), hhalf = wid >> 2;     // attention roles: query block, head slot (heads 4 hhalf .. + 3)
+  const bool attn_wave = QBN == 4 || !(wid & 2);        // wave-uniform
   const int c = lane & 31, hh = lane >> 5;
   const int m0 = blockIdx.x * BM;
   const int b = m0 / p.HW, pix0 = m0 - b * p.HW;        // tiles stay inside one image (HW % 128 == 0)
 
-  panel_load_dma<C>(PRE ? p.o1 : p.h, m0, p.M, panel, wid, lane);
+  panel_load_dma<C, BM>(PRE ? p.o1 : p.h, m0, p.M, panel, wid, lane);
 
   // K / V staging of this wave's head half: pad chunks once, then head `h` through registers
   char* sK = kvs + hhalf * KVSTAGE;
   char* sV = sK + KEYS * KPITCH;
   const int t4 = tid & 255;
-  for (int i = t4; i < KEYS * 2; i += 256) { const int r = i >> 1, cc = CH + (i & 1); *(u32x4*)(sK + r * KPITCH + cc * 16) = u32x4{0, 0, 0, 0}; }
-  for (int i = t4; i < KEYS * 7; i += 256) { const int r = i / 7, cc = CH + i % 7; *(u32x4*)(sV + r * VPITCH + cc * 16) = u32x4{0, 0, 0, 0}; }
+  constexpr int KPADC = KPITCH / 16 - CH, VPADC = VPITCH / 16 - CH;          // pad chunks behind the real d columns (never overwritten)
+  for (int i = t4; i < KEYS * KPADC; i += 256) { const int r = i / KPADC, cc = CH + i % KPADC; *(u32x4*)(sK + r * KPITCH + cc * 16) = u32x4{0, 0, 0, 0}; }
+  for (int i = t4; i < KEYS * VPADC; i += 256) { const int r = i / VPADC, cc = CH + i % VPADC; *(u32x4*)(sV + r * VPITCH + cc * 16) = u32x4{0, 0, 0, 0}; }
   u32x4 kreg[LD_IT], vreg[LD_IT];
   unsigned kvoff[LD_IT];
 #pragma unroll
@@ -526,23 +547,22 @@ __global__ __launch_bounds__(512, 2) void attn_chain_kernel(const AttnChainP p) 
 
   // ---- GEMM stage: acc[4][NI] = W[80 nq .. +80][:] . panel[64 mh .. +64][:]^T ----
   const int rbase = 64 * mh + px;
-  const int sx = (px >> 1) & 7;
-  const int xoff0 = ((q ^ sx) << 4), xoff1 = (((4 + q) ^ sx) << 4);
+  const XOff<C> xo(q, px);
   const char* xrow = panel + rbase * PITCH;
   f32x4 acc[4][NI];
   u32x4 ring[TB_F];
   const unsigned lane16 = (unsigned)lane * 16u;
   const unsigned wbase = __builtin_amdgcn_readfirstlane((unsigned)(nq * KS * NI) * 1024u);
   auto gemm_head = [&](const bf16_t* wf) { panel_gemm_head<C>(ring, wf, wbase, lane16); };
-  auto gemm_body = [&](const bf16_t* wf) { panel_gemm_body<C>(ring, acc, wf, wbase, lane16, xrow, xoff0, xoff1); };
-  const int ncol0 = (C / 4) * nq + 4 * NI * q;          // first of this lane's 4 NI consecutive channels (GEMM epilogues)
+  auto gemm_body = [&](const bf16_t* wf) { panel_gemm_body<C>(ring, acc, wf, wbase, lane16, xrow, xo); };
+  const int ncol0 = 16 * NI * nq + 4 * NI * q;          // first of this lane's 4 NI consecutive channels (GEMM epilogues)
 
   if constexpr (PRE) gemm_head(p.wo1f);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (also drains the ring's head: it is ten L2-resident KiB)
   __syncthreads();
   kv_store();
   if constexpr (!PRE) {
-    panel_row_stats<C>(panel, lnst, tid, p.ln_eps);
+    panel_row_stats<C, BM>(panel, lnst, tid, p.ln_eps);
     __syncthreads();
     gemm_head(p.wqf);                                   // the first to_q weight fragments fly under the normalisation pass
   }
@@ -589,7 +609,7 @@ __global__ __launch_bounds__(512, 2) void attn_chain_kernel(const AttnChainP p) 
       const int row = rbase + 16 * i;
       float S = 0.f, Q = 0.f;
 #pragma unroll
-      for (int w = 0; w < 4; ++w) { const f32x2_t v = *(const f32x2_t*)(pst + (w * BM + row) * 2); S += v[0]; Q += v[1]; }      // fixed order: reproducible
+      for (int w = 0; w < NQ; ++w) { const f32x2_t v = *(const f32x2_t*)(pst + (w * BM + row) * 2); S += v[0]; Q += v[1]; }      // fixed order: reproducible
       const float mu = S * (1.0f / C);
       float var = Q * (1.0f / C) - mu * mu; var = var < 0.f ? 0.f : var;
       const float rstd = rsqrtf(var + p.ln_eps);
@@ -599,14 +619,14 @@ __global__ __launch_bounds__(512, 2) void attn_chain_kernel(const AttnChainP p) 
         u32x2 pk;
         pk[0] = pack_bf2((acc[i][t][0] - mu) * rstd * g2[4 * t] + b2[4 * t], (acc[i][t][1] - mu) * rstd * g2[4 * t + 1] + b2[4 * t + 1]);
         pk[1] = pack_bf2((acc[i][t][2] - mu) * rstd * g2[4 * t + 2] + b2[4 * t + 2], (acc[i][t][3] - mu) * rstd * g2[4 * t + 3] + b2[4 * t + 3]);
-        *(u32x2*)(panel + row * PITCH + panel_swz(n >> 3, row) * 16 + (n & 7) * 2) = pk;
+        *(u32x2*)(panel + row * PITCH + panel_swz<C>(n >> 3, row) * 16 + (n & 7) * 2) = pk;
       }
     }
   } else {
   // ---- norm2 in place: x^ = (h - mu) rstd gamma + beta, rounded to bf16 (what the LayerNorm kernel stores) ----
 #pragma unroll 2
   for (int i = 0; i < BM * CHR / 512; ++i) {
-    const int pos = i * 512 + tid, row = pos / CHR, pc = pos - row * CHR, lc = panel_swz(pc, row);
+    const int pos = i * 512 + tid, row = pos / CHR, pc = pos - row * CHR, lc = panel_swz<C>(pc, row);
     u32x4 v = *(u32x4*)(panel + row * PITCH + pc * 16);
     const f32x2_t st = *(const f32x2_t*)(lnst + row * 2);
     const f32x4 g0 = *(const f32x4*)(p.gamma + lc * 8), g1 = *(const f32x4*)(p.gamma + lc * 8 + 4);
@@ -630,9 +650,9 @@ __global__ __launch_bounds__(512, 2) void attn_chain_kernel(const AttnChainP p) 
     const int row = rbase + 16 * i;
 #pragma unroll
     for (int t = 0; t < NI; ++t) {
-      const int n = (C / 4) * nq + 4 * NI * q + 4 * t;
+      const int n = ncol0 + 4 * t;
       u32x2 pk; pk[0] = pack_bf2(acc[i][t][0], acc[i][t][1]); pk[1] = pack_bf2(acc[i][t][2], acc[i][t][3]);
-      *(u32x2*)(panel + row * PITCH + panel_swz(n >> 3, row) * 16 + (n & 7) * 2) = pk;
+      *(u32x2*)(panel + row * PITCH + panel_swz<C>(n >> 3, row) * 16 + (n & 7) * 2) = pk;
     }
   }
   __syncthreads();
@@ -676,12 +696,13 @@ __global__ __launch_bounds__(512, 2) void attn_chain_kernel(const AttnChainP p) 
     for (int hi = 0; hi < 4; ++hi) {
       const int h = 4 * hhalf + hi;
       if (hi + 1 < 4) kv_load(h + 1);                  // next head's K / V under this head's work
+      if (attn_wave) {
       bf16x8 qf[KSTEPS];
 #pragma unroll
       for (int s = 0; s < KSTEPS; ++s) {
         const int d0 = 16 * s + 8 * hh;
         u32x4 v = u32x4{0, 0, 0, 0};
-        if (d0 < D) v = *(const u32x4*)(prow + panel_swz(CH * h + 2 * s + hh, qr) * 16);
+        if (d0 < D) v = *(const u32x4*)(prow + panel_swz<C>(CH * h + 2 * s + hh, qr) * 16);
         qf[s] = __builtin_bit_cast(bf16x8, v);
       }
       f32x16 sacc[KB];
@@ -751,7 +772,7 @@ __global__ __launch_bounds__(512, 2) void attn_chain_kernel(const AttnChainP p) 
             u32x2 pk;
             pk[0] = pack_bf2(oacc[db][4 * g + 0] * inv, oacc[db][4 * g + 1] * inv);
             pk[1] = pack_bf2(oacc[db][4 * g + 2] * inv, oacc[db][4 * g + 3] * inv);
-            *(u32x2*)(prow + panel_swz(CH * h + (d0 >> 3), qr) * 16 + (d0 & 7) * 2) = pk;
+            *(u32x2*)(prow + panel_swz<C>(CH * h + (d0 >> 3), qr) * 16 + (d0 & 7) * 2) = pk;
           }
         }
       // recorder: head groups smaller than a head half are flushed by the wave that owns them
@@ -762,6 +783,7 @@ __global__ __launch_bounds__(512, 2) void attn_chain_kernel(const AttnChainP p) 
 #pragma unroll
           for (int j = 0; j < 16; ++j) pacc[kb][j] = 0.f;
       }
+      }
       __syncthreads();                                 // every wave is done with this head's K / V
       if (hi + 1 < 4) { kv_store(); __syncthreads(); }
     }
@@ -769,14 +791,14 @@ __global__ __launch_bounds__(512, 2) void attn_chain_kernel(const AttnChainP p) 
     // all heads in one recorder slice: the upper head half hands its sum to the lower one through LDS (the K / V stage is free now)
     if (p.record && hpb == H) {
       float* xch = (float*)kvs + (qb * 48) * 64 + lane;
-      if (hhalf == 1 && recb) {
+      if (hhalf == 1 && recb && attn_wave) {
 #pragma unroll
         for (int kb = 0; kb < KB; ++kb)
 #pragma unroll
           for (int i = 0; i < 16; ++i) xch[(kb * 16 + i) * 64] = pacc[kb][i];
       }
       __syncthreads();
-      if (hhalf == 0 && recb) {
+      if (hhalf == 0 && recb && attn_wave) {
 #pragma unroll
         for (int kb = 0; kb < KB; ++kb)
 #pragma unroll
@@ -794,7 +816,7 @@ __global__ __launch_bounds__(512, 2) void attn_chain_kernel(const AttnChainP p) 
   gemm_body(p.wof);
   float bv[NI * 4];
 #pragma unroll
-  for (int t = 0; t < NI; ++t) *(f32x4*)&bv[4 * t] = *(const f32x4*)(p.bo + (C / 4) * nq + 4 * NI * q + 4 * t);
+  for (int t = 0; t < NI; ++t) *(f32x4*)&bv[4 * t] = *(const f32x4*)(p.bo + ncol0 + 4 * t);
   float rs[4], rq[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -820,7 +842,7 @@ __global__ __launch_bounds__(512, 2) void attn_chain_kernel(const AttnChainP p) 
       rs[i] += __shfl_xor(rs[i], 16); rs[i] += __shfl_xor(rs[i], 32);
       rq[i] += __shfl_xor(rq[i], 16); rq[i] += __shfl_xor(rq[i], 32);
     }
-    float* stg = (float*)kvs;                            // [4 nq][BM][2]
+    float* stg = (float*)kvs;                            // [NQ][BM][2]
     if (q == 0) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) { stg[(nq * BM + rbase + 16 * i) * 2] = rs[i]; stg[(nq * BM + rbase + 16 * i) * 2 + 1] = rq[i]; }
@@ -829,29 +851,33 @@ __global__ __launch_bounds__(512, 2) void attn_chain_kernel(const AttnChainP p) 
     if (tid < BM) {
       float S = 0.f, Q = 0.f;
 #pragma unroll
-      for (int w = 0; w < 4; ++w) { S += stg[(w * BM + tid) * 2]; Q += stg[(w * BM + tid) * 2 + 1]; }
+      for (int w = 0; w < NQ; ++w) { S += stg[(w * BM + tid) * 2]; Q += stg[(w * BM + tid) * 2 + 1]; }
       *(f32x2_t*)(p.rowstat_out + (long long)(m0 + tid) * 2) = f32x2_t{S, Q};
     }
   }
 }
 
 int launch_attn_chain(const AttnChainP& p, int C, int heads, hipStream_t st) {
-  if (C != 320 || heads != 8) { agd_set_error("attn_chain: C = %d / heads = %d is not built (320 / 8 only)", C, heads); return -1; }
-  if (p.M < 128 || p.M % 128 || p.HW % 128 || p.M % p.HW) { agd_set_error("attn_chain: M %d / HW %d must be multiples of 128 (whole images)", p.M, p.HW); return -1; }
+  if ((C != 320 && C != 640) || heads != 8) { agd_set_error("attn_chain: C = %d / heads = %d is not built (320 or 640 / 8 only)", C, heads); return -1; }
+  const int BM = C == 320 ? 128 : 64;
+  if (p.M < BM || p.M % BM || p.HW % BM || p.M % p.HW) { agd_set_error("attn_chain: M %d / HW %d must be multiples of %d (whole images)", p.M, p.HW, BM); return -1; }
   if (p.T < 1 || p.T > 96) { agd_set_error("attn_chain: %d keys (1..96)", p.T); return -1; }
   if ((long long)p.M * C * 2 >= (1LL << 31)) { agd_set_error("attn_chain: activation too large for 32-bit offsets"); return -1; }
   if (p.record && (p.rec_hpb < 1 || 8 % p.rec_hpb || !p.rec)) { agd_set_error("attn_chain: recorder head group %d", p.rec_hpb); return -1; }
-  constexpr int lds = 128 * 320 * 2 + 2 * 96 * (7 * 16 + 3 * 64) + 128 * 8 + 4 * 128 * 8;
+  const int D = C / 8, ks = (D + 15) / 16, db = (D + 31) / 32;
+  const int lds = BM * C * 2 + 2 * 96 * ((((2 * ks) | 1) * 16) + ((db | 1) * 64)) + BM * 8 + (C / 80) * BM * 8;
   const bool pre = p.o1 != nullptr;
   if (pre && (!p.wo1f || !p.bo1 || p.out == p.h)) { agd_set_error("attn_chain: the to_out prologue needs its weights and out != h"); return -1; }
-  const void* kfn = pre ? (const void*)attn_chain_kernel<320, 1> : (const void*)attn_chain_kernel<320, 0>;
-  static bool attr[AGD_MAX_DEVICES][2] = {};
+  const void* kfn = C == 320 ? (pre ? (const void*)attn_chain_kernel<320, 1> : (const void*)attn_chain_kernel<320, 0>)
+                             : (pre ? (const void*)attn_chain_kernel<640, 1> : (const void*)attn_chain_kernel<640, 0>);
+  static bool attr[AGD_MAX_DEVICES][4] = {};
   int dev = 0; HIP_CHECK_RET(hipGetDevice(&dev));
   if (dev < 0 || dev >= AGD_MAX_DEVICES) { agd_set_error("attn_chain: device ordinal %d out of range", dev); return -1; }
-  if (!attr[dev][pre]) { HIP_CHECK_RET(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); attr[dev][pre] = true; }
+  const int slot = (C == 640 ? 2 : 0) + (pre ? 1 : 0);
+  if (!attr[dev][slot]) { HIP_CHECK_RET(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); attr[dev][slot] = true; }
   AttnChainP pp = p;
   void* args[] = {&pp};
-  HIP_CHECK_RET(hipLaunchKernel(kfn, dim3(p.M / 128), dim3(512), args, lds, st));
+  HIP_CHECK_RET(hipLaunchKernel(kfn, dim3(p.M / BM), dim3(512), args, lds, st));
   return 0;
 }
 
@@ -893,7 +919,8 @@ __global__ __launch_bounds__(512, 2) void qkv_chain_kernel(const QkvChainP p) {
   __syncthreads();
 
   // ---- proj_in: h = x . Wb[img]^T + row[img], rounded once, stored; its row statistics ----
-  panel_gemm_body<C>(ring, acc, wimg, wbase, lane16, xrow, xoff0, xoff1);
+  const XOff<C> xo(q, px);
+  panel_gemm_body<C>(ring, acc, wimg, wbase, lane16, xrow, xo);
   panel_gemm_head<C>(ring, p.wqkvf, wbase, lane16, 3u * C * C * 2);
   {
     float rv[NI * 4];
@@ -940,7 +967,7 @@ __global__ __launch_bounds__(512, 2) void qkv_chain_kernel(const QkvChainP p) {
         u32x2 pk;
         pk[0] = pack_bf2((acc[i][t][0] - mu) * rstd * g1[4 * t] + b1[4 * t], (acc[i][t][1] - mu) * rstd * g1[4 * t + 1] + b1[4 * t + 1]);
         pk[1] = pack_bf2((acc[i][t][2] - mu) * rstd * g1[4 * t + 2] + b1[4 * t + 2], (acc[i][t][3] - mu) * rstd * g1[4 * t + 3] + b1[4 * t + 3]);
-        *(u32x2*)(panel + row * PITCH + panel_swz(n >> 3, row) * 16 + (n & 7) * 2) = pk;
+        *(u32x2*)(panel + row * PITCH + panel_swz<C>(n >> 3, row) * 16 + (n & 7) * 2) = pk;
       }
     }
   }
@@ -951,7 +978,7 @@ __global__ __launch_bounds__(512, 2) void qkv_chain_kernel(const QkvChainP p) {
   for (int s = 0; s < 3; ++s) {
     const unsigned wb_s = __builtin_amdgcn_readfirstlane((unsigned)((4 * s + nq) * KS * NI) * 1024u);
     if (s > 0) panel_gemm_head<C>(ring, p.wqkvf, wb_s, lane16, 3u * C * C * 2);
-    panel_gemm_body<C>(ring, acc, p.wqkvf, wb_s, lane16, xrow, xoff0, xoff1, 3u * C * C * 2);
+    panel_gemm_body<C>(ring, acc, p.wqkvf, wb_s, lane16, xrow, xo, 3u * C * C * 2);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int m = m0 + rbase + 16 * i;

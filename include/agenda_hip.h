@@ -117,10 +117,10 @@ int agd_vae_encode(agd_ctx* ctx, const float* image, int batch, int side, float*
  * "igemm8p" (default 1): launches with enough 256-row tiles (wide 1x1 projections, 3x3 convs with N a multiple of 256, the
  * upsampling convs) run the 8-wave / 8-phase implicit-GEMM kernel (igemm8p.h); 0 = the 4-wave kernels everywhere; tests: 2 / 3 / 4
  * force its 256-wide / 160-wide / any legal tile.
- * "tblock_fuse" (default 31): fused row-panel kernels of the transformer blocks at C = 320 (tblock.hip) -- bit 0: norm3 -> GEGLU ->
+ * "tblock_fuse" (default 63): fused row-panel kernels of the transformer blocks at C = 320 (tblock.hip) -- bit 0: norm3 -> GEGLU ->
  * ff.net.2 + residual as one launch, bit 1: norm2 -> to_q -> cross-attention (+ recorder) -> to_out + residual as one launch, bit 2: that
  * launch starts at attn1.to_out + residual, bit 3: the feed-forward launch ends with proj_out + residual (+ the next GroupNorm's sums), bit 4: proj_in (GroupNorm folded) -> norm1 ->
- * q / k / v projections as one launch. */
+ * q / k / v projections as one launch, bit 5: the attn2 chain (bits 1, 2) for the C = 640 blocks of the 32 x 32 maps as well (64-row panels). */
 int agd_set_option(agd_ctx* ctx, const char* name, int value);
 
 /* ---- heat-map recording (daam.trace / hook.py UNetCrossAttentionHooker state)
@@ -193,7 +193,7 @@ int agd_op_ff_fused(const float* x, const float* gamma, const float* beta, const
 /* BasicTransformerBlock's attn2 section as ONE launch (tblock.hip): y = x + to_out(softmax(scale to_q(norm2(x)) k^T) v), the processor body of
  * reference data_generation/hook.py:91-120 with the LayerNorm in front and the residual behind it; x / y [B * HW][C] fp32, kv [B][T][2C] =
  * the projected context (to_k columns then to_v columns), probs_sum (optional) [B][T][HW] = the probabilities summed over the heads;
- * C = 320, 8 heads, T <= 96, HW a multiple of 128 */
+ * C = 320 (HW a multiple of 128) or C = 640 (HW a multiple of 64), 8 heads, T <= 96 */
 int agd_op_attn_chain(const float* x, const float* gamma, const float* beta, const float* wq, const float* kv, const float* wo,
                       const float* bo, float* y, float* probs_sum, int B, int HW, int T, int C, int heads, float eps, void* stream);
 int agd_op_groupnorm(const float* x_nchw, const float* gamma, const float* beta, float* y_nchw, int B, int C, int HW,

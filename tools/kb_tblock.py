@@ -47,3 +47,23 @@ for rnd in range(3):
     print(f"[{rnd}] attn_chain {ch:7.1f} us   vs to_q {tq:6.1f} + attention(record) {at:6.1f} + to_out {to:6.1f} = {tq + at + to:6.1f} us", flush=True)
     po = lin(Cc, Cc, res=1)
     print(f"[{rnd}] ff_fused + proj_out {tb(2):7.1f} us (vs {ff:6.1f} + C->C launch {po:5.1f});  chain from attn1.to_out {tb(3):7.1f} us (vs {ch:6.1f} + C->C launch {to:5.1f})", flush=True)
+
+# the attn2 chain at C = 640 (32 x 32 maps, 64-row panels on M / 64 = 128 workgroups) against the launches it replaces
+def tb640(kind):
+    ms = C.c_double()
+    if lib.agd_bench_tblock(kind, B, 1024, 50, C.byref(ms)):
+        print("ERR", lib.agd_last_error(None)); return float("nan")
+    return ms.value * 1e3
+
+
+def lin32(K, N, geglu=0, res=0):
+    ms = C.c_double()
+    if lib.agd_bench_conv(B, 32, 32, K, 0, N, 1, 1, 1, geglu, res, 50, C.byref(ms)):
+        return float("nan")
+    return ms.value * 1e3
+
+
+for rnd in range(2):
+    tq, to = lin32(640, 640, geglu=4), lin32(640, 640, geglu=2, res=1)
+    ms = C.c_double(); lib.agd_bench_attention(B, 8, 80, 1024, 77, 1, 50, C.byref(ms)); at = ms.value * 1e3
+    print(f"[{rnd}] C=640 attn_chain {tb640(4):6.1f} us (from attn1.to_out {tb640(5):6.1f})   vs to_q {tq:5.1f} + attention(record) {at:5.1f} + to_out {to:5.1f} = {tq + at + to:5.1f} (+ {to:5.1f})", flush=True)
