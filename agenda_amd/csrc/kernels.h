@@ -96,6 +96,7 @@ struct FFusedP {
   // optional proj_out stage behind it (wpf != NULL): pout = (h + FF(h)) . Wp^T + bp + xres; `out` is then not written.
   // colstat (optional): [M / 128][C] float2 per-(tile, channel) sums of the bf16 outputs for the GroupNorm that reads pout
   const bf16_t* wpf; const float* bp; const bf16_t* xres; bf16_t* pout; float* colstat;
+  int xres_rows;                    // > 0: xres holds xres_rows rows, output row m adds row m % xres_rows (CFG-shared prefix)
 };
 int launch_ff_fused(const FFusedP& p, int C, hipStream_t st);
 // norm2 -> to_q -> cross-attention (77 keys, recorder optional) -> to_out + bias + residual in one launch; 8 heads of 40
@@ -110,6 +111,8 @@ struct AttnChainP {
   float* rowstat_out;               // optional: [M] float2 (sum, sum of squares) of the bf16 outputs (LayerNorm-fold producer, one slot)
   // optional prologue (o1 != NULL): h1 = o1 . Wo1^T + bo1 + h first (attn1.to_out + residual); h1 goes to `out` (!= h) and is the chain's input
   const bf16_t* o1; const bf16_t* wo1f; const float* bo1;
+  int src_rows;                     // > 0: the INPUT tensors (h, o1) hold src_rows rows and output row m reads input row m % src_rows -- the CFG-shared prefix's
+                                    // duplication happens here instead of in copy launches (needs out != h)
 };
 int launch_attn_chain(const AttnChainP& p, int C, int heads, hipStream_t st);
 // proj_in (GroupNorm folded into per-image matrices, launch_gn_fold_weight with frag_ni = C / 64) -> h (stored) -> norm1 -> fused q / k / v

@@ -115,8 +115,8 @@ struct agd_ctx {
   int opt_gn_proj_fold = 1;                           // agd_set_option("gn_proj_fold"): the transformers' GroupNorm folded into per-image proj_in matrices (1: C <= 320, 2: C <= 640)
   int opt_p8 = 1;                                     // agd_set_option("igemm8p"): 256-row 8-wave / 8-phase igemm for launches with enough tiles (igemm8p.h)
   int opt_halo = 1;                                   // agd_set_option("conv_halo"): 3x3 stride-1 convs through the row-halo kernel (igemm_halo.h)
-  int opt_tb_fuse = 63;                               // agd_set_option("tblock_fuse"): fused row-panel kernels of the C = 320 transformer blocks (tblock.hip): bit 0 = feed-forward (bit 3: + proj_out),
-                                                      // bit 1 = attn2 chain (bit 2: + attn1.to_out in front of it), bit 4 = proj_in -> norm1 -> qkv, bit 5 = the attn2 chain for the C = 640 blocks too
+  int opt_tb_fuse = 127;                               // agd_set_option("tblock_fuse"): fused row-panel kernels of the C = 320 transformer blocks (tblock.hip): bit 0 = feed-forward (bit 3: + proj_out),
+                                                      // bit 1 = attn2 chain (bit 2: + attn1.to_out in front of it), bit 4 = proj_in -> norm1 -> qkv, bit 5 = the attn2 chain for the C = 640 blocks too, bit 6 = the CFG-shared prefix's duplication inside the fused kernels
   int opt_smap = 1;                                   // agd_set_option("conv_smap"): 3x3 convs of the 8 x 8 maps through the whole-images-resident kernel (igemm_smap.h)
   int opt_reduce_gn = 1;                              // agd_set_option("reduce_gn"): split-K slab sum + the GroupNorm that reads it as one launch (igemm.hip splitk_reduce_gn_kernel)
   int opt_touch = 3;                                  // agd_set_option("weight_touch"): n > 0 = stream 1x1 weight matrices of >= n MB through the caches right before their launch
@@ -501,7 +501,10 @@ static int transformer(agd_ctx* c, hipStream_t st, const std::string& pre, const
   const bool ff_fused = (c->opt_tb_fuse & 1) && fold && C == 320 && c->W.count(t + "ff.w1.frag");
   const bool chain_fuse = (c->opt_tb_fuse & 2) && (C == 320 || (C == 640 && (c->opt_tb_fuse & 32))) && heads == 8 && HW % (C == 320 ? 128 : 64) == 0 && c->ctx_T <= 96 &&
                           c->rec_mode != 2 && c->W.count(t + "attn2.to_q.frag");
-  const bool chain_pre = chain_fuse && (c->opt_tb_fuse & 4) && !dup && c->W.count(t + "attn1.to_out.frag");     // attn1.to_out + residual inside the chain launch
+  // CFG-shared prefix with the fused kernels behind it: the duplication of the B' rows happens INSIDE them (the chain reads input row m % M', the feed-forward's
+  // proj_out stage adds block-input row m % M'): no copy launches, and attn1.to_out joins the chain here too
+  const bool lazy_dup = dup && (c->opt_tb_fuse & 64) && chain_fuse && C == 320 && ff_fused && (c->opt_tb_fuse & 8) && c->W.count(pre + "proj_out.frag");
+  const bool chain_pre = chain_fuse && (c->opt_tb_fuse & 4) && (!dup || lazy_dup) && c->W.count(t + "attn1.to_out.frag");     // attn1.to_out + residual inside the chain launch
   // --- self attention ---
   { if (!qkv_done) CK(consume(t + "norm1", t + "attn1.qkv", nullptr, 0, qkv));
     AttnP a{}; a.q = qkv; a.k = qkv + C; a.v = qkv + 2 * C; a.o = att;
@@ -512,7 +515,9 @@ static int transformer(agd_ctx* c, hipStream_t st, const std::string& pre, const
     GemmOpt oo; oo.bias = bo; oo.residual = h.p;
     // (the fused attn2 chain takes norm2's statistics from the rows themselves; with bit 2 it also starts at this very GEMM)
     if (!chain_pre) CK(produce(att, C, *wo, oo, h.p, false, !chain_fuse)); }
-  if (dup) {                                           // the halves diverge from here on (text context)
+  const int Mshared = M;                               // rows of the shared part
+  if (dup && lazy_dup) M = B * HW;
+  else if (dup) {                                      // the halves diverge from here on (text context)
     CK(dup_half(c, st, h.p, (long long)M * C));
     if (fold && stats) { ProfScope ps(c, st, PC_ELEM, 0);
       if (hipMemcpyAsync(stats + (size_t)M * slots * 2, stats, (size_t)M * slots * 2 * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) FAIL("dup stats copy failed"); }
@@ -546,7 +551,8 @@ static int transformer(agd_ctx* c, hipStream_t st, const std::string& pre, const
         GETW(f1o, t + "attn1.to_out.frag"); GETV(bo1, t + "attn1.to_out.0.bias");
         bf16_t* h2 = (bf16_t*)c->arena.alloc((size_t)M * C * 2); if (!h2) return -1;
         ap.o1 = att; ap.wo1f = f1o->w; ap.bo1 = bo1; ap.out = h2;
-      }
+      } else if (lazy_dup) { bf16_t* h2 = (bf16_t*)c->arena.alloc((size_t)M * C * 2); if (!h2) return -1; ap.out = h2; }
+      if (lazy_dup) ap.src_rows = Mshared;
       if (fold && !ff_fused) {                           // the GEGLU consumer of the LayerNorm fold reads one slot of row statistics
         slots = 1; stats = (float*)c->arena.alloc((size_t)M * 2 * sizeof(float)); if (!stats) return -1;
         ap.rowstat_out = stats;
@@ -554,7 +560,7 @@ static int transformer(agd_ctx* c, hipStream_t st, const std::string& pre, const
       ProfScope ps(c, st, PC_ATTN_CROSS, (chain_pre ? 6.0 : 4.0) * M * (double)C * C + 4.0 * B * heads * (double)HW * T * D,
                    (chain_pre ? 6.0 : 4.0) * M * (double)C + (chain_pre ? 6.0 : 4.0) * C * (double)C + 4.0 * B * (double)T * C + rec_bytes);
       CK(launch_attn_chain(ap, C, heads, st));
-      if (chain_pre) h.p = ap.out;                       // the residual stream continues in the second buffer
+      if (ap.out != ap.h) h.p = ap.out;                  // the residual stream continues in the second buffer
       chain_done = true;
     }
   }
@@ -577,6 +583,7 @@ static int transformer(agd_ctx* c, hipStream_t st, const std::string& pre, const
     if ((c->opt_tb_fuse & 8) && c->W.count(pre + "proj_out.frag")) {      // proj_out + residual (+ the next GroupNorm's partial sums) behind it, same launch
       GETW(fpw, pre + "proj_out.frag"); GETV(bp, pre + "proj_out.bias");
       fp.wpf = fpw->w; fp.bp = bp; fp.xres = xres; fp.pout = out.p;
+      if (lazy_dup) fp.xres_rows = Mshared;             // xres is still the B'-row block input
       out.cpart_bm = 0;
       if (out.cpart && c->opt_gn_fused && HW % 128 == 0) { fp.colstat = out.cpart; out.cpart_bm = 128; }
       proj_done = true;

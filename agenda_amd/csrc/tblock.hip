@@ -395,7 +395,7 @@ __global__ __launch_bounds__(512, 2) void ff_fused_kernel(const FFusedP p) {
   __syncthreads();                                       // h3 complete in the panel (every GEMM1 read of the raw rows is long done)
   u32x2 xr[4][NI2];                                      // the residual rows (HBM-cold) are requested ahead of the GEMM, not in its epilogue
 #pragma unroll
-  for (int i = 0; i < 4; ++i) { const int m = m0 + rbase + 16 * i; load_row_chunk<NI2>(p.xres + (long long)(m < p.M ? m : 0) * C + ncol0, xr[i]); }
+  for (int i = 0; i < 4; ++i) { const int m = m0 + rbase + 16 * i, ms = m < p.M ? (p.xres_rows > 0 ? m % p.xres_rows : m) : 0; load_row_chunk<NI2>(p.xres + (long long)ms * C + ncol0, xr[i]); }
   panel_gemm_body<C>(ring, acc2, p.wpf, pwbase, lane16, xrow, XOff<C>(q, px));
   float bpv[NI2 * 4];
 #pragma unroll
@@ -508,8 +508,9 @@ __global__ __launch_bounds__(512, 2) void attn_chain_kernel(const AttnChainP p) 
   const int c = lane & 31, hh = lane >> 5;
   const int m0 = blockIdx.x * BM;
   const int b = m0 / p.HW, pix0 = m0 - b * p.HW;        // tiles stay inside one image (HW % 128 == 0)
+  const int m0s = p.src_rows > 0 ? m0 % p.src_rows : m0;     // first INPUT row of this tile (CFG-shared prefix: both halves read the same rows)
 
-  panel_load_dma<C, BM>(PRE ? p.o1 : p.h, m0, p.M, panel, wid, lane);
+  panel_load_dma<C, BM>(PRE ? p.o1 : p.h, m0s, p.src_rows > 0 ? p.src_rows : p.M, panel, wid, lane);
 
   // K / V staging of this wave's head half: pad chunks once, then head `h` through registers
   char* sK = kvs + hhalf * KVSTAGE;
@@ -571,7 +572,7 @@ __global__ __launch_bounds__(512, 2) void attn_chain_kernel(const AttnChainP p) 
     // ---- attn1.to_out + bias + residual -> h1 (rounded once, stored), its row statistics, norm2 from registers into the panel ----
     u32x2 hr[4][NI];                                    // residual rows of h, requested ahead of the GEMM
 #pragma unroll
-    for (int i = 0; i < 4; ++i) load_row_chunk<NI>(p.h + (long long)(m0 + rbase + 16 * i) * C + ncol0, hr[i]);
+    for (int i = 0; i < 4; ++i) load_row_chunk<NI>(p.h + (long long)(m0s + rbase + 16 * i) * C + ncol0, hr[i]);
     gemm_body(p.wo1f);
     gemm_head(p.wqf);
     float bv1[NI * 4];
@@ -812,7 +813,7 @@ __global__ __launch_bounds__(512, 2) void attn_chain_kernel(const AttnChainP p) 
   // ---- to_out + bias + residual, one rounding; optional norm3 row statistics of the rounded outputs ----
   u32x2 fr[4][NI];                                      // residual rows, requested ahead of the GEMM (PRE: h1, stored by this very lane above)
 #pragma unroll
-  for (int i = 0; i < 4; ++i) load_row_chunk<NI>((PRE ? (const bf16_t*)p.out : p.h) + (long long)(m0 + rbase + 16 * i) * C + ncol0, fr[i]);
+  for (int i = 0; i < 4; ++i) load_row_chunk<NI>((PRE ? (const bf16_t*)p.out : p.h) + (long long)((PRE ? m0 : m0s) + rbase + 16 * i) * C + ncol0, fr[i]);
   gemm_body(p.wof);
   float bv[NI * 4];
 #pragma unroll
@@ -868,6 +869,7 @@ int launch_attn_chain(const AttnChainP& p, int C, int heads, hipStream_t st) {
   const int lds = BM * C * 2 + 2 * 96 * ((((2 * ks) | 1) * 16) + ((db | 1) * 64)) + BM * 8 + (C / 80) * BM * 8;
   const bool pre = p.o1 != nullptr;
   if (pre && (!p.wo1f || !p.bo1 || p.out == p.h)) { agd_set_error("attn_chain: the to_out prologue needs its weights and out != h"); return -1; }
+  if (p.src_rows > 0 && (p.src_rows % BM || p.M % p.src_rows || p.out == p.h)) { agd_set_error("attn_chain: src_rows %d must divide M, be a multiple of %d and out != h", p.src_rows, BM); return -1; }
   const void* kfn = C == 320 ? (pre ? (const void*)attn_chain_kernel<320, 1> : (const void*)attn_chain_kernel<320, 0>)
                              : (pre ? (const void*)attn_chain_kernel<640, 1> : (const void*)attn_chain_kernel<640, 0>);
   static bool attr[AGD_MAX_DEVICES][4] = {};

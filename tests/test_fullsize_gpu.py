@@ -203,7 +203,7 @@ def test_fused_transformer_block_kernels_match_the_kernel_chain_512px(sd15_host_
                 again = pipe.engine.unet_forward(x, 981.0)
                 assert torch.equal(got, again) and torch.equal(hm, pipe.engine.daam_global(0, 77, L).cpu())
     finally:
-        pipe.engine.set_option("tblock_fuse", 63)
+        pipe.engine.set_option("tblock_fuse", 127)
         pipe.engine.set_option("reduce_gn", 1)
         pipe.engine.record_config(0)
     base, bhm = outs[(0, 0)]
@@ -214,6 +214,44 @@ def test_fused_transformer_block_kernels_match_the_kernel_chain_512px(sd15_host_
         assert e_o < 2.0 ** -6, (key, e_o)
         assert e_b < 2.0 ** -5, (key, e_b)
         assert h_o < 0.02, (key, h_o)
+
+
+def test_cfg_shared_prefix_inside_the_fused_kernels_512px(sd15_pipe):
+    """`cfg_shared_prefix` with the fused block kernels behind it (tblock_fuse bit 6): the B' shared rows are not copied -- the attn2 chain reads input
+    row m % M' (and starts at attn1.to_out), the feed-forward's proj_out stage adds block-input row m % M'.  Two denoise steps at 512 px against the
+    same run with explicit copies (bit 6 off) and against the run that shares nothing: every row sees the same inputs either way, the kernels that
+    produce them differ (fused vs separate to_out), so agreement is to bf16 noise (amplified by the guidance scale: the bound is on two steps'
+    latents, calibrated against the distance between the two older forms), and the lazy form is run-to-run identical."""
+    from agenda_amd import synthetic, trace
+    pipe = sd15_pipe
+    cfg = pipe.cfg
+    ctx = synthetic.make_context(cfg, 2, seed=5)
+    lat = synthetic.make_latents(cfg, [3, 4], 64)
+
+    def run():
+        with trace(pipe) as trc:
+            out = pipe(prompt_embeds=ctx, latents=lat, num_inference_steps=2, output_type="latent")
+            maps = torch.stack([trc.compute_global_heat_map(image_index=i).heat_maps for i in range(2)])
+        return out.latents.clone(), maps.clone()
+
+    try:
+        a = run(); a2 = run()
+        pipe.engine.set_option("tblock_fuse", 63)
+        b = run()
+        pipe.engine.set_option("cfg_shared_prefix", 0)
+        c0 = run()
+    finally:
+        pipe.engine.set_option("tblock_fuse", 127)
+        pipe.engine.set_option("cfg_shared_prefix", 1)
+    assert torch.equal(a[0], a2[0]) and torch.equal(a[1], a2[1])
+    # calibration: how far two VALID realisations of the same two steps drift apart (classifier-free guidance multiplies the bf16 noise of eps by ~10)
+    base = _rms_rel(b[0], c0[0].cpu())
+    for other, name in ((b, "copies"), (c0, "unshared")):
+        e_l = _rms_rel(a[0], other[0].cpu()); e_m = float((a[1] - other[1]).abs().max() / other[1].abs().max())
+        print(f"lazy shared prefix vs {name}: latents rms rel {e_l:.5f} (copies vs unshared: {base:.5f}), heat maps {e_m:.4f}")
+        assert e_l < 0.08 and e_m < 0.02, (name, e_l, e_m)
+    # sharing nothing runs the very same kernels on every row (attn1.to_out inside the chain either way): the lazy form is bit-identical to it
+    assert torch.equal(a[0], c0[0]) and torch.equal(a[1], c0[1])
 
 
 def test_sd15_unet_forward_512px_batch4_matches_oracle(sd15_host_weights, sd15_pipe):
