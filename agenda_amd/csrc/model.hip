@@ -117,6 +117,8 @@ struct agd_ctx {
   int opt_halo = 1;                                   // agd_set_option("conv_halo"): 3x3 stride-1 convs through the row-halo kernel (igemm_halo.h)
   int opt_tb_fuse = 127;                               // agd_set_option("tblock_fuse"): fused row-panel kernels of the C = 320 transformer blocks (tblock.hip): bit 0 = feed-forward (bit 3: + proj_out),
                                                       // bit 1 = attn2 chain (bit 2: + attn1.to_out in front of it), bit 4 = proj_in -> norm1 -> qkv, bit 5 = the attn2 chain for the C = 640 blocks too, bit 6 = the CFG-shared prefix's duplication inside the fused kernels
+  int opt_side = 0;                                   // agd_set_option("side_stream"): a resnet's 1x1 conv_shortcut runs on a second stream beside norm1 / conv1 / norm2
+  hipStream_t side = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   int opt_smap = 1;                                   // agd_set_option("conv_smap"): 3x3 convs of the 8 x 8 maps through the whole-images-resident kernel (igemm_smap.h)
   int opt_reduce_gn = 1;                              // agd_set_option("reduce_gn"): split-K slab sum + the GroupNorm that reads it as one launch (igemm.hip splitk_reduce_gn_kernel)
   int opt_touch = 3;                                  // agd_set_option("weight_touch"): n > 0 = stream 1x1 weight matrices of >= n MB through the caches right before their launch
@@ -286,6 +288,26 @@ static int resnet(agd_ctx* c, hipStream_t st, const std::string& pre, const Act&
   bf16_t* out_normed = nullptr;
   if (next && next->gamma && c->opt_reduce_gn) { out_normed = (bf16_t*)c->arena.alloc((size_t)out.n() * 2); if (!out_normed) return -1; }   // lives as long as `out`
   const size_t mk = c->arena.mark();
+  // the 1x1 conv_shortcut depends on the block's input alone: with the option on it runs on a second stream beside norm1 / conv1 / norm2
+  // (those launches are one workgroup per CU or fewer on the small maps); unsplit launches only -- the split-K workspace is the main stream's
+  bf16_t* side_out = nullptr;
+  const bool has_sc = c->W.count(pre + "conv_shortcut.weight") != 0;
+  if (has_sc && c->opt_side) {
+    GETW(ws, pre + "conv_shortcut.weight"); GETV(bs, pre + "conv_shortcut.bias");
+    GemmOpt os; os.bias = bs; int cfg[3] = {0, 0, 0}; os.query_cfg = cfg;
+    CK(run_conv(c, st, x0.p, x0.C, x1 ? x1->p : nullptr, C1, B, H, Wd, *ws, 1, nullptr, os, c->zero_page));
+    if (cfg[2] == 1) {
+      if (!c->side) {
+        if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) FAIL("side stream");
+      }
+      side_out = (bf16_t*)c->arena.alloc((size_t)B * HW * Cout * 2); if (!side_out) return -1;
+      os.query_cfg = nullptr;
+      if (hipEventRecord(c->ev_fork, st) != hipSuccess || hipStreamWaitEvent(c->side, c->ev_fork, 0) != hipSuccess) FAIL("side stream fork");
+      CK(run_conv(c, c->side, x0.p, x0.C, x1 ? x1->p : nullptr, C1, B, H, Wd, *ws, 1, side_out, os, c->zero_page));
+      if (hipEventRecord(c->ev_join, c->side) != hipSuccess) FAIL("side stream join");
+    }
+  }
   Act n1 = alloc_act(c, B, H, Wd, Cin); if (!n1.p) return -1;
   GETV(g1, pre + "norm1.weight"); GETV(b1, pre + "norm1.bias");
   const bf16_t* n1p = n1.p;
@@ -307,7 +329,10 @@ static int resnet(agd_ctx* c, hipStream_t st, const std::string& pre, const Act&
   CK(run_conv(c, st, n1p, Cin, nullptr, 0, B, H, Wd, *w1, 3, h.p, o1, c->zero_page));
   if (!gn_done) CK(run_gn(c, st, h.p, Cout, nullptr, 0, B, HW, g2, b2, groups, eps, 1, n2.p, &h));
   const bf16_t* res = x0.p;
-  if (c->W.count(pre + "conv_shortcut.weight")) {
+  if (side_out) {
+    if (hipStreamWaitEvent(st, c->ev_join, 0) != hipSuccess) FAIL("side stream wait");
+    res = side_out;
+  } else if (has_sc) {
     GETW(ws, pre + "conv_shortcut.weight"); GETV(bs, pre + "conv_shortcut.bias");
     GemmOpt os; os.bias = bs;
     CK(run_conv(c, st, x0.p, x0.C, x1 ? x1->p : nullptr, C1, B, H, Wd, *ws, 1, h.p, os, c->zero_page));  // h is free again
@@ -869,6 +894,7 @@ AGD_API void agd_destroy(agd_ctx* c) {
   c->ctxb.release(); c->hook_sumb.release(); c->hook_scratchb.release(); c->hook_headsb.release(); c->hook_storeb.release(); c->bwd_wsb.release();
   for (auto& xl : c->xl) { xl.wqTb.release(); xl.wkvTb.release(); xl.woTb.release(); }
   c->latb.release(); c->epsb.release(); c->vae_imgb.release(); c->plmsb.release();
+  if (c->side) { hipStreamDestroy(c->side); hipEventDestroy(c->ev_fork); hipEventDestroy(c->ev_join); }
   if (c->splitk.p) hipFree(c->splitk.p);
   if (c->arena.base) hipFree(c->arena.base);
   if (c->stage) hipFree(c->stage);
@@ -1230,6 +1256,7 @@ AGD_API int agd_set_option(agd_ctx* c, const char* name, int value) {
   if (!strcmp(name, "tblock_fuse")) { c->opt_tb_fuse = value < 0 ? 0 : value; return 0; }   // bit 0: fused feed-forward, bit 1: fused attn2 chain (C = 320 blocks)
   if (!strcmp(name, "reduce_gn")) { c->opt_reduce_gn = value != 0; return 0; }
   if (!strcmp(name, "conv_smap")) { c->opt_smap = value != 0; return 0; }
+  if (!strcmp(name, "side_stream")) { c->opt_side = value != 0; return 0; }
   if (!strcmp(name, "igemm8p")) { c->opt_p8 = value < 0 ? 0 : value; return 0; }   // 0 off, 1 on (the launcher decides per launch); tests: 2 / 3 / 4 force the 256-wide / 160-wide / any legal tile
   agd_set_error("set_option: unknown option '%s'", name);
   return fail_ctx(c);
