@@ -120,7 +120,11 @@ int agd_vae_encode(agd_ctx* ctx, const float* image, int batch, int side, float*
  * "tblock_fuse" (default 127): fused row-panel kernels of the transformer blocks at C = 320 (tblock.hip) -- bit 0: norm3 -> GEGLU ->
  * ff.net.2 + residual as one launch, bit 1: norm2 -> to_q -> cross-attention (+ recorder) -> to_out + residual as one launch, bit 2: that
  * launch starts at attn1.to_out + residual, bit 3: the feed-forward launch ends with proj_out + residual (+ the next GroupNorm's sums), bit 4: proj_in (GroupNorm folded) -> norm1 ->
- * q / k / v projections as one launch, bit 5: the attn2 chain (bits 1, 2) for the C = 640 blocks of the 32 x 32 maps as well (64-row panels), bit 6: under `cfg_shared_prefix` the duplication of the shared rows happens inside the fused kernels (no copy launches). */
+ * q / k / v projections as one launch, bit 5: the attn2 chain (bits 1, 2) for the C = 640 blocks of the 32 x 32 maps as well (64-row panels), bit 6: under `cfg_shared_prefix` the duplication of the shared rows happens inside the fused kernels (no copy launches).
+ * "reduce_gn" (default 1): the slab-sum pass of a split-K conv also applies the GroupNorm (+ SiLU) that reads its output next (conv1 -> norm2 of a
+ * ResnetBlock2D; conv2 -> the following module's norm where that reads this output alone); 0 = separate statistics / apply launches.
+ * "conv_smap" (default 1): 3x3 convs of the 8 x 8 maps run the whole-images-resident kernel (igemm_smap.h).
+ * "side_stream" (default 0; measured slower, kept for the A/B): a resnet's 1x1 conv_shortcut runs on a second stream beside norm1 / conv1 / norm2. */
 int agd_set_option(agd_ctx* ctx, const char* name, int value);
 
 /* ---- heat-map recording (daam.trace / hook.py UNetCrossAttentionHooker state)
