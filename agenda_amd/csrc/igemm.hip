@@ -368,21 +368,24 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const IgemmP p, int 
 // [HW][C / groups] block of the output -- sums its slab rows in slice order (deterministic), applies the conv epilogue, rounds to bf16,
 // takes the group's mean / variance from the ROUNDED values it holds in registers (what the separate statistics kernel would read back)
 // and writes silu?((x - mean) rstd gamma + beta).  Replaces three launches (slab sum, gn_stats, gn_apply) that each re-read the last
-// one's output; MAXQ = float4 quads per thread.
-template <int MAXQ>
-__global__ __launch_bounds__(256) void splitk_reduce_gn_kernel(const IgemmP p, int S) {
-  __shared__ float red[2][4];
+// one's output; MAXQ = float4 quads per thread.  The pass is a chain of memory round trips (slabs -> epilogue operands -> statistics ->
+// stores) on 256 workgroups, so it runs 1024 threads per workgroup (16 waves per CU in flight instead of 4) and issues EVERY load it
+// will need -- slabs in chunks of SU, residual, bias, row add, gamma, beta -- before the first use.
+template <int MAXQ, int SU>
+__global__ __launch_bounds__(1024) void splitk_reduce_gn_kernel(const IgemmP p, int S) {
+  constexpr int NT = 1024;
+  __shared__ float red[2][NT / 64];
   const int HWo = p.Hout * p.Wout, cpg = p.N / p.gn_groups, nq = cpg >> 2;
   const int grp = blockIdx.x, img = blockIdx.y, tid = threadIdx.x;
   const int total = HWo * nq;
   const int n0 = grp * cpg;
   const long long slab = (long long)p.M * p.N;
-  // every load of a pass is issued before the first use (indices of the tail quads are clamped, only their stores are predicated):
-  // a branch around each load would make the compiler wait for every one of them in turn
+  // indices of the tail quads are clamped, only their stores are predicated: a branch around each load would make the compiler wait
+  // for every one of them in turn
   long long off[MAXQ]; int nn[MAXQ]; bool ok[MAXQ];
 #pragma unroll
   for (int k = 0; k < MAXQ; ++k) {
-    const int qi0 = tid + k * 256;
+    const int qi0 = tid + k * NT;
     ok[k] = qi0 < total;
     const int qi = ok[k] ? qi0 : total - 1;
     const int px = qi / nq;
@@ -392,22 +395,45 @@ __global__ __launch_bounds__(256) void splitk_reduce_gn_kernel(const IgemmP p, i
   f32x4 a[MAXQ];
 #pragma unroll
   for (int k = 0; k < MAXQ; ++k) a[k] = *(const f32x4*)(p.splitk_ws + off[k]);
-  for (int s = 1; s < S; ++s) {
-    f32x4 t[MAXQ];
+  // epilogue operands: requested now, used after the slab sums (absent ones read a valid dummy address and are not added)
+  const bf16_t* rbase = p.residual ? p.residual : (const bf16_t*)p.splitk_ws;
+  const int ldr = p.residual ? p.ldr : p.N;
+  const float* bbase = p.bias_mode == 1 ? p.bias : p.gn_gamma;
+  const float* abase = p.rowadd ? p.rowadd + (long long)img * p.rowadd_ld : p.gn_gamma;
+  u32x2 rr[MAXQ]; f32x4 bb[MAXQ], ra[MAXQ], ga[MAXQ], be[MAXQ];
 #pragma unroll
-    for (int k = 0; k < MAXQ; ++k) t[k] = *(const f32x4*)(p.splitk_ws + s * slab + off[k]);
+  for (int k = 0; k < MAXQ; ++k) {
+    const long long m = (off[k] - nn[k]) / p.N;
+    rr[k] = *(const u32x2*)(rbase + m * ldr + nn[k]);
+    bb[k] = *(const f32x4*)(bbase + nn[k]);
+    ra[k] = *(const f32x4*)(abase + nn[k]);
+    ga[k] = *(const f32x4*)(p.gn_gamma + nn[k]);
+    be[k] = *(const f32x4*)(p.gn_beta + nn[k]);
+  }
+  for (int s = 1; s < S; s += SU) {
+    f32x4 t[SU][MAXQ];
 #pragma unroll
-    for (int k = 0; k < MAXQ; ++k) a[k] += t[k];
+    for (int u = 0; u < SU; ++u) {
+      const int sc = s + u < S ? s + u : S - 1;
+#pragma unroll
+      for (int k = 0; k < MAXQ; ++k) t[u][k] = *(const f32x4*)(p.splitk_ws + sc * slab + off[k]);
+    }
+#pragma unroll
+    for (int u = 0; u < SU; ++u)
+      if (s + u < S) {
+#pragma unroll
+        for (int k = 0; k < MAXQ; ++k) a[k] += t[u][k];
+      }
   }
   float s1 = 0.f, s2 = 0.f;
 #pragma unroll
   for (int k = 0; k < MAXQ; ++k) {
     const int n = nn[k];
     const long long m = (off[k] - n) / p.N;
-    if (p.bias_mode == 1) a[k] += *(const f32x4*)(p.bias + n); else if (p.bias_mode == 2) a[k] += p.bias[m];
-    if (p.rowadd) a[k] += *(const f32x4*)(p.rowadd + (long long)img * p.rowadd_ld + n);
+    if (p.bias_mode == 1) a[k] += bb[k]; else if (p.bias_mode == 2) a[k] += p.bias[m];
+    if (p.rowadd) a[k] += ra[k];
     if (p.residual) {
-      const u32x2 r = *(const u32x2*)(p.residual + m * p.ldr + n);
+      const u32x2 r = rr[k];
       a[k] += f32x4{__uint_as_float(r[0] << 16), __uint_as_float(r[0] & 0xFFFF0000u), __uint_as_float(r[1] << 16), __uint_as_float(r[1] & 0xFFFF0000u)};
     }
 #pragma unroll
@@ -427,20 +453,19 @@ __global__ __launch_bounds__(256) void splitk_reduce_gn_kernel(const IgemmP p, i
   if ((tid & 63) == 0) { red[0][tid >> 6] = s1; red[1][tid >> 6] = s2; }
   __syncthreads();
   const double cnt = (double)HWo * cpg;
-  const double S1 = (double)red[0][0] + (double)red[0][1] + (double)red[0][2] + (double)red[0][3];
-  const double S2 = (double)red[1][0] + (double)red[1][1] + (double)red[1][2] + (double)red[1][3];
+  double S1 = 0.0, S2 = 0.0;
+#pragma unroll
+  for (int w = 0; w < NT / 64; ++w) { S1 += (double)red[0][w]; S2 += (double)red[1][w]; }      // fixed order
   const double mean = S1 / cnt;
   double var = S2 / cnt - mean * mean; if (var < 0) var = 0;
   const float mu = (float)mean, rstd = (float)(1.0 / sqrt(var + (double)p.gn_eps));
 #pragma unroll
   for (int k = 0; k < MAXQ; ++k) {
-    const int n = nn[k];
-    const f32x4 ga = *(const f32x4*)(p.gn_gamma + n), be = *(const f32x4*)(p.gn_beta + n);
     float o[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const float sc = rstd * ga[e];                      // same affine form as gn_apply: x * scale + shift
-      const float r = fmaf(a[k][e], sc, be[e] - mu * sc);
+      const float sc = rstd * ga[k][e];                   // same affine form as gn_apply: x * scale + shift
+      const float r = fmaf(a[k][e], sc, be[k][e] - mu * sc);
       o[e] = p.gn_silu ? silu_f(r) : r;
     }
     if (ok[k]) { u32x2 pk; pk[0] = pack_bf2(o[0], o[1]); pk[1] = pack_bf2(o[2], o[3]); *(u32x2*)(p.gn_y + off[k]) = pk; }
@@ -451,7 +476,7 @@ static bool reduce_gn_ok(const IgemmP& p) {
   if (!p.gn_y || !p.gn_gamma || !p.gn_beta || p.gn_groups < 1 || p.out_f32 || p.geglu || p.batch > 1) return false;
   const int HWo = p.Hout * p.Wout;
   if (p.N % p.gn_groups || (p.N / p.gn_groups) % 4 || p.M % HWo || p.ldo != p.N || (p.residual && p.ldr % 4)) return false;
-  return (long long)HWo * (p.N / p.gn_groups / 4) <= 256 * 10 && p.act <= 1;
+  return (long long)HWo * (p.N / p.gn_groups / 4) <= 1024 * 3 && p.act <= 1;
 }
 
 // the slab pass of a split-K launch: out = epilogue(sum of the S slabs), fused with the GroupNorm that reads it where the caller asked for it
@@ -459,9 +484,10 @@ static int launch_splitk_reduce(const IgemmP& p, int splits, hipStream_t st) {
   if (reduce_gn_ok(p)) {
     const long long quads = (long long)p.Hout * p.Wout * (p.N / p.gn_groups / 4);
     const dim3 g(p.gn_groups, p.M / (p.Hout * p.Wout));
-    if (quads <= 256 * 3) hipLaunchKernelGGL(splitk_reduce_gn_kernel<3>, g, dim3(256), 0, st, p, splits);
-    else if (quads <= 256 * 5) hipLaunchKernelGGL(splitk_reduce_gn_kernel<5>, g, dim3(256), 0, st, p, splits);
-    else hipLaunchKernelGGL(splitk_reduce_gn_kernel<10>, g, dim3(256), 0, st, p, splits);
+    // slab loads per round: all of a 2-way split at once; the 8 x 8 maps' 8 - 10 slabs (one quad per thread) all at once
+    if (quads <= 1024) hipLaunchKernelGGL((splitk_reduce_gn_kernel<1, 9>), g, dim3(1024), 0, st, p, splits);
+    else if (quads <= 2048) hipLaunchKernelGGL((splitk_reduce_gn_kernel<2, 2>), g, dim3(1024), 0, st, p, splits);
+    else hipLaunchKernelGGL((splitk_reduce_gn_kernel<3, 1>), g, dim3(1024), 0, st, p, splits);
     HIP_CHECK_RET(hipGetLastError());
     if (p.gn_fused) *p.gn_fused = 1;
     return 0;
