@@ -125,6 +125,11 @@ struct QkvChainP {
   const bf16_t* wqkvf;              // attn1 [3C][C] (q rows, k rows, v rows) in fragment order (NI = C / 64, KC = C)
   bf16_t* qkv;                      // [M][3C]
   int M, HW;
+  long long rowadd_stride;          // elements between the images' rows of `rowadd` (0: one row -- the plain proj_in bias)
+  // gn_part != nullptr: x is the RAW activation and the kernel applies the transformer's GroupNorm itself -- statistics from the producer's
+  // per-(M tile, channel) partial sums [B][HW / gn_bm][C][2], rows normalised (and rounded to bf16, as gn_apply would) inside the LDS panel;
+  // wbf is then the plain proj_in matrix in fragment order (wb_stride 0) and rowadd its bias
+  const float* gn_part; int gn_bm, gn_groups; float gn_eps; const float* gn_gamma; const float* gn_beta;
 };
 int launch_qkv_chain(const QkvChainP& p, int C, hipStream_t st);
 int launch_frag_order_w1(const bf16_t* src, bf16_t* dst, int C, int HID, hipStream_t st);

@@ -115,8 +115,8 @@ struct agd_ctx {
   int opt_gn_proj_fold = 1;                           // agd_set_option("gn_proj_fold"): the transformers' GroupNorm folded into per-image proj_in matrices (1: C <= 320, 2: C <= 640)
   int opt_p8 = 1;                                     // agd_set_option("igemm8p"): 256-row 8-wave / 8-phase igemm for launches with enough tiles (igemm8p.h)
   int opt_halo = 1;                                   // agd_set_option("conv_halo"): 3x3 stride-1 convs through the row-halo kernel (igemm_halo.h)
-  int opt_tb_fuse = 127;                               // agd_set_option("tblock_fuse"): fused row-panel kernels of the C = 320 transformer blocks (tblock.hip): bit 0 = feed-forward (bit 3: + proj_out),
-                                                      // bit 1 = attn2 chain (bit 2: + attn1.to_out in front of it), bit 4 = proj_in -> norm1 -> qkv, bit 5 = the attn2 chain for the C = 640 blocks too, bit 6 = the CFG-shared prefix's duplication inside the fused kernels
+  int opt_tb_fuse = 255;                               // agd_set_option("tblock_fuse"): fused row-panel kernels of the C = 320 transformer blocks (tblock.hip): bit 0 = feed-forward (bit 3: + proj_out),
+                                                      // bit 1 = attn2 chain (bit 2: + attn1.to_out in front of it), bit 4 = proj_in -> norm1 -> qkv, bit 5 = the attn2 chain for the C = 640 blocks too, bit 6 = the CFG-shared prefix's duplication inside the fused kernels, bit 7 = the GroupNorm applied inside the bit-4 launch (no fold launch)
   int opt_side = 0;                                   // agd_set_option("side_stream"): a resnet's 1x1 conv_shortcut runs on a second stream beside norm1 / conv1 / norm2
   hipStream_t side = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   int opt_smap = 1;                                   // agd_set_option("conv_smap"): 3x3 convs of the 8 x 8 maps through the whole-images-resident kernel (igemm_smap.h)
@@ -497,16 +497,27 @@ static int transformer(agd_ctx* c, hipStream_t st, const std::string& pre, const
   { GETW(w, pre + "proj_in.weight"); GETV(b, pre + "proj_in.bias");
     if (gfold) {
       if (w->taps != 1 || w->Cpad != C) FAIL("gn_proj_fold: proj_in weight [N=%d taps=%d Cpad=%d] is not a 1x1 over %d channels", w->N, w->taps, w->Cpad, C);
-      bf16_t* wb = (bf16_t*)c->arena.alloc((size_t)Bs * w->N * C * 2);
-      float* radd = (float*)c->arena.alloc((size_t)Bs * w->N * sizeof(float));
-      if (!wb || !radd) return -1;
       const bool qkv_fuse = (c->opt_tb_fuse & 16) && C == 320 && w->N == C && c->W.count(t + "attn1.qkv.frag");
-      { ProfScope ps(c, st, PC_GN, 0, 2.0 * Bs * (double)w->N * C * 2);
-        CK(launch_gn_fold_weight(x.cpart, x.cpart_bm, Bs, HW, C, groups, 1e-6f, gg, gb, w->w, b, w->N, wb, radd, st, qkv_fuse ? C / 64 : 0)); }
+      // bit 7: the qkv chain kernel applies the GroupNorm itself (statistics from the partial sums, rows normalised in its LDS panel): no fold launch
+      const bool gn_inside = qkv_fuse && (c->opt_tb_fuse & 128) && groups <= 32 && c->W.count(pre + "proj_in.frag");
+      bf16_t* wb = nullptr; float* radd = nullptr;
+      if (!gn_inside) {
+        wb = (bf16_t*)c->arena.alloc((size_t)Bs * w->N * C * 2);
+        radd = (float*)c->arena.alloc((size_t)Bs * w->N * sizeof(float));
+        if (!wb || !radd) return -1;
+        ProfScope ps(c, st, PC_GN, 0, 2.0 * Bs * (double)w->N * C * 2);
+        CK(launch_gn_fold_weight(x.cpart, x.cpart_bm, Bs, HW, C, groups, 1e-6f, gg, gb, w->w, b, w->N, wb, radd, st, qkv_fuse ? C / 64 : 0));
+      }
       if (qkv_fuse) {      // proj_in -> h -> norm1 -> q / k / v in one launch (tblock.hip); norm1's statistics come from the rows themselves
         GETW(fqkv, t + "attn1.qkv.frag"); GETV(g1, t + "norm1.weight"); GETV(b1_, t + "norm1.bias");
-        QkvChainP qp{}; qp.x = x.p; qp.wbf = wb; qp.wb_stride = (long long)w->N * C; qp.rowadd = radd; qp.h = h.p; qp.gamma = g1; qp.beta = b1_; qp.ln_eps = lneps;
+        QkvChainP qp{}; qp.x = x.p; qp.wbf = wb; qp.wb_stride = (long long)w->N * C; qp.rowadd = radd; qp.rowadd_stride = C; qp.h = h.p; qp.gamma = g1; qp.beta = b1_; qp.ln_eps = lneps;
         qp.wqkvf = fqkv->w; qp.qkv = qkv; qp.M = M; qp.HW = HW;
+        if (gn_inside) {
+          GETW(fpi, pre + "proj_in.frag");
+          if (!b) FAIL("proj_in without bias");
+          qp.wbf = fpi->w; qp.wb_stride = 0; qp.rowadd = b; qp.rowadd_stride = 0;
+          qp.gn_part = x.cpart; qp.gn_bm = x.cpart_bm; qp.gn_groups = groups; qp.gn_eps = 1e-6f; qp.gn_gamma = gg; qp.gn_beta = gb;
+        }
         stats = nullptr; slots = 0;
         ProfScope ps(c, st, PC_GEMM, 8.0 * M * (double)C * C, 2.0 * M * (double)C * 5.0 + 2.0 * (Bs + 3.0) * C * (double)C);
         CK(launch_qkv_chain(qp, C, st));
@@ -1005,6 +1016,13 @@ AGD_API int agd_finalize(agd_ctx* c) {
           WMat fp_ = *wp; fp_.w = dmalloc<bf16_t>(c, (size_t)C * C); if (!fp_.w) return fail_ctx(c);
           API_CK(c, launch_frag_order_w(wp->w, fp_.w, C, C, C / 64, C, 0));
           c->W[pr.first + "proj_out.frag"] = fp_;
+        }
+        const WMat* wi = getW(c, pr.first + "proj_in.weight");
+        if (!wi) return fail_ctx(c);
+        if (wi->N == C && wi->Cpad == C && wi->taps == 1) {
+          WMat fi = *wi; fi.w = dmalloc<bf16_t>(c, (size_t)C * C); if (!fi.w) return fail_ctx(c);
+          API_CK(c, launch_frag_order_w(wi->w, fi.w, C, C, C / 64, C, 0));
+          c->W[pr.first + "proj_in.frag"] = fi;
         }
       }
       const WMat* wq = getW(c, t + "attn2.to_q.weight"); const WMat* wo = getW(c, t + "attn2.to_out.0.weight");

@@ -159,6 +159,27 @@ __global__ __launch_bounds__(512) void gn_apply_part_kernel(const bf16_t* __rest
   const int C = C0 + C1, cpg = C / groups, gps = groups / GN_SLICES, Cs = C / GN_SLICES;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b = blockIdx.y, slice = blockIdx.z;
+  // The launch is a chain of memory round trips (partial sums -> gamma / beta -> activation -> stores) on a few hundred blocks: request
+  // the affine parameters and the first eight activation vectors of this lane BEFORE the statistics are reduced -- none of them depends
+  // on the statistics, only the arithmetic does.  Ragged ends are clamped loads and predicated stores (no branch around a load).
+  const int nvec = Cs >> 3, PR = 512 / nvec;
+  const int vcol = tid % nvec, prow_raw = tid / nvec;
+  const bool active = prow_raw < PR;
+  const int prow = active ? prow_raw : 0;
+  const int p0 = blockIdx.x * ppb, p1 = min(HW, p0 + ppb);
+  const int ch = slice * Cs + vcol * 8;
+  const bf16_t* base; int Csrc, cc;
+  if (ch < C0) { base = x0; Csrc = C0; cc = ch; } else { base = x1; Csrc = C1; cc = ch - C0; }
+  base += (long long)b * HW * Csrc + cc;
+  bf16_t* yb = y + (long long)b * HW * C + ch;
+  const f32x4 g0 = *(const f32x4*)(gamma + ch), g1 = *(const f32x4*)(gamma + ch + 4);
+  const f32x4 b0 = *(const f32x4*)(beta + ch), b1 = *(const f32x4*)(beta + ch + 4);
+  s16x8 v[8];
+  {
+    const int px = p0 + prow;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { const int q = px + u * PR < p1 ? px + u * PR : p1 - 1; v[u] = *(const s16x8*)(base + (long long)q * Csrc); }
+  }
   if (wave < gps) {
     const int g = slice * gps + wave;
     const int nt0 = HW / bm0, nt1 = C1 ? HW / bm1 : 0;
@@ -166,61 +187,56 @@ __global__ __launch_bounds__(512) void gn_apply_part_kernel(const bf16_t* __rest
     double a = 0.0, q = 0.0;
     // eight independent 8-byte loads in flight per lane and round: one at a time, a 64 x 64 map's 320 .. 960 partial sums per group
     // cost the block 5 .. 15 dependent L2 round trips (3 - 10 us) before its first activation byte moved; same summation order
-    const int n = cpg * ntm;
+    const int n = cpg * ntm;                           // < 2^16 (launcher): idx / cpg through a float reciprocal is exact there
+    const float rcpg = 1.0f / (float)cpg;
+    const int nt1c = nt1 > 0 ? nt1 : 1;
     for (int i0 = lane; i0 < n; i0 += 64 * 8) {
-      f32x2 v[8];
+      f32x2 pv[8]; bool pok[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int idx = i0 + 64 * u;
-        v[u] = f32x2{0.f, 0.f};
-        if (idx < n) {
-          const int tile = idx / cpg, ch = g * cpg + (idx - tile * cpg);
-          if (ch < C0) { if (tile < nt0) v[u] = *(const f32x2*)(part0 + (((long long)b * nt0 + tile) * C0 + ch) * 2); }
-          else if (tile < nt1) v[u] = *(const f32x2*)(part1 + (((long long)b * nt1 + tile) * C1 + (ch - C0)) * 2);
-        }
+      for (int u = 0; u < 8; ++u) {                      // clamped addresses, unconditional loads, masked adds: no branch, no integer division
+        const int idx = i0 + 64 * u, idc = idx < n ? idx : n - 1;
+        const int tile = (int)(((float)idc + 0.5f) * rcpg), chn = g * cpg + (idc - tile * cpg);
+        const bool in0 = chn < C0;
+        const int nt = in0 ? nt0 : nt1c, tc = tile < nt ? tile : nt - 1;
+        const float* src = in0 ? part0 + (((long long)b * nt0 + tc) * C0 + chn) * 2 : part1 + (((long long)b * nt1c + tc) * C1 + (chn - C0)) * 2;
+        pv[u] = *(const f32x2*)src;
+        pok[u] = idx < n && tile < (in0 ? nt0 : nt1);
       }
 #pragma unroll
-      for (int u = 0; u < 8; ++u) { a += (double)v[u][0]; q += (double)v[u][1]; }
+      for (int u = 0; u < 8; ++u) { a += pok[u] ? (double)pv[u][0] : 0.0; q += pok[u] ? (double)pv[u][1] : 0.0; }
     }
     for (int o = 32; o >= 1; o >>= 1) { a += __shfl_xor(a, o); q += __shfl_xor(q, o); }
     if (lane == 0) {
-      const double n = (double)HW * cpg;
-      const double mean = a / n;
-      double var = q / n - mean * mean;
+      const double nn = (double)HW * cpg;
+      const double mean = a / nn;
+      double var = q / nn - mean * mean;
       if (var < 0) var = 0;
       smean[wave] = (float)mean; srstd[wave] = (float)(1.0 / sqrt(var + (double)eps));
     }
   }
   __syncthreads();
-  const int nvec = Cs >> 3, PR = 512 / nvec;
-  const int vcol = tid % nvec, prow = tid / nvec;
-  if (prow >= PR) return;
-  const int p0 = blockIdx.x * ppb, p1 = min(HW, p0 + ppb);
-  const int ch = slice * Cs + vcol * 8;
-  const bf16_t* base; int Csrc, cc;
-  if (ch < C0) { base = x0; Csrc = C0; cc = ch; } else { base = x1; Csrc = C1; cc = ch - C0; }
-  base += (long long)b * HW * Csrc + cc;
-  bf16_t* yb = y + (long long)b * HW * C + ch;
+  if (!active) return;
   float sc[8], sh[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
     const int gl = (ch + e) / cpg - slice * gps;
-    sc[e] = srstd[gl] * gamma[ch + e];
-    sh[e] = beta[ch + e] - smean[gl] * sc[e];
+    const float ga = e < 4 ? g0[e & 3] : g1[e & 3], be = e < 4 ? b0[e & 3] : b1[e & 3];
+    sc[e] = srstd[gl] * ga;
+    sh[e] = be - smean[gl] * sc[e];
   }
-  auto one = [&](const s16x8 v, int px) {
+  auto one = [&](const s16x8 vv, int px) {
     float o[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { const float r = fmaf(bf2f((bf16_t)v[e]), sc[e], sh[e]); o[e] = silu ? silu_f(r) : r; }
+    for (int e = 0; e < 8; ++e) { const float r = fmaf(bf2f((bf16_t)vv[e]), sc[e], sh[e]); o[e] = silu ? silu_f(r) : r; }
     u32x4 pk;
     pk[0] = pack_bf2(o[0], o[1]); pk[1] = pack_bf2(o[2], o[3]); pk[2] = pack_bf2(o[4], o[5]); pk[3] = pack_bf2(o[6], o[7]);
     *(u32x4*)(yb + (long long)px * C) = pk;
   };
-  // up to eight 16-byte loads in flight per lane; the ragged end of the chunk is predicated, not a one-load-at-a-time tail loop
   for (int px = p0 + prow; px < p1; px += 8 * PR) {
-    s16x8 v[8];
+    if (px != p0 + prow) {
 #pragma unroll
-    for (int u = 0; u < 8; ++u) if (px + u * PR < p1) v[u] = *(const s16x8*)(base + (long long)(px + u * PR) * Csrc);
+      for (int u = 0; u < 8; ++u) { const int q = px + u * PR < p1 ? px + u * PR : p1 - 1; v[u] = *(const s16x8*)(base + (long long)q * Csrc); }
+    }
 #pragma unroll
     for (int u = 0; u < 8; ++u) if (px + u * PR < p1) one(v[u], px + u * PR);
   }
@@ -232,6 +248,7 @@ static bool gn_part_ok(const GroupNormP& p) {
   if (!p.part0 || p.bm0 <= 0 || (p.C1 && (!p.part1 || p.bm1 <= 0))) return false;
   if (p.groups % GN_SLICES || p.groups / GN_SLICES > 8 || C % (8 * GN_SLICES) || C % p.groups) return false;
   if ((C / GN_SLICES) % (C / p.groups)) return false;                 // a slice holds whole groups
+  if ((long long)(C / p.groups) * (p.HW / p.bm0) >= 65536 || (p.C1 && (long long)(C / p.groups) * (p.HW / p.bm1) >= 65536)) return false;   // the kernel's float-reciprocal index split
   if (p.HW % p.bm0 || (p.C1 && p.HW % p.bm1) || (p.C0 % 8)) return false;
   return (C / GN_SLICES) / 8 <= 512;
 }

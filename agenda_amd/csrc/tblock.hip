@@ -907,8 +907,6 @@ __global__ __launch_bounds__(512, 2) void qkv_chain_kernel(const QkvChainP p) {
 
   panel_load_dma<C>(p.x, m0, p.M, panel, wid, lane);
   const int rbase = 64 * mh + px;
-  const int sx = (px >> 1) & 7;
-  const int xoff0 = ((q ^ sx) << 4), xoff1 = (((4 + q) ^ sx) << 4);
   const char* xrow = panel + rbase * PITCH;
   f32x4 acc[4][NI];
   u32x4 ring[TB_F];
@@ -917,8 +915,60 @@ __global__ __launch_bounds__(512, 2) void qkv_chain_kernel(const QkvChainP p) {
   const unsigned wbase = __builtin_amdgcn_readfirstlane((unsigned)(nq * KS * NI) * 1024u);
   const bf16_t* wimg = p.wbf + (long long)img * p.wb_stride;
   panel_gemm_head<C>(ring, wimg, wbase, lane16);
+  if (p.gn_part) {
+    // the transformer's GroupNorm, applied here: the image's group statistics from the producer's partial sums (channel sums over the image's
+    // tiles, then the groups' channels, fp64, fixed order -- gn_apply_part's arithmetic), under the panel DMA and the first weight fragments
+    double* csum = (double*)(smem + BM * PITCH + 4 * BM * 8);        // [C][2]
+    float* gst = (float*)(csum + 2 * C);                              // [groups][2] (mean, rstd)
+    float* ab = gst + 64;                                             // [C][2] (scale, shift)
+    const int nt = p.HW / p.gn_bm, cpg = C / p.gn_groups;
+    const int cch = tid < C ? tid : C - 1;
+    const float gam = p.gn_gamma[cch], bet = p.gn_beta[cch];
+    {
+      const float* pp = p.gn_part + ((long long)img * nt * C + cch) * 2;
+      double a = 0.0, qq = 0.0;
+      for (int t0 = 0; t0 < nt; t0 += 16) {
+        f32x2_t v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) { const int tc = t0 + u < nt ? t0 + u : nt - 1; v[u] = *(const f32x2_t*)(pp + (long long)tc * C * 2); }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) if (t0 + u < nt) { a += (double)v[u][0]; qq += (double)v[u][1]; }
+      }
+      if (tid < C) { csum[2 * tid] = a; csum[2 * tid + 1] = qq; }
+    }
+    __syncthreads();
+    if (tid < p.gn_groups) {
+      double a = 0.0, qq = 0.0;
+      for (int e = 0; e < cpg; ++e) { a += csum[2 * (tid * cpg + e)]; qq += csum[2 * (tid * cpg + e) + 1]; }
+      const double cnt = (double)p.HW * cpg, mean = a / cnt;
+      double var = qq / cnt - mean * mean; if (var < 0) var = 0;
+      gst[2 * tid] = (float)mean; gst[2 * tid + 1] = (float)(1.0 / sqrt(var + (double)p.gn_eps));
+    }
+    __syncthreads();
+    if (tid < C) { const int g = tid / cpg; const float sc = gst[2 * g + 1] * gam; ab[2 * tid] = sc; ab[2 * tid + 1] = bet - gst[2 * g] * sc; }
+  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  if (p.gn_part) {
+    // rows := bf16(x * scale + shift) in place (the same affine form and rounding as gn_apply): thread owns 16-byte chunks tid, tid + 512, ...
+    const float* ab = (const float*)(smem + BM * PITCH + 4 * BM * 8 + 2 * C * 8) + 64;
+    constexpr int CHR = C / 8;
+#pragma unroll
+    for (int k = 0; k < BM * CHR / 512; ++k) {
+      const int id = tid + 512 * k, row = id / CHR, pc = id - row * CHR;
+      const int c0 = panel_swz<C>(pc, row) * 8;                      // logical channels of this physical chunk
+      u32x4* cp = (u32x4*)(panel + row * PITCH + pc * 16);
+      const u32x4 v = *cp;
+      u32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const f32x4 sab = *(const f32x4*)(ab + 2 * (c0 + 2 * e));   // (scale, shift) of two channels
+        o[e] = pack_bf2(fmaf(__uint_as_float(v[e] << 16), sab[0], sab[1]), fmaf(__uint_as_float(v[e] & 0xFFFF0000u), sab[2], sab[3]));
+      }
+      *cp = o;
+    }
+    __syncthreads();
+  }
 
   // ---- proj_in: h = x . Wb[img]^T + row[img], rounded once, stored; its row statistics ----
   const XOff<C> xo(q, px);
@@ -927,7 +977,7 @@ __global__ __launch_bounds__(512, 2) void qkv_chain_kernel(const QkvChainP p) {
   {
     float rv[NI * 4];
 #pragma unroll
-    for (int t = 0; t < NI; ++t) *(f32x4*)&rv[4 * t] = *(const f32x4*)(p.rowadd + (long long)img * C + ncol0 + 4 * t);
+    for (int t = 0; t < NI; ++t) *(f32x4*)&rv[4 * t] = *(const f32x4*)(p.rowadd + (long long)img * p.rowadd_stride + ncol0 + 4 * t);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int m = m0 + rbase + 16 * i;
@@ -997,7 +1047,8 @@ int launch_qkv_chain(const QkvChainP& p, int C, hipStream_t st) {
   if (p.M < 128 || p.M % 128 || p.HW % 128 || p.M % p.HW) { agd_set_error("qkv_chain: M %d / HW %d must be multiples of 128 (whole images)", p.M, p.HW); return -1; }
   if (!p.x || !p.wbf || !p.rowadd || !p.h || !p.gamma || !p.beta || !p.wqkvf || !p.qkv) { agd_set_error("qkv_chain: bad arguments"); return -1; }
   if ((long long)p.M * C * 6 >= (1LL << 31)) { agd_set_error("qkv_chain: activation too large for 32-bit offsets"); return -1; }
-  constexpr int lds = 128 * 320 * 2 + 4 * 128 * 8;
+  if (p.gn_part && (p.gn_bm < 1 || p.HW % p.gn_bm || p.gn_groups < 1 || p.gn_groups > 32 || C % p.gn_groups || !p.gn_gamma || !p.gn_beta)) { agd_set_error("qkv_chain: bad GroupNorm arguments"); return -1; }
+  constexpr int lds = 128 * 320 * 2 + 4 * 128 * 8 + 320 * 16 + 256 + 320 * 8;      // panel, h row statistics, GroupNorm: channel sums, group statistics, (scale, shift)
   const void* kfn = (const void*)qkv_chain_kernel<320>;
   static bool attr[AGD_MAX_DEVICES] = {};
   int dev = 0; HIP_CHECK_RET(hipGetDevice(&dev));

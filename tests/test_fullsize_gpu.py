@@ -171,7 +171,7 @@ def test_sd15_unet_forward_512px_matches_oracle(sd15_host_weights, sd15_pipe, p8
 def test_fused_transformer_block_kernels_match_the_kernel_chain_512px(sd15_host_weights, sd15_pipe):
     """opt "tblock_fuse" (tblock.hip, the C = 320 blocks of the 64 x 64 maps): bit 0 norm3 -> GEGLU -> ff.net.2 + residual in one launch, bit 1
     norm2 -> to_q -> cross-attention (+ DAAM record) -> to_out + residual in one launch, bit 2 that launch starting at attn1.to_out, bit 3 the
-    feed-forward launch ending with proj_out (+ the next GroupNorm's partial sums), bit 4 proj_in -> norm1 -> q / k / v in one launch, bit 5 the attn2 chain for the C = 640 blocks (32 x 32 maps) too; opt "reduce_gn": split-K slab sum + GroupNorm in one launch.
+    feed-forward launch ending with proj_out (+ the next GroupNorm's partial sums), bit 4 proj_in -> norm1 -> q / k / v in one launch, bit 5 the attn2 chain for the C = 640 blocks (32 x 32 maps) too, bit 7 the transformer's GroupNorm applied inside the bit-4 launch (no fold launch); opt "reduce_gn": split-K slab sum + GroupNorm in one launch.
     Every combination against the fp32 oracle (UNet output and DAAM heat maps) and against the unfused kernel chain: the same fp32 function
     with bf16 roundings at different points, so within bf16 noise of each other, each within the oracle bound."""
     from agenda_amd import synthetic
@@ -189,7 +189,7 @@ def test_fused_transformer_block_kernels_match_the_kernel_chain_512px(sd15_host_
     want, whm, _ = _ORACLE_CACHE["unet512"]
     outs = {}
     try:
-        for fuse, rg in ((0, 0), (1, 1), (2, 1), (6, 1), (9, 1), (16, 1), (31, 1), (34, 1), (63, 1), (63, 0)):
+        for fuse, rg in ((0, 0), (1, 1), (2, 1), (6, 1), (9, 1), (16, 1), (31, 1), (34, 1), (63, 1), (63, 0), (144, 1), (255, 1)):
             pipe.engine.set_option("tblock_fuse", fuse)
             pipe.engine.set_option("reduce_gn", rg)
             pipe.engine.set_context(ctx)
@@ -203,7 +203,7 @@ def test_fused_transformer_block_kernels_match_the_kernel_chain_512px(sd15_host_
                 again = pipe.engine.unet_forward(x, 981.0)
                 assert torch.equal(got, again) and torch.equal(hm, pipe.engine.daam_global(0, 77, L).cpu())
     finally:
-        pipe.engine.set_option("tblock_fuse", 127)
+        pipe.engine.set_option("tblock_fuse", 255)
         pipe.engine.set_option("reduce_gn", 1)
         pipe.engine.record_config(0)
     base, bhm = outs[(0, 0)]
@@ -236,12 +236,12 @@ def test_cfg_shared_prefix_inside_the_fused_kernels_512px(sd15_pipe):
 
     try:
         a = run(); a2 = run()
-        pipe.engine.set_option("tblock_fuse", 63)
+        pipe.engine.set_option("tblock_fuse", 255 & ~64)
         b = run()
         pipe.engine.set_option("cfg_shared_prefix", 0)
         c0 = run()
     finally:
-        pipe.engine.set_option("tblock_fuse", 127)
+        pipe.engine.set_option("tblock_fuse", 255)
         pipe.engine.set_option("cfg_shared_prefix", 1)
     assert torch.equal(a[0], a2[0]) and torch.equal(a[1], a2[1])
     # calibration: how far two VALID realisations of the same two steps drift apart (classifier-free guidance multiplies the bf16 noise of eps by ~10)
