@@ -116,7 +116,7 @@ struct agd_ctx {
   int opt_p8 = 1;                                     // agd_set_option("igemm8p"): 256-row 8-wave / 8-phase igemm for launches with enough tiles (igemm8p.h)
   int opt_halo = 1;                                   // agd_set_option("conv_halo"): 3x3 stride-1 convs through the row-halo kernel (igemm_halo.h)
   int opt_tb_fuse = 255;                               // agd_set_option("tblock_fuse"): fused row-panel kernels of the C = 320 transformer blocks (tblock.hip): bit 0 = feed-forward (bit 3: + proj_out),
-                                                      // bit 1 = attn2 chain (bit 2: + attn1.to_out in front of it), bit 4 = proj_in -> norm1 -> qkv, bit 5 = the attn2 chain for the C = 640 blocks too, bit 6 = the CFG-shared prefix's duplication inside the fused kernels, bit 7 = the GroupNorm applied inside the bit-4 launch (no fold launch)
+                                                      // bit 1 = attn2 chain (bit 2: + attn1.to_out in front of it), bit 4 = proj_in -> norm1 -> qkv, bit 5 = the attn2 chain for the C = 640 blocks too, bit 6 = the CFG-shared prefix's duplication inside the fused kernels, bit 7 = the GroupNorm applied inside the bit-4 launch (no fold launch), bit 8 (off) = the bit-4 launch with the GroupNorm inside for the C = 640 blocks
   int opt_side = 0;                                   // agd_set_option("side_stream"): a resnet's 1x1 conv_shortcut runs on a second stream beside norm1 / conv1 / norm2
   hipStream_t side = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   int opt_smap = 1;                                   // agd_set_option("conv_smap"): 3x3 convs of the 8 x 8 maps through the whole-images-resident kernel (igemm_smap.h)
@@ -450,7 +450,12 @@ static int transformer(agd_ctx* c, hipStream_t st, const std::string& pre, const
   // a GroupNorm kernel.  Default C <= 320 (the 64 x 64 maps: the fold launch takes 8.5 us against the 17 us apply pass; in situ 522.4 -> 521.3 ms
   // per batch, tools/ab_option.py); at C = 640 the fold (16.8 us, 6.5 MB of matrices) costs more than the 10.8 us pass it replaces.
   const bool gfold = c->opt_gn_proj_fold && c->opt_gn_fused && C <= (c->opt_gn_proj_fold >= 2 ? 640 : 320) && x.cpart && x.cpart_bm > 0 && HW % 128 == 0 && HW % x.cpart_bm == 0;
-  if (!gfold) {
+  // C = 640 (the 32 x 32 maps): no fold, but the qkv chain kernel (tblock.hip) takes the raw rows and applies the GroupNorm itself -- the apply launch disappears
+  // (bit 8, default off: measured 71 us against 65 for the three launches it replaces -- 128 workgroups each streaming 3.3 MB of weights)
+  const bool qkv640 = !gfold && C == 640 && (c->opt_tb_fuse & 16) && (c->opt_tb_fuse & 256) && (c->opt_tb_fuse & 128) && c->opt_gn_fused && x.cpart && x.cpart_bm > 0 &&
+                      HW % 64 == 0 && HW % x.cpart_bm == 0 && groups <= 32 && !(x.normed && x.normed_gamma == gg) && !dup &&
+                      c->W.count(pre + "proj_in.frag") && c->W.count(t + "attn1.qkv.frag");
+  if (!gfold && !qkv640) {
     if (x.normed && x.normed_gamma == gg) n.p = x.normed;          // the producing resnet's slab pass already applied this norm
     else CK(run_gn(c, st, x.p, C, nullptr, 0, Bs, HW, gg, gb, groups, 1e-6f, 0, n.p, &x));
   }
@@ -527,6 +532,16 @@ static int transformer(agd_ctx* c, hipStream_t st, const std::string& pre, const
       GemmOpt o; o.rowadd = radd; o.rowadd_ld = w->N; o.w_per_image = 1;
       CK(produce(x.p, C, wi, o, h.p, true));
       }
+    } else if (qkv640) {
+      if (w->taps != 1 || w->Cpad != C || w->N != C || !b) FAIL("qkv chain: proj_in weight [N=%d taps=%d Cpad=%d] is not a biased 1x1 over %d channels", w->N, w->taps, w->Cpad, C);
+      GETW(fpi, pre + "proj_in.frag"); GETW(fqkv, t + "attn1.qkv.frag"); GETV(g1, t + "norm1.weight"); GETV(b1_, t + "norm1.bias");
+      QkvChainP qp{}; qp.x = x.p; qp.wbf = fpi->w; qp.wb_stride = 0; qp.rowadd = b; qp.rowadd_stride = 0; qp.h = h.p; qp.gamma = g1; qp.beta = b1_; qp.ln_eps = lneps;
+      qp.wqkvf = fqkv->w; qp.qkv = qkv; qp.M = M; qp.HW = HW;
+      qp.gn_part = x.cpart; qp.gn_bm = x.cpart_bm; qp.gn_groups = groups; qp.gn_eps = 1e-6f; qp.gn_gamma = gg; qp.gn_beta = gb;
+      stats = nullptr; slots = 0;
+      ProfScope ps(c, st, PC_GEMM, 8.0 * M * (double)C * C, 2.0 * M * (double)C * 5.0 + 2.0 * 4.0 * C * (double)C);
+      CK(launch_qkv_chain(qp, C, st));
+      qkv_done = true;
     } else {
       GemmOpt o; o.bias = b;
       CK(produce(n.p, C, *w, o, h.p));
@@ -1017,14 +1032,15 @@ AGD_API int agd_finalize(agd_ctx* c) {
           API_CK(c, launch_frag_order_w(wp->w, fp_.w, C, C, C / 64, C, 0));
           c->W[pr.first + "proj_out.frag"] = fp_;
         }
-        const WMat* wi = getW(c, pr.first + "proj_in.weight");
+
+      }
+      { const WMat* wi = getW(c, pr.first + "proj_in.weight");
         if (!wi) return fail_ctx(c);
         if (wi->N == C && wi->Cpad == C && wi->taps == 1) {
           WMat fi = *wi; fi.w = dmalloc<bf16_t>(c, (size_t)C * C); if (!fi.w) return fail_ctx(c);
-          API_CK(c, launch_frag_order_w(wi->w, fi.w, C, C, C / 64, C, 0));
+          API_CK(c, launch_frag_order_w(wi->w, fi.w, C, C, 5, C, 0));
           c->W[pr.first + "proj_in.frag"] = fi;
-        }
-      }
+        } }
       const WMat* wq = getW(c, t + "attn2.to_q.weight"); const WMat* wo = getW(c, t + "attn2.to_out.0.weight");
       if (!wq || !wo) return fail_ctx(c);
       if (wq->N == C && wq->Cpad == C && wq->taps == 1 && wo->N == C && wo->Cpad == C && wo->taps == 1 && xl.heads == 8) {
@@ -1035,9 +1051,9 @@ AGD_API int agd_finalize(agd_ctx* c) {
         API_CK(c, launch_frag_order_w(wo->w, fo.w, C, C, 5, C, 0));
         c->W[t + "attn2.to_q.frag"] = fq; c->W[t + "attn2.to_out.frag"] = fo;
         { const WMat* wqkv = getW(c, t + "attn1.qkv"); if (!wqkv) return fail_ctx(c);
-          if (C == 320 && wqkv->N == 3 * C && wqkv->Cpad == C && wqkv->taps == 1) {
+          if (wqkv->N == 3 * C && wqkv->Cpad == C && wqkv->taps == 1) {
             WMat fqkv = *wqkv; fqkv.w = dmalloc<bf16_t>(c, (size_t)3 * C * C); if (!fqkv.w) return fail_ctx(c);
-            API_CK(c, launch_frag_order_w(wqkv->w, fqkv.w, 3 * C, C, C / 64, C, 0));
+            API_CK(c, launch_frag_order_w(wqkv->w, fqkv.w, 3 * C, C, 5, C, 0));
             c->W[t + "attn1.qkv.frag"] = fqkv;
           } }
         const WMat* wo1 = getW(c, t + "attn1.to_out.0.weight");

@@ -894,37 +894,41 @@ int launch_attn_chain(const AttnChainP& p, int C, int heads, hipStream_t st) {
 // ---------------------------------------------------------------------------------------------------------------------------
 template <int C>
 __global__ __launch_bounds__(512, 2) void qkv_chain_kernel(const QkvChainP p) {
-  constexpr int BM = 128, KS = C / 32, NI = C / 64, PITCH = C * 2;
+  // C = 320: 128-row panels, waves 2 row halves x 4 column quarters; C = 640: 64-row panels, 1 x 8 -- a wave's GEMM tile is 64 rows x 80 columns either way
+  constexpr int NQ = C / 80, MH = 8 / NQ, BM = 64 * MH, KS = C / 32, NI = 5, PITCH = C * 2;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* panel = smem;
-  float* pst = (float*)(smem + BM * PITCH);            // [4 column quarters][BM] (sum, sum of squares) of h
+  float* pst = (float*)(smem + BM * PITCH);            // [NQ column ranges][BM] (sum, sum of squares) of h
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int mh = wid >> 2, nq = wid & 3;
+  const int mh = wid / NQ, nq = wid % NQ;
   const int q = lane >> 4, px = lane & 15;
   const int m0 = blockIdx.x * BM;
-  const int img = m0 / p.HW;                           // tiles stay inside one image (HW % 128 == 0)
+  const int img = m0 / p.HW;                           // tiles stay inside one image (HW % BM == 0)
 
-  panel_load_dma<C>(p.x, m0, p.M, panel, wid, lane);
+  panel_load_dma<C, BM>(p.x, m0, p.M, panel, wid, lane);
   const int rbase = 64 * mh + px;
   const char* xrow = panel + rbase * PITCH;
   f32x4 acc[4][NI];
   u32x4 ring[TB_F];
   const unsigned lane16 = (unsigned)lane * 16u;
-  const int ncol0 = (C / 4) * nq + 4 * NI * q;
+  const int ncol0 = 80 * nq + 4 * NI * q;
   const unsigned wbase = __builtin_amdgcn_readfirstlane((unsigned)(nq * KS * NI) * 1024u);
   const bf16_t* wimg = p.wbf + (long long)img * p.wb_stride;
   panel_gemm_head<C>(ring, wimg, wbase, lane16);
   if (p.gn_part) {
     // the transformer's GroupNorm, applied here: the image's group statistics from the producer's partial sums (channel sums over the image's
     // tiles, then the groups' channels, fp64, fixed order -- gn_apply_part's arithmetic), under the panel DMA and the first weight fragments
-    double* csum = (double*)(smem + BM * PITCH + 4 * BM * 8);        // [C][2]
+    double* csum = (double*)(smem + BM * PITCH + NQ * BM * 8);        // [C][2]
     float* gst = (float*)(csum + 2 * C);                              // [groups][2] (mean, rstd)
     float* ab = gst + 64;                                             // [C][2] (scale, shift)
     const int nt = p.HW / p.gn_bm, cpg = C / p.gn_groups;
-    const int cch = tid < C ? tid : C - 1;
-    const float gam = p.gn_gamma[cch], bet = p.gn_beta[cch];
-    {
+    constexpr int CPT = (C + 511) / 512;                              // channels per thread
+    float gam[CPT], bet[CPT];
+#pragma unroll
+    for (int r = 0; r < CPT; ++r) {
+      const int cch = tid + 512 * r < C ? tid + 512 * r : C - 1;
+      gam[r] = p.gn_gamma[cch]; bet[r] = p.gn_beta[cch];
       const float* pp = p.gn_part + ((long long)img * nt * C + cch) * 2;
       double a = 0.0, qq = 0.0;
       for (int t0 = 0; t0 < nt; t0 += 16) {
@@ -934,7 +938,7 @@ __global__ __launch_bounds__(512, 2) void qkv_chain_kernel(const QkvChainP p) {
 #pragma unroll
         for (int u = 0; u < 16; ++u) if (t0 + u < nt) { a += (double)v[u][0]; qq += (double)v[u][1]; }
       }
-      if (tid < C) { csum[2 * tid] = a; csum[2 * tid + 1] = qq; }
+      if (tid + 512 * r < C) { csum[2 * (tid + 512 * r)] = a; csum[2 * (tid + 512 * r) + 1] = qq; }
     }
     __syncthreads();
     if (tid < p.gn_groups) {
@@ -945,13 +949,17 @@ __global__ __launch_bounds__(512, 2) void qkv_chain_kernel(const QkvChainP p) {
       gst[2 * tid] = (float)mean; gst[2 * tid + 1] = (float)(1.0 / sqrt(var + (double)p.gn_eps));
     }
     __syncthreads();
-    if (tid < C) { const int g = tid / cpg; const float sc = gst[2 * g + 1] * gam; ab[2 * tid] = sc; ab[2 * tid + 1] = bet - gst[2 * g] * sc; }
+#pragma unroll
+    for (int r = 0; r < CPT; ++r) {
+      const int cch = tid + 512 * r;
+      if (cch < C) { const int g = cch / cpg; const float sc = gst[2 * g + 1] * gam[r]; ab[2 * cch] = sc; ab[2 * cch + 1] = bet[r] - gst[2 * g] * sc; }
+    }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (p.gn_part) {
     // rows := bf16(x * scale + shift) in place (the same affine form and rounding as gn_apply): thread owns 16-byte chunks tid, tid + 512, ...
-    const float* ab = (const float*)(smem + BM * PITCH + 4 * BM * 8 + 2 * C * 8) + 64;
+    const float* ab = (const float*)(smem + BM * PITCH + NQ * BM * 8 + 2 * C * 8) + 64;
     constexpr int CHR = C / 8;
 #pragma unroll
     for (int k = 0; k < BM * CHR / 512; ++k) {
@@ -1009,7 +1017,7 @@ __global__ __launch_bounds__(512, 2) void qkv_chain_kernel(const QkvChainP p) {
       const int row = rbase + 16 * i;
       float S = 0.f, Q = 0.f;
 #pragma unroll
-      for (int w = 0; w < 4; ++w) { const f32x2_t v = *(const f32x2_t*)(pst + (w * BM + row) * 2); S += v[0]; Q += v[1]; }
+      for (int w = 0; w < NQ; ++w) { const f32x2_t v = *(const f32x2_t*)(pst + (w * BM + row) * 2); S += v[0]; Q += v[1]; }
       const float mu = S * (1.0f / C);
       float var = Q * (1.0f / C) - mu * mu; var = var < 0.f ? 0.f : var;
       const float rstd = rsqrtf(var + p.ln_eps);
@@ -1028,7 +1036,7 @@ __global__ __launch_bounds__(512, 2) void qkv_chain_kernel(const QkvChainP p) {
   // ---- q, k, v: three C -> C stages over the normalised rows, each straight to its third of the packed row ----
 #pragma unroll
   for (int s = 0; s < 3; ++s) {
-    const unsigned wb_s = __builtin_amdgcn_readfirstlane((unsigned)((4 * s + nq) * KS * NI) * 1024u);
+    const unsigned wb_s = __builtin_amdgcn_readfirstlane((unsigned)((NQ * s + nq) * KS * NI) * 1024u);
     if (s > 0) panel_gemm_head<C>(ring, p.wqkvf, wb_s, lane16, 3u * C * C * 2);
     panel_gemm_body<C>(ring, acc, p.wqkvf, wb_s, lane16, xrow, xo, 3u * C * C * 2);
 #pragma unroll
@@ -1043,19 +1051,20 @@ __global__ __launch_bounds__(512, 2) void qkv_chain_kernel(const QkvChainP p) {
 }
 
 int launch_qkv_chain(const QkvChainP& p, int C, hipStream_t st) {
-  if (C != 320) { agd_set_error("qkv_chain: C = %d is not built (320 only)", C); return -1; }
-  if (p.M < 128 || p.M % 128 || p.HW % 128 || p.M % p.HW) { agd_set_error("qkv_chain: M %d / HW %d must be multiples of 128 (whole images)", p.M, p.HW); return -1; }
+  if (C != 320 && C != 640) { agd_set_error("qkv_chain: C = %d is not built (320, 640)", C); return -1; }
+  const int BM = C == 320 ? 128 : 64;
+  if (p.M < BM || p.M % BM || p.HW % BM || p.M % p.HW) { agd_set_error("qkv_chain: M %d / HW %d must be multiples of %d (whole images)", p.M, p.HW, BM); return -1; }
   if (!p.x || !p.wbf || !p.rowadd || !p.h || !p.gamma || !p.beta || !p.wqkvf || !p.qkv) { agd_set_error("qkv_chain: bad arguments"); return -1; }
   if ((long long)p.M * C * 6 >= (1LL << 31)) { agd_set_error("qkv_chain: activation too large for 32-bit offsets"); return -1; }
   if (p.gn_part && (p.gn_bm < 1 || p.HW % p.gn_bm || p.gn_groups < 1 || p.gn_groups > 32 || C % p.gn_groups || !p.gn_gamma || !p.gn_beta)) { agd_set_error("qkv_chain: bad GroupNorm arguments"); return -1; }
-  constexpr int lds = 128 * 320 * 2 + 4 * 128 * 8 + 320 * 16 + 256 + 320 * 8;      // panel, h row statistics, GroupNorm: channel sums, group statistics, (scale, shift)
-  const void* kfn = (const void*)qkv_chain_kernel<320>;
-  static bool attr[AGD_MAX_DEVICES] = {};
+  const int lds = BM * C * 2 + 4096 + C * 16 + 256 + C * 8;      // panel, h row statistics, GroupNorm: channel sums, group statistics, (scale, shift)
+  const void* kfn = C == 320 ? (const void*)qkv_chain_kernel<320> : (const void*)qkv_chain_kernel<640>;
+  static bool attr[AGD_MAX_DEVICES][2] = {};
   int dev = 0; HIP_CHECK_RET(hipGetDevice(&dev));
   if (dev < 0 || dev >= AGD_MAX_DEVICES) { agd_set_error("qkv_chain: device ordinal %d out of range", dev); return -1; }
-  if (!attr[dev]) { HIP_CHECK_RET(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); attr[dev] = true; }
+  if (!attr[dev][C == 640]) { HIP_CHECK_RET(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); attr[dev][C == 640] = true; }
   QkvChainP pp = p;
   void* args[] = {&pp};
-  HIP_CHECK_RET(hipLaunchKernel(kfn, dim3(p.M / 128), dim3(512), args, lds, st));
+  HIP_CHECK_RET(hipLaunchKernel(kfn, dim3(p.M / BM), dim3(512), args, lds, st));
   return 0;
 }
