@@ -38,10 +38,15 @@ template <int N> AGD_DEV void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" 
 
 #define OOB_OFF 0x80000000u      // >= num_records (0x7FFFFFF0): buffer range check returns zeros
 
-template <int BM, int BN, int WM, int WN, int KS, int STAGES, int GEGLU, int SPLITK>
-__global__ __launch_bounds__(WM * WN * 64, 2) void igemm_kernel(const IgemmP p) {
-  constexpr int NT = WM * WN * 64;
+// KG = 2 (plain 1x1 launches of one source, no split-K; launches of <= 256 tiles, i.e. ONE workgroup per CU): the workgroup is two groups of
+// WM x WN waves, group g runs K steps g, g + 2, ... through its own STAGES-slot ring into its own accumulators; group 1 hands its
+// accumulators to group 0 through LDS before the epilogue.  One wave per SIMD is a chain of barrier -> fragment reads -> MFMAs per K step with
+// nothing to overlap it (tools/kb_m512.py: the launch takes as long with every load dropped); two independent chains per SIMD overlap.
+template <int BM, int BN, int WM, int WN, int KS, int STAGES, int GEGLU, int SPLITK, int KG = 1>
+__global__ __launch_bounds__(WM * WN * 64 * KG, 2) void igemm_kernel(const IgemmP p) {
+  constexpr int NT = WM * WN * 64;                   // threads of one K group
   constexpr int NW = WM * WN;
+  static_assert(KG == 1 || (KG == 2 && KS == 1 && !GEGLU && !SPLITK), "K groups: plain 1x1 launches only");
   constexpr int WTM = BM / WM, WTN = BN / WN;
   constexpr int MI = WTM / 16, NI = WTN / 16;
   constexpr int A_IT = (BM * 8 + NT - 1) / NT, B_IT = (BN * 8 + NT - 1) / NT;   // DMA instructions per wave (last may be partial)
@@ -56,9 +61,11 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_kernel(const IgemmP p) 
 #ifdef AGD_EXPERIMENTS
   if (p.dbg & 32) return;                          // timing experiment (AGD_IGEMM_CFG=512): dispatch cost of this grid only
 #endif
-  const int tid = threadIdx.x, lane = tid & 63;
+  const int tid = threadIdx.x % NT, lane = tid & 63;
+  const int kg = KG == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)threadIdx.x / NT);
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wid / WN, wn = wid % WN;
+  char* const ring = smem + kg * (STAGES * (BM + BN) * 128);
   // Phase stagger (short-K launches with several tiles per CU slot): the two workgroups that share a CU start in
   // lockstep and stay there -- both in the LDS/MFMA-bound main loop, then both in the store/VALU-bound epilogue.  The
   // second occupant of each CU (blocks 256..511 of the first dispatch wave) starts `stagger` x 1024 cycles late, so one
@@ -133,7 +140,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_kernel(const IgemmP p) 
 
   // K-steps of this block: [ks0, ks0 + nk)  (split-K: grid.z slices the K range)
   const int nk_total = p.K >> 6;
-  int ks0 = 0, nk = nk_total;
+  int ks0 = kg, nk = KG == 1 ? nk_total : (nk_total - kg + KG - 1) / KG;      // K groups: steps kg, kg + KG, ...
   if constexpr (SPLITK) {
     constexpr int Q = (KS == 3) ? 9 : 1;             // 3x3: slice on whole channel chunks (9 taps each)
     const int per = ((nk_total / Q + (int)gridDim.z - 1) / (int)gridDim.z) * Q;
@@ -146,7 +153,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_kernel(const IgemmP p) 
     tap = tap_; cursrc = src_;
     const int kh = (KS == 3) ? tap / 3 : 0, kw = (KS == 3) ? tap - kh * 3 : 0;
     const int Cs = cursrc ? p.C1 : p.C0;
-    seg_left = (Cs >> 6) - off_steps;
+    seg_left = KG == 1 ? (Cs >> 6) - off_steps : (1 << 30);     // K groups: one source, one tap (launcher) -- the segment never ends
     asoff = (unsigned)off_steps * 128u;
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
@@ -179,8 +186,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_kernel(const IgemmP p) 
     if (lin < nb) {
       const long long pieces = ((long long)p.N * p.K * 2) >> 10;
       const long long p0 = pieces * lin / nb, p1 = pieces * (lin + 1) / nb;
-      char* wl = smem + STAGES * STAGE + wid * 1024;
-      for (long long pc = p0 + wid; pc < p1; pc += NW) bufdma16(baseW, wl, (unsigned)(pc * 1024 + lane * 16), 0u);
+      char* wl = smem + KG * STAGES * STAGE + (kg * NW + wid) * 1024;
+      for (long long pc = p0 + kg * NW + wid; pc < p1; pc += NW * KG) bufdma16(baseW, wl, (unsigned)(pc * 1024 + lane * 16), 0u);
     }
   } else if (p.warm && blockIdx.y == 0 && blockIdx.z == 0 && (blockIdx.x >> 3) < 64) {
     const int nwg = gridDim.x, x = blockIdx.x & 7, j = blockIdx.x >> 3;
@@ -192,8 +199,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_kernel(const IgemmP p) 
       const int r0 = tn0 * BN, r1 = (tn1 + 1) * BN < p.N ? (tn1 + 1) * BN : p.N;
       const long long b0 = (long long)r0 * p.K * 2, pieces = ((long long)(r1 - r0) * p.K * 2) >> 10;
       const long long p0 = pieces * j / 64, p1 = pieces * (j + 1) / 64;
-      char* wl = smem + STAGES * STAGE + wid * 1024;
-      for (long long pc = p0 + wid; pc < p1; pc += NW) bufdma16(baseW, wl, (unsigned)(b0 + pc * 1024 + lane * 16), 0u);
+      char* wl = smem + KG * STAGES * STAGE + (kg * NW + wid) * 1024;
+      for (long long pc = p0 + kg * NW + wid; pc < p1; pc += NW * KG) bufdma16(baseW, wl, (unsigned)(b0 + pc * 1024 + lane * 16), 0u);
     }
   }
 
@@ -204,7 +211,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_kernel(const IgemmP p) 
     if (p.dbg & 4) return;                      // timing experiment: no DMA instructions at all
 #endif
     if (live && seg_left == 0) new_segment();
-    char* sA = smem + slot * STAGE;
+    char* sA = ring + slot * STAGE;
     char* sB = sA + A_BYTES;
     // make the scalar operands provably wave-uniform (else hipcc wraps every load in a waterfall loop)
     const unsigned aso = __builtin_amdgcn_readfirstlane(asoff), bso = __builtin_amdgcn_readfirstlane(bsoff);
@@ -221,7 +228,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_kernel(const IgemmP p) 
 #pragma unroll
     for (int i = 0; i < B_IT; ++i)
       if (i * NW + wid < B_Q) bufdma16(baseW, sB + (i * NW + wid) * 1024, bvoff[i], bso, nrB);
-    if (live) { asoff += 128u; bsoff += 128u; --seg_left; }
+    if (live) { asoff += 128u * KG; bsoff += 128u * KG; --seg_left; }
   };
 
   f32x4 acc[MI][NI];
@@ -251,10 +258,10 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_kernel(const IgemmP p) 
 
   // one K step: barrier, then {kk0 fragment reads | (2 MFMA, 1 DMA, 1 kk1 read) x n | remaining MFMAs}
   auto kstep = [&](int cur, int dst, const bf16_t* baseA, const unsigned (&av)[A_IT], unsigned aso, unsigned bso, unsigned nrA, unsigned nrB) {
-    char* dA = smem + dst * STAGE;
+    char* dA = ring + dst * STAGE;
     char* dB = dA + A_BYTES;
-    const char* sA = smem + cur * STAGE + wm * WTM * 128;
-    const char* sB = smem + cur * STAGE + A_BYTES + wn * WTN * 128;
+    const char* sA = ring + cur * STAGE + wm * WTM * 128;
+    const char* sB = ring + cur * STAGE + A_BYTES + wn * WTN * 128;
     bf16x8 a0[MI], b0[NI], a1[MI], b1[NI];
 #pragma unroll
     for (int i = 0; i < MI; ++i) a0[i] = *(const bf16x8*)(sA + i * 2048 + foff[0]);
@@ -295,24 +302,27 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_kernel(const IgemmP p) 
 
   // LayerNorm-fold consumer: one thread per tile row sums the producer's partial sums while the prologue stages are in flight and
   // leaves (mean, rstd) in LDS behind the ring (the epilogue then reads two floats per row instead of chasing `slots` loads)
-  float* const lnst = (float*)(smem + STAGES * STAGE + 4096);
-  if (!SPLITK && p.ln_stats && tid < BM) {
-    const int m = m0 + tid;
+  float* const lnst = (float*)(smem + KG * (STAGES * STAGE + 4096));
+  if (!SPLITK && p.ln_stats && threadIdx.x < BM) {
+    const int m = m0 + (int)threadIdx.x;
     float S = 0.f, Q = 0.f;
     if (m < p.M) for (int k = 0; k < p.ln_slots; ++k) { const f32x2 v = *(const f32x2*)(p.ln_stats + ((long long)m * p.ln_slots + k) * 2); S += v[0]; Q += v[1]; }
     const float mu = S * p.ln_invC;
     float var = Q * p.ln_invC - mu * mu; var = var < 0.f ? 0.f : var;
-    *(f32x2*)(lnst + tid * 2) = f32x2{mu, rsqrtf(var + p.ln_eps)};
+    *(f32x2*)(lnst + threadIdx.x * 2) = f32x2{mu, rsqrtf(var + p.ln_eps)};
   }
   {
     // STAGES-deep ring: stages ks+1 .. ks+STAGES-2 stay in flight across the barrier (counted vmcnt), the stage
     // for step ks+STAGES-1 is issued inside step ks into the slot step ks-1 just released.  A deeper ring is what
     // covers the L2/HBM latency when few workgroups share a CU (small feature maps).
-    if (nk > 0) {
+    if (nk > 0 || KG > 1) {
 #pragma unroll
       for (int s_ = 0; s_ < STAGES - 1; ++s_) issue(s_, s_ < nk);
     }
-    for (int ks = 0; ks < nk; ++ks) {
+    // (K groups: both groups pass the same number of barriers -- group 1 of an odd K runs one step on a dead slot: its loads were issued through
+    //  zero-record descriptors, the hardware wrote zeros, the MFMAs add nothing)
+    const int nloop = KG == 1 ? nk : (nk_total + KG - 1) / KG;
+    for (int ks = 0; ks < nloop; ++ks) {
       wait_vmcnt<(STAGES - 2) * LPS>();
       asm volatile("s_barrier" ::: "memory");
       const int nxt = ks + STAGES - 1;
@@ -321,7 +331,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_kernel(const IgemmP p) 
       const bf16_t* baseA = __builtin_amdgcn_readfirstlane(cursrc) ? base1 : base0;
       const unsigned aso = __builtin_amdgcn_readfirstlane(asoff), bso = __builtin_amdgcn_readfirstlane(bsoff);
       kstep(ks % STAGES, nxt % STAGES, baseA, avoff, aso, bso, more ? nrecA : 0u, more ? nrecB : 0u);
-      if (more) { asoff += 128u; bsoff += 128u; --seg_left; }
+      if (more) { asoff += 128u * KG; bsoff += 128u * KG; --seg_left; }
     }
   }
 
@@ -339,7 +349,25 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_kernel(const IgemmP p) 
     return;
   }
 #endif
-  igemm_epilogue<BM, BN, WM, WN, GEGLU, SPLITK>(p, acc, smem, lane, wm, wn, m0, n0, tn, bz, (!SPLITK && p.ln_stats && nk > 0) ? lnst : nullptr);
+  if constexpr (KG == 2) {
+    // group 1's accumulators -> LDS (the rings are free: every wave has left the K loop) -> group 0 adds them and finishes the tile; group 1
+    // only keeps the epilogue's workgroup barriers company
+    __syncthreads();
+    f32x4* xch = (f32x4*)smem + (wid * MI * NI) * 64 + lane;
+    if (kg == 1) {
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) xch[(i * NI + j) * 64] = acc[i][j];
+    }
+    __syncthreads();
+    if (kg == 1) { igemm_epilogue_ghost(p); return; }
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NI; ++j) acc[i][j] += xch[(i * NI + j) * 64];
+  }
+  igemm_epilogue<BM, BN, WM, WN, GEGLU, SPLITK>(p, acc, smem, lane, wm, wn, m0, n0, tn, bz, (!SPLITK && p.ln_stats && nk_total > 0) ? lnst : nullptr);
 }
 
 // split-K second pass: out = epilogue(sum_s partial[s])   (deterministic slab sum, no atomics)
@@ -499,14 +527,15 @@ static int launch_splitk_reduce(const IgemmP& p, int splits, hipStream_t st) {
   return 0;
 }
 
-template <int BM, int BN, int WM, int WN, int KS, int STAGES, int GEGLU, int SPLITK>
+template <int BM, int BN, int WM, int WN, int KS, int STAGES, int GEGLU, int SPLITK, int KG = 1>
 static int launch_one(const IgemmP& p, int splits, hipStream_t st) {
-  constexpr int NT = WM * WN * 64;
+  constexpr int NT = WM * WN * 64 * KG;
   constexpr int stage = (BM + BN) * 128;
-  constexpr int lds = STAGES * stage + 4096 + BM * 8;    // + one scratch KiB per wave (cold-weight warm-up pieces) + (mean, rstd) of the tile's rows
+  constexpr int lds = KG * (STAGES * stage + 4096) + BM * 8;    // per K group: the ring + one scratch KiB per wave (cold-weight warm-up pieces); + (mean, rstd) of the tile's rows
+  static_assert(lds <= 160 * 1024, "LDS");
   const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
   dim3 grid(tiles, p.batch > 0 ? p.batch : 1, splits);
-  auto kfn = igemm_kernel<BM, BN, WM, WN, KS, STAGES, GEGLU, SPLITK>;
+  auto kfn = igemm_kernel<BM, BN, WM, WN, KS, STAGES, GEGLU, SPLITK, KG>;
   // the dynamic-LDS attribute is per device: latch it per (instantiation, device)
   static bool attr[AGD_MAX_DEVICES] = {};
   int dev = 0; HIP_CHECK_RET(hipGetDevice(&dev));
@@ -539,7 +568,7 @@ static int launch_halo(const IgemmP& p, int splits, hipStream_t st) {
   return 0;
 }
 
-template <int BM, int BN, int WM, int WN, int STAGES = 2>
+template <int BM, int BN, int WM, int WN, int STAGES = 2, int KG = 1, int KGS = 2>      // KGS: ring slots per K group when KG = 2
 static int launch_cfg(const IgemmP& p, int splits, hipStream_t st) {
   if (p.cfg_out) { p.cfg_out[0] = BM; p.cfg_out[1] = BN; p.cfg_out[2] = splits; return 0; }   // igemm_query: report the dispatch decision only
   if ((p.rowstat_out || p.ln_stats) && splits > 1) { agd_set_error("igemm: LayerNorm fold on a split-K launch"); return -1; }
@@ -564,6 +593,11 @@ static int launch_cfg(const IgemmP& p, int splits, hipStream_t st) {
   }
   if constexpr (HALO_TILE) { if (halo_ok(p)) return launch_halo<BN, 0, STAGES == 4 ? 4 : 2>(p, 1, st); }
   if (p.ksize == 3) return launch_one<BM, BN, WM, WN, 3, STAGES, 0, 0>(p, 1, st);
+  if constexpr (KG == 2) {
+    // two K groups of waves per workgroup: plain single-source 1x1 launches (the kernel's K walk has one segment)
+    if (p.C1 == 0 && p.stride == 1 && p.up == 1 && p.pad == 0 && p.Hin == p.Hout && p.Win == p.Wout && (p.batch <= 1) && !p.w_per_image)
+      return launch_one<BM, BN, WM, WN, 1, KGS, 0, 0, 2>(p, 1, st);
+  }
   return launch_one<BM, BN, WM, WN, 1, STAGES, 0, 0>(p, 1, st);
 }
 
@@ -775,6 +809,8 @@ int launch_igemm(const IgemmP& p_in, hipStream_t st) {
   // the 128-row tiles; in situ also: 512 tiles of 64 x 160 for the 32x32 maps' C->C launches (+0.5 .. 8 ms) and 64 x 128 GEGLU tiles for M <= 2048 (+0.3 ms).
   if (!KNOB(14) && batch == 1 && p.ksize == 1 && (p.N % 160) == 0 && (p.M % 64) == 0 && nk >= 16) {
     const long long t64 = (long long)(p.M / 64) * (p.N / 160);
+    // (two K groups of waves on these tiles: 14.3 -> 17.5 us at M = 2048, K = N = 1280 -- each wave issues 7 LDS-DMA pieces per 20 MFMAs and that issue
+    //  cost, not latency, is what a K step waits for; a second group doubles it.  tools/kb_m512.py)
     if (t64 >= 192 && t64 <= 256) return launch_cfg<64, 160, 2, 2, 4>(p, 1, st);
     if (t64 <= 64 && nk >= 64 && !nosplit) {
       int S = (int)(256 / t64); if (S > nk / 16) S = nk / 16;
@@ -833,6 +869,7 @@ int launch_igemm(const IgemmP& p_in, hipStream_t st) {
   // 128..191 tiles of 128x128 with a long K (M=2048 K=1280 N=1280: 160 tiles): one workgroup per CU on the deep ring beats 640
   // tiles of 64x64, whose LDS traffic per MFMA is twice as high (19.7 -> 16.5 us)
   if (t128 >= 128 && nk >= 16 && !KNOB(13)) return launch_cfg<128, 128, 2, 2, 4>(p, 1, st);
+  if (p.kg2 && p.ksize == 1 && nk >= 8 && (long long)((p.M + 63) / 64) * ((p.N + 63) / 64) <= 256) return launch_cfg<64, 64, 2, 2, 4, 2, 4>(p, 1, st);
   return launch_cfg<64, 64, 2, 2, 4>(p, 1, st);
 }
 

@@ -46,6 +46,13 @@ AGD_DEV void ln_row_stats(const IgemmP& p, int mrow0, int row0_tile, const float
 
 // FAST_ONLY: the launcher guarantees that every lane's channel run is whole and aligned (N, ldo, ldr multiples of the run): the
 // element-by-element path for ragged tiles is compiled out (igemm8p.h: with 128 accumulators per lane it would put them in scratch)
+// The waves of a workgroup that hold no output (igemm_kernel's second K group) pass exactly the workgroup barriers igemm_epilogue passes --
+// KEEP IN STEP with the __syncthreads() calls below (all of them sit at function level behind wave-uniform kernel arguments).
+AGD_DEV void igemm_epilogue_ghost(const IgemmP& p) {
+  if (p.colstat_out) { __syncthreads(); __syncthreads(); __syncthreads(); }
+  if (p.rowstat_out) { __syncthreads(); __syncthreads(); }
+}
+
 template <int BM, int BN, int WM, int WN, int GEGLU, int SPLITK, int FAST_ONLY = 0>
 AGD_DEV void igemm_epilogue(const IgemmP& p, f32x4 (&acc)[BM / WM / 16][BN / WN / 16], char* smem, int lane, int wm, int wn, int m0,
                             int n0, int tn, int bz, const float* lds_stats = nullptr) {

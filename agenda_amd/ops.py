@@ -32,7 +32,7 @@ def conv2d(x, w, bias=None, stride=1, padding=None, upsample=False, halo=False, 
     return y
 
 
-def linear(x, w, bias=None, residual=None, geglu=False, p8=0, wreg=False):
+def linear(x, w, bias=None, residual=None, geglu=False, p8=0, wreg=False, kgroups=False):
     lib = _lib.load()
     x2 = _f32c(x).reshape(-1, x.shape[-1])
     w = _f32c(w)
@@ -42,7 +42,7 @@ def linear(x, w, bias=None, residual=None, geglu=False, p8=0, wreg=False):
     b = _f32c(bias) if bias is not None else None
     r = _f32c(residual).reshape(M, Nout) if residual is not None else None
     y = torch.empty(M, Nout, device=x.device, dtype=torch.float32)
-    _lib.check(lib.agd_op_linear(_lib.ptr(x2), _lib.ptr(w), _lib.ptr(b), _lib.ptr(r), _lib.ptr(y), M, K, N, int(geglu) | _P8[p8] | (16 if wreg else 0),
+    _lib.check(lib.agd_op_linear(_lib.ptr(x2), _lib.ptr(w), _lib.ptr(b), _lib.ptr(r), _lib.ptr(y), M, K, N, int(geglu) | _P8[p8] | (16 if wreg else 0) | (32 if kgroups else 0),
                                  _lib.current_stream_ptr()), None, "agd_op_linear")
     return y.reshape(*x.shape[:-1], Nout)
 
