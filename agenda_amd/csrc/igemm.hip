@@ -783,8 +783,11 @@ int launch_igemm(const IgemmP& p_in, hipStream_t st) {
   if (p.Wfrag && p.wreg && p.ksize == 1 && batch == 1 && !p.w_per_image && p.C1 == 0 && p.C0 == p.K && p.stride == 1 && p.up == 1 && p.pad == 0 &&
       p.Hin == p.Hout && p.Win == p.Wout && !p.out_f32 && p.M >= p.wreg_mmin && p.M <= p.wreg_mmax &&
       (p.geglu ? (p.wfrag_ni == 4 && (p.wreg & 2) && p.N % 256 == 0) : (p.wfrag_ni == 2 && (p.wreg & 1) && p.N % 128 == 0))) {
-    const int bn = p.geglu ? 256 : 128;
-    const long long tiles = (long long)((p.M + 63) / 64) * (p.N / bn);
+    // plain launches: 160-wide tiles (five waves) where they give a fuller single wave of workgroups than the 128-wide ones
+    const long long mt64 = (p.M + 63) / 64;
+    const bool w160 = !p.geglu && p.N % 160 == 0 && mt64 * (p.N / 160) <= 256 && mt64 * (p.N / 128) > 256;
+    const int bn = p.geglu ? 256 : w160 ? 160 : 128;
+    const long long tiles = mt64 * (p.N / bn);
     if (tiles >= 128) {
       if (p.cfg_out) { p.cfg_out[0] = 64; p.cfg_out[1] = bn; p.cfg_out[2] = 1; return 0; }
       if (p.colstat_out && (p.colstat_rows < 1 || p.colstat_rows % 64)) { agd_set_error("igemm_wreg: column statistics need M tiles inside one image"); return -1; }
@@ -793,10 +796,10 @@ int launch_igemm(const IgemmP& p_in, hipStream_t st) {
       { static const bool logit = getenv("AGD_IGEMM_LOG") != nullptr;
         if (logit) fprintf(stderr, "IGEMM M=%d N=%d K=%d ks=1 stride=1 up=1 geglu=%d res=%d tile=64x%d splits=1 batch=1\n", p.M, p.N, p.K, p.geglu, p.residual ? 1 : 0, bn); }
 #endif
-      const void* kfn = p.geglu ? (const void*)igemm_wreg_kernel<4, 1> : (const void*)igemm_wreg_kernel<2, 0>;
+      const void* kfn = p.geglu ? (const void*)igemm_wreg_kernel<4, 1> : w160 ? (const void*)igemm_wreg_kernel<2, 0, 5> : (const void*)igemm_wreg_kernel<2, 0>;
       IgemmP pp = p;
       void* args[] = {&pp};
-      HIP_CHECK_RET(hipLaunchKernel(kfn, dim3((unsigned)tiles), dim3(256), args, 3 * 64 * 128, st));
+      HIP_CHECK_RET(hipLaunchKernel(kfn, dim3((unsigned)tiles), dim3(w160 ? 320 : 256), args, 3 * 64 * 128, st));
       return 0;
     }
   }

@@ -14,9 +14,9 @@
 
 #define WR_F 8      // weight-fragment ring (registers), filled WR_D fragments ahead
 #define WR_D 6
-template <int NI, int GEGLU>
-__global__ __launch_bounds__(256, 2) void igemm_wreg_kernel(const IgemmP p) {
-  constexpr int BM = 64, WN = 4, BN = WN * NI * 16, WTN = NI * 16, MI = 4;
+template <int NI, int GEGLU, int WN = 4>        // WN = 5: 160-wide tiles (N = 1280 at M = 2048: exactly 256 workgroups); waves 0 - 3 stage the activations
+__global__ __launch_bounds__(WN * 64, 2) void igemm_wreg_kernel(const IgemmP p) {
+  constexpr int BM = 64, BN = WN * NI * 16, WTN = NI * 16, MI = 4;
   constexpr int STG = 3, A_BYTES = BM * 128;           // activation ring: 3 stages of [64 rows][64 k] bf16, 128-byte rows, chunk ^ (row & 7)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -29,19 +29,24 @@ __global__ __launch_bounds__(256, 2) void igemm_wreg_kernel(const IgemmP p) {
   const int nk = p.K >> 6;                              // stages of 64 k
 
   // activation staging: thread t fetches chunks (row = t / 8 + 32 u, chunk t % 8), u = 0, 1, of every stage
-  const int arow = tid >> 3, ach = tid & 7;
+  const int arow = (tid & 255) >> 3, ach = tid & 7;
   const bf16_t* ap[2]; bool aok[2];
 #pragma unroll
   for (int u = 0; u < 2; ++u) { const int m = m0 + arow + 32 * u; aok[u] = m < p.M; ap[u] = p.src0 + (long long)(aok[u] ? m : 0) * p.K + ach * 8; }
   const int awoff[2] = {(arow) * 128 + ((ach ^ (arow & 7)) << 4), (arow + 32) * 128 + ((ach ^ (arow & 7)) << 4)};
   u32x4 areg[2][2];                                     // two stages in flight
+  const bool stager = WN == 4 || wid < 4;               // wave-uniform
   auto a_load = [&](int slot, int s) {
+    if (stager) {
 #pragma unroll
-    for (int u = 0; u < 2; ++u) areg[slot][u] = aok[u] ? *(const u32x4*)(ap[u] + s * 64) : u32x4{0, 0, 0, 0};
+      for (int u = 0; u < 2; ++u) areg[slot][u] = aok[u] ? *(const u32x4*)(ap[u] + s * 64) : u32x4{0, 0, 0, 0};
+    }
   };
   auto a_store = [&](int slot, int stg) {
+    if (stager) {
 #pragma unroll
-    for (int u = 0; u < 2; ++u) *(u32x4*)(smem + stg * A_BYTES + awoff[u]) = areg[slot][u];
+      for (int u = 0; u < 2; ++u) *(u32x4*)(smem + stg * A_BYTES + awoff[u]) = areg[slot][u];
+    }
   };
 
   // weight stream of this wave: fragments (k-step of 32, tile j) in consumption order, (n0 / 16 / NI + wid) is the wave's column range

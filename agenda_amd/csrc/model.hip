@@ -117,6 +117,7 @@ struct agd_ctx {
   int opt_halo = 1;                                   // agd_set_option("conv_halo"): 3x3 stride-1 convs through the row-halo kernel (igemm_halo.h)
   int opt_tb_fuse = 255;                               // agd_set_option("tblock_fuse"): fused row-panel kernels of the C = 320 transformer blocks (tblock.hip): bit 0 = feed-forward (bit 3: + proj_out),
                                                       // bit 1 = attn2 chain (bit 2: + attn1.to_out in front of it), bit 4 = proj_in -> norm1 -> qkv, bit 5 = the attn2 chain for the C = 640 blocks too, bit 6 = the CFG-shared prefix's duplication inside the fused kernels, bit 7 = the GroupNorm applied inside the bit-4 launch (no fold launch), bit 8 (off) = the bit-4 launch with the GroupNorm inside for the C = 640 blocks
+  int opt_wreg = 2;                                   // agd_set_option("wreg_mask"): weight-streaming kernel (igemm_wreg.h) for bit 1: proj_in / proj_out of the C = 640 blocks (bit 0, the C = 1280 GEGLU at M = 2048: measured slower in situ, removed)
   int opt_kg2 = 1;                                    // agd_set_option("igemm_kgroups"): two K groups of waves per workgroup on the one-workgroup-per-CU 1x1 launches of the small maps
   int opt_side = 0;                                   // agd_set_option("side_stream"): a resnet's 1x1 conv_shortcut runs on a second stream beside norm1 / conv1 / norm2
   hipStream_t side = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -547,6 +548,7 @@ static int transformer(agd_ctx* c, hipStream_t st, const std::string& pre, const
       qkv_done = true;
     } else {
       GemmOpt o; o.bias = b;
+      if (C == 640 && (c->opt_wreg & 2)) o.wreg = 1;
       CK(produce(n.p, C, *w, o, h.p));
     }
   }
@@ -653,6 +655,7 @@ static int transformer(agd_ctx* c, hipStream_t st, const std::string& pre, const
     CK(run_conv(c, st, ff, 4 * C, nullptr, 0, 1, 1, M, *w2, 1, h.p, o2, c->zero_page)); }
   if (!proj_done)
   { GETW(w, pre + "proj_out.weight"); GETV(b, pre + "proj_out.bias"); GemmOpt o; o.bias = b; o.residual = xres; o.out_act = &out; o.rows_per_image = HW;
+    if (C == 640 && (c->opt_wreg & 2)) o.wreg = 1;
     CK(run_conv(c, st, h.p, C, nullptr, 0, 1, 1, M, *w, 1, out.p, o, c->zero_page)); }
   c->arena.release(mk);
   return 0;
@@ -1037,6 +1040,16 @@ AGD_API int agd_finalize(agd_ctx* c) {
         }
 
       }
+      if (C == 640) {                                   // proj_in / proj_out once more in igemm_wreg.h's fragment order (option wreg_mask bit 1)
+        for (const char* nm : {"proj_in.weight", "proj_out.weight"}) {
+          auto it = c->W.find(pr.first + nm); if (it == c->W.end()) return fail_ctx(c);
+          WMat& wm_ = it->second;
+          if (wm_.taps == 1 && wm_.N % 128 == 0 && wm_.Cpad % 64 == 0) {
+            wm_.wfrag = dmalloc<bf16_t>(c, (size_t)wm_.N * wm_.Cpad); if (!wm_.wfrag) return fail_ctx(c);
+            API_CK(c, launch_frag_order_w(wm_.w, wm_.wfrag, wm_.N, wm_.Cpad, 2, wm_.Cpad, 0)); wm_.wfrag_ni = 2;
+          }
+        }
+      }
       { const WMat* wi = getW(c, pr.first + "proj_in.weight");
         if (!wi) return fail_ctx(c);
         if (wi->N == C && wi->Cpad == C && wi->taps == 1) {
@@ -1295,6 +1308,7 @@ AGD_API int agd_set_option(agd_ctx* c, const char* name, int value) {
   if (!strcmp(name, "conv_smap")) { c->opt_smap = value != 0; return 0; }
   if (!strcmp(name, "side_stream")) { c->opt_side = value != 0; return 0; }
   if (!strcmp(name, "igemm_kgroups")) { c->opt_kg2 = value != 0; return 0; }
+  if (!strcmp(name, "wreg_mask")) { c->opt_wreg = value & 2; return 0; }
   if (!strcmp(name, "igemm8p")) { c->opt_p8 = value < 0 ? 0 : value; return 0; }   // 0 off, 1 on (the launcher decides per launch); tests: 2 / 3 / 4 force the 256-wide / 160-wide / any legal tile
   agd_set_error("set_option: unknown option '%s'", name);
   return fail_ctx(c);
