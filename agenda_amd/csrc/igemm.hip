@@ -796,10 +796,15 @@ int launch_igemm(const IgemmP& p_in, hipStream_t st) {
       { static const bool logit = getenv("AGD_IGEMM_LOG") != nullptr;
         if (logit) fprintf(stderr, "IGEMM M=%d N=%d K=%d ks=1 stride=1 up=1 geglu=%d res=%d tile=64x%d splits=1 batch=1\n", p.M, p.N, p.K, p.geglu, p.residual ? 1 : 0, bn); }
 #endif
-      const void* kfn = p.geglu ? (const void*)igemm_wreg_kernel<4, 1> : w160 ? (const void*)igemm_wreg_kernel<2, 0, 5> : (const void*)igemm_wreg_kernel<2, 0>;
+      // bit 2 of p.wreg: two K groups of waves per workgroup on the plain launches of at most one workgroup per CU (an even number of 64-deep stages each)
+      const bool kg2 = (p.wreg & 4) && !p.geglu && tiles <= 256 && ((p.K >> 6) & 1) == 0 && (p.K >> 6) >= 8;
+      const void* kfn = p.geglu ? (const void*)igemm_wreg_kernel<4, 1> :
+                        w160 ? (kg2 ? (const void*)igemm_wreg_kernel<2, 0, 5, 2> : (const void*)igemm_wreg_kernel<2, 0, 5>) :
+                               (kg2 ? (const void*)igemm_wreg_kernel<2, 0, 4, 2> : (const void*)igemm_wreg_kernel<2, 0>);
+      const int wn = w160 ? 5 : 4, kgn = kg2 ? 2 : 1;
       IgemmP pp = p;
       void* args[] = {&pp};
-      HIP_CHECK_RET(hipLaunchKernel(kfn, dim3((unsigned)tiles), dim3(w160 ? 320 : 256), args, 3 * 64 * 128, st));
+      HIP_CHECK_RET(hipLaunchKernel(kfn, dim3((unsigned)tiles), dim3(wn * 64 * kgn), args, kgn * (3 * 64 * 128 + wn * 1024), st));
       return 0;
     }
   }

@@ -14,21 +14,38 @@
 
 #define WR_F 8      // weight-fragment ring (registers), filled WR_D fragments ahead
 #define WR_D 6
-template <int NI, int GEGLU, int WN = 4>        // WN = 5: 160-wide tiles (N = 1280 at M = 2048: exactly 256 workgroups); waves 0 - 3 stage the activations
-__global__ __launch_bounds__(WN * 64, 2) void igemm_wreg_kernel(const IgemmP p) {
-  constexpr int BM = 64, BN = WN * NI * 16, WTN = NI * 16, MI = 4;
+// WN = 5: 160-wide tiles (N = 1280 at M = 2048: exactly 256 workgroups); waves 0 - 3 of a group stage the activations.
+// KG = 2: two K groups of WN waves per workgroup -- group g walks the 64-deep stages g, g + 2, ... with its own activation ring, weight-fragment ring and
+// accumulators and hands its sums to group 0 through LDS before the epilogue (igemm_kernel's KG = 2, where the LDS-DMA path made it lose on these tiles;
+// here the operands arrive over the vector-memory path, which one K step per CU does not fill).  K must hold an even number of stages (launcher).
+template <int NI, int GEGLU, int WN = 4, int KG = 1>
+__global__ __launch_bounds__(WN * 64 * KG, 2) void igemm_wreg_kernel(const IgemmP p) {
+  constexpr int BM = 64, BN = WN * NI * 16, WTN = NI * 16, MI = 4, NTG = WN * 64;
   constexpr int STG = 3, A_BYTES = BM * 128;           // activation ring: 3 stages of [64 rows][64 k] bf16, 128-byte rows, chunk ^ (row & 7)
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63;
+  extern __shared__ __attribute__((aligned(16))) char smem_all[];
+  const int kg = KG == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)threadIdx.x / NTG);
+  char* const smem = smem_all + kg * (STG * A_BYTES);
+  const int tid = threadIdx.x % NTG, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int tiles_n = p.N / BN, tiles_m = (p.M + BM - 1) / BM;
   const int bid = xcd_remap(blockIdx.x, gridDim.x);
   int tn, tm;
   if (p.wmajor) { tm = bid % tiles_m; tn = bid / tiles_m; } else { tn = bid % tiles_n; tm = bid / tiles_n; }
   const int m0 = tm * BM, n0 = tn * BN;
-  const int nk = p.K >> 6;                              // stages of 64 k
+  const int nk = (p.K >> 6) / KG;                       // this group's stages of 64 k: global stage KG * s + kg
 
-  // activation staging: thread t fetches chunks (row = t / 8 + 32 u, chunk t % 8), u = 0, 1, of every stage
+  // cold-weight warm-up (p.warm, as in igemm_kernel): the launch's first workgroups stream the fragment-ordered matrix through the caches once, 1 / nb each
+  if (p.warm) {
+    const int tot = gridDim.x, nb = tot < 512 ? tot : 512;
+    if ((int)blockIdx.x < nb) {
+      const long long pieces = ((long long)p.N * p.K * 2) >> 10;
+      const long long p0 = pieces * blockIdx.x / nb, p1 = pieces * (blockIdx.x + 1) / nb;
+      char* wl = smem_all + KG * STG * A_BYTES + (kg * WN + wid) * 1024;
+      for (long long pc = p0 + kg * WN + wid; pc < p1; pc += WN * KG) bufdma16(p.Wfrag, wl, (unsigned)(pc * 1024 + lane * 16), 0u);
+    }
+  }
+
+  // activation staging: thread t (of the group's first four waves) fetches chunks (row = t / 8 + 32 u, chunk t % 8), u = 0, 1, of every stage
   const int arow = (tid & 255) >> 3, ach = tid & 7;
   const bf16_t* ap[2]; bool aok[2];
 #pragma unroll
@@ -36,10 +53,10 @@ __global__ __launch_bounds__(WN * 64, 2) void igemm_wreg_kernel(const IgemmP p) 
   const int awoff[2] = {(arow) * 128 + ((ach ^ (arow & 7)) << 4), (arow + 32) * 128 + ((ach ^ (arow & 7)) << 4)};
   u32x4 areg[2][2];                                     // two stages in flight
   const bool stager = WN == 4 || wid < 4;               // wave-uniform
-  auto a_load = [&](int slot, int s) {
+  auto a_load = [&](int slot, int s) {                  // s: the group's stage
     if (stager) {
 #pragma unroll
-      for (int u = 0; u < 2; ++u) areg[slot][u] = aok[u] ? *(const u32x4*)(ap[u] + s * 64) : u32x4{0, 0, 0, 0};
+      for (int u = 0; u < 2; ++u) areg[slot][u] = aok[u] ? *(const u32x4*)(ap[u] + (KG * s + kg) * 64) : u32x4{0, 0, 0, 0};
     }
   };
   auto a_store = [&](int slot, int stg) {
@@ -49,13 +66,18 @@ __global__ __launch_bounds__(WN * 64, 2) void igemm_wreg_kernel(const IgemmP p) 
     }
   };
 
-  // weight stream of this wave: fragments (k-step of 32, tile j) in consumption order, (n0 / 16 / NI + wid) is the wave's column range
+  // weight stream of this wave: fragments (k-step of 32, tile j) in consumption order, (n0 / 16 / NI + wid) is the wave's column range;
+  // the group's fragment n = s * FPS + r (stage s of the group, r < FPS) is fragment (KG * s + kg) * FPS + r of the matrix
   const auto wrs = __builtin_amdgcn_make_buffer_rsrc((void*)p.Wfrag, 0, (unsigned)((long long)p.N * p.K * 2), 0x00020000);
   const unsigned lane16 = (unsigned)lane * 16u;
-  const int KS = p.K >> 5, NFR = KS * NI;
+  constexpr int FPS = 2 * NI;
+  const int KS = p.K >> 5, NFR = nk * FPS;
   const unsigned wbase = __builtin_amdgcn_readfirstlane((unsigned)(((n0 / WTN + wid) * KS) * NI) * 1024u);
   u32x4 ring[WR_F];
-  auto ldw = [&](int f) { return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, lane16, wbase + (unsigned)f * 1024u, 0)); };
+  auto ldw = [&](int n) {
+    const int fg = KG == 1 ? n : (KG * (n / FPS) + kg) * FPS + n % FPS;
+    return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, lane16, wbase + (unsigned)fg * 1024u, 0));
+  };
 
   f32x4 acc[MI][NI];
 #pragma unroll
@@ -76,7 +98,7 @@ __global__ __launch_bounds__(WN * 64, 2) void igemm_wreg_kernel(const IgemmP p) 
   // per stage: {store stage s+1 (requested two stages ago) | request stage s+2 | 2 k-steps of (NI weight fragments, 4 activation fragments,
   // 4 NI MFMAs)} | barrier.  Fragment f = 2 NI s + NI kk + j sits in ring slot f % WR_F: the stage loop is unrolled by WR_F / gcd so that
   // slots are compile-time -- 2 NI fragments per stage and WR_F = 8 give a period of 2 (NI = 2) or 1 (NI = 4) stages.
-  constexpr int FPS = 2 * NI, PER = WR_F / FPS > 0 ? WR_F / FPS : 1;
+  constexpr int PER = WR_F / FPS > 0 ? WR_F / FPS : 1;
   static_assert(WR_F % FPS == 0 || FPS % WR_F == 0, "ring period");
   auto stage = [&](int s, auto ph_tag) {
     constexpr int PH = decltype(ph_tag)::value;         // s % PER
@@ -89,7 +111,6 @@ __global__ __launch_bounds__(WN * 64, 2) void igemm_wreg_kernel(const IgemmP p) 
       bf16x8 xf[MI];
 #pragma unroll
       for (int j = 0; j < NI; ++j) {
-        constexpr int dummy = 0; (void)dummy;
         const int fl = (PH * FPS + kk * NI + j);          // fragment index within the period
         const int f = s * FPS + kk * NI + j;
         const int tgt = f + WR_D;
@@ -115,5 +136,21 @@ __global__ __launch_bounds__(WN * 64, 2) void igemm_wreg_kernel(const IgemmP p) 
     }
     if constexpr (PER > 1) { if (s < nk) stage(s, P0{}); }
   }
-  igemm_epilogue<BM, BN, 1, WN, GEGLU, 0>(p, acc, smem, lane, 0, wid, m0, n0, tn, 0, nullptr);
+  if constexpr (KG == 2) {
+    // group 1's accumulators -> LDS (both activation rings are free: the last stage ended with a barrier) -> group 0 adds them and finishes the tile
+    f32x4* xch = (f32x4*)smem_all + (wid * MI * NI) * 64 + lane;
+    if (kg == 1) {
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) xch[(i * NI + j) * 64] = acc[i][j];
+    }
+    __syncthreads();
+    if (kg == 1) { igemm_epilogue_ghost(p); return; }
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NI; ++j) acc[i][j] += xch[(i * NI + j) * 64];
+  }
+  igemm_epilogue<BM, BN, 1, WN, GEGLU, 0>(p, acc, smem_all, lane, 0, wid, m0, n0, tn, 0, nullptr);
 }

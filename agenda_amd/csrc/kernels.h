@@ -52,7 +52,7 @@ struct IgemmP {
   const float* gn_gamma; const float* gn_beta; bf16_t* gn_y; int gn_groups; float gn_eps; int gn_silu; int gn_keep_out; int* gn_fused;
   int kg2;                          // caller: 1 = unsplit 1x1 launches on 64-row tiles (one workgroup per CU) run two K groups of waves per workgroup (igemm_kernel KG = 2)
   int smap;                         // caller: 1 = 3x3 stride-1 convs on 8 x 8 maps take the whole-images-resident kernel (igemm_smap.h)
-  int wreg, wreg_mmin, wreg_mmax;   // caller: bit 0 = plain / bit 1 = GEGLU 1x1 launches with wreg_mmin <= M <= wreg_mmax take the weight-streaming kernel when Wfrag is set
+  int wreg, wreg_mmin, wreg_mmax;   // caller: bit 0 = plain / bit 1 = GEGLU 1x1 launches with wreg_mmin <= M <= wreg_mmax take the weight-streaming kernel when Wfrag is set; bit 2 = two K groups of waves where the launch is at most one workgroup per CU
   const bf16_t* Wfrag; int wfrag_ni; // the same matrix in MFMA fragment order for the weight-streaming kernel (igemm_wreg.h): column ranges of wfrag_ni x 16, KC = K
   int stagger;                      // timing experiments only: start delay of the CU's second workgroup, x1024 cycles
   int dbg;                          // timing experiments only (builds with -DAGD_EXPERIMENTS)

@@ -1645,7 +1645,7 @@ AGD_API int agd_op_linear(const float* x, const float* w, const float* bias, con
     if (N % (ni * 64)) { agd_set_error("op_linear: the weight-streaming kernel needs N %% %d == 0", ni * 64); return -1; }
     wm.wfrag = tmp.get<bf16_t>((size_t)N * K); bf16_t* yb = tmp.get<bf16_t>((size_t)M * Nout); if (!wm.wfrag || !yb) return -1;
     CK(launch_frag_order_w(wb, wm.wfrag, N, K, ni, K, st));
-    wm.wfrag_ni = ni; o.wreg = 3; o.out_f32 = 0;
+    wm.wfrag_ni = ni; o.wreg = (flags & 64) ? 7 : 3; o.out_f32 = 0;
     CK(run_conv(nullptr, st, xb, K, nullptr, 0, 1, 1, M, wm, 1, yb, o, op_zero_page()));
     CK(launch_bf16_to_f32(yb, y, (long long)M * Nout, st));
     hipStreamSynchronize(st);
@@ -1869,7 +1869,7 @@ AGD_API int agd_bench_conv(int B, int H, int W, int C0, int C1, int Cout, int ks
     wm.wfrag = tmp.get<bf16_t>((size_t)Cout * taps * Ctot); if (!wm.wfrag) return -1;
     if (taps != 1 || C1) { agd_set_error("bench: wreg is for plain 1x1 launches"); return -1; }
     CK(launch_frag_order_w(w, wm.wfrag, Cout, Ctot, ni, Ctot, 0));
-    wm.wfrag_ni = ni; o.wreg = 3;
+    wm.wfrag_ni = ni; o.wreg = (mode & 1024) ? 7 : 3;
   }
   float* stats = nullptr; float* cs = nullptr;
   if (mode & 6) {

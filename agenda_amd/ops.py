@@ -42,7 +42,7 @@ def linear(x, w, bias=None, residual=None, geglu=False, p8=0, wreg=False, kgroup
     b = _f32c(bias) if bias is not None else None
     r = _f32c(residual).reshape(M, Nout) if residual is not None else None
     y = torch.empty(M, Nout, device=x.device, dtype=torch.float32)
-    _lib.check(lib.agd_op_linear(_lib.ptr(x2), _lib.ptr(w), _lib.ptr(b), _lib.ptr(r), _lib.ptr(y), M, K, N, int(geglu) | _P8[p8] | (16 if wreg else 0) | (32 if kgroups else 0),
+    _lib.check(lib.agd_op_linear(_lib.ptr(x2), _lib.ptr(w), _lib.ptr(b), _lib.ptr(r), _lib.ptr(y), M, K, N, int(geglu) | _P8[p8] | (16 if wreg else 0) | (32 if kgroups else 0) | (64 if (wreg and kgroups) else 0),
                                  _lib.current_stream_ptr()), None, "agd_op_linear")
     return y.reshape(*x.shape[:-1], Nout)
 

@@ -160,6 +160,11 @@ def test_linear_two_k_groups_per_workgroup(ops, M, K, N, res):
     assert rel_err(got, y) < 1e-4, rel_err(got, y)            # fp32 output of bf16-exact operands
     assert rel_err(got, ref.cpu()) < 1e-4
     assert torch.equal(got, ops.linear(*args, kgroups=True))
+    if N % 128 == 0 and (K // 64) % 2 == 0 and K >= 512:
+        # the same decomposition on the weight-streaming kernel (igemm_wreg.h KG = 2; bf16 output)
+        g2 = ops.linear(*args, wreg=True, kgroups=True)
+        assert rel_err(g2, y) < REL and rel_err(g2, ops.linear(*args, wreg=True).cpu()) < REL
+        assert torch.equal(g2, ops.linear(*args, wreg=True, kgroups=True))
 
 
 @pytest.mark.parametrize("M", [128, 1000, 4096 * 2])      # one tile; ragged tail (1000 = 7 x 128 + 104); many tiles

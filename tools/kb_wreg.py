@@ -25,7 +25,8 @@ tot = [0.0, 0.0]
 for side, K, N, g, r, n, what in shapes:
     base = lin(side, K, N, g | 16, r)                 # the launcher's choice (8-phase kernel allowed, as in the walk)
     wr = lin(side, K, N, g | 128, r)
+    wr2 = lin(side, K, N, g | 128 | 1024, r)            # two K groups of waves (plain launches of <= 256 tiles only; else the same kernel)
     fl = 2.0 * B * side * side * K * N
     tot[0] += base * n; tot[1] += min(base, wr) * n
-    print(f"{what:14s} M={B*side*side:5d} K={K:5d} N={N:5d}: launcher {base:6.1f} us ({fl / base / 1e6:5.0f} TF/s)   wreg {wr:6.1f} us ({fl / wr / 1e6:5.0f} TF/s)  x{n}", flush=True)
+    print(f"{what:14s} M={B*side*side:5d} K={K:5d} N={N:5d}: launcher {base:6.1f} us ({fl / base / 1e6:5.0f} TF/s)   wreg {wr:6.1f} us ({fl / wr / 1e6:5.0f} TF/s)  wreg, 2 K groups {wr2:6.1f}  x{n}", flush=True)
 print(f"per forward: launcher {tot[0]:.0f} us, best of both {tot[1]:.0f} us")
