@@ -32,11 +32,35 @@ STATS_CSV = os.path.join("profiles", "r04_bench_kernel_stats.csv")
 # igemm_halo_kernel<BN, SPLITK, BST> (3x3 only), igemm8p_kernel<WM, WN, MI, NI0, NI1, KS, GEGLU>
 # round 4: the fused row-panel kernels of the C = 320 blocks (tblock.hip) are booked where the launches they replace were: ff_fused / qkv_chain
 # under the linears, attn_chain under cross-attention; igemm_smap_kernel (8 x 8 maps) and the split-K slab passes under the convs
-CLASS_KERNEL = {"igemm_conv3x3": [("igemm_kernel<", ", 3, "), ("igemm_halo_kernel<", ""), ("igemm8p_kernel<", ", 3, 0>"), ("igemm_smap_kernel<", "")],
-                "igemm_linear_1x1": [("igemm_kernel<", ", 1, "), ("igemm8p_kernel<", ", 1, 0>"), ("igemm8p_kernel<", ", 1, 1>"), ("ff_fused_kernel<", ""), ("qkv_chain_kernel<", "")],
-                "attn_self_flash": [("attn_kernel<", ", 0, 0>")],
-                "attn_cross_daam": [("attn_kernel<", ", 1, 0>"), ("attn_kernel<", ", 2, 0>"), ("attn_chain_kernel<", "")],
-                "groupnorm": [("gn_", "")], "layernorm": [("layernorm_kernel", "")]}
+CLASS_REP = {"igemm_conv3x3": "igemm_kernel", "igemm_linear_1x1": "igemm_kernel", "attn_self_flash": "attn_kernel", "attn_cross_daam": "attn_kernel", "groupnorm": "gn_apply_part_kernel"}
+
+
+def _targs(name, prefix):
+    """template arguments of kernel `prefix<...>` in a rocprof kernel name, or None"""
+    i = name.find(prefix + "<")
+    if i < 0:
+        return None
+    j = name.find(">", i)
+    return [a.strip() for a in name[i + len(prefix) + 1:j].split(",")]
+
+
+def _is(name, cls):
+    """does the rocprofv3 kernel name belong to the bench's kernel class?  (igemm_kernel<BM, BN, WM, WN, KS, STAGES, GEGLU, SPLITK, KG>,
+    igemm8p_kernel<WM, WN, MI, NI0, NI1, KS, GEGLU>, attn_kernel<D, KB, QB, RECORD, AMASK>)"""
+    ig, i8, at = _targs(name, "igemm_kernel"), _targs(name, "igemm8p_kernel"), _targs(name, "attn_kernel")
+    if cls == "igemm_conv3x3":
+        return (ig is not None and ig[4] == "3") or (i8 is not None and i8[5] == "3") or "igemm_halo_kernel<" in name or "igemm_smap_kernel<" in name
+    if cls == "igemm_linear_1x1":
+        return (ig is not None and ig[4] == "1") or (i8 is not None and i8[5] == "1") or any(k in name for k in ("ff_fused_kernel<", "qkv_chain_kernel<", "igemm_wreg_kernel<"))
+    if cls == "attn_self_flash":
+        return at is not None and at[3] == "0"
+    if cls == "attn_cross_daam":
+        return (at is not None and at[3] != "0") or "attn_chain_kernel<" in name
+    if cls == "groupnorm":
+        return "gn_" in name and "splitk_reduce" not in name
+    if cls == "layernorm":
+        return "layernorm_kernel" in name
+    return False
 
 
 def self_launch_command(gpus, argv, n_devices):
@@ -61,11 +85,10 @@ def pmc_traffic(cls):
     correction + WRITE_SIZE; tools/pmc_traffic.py writes the CSV).  PMC counters cannot be sampled from inside this
     process, so this is the offline figure of the same command, or None."""
     try:
-        pats = CLASS_KERNEL[cls]
         n = mb = 0.0
         for line in open(os.path.join(ROOT, PMC_CSV)).read().splitlines()[1:]:
             f = line.rsplit(",", 5)                            # kernel, launches, avg_us, fetch_MB, write_MB, total_MB
-            if any(a in f[0] and b in f[0] for a, b in pats):
+            if _is(f[0], cls):
                 n += float(f[1]); mb += float(f[1]) * float(f[5])
         # (a committed rocprofv3 --pmc pass of the same command, NOT a measurement of this run: the counters cannot be sampled in-process)
         return {"MB_per_launch": round(mb / n, 2), "launches_profiled": int(n), "source": PMC_CSV, "measured_in_this_run": False} if n else None
@@ -77,13 +100,12 @@ def heaviest_instantiation(cls):
     """The single kernel instantiation of a class with the most total time in the committed `rocprofv3 --kernel-trace --stats` summary of
     this command (so that the class-level fraction can be re-derived from one row of that file), or None."""
     try:
-        pats = CLASS_KERNEL[cls]
         best = None
         import csv
         with open(os.path.join(ROOT, STATS_CSV)) as f:
             for r in csv.DictReader(f):
                 name = r.get("Name") or r.get("KernelName") or ""
-                if any(a in name and b in name for a, b in pats):
+                if _is(name, cls):
                     tot = float(r.get("TotalDurationNs") or 0.0)
                     if best is None or tot > best[0]:
                         best = (tot, name, int(float(r.get("Calls") or 0)), float(r.get("AverageNs") or 0.0))
@@ -252,7 +274,7 @@ def main():
         mfma_bound = d["frac_mfma"] >= d["frac_hbm"]
         ig_ms = sum(table[k]["ms"] for k in table if k.startswith("igemm"))
         ig_fl = sum(classes[k]["flops"] for k in table if k.startswith("igemm"))
-        roof = {"bound": "mfma" if mfma_bound else "hbm", "kernel": f"{CLASS_KERNEL.get(dom, [(dom, '')])[0][0].rstrip('<')} [{dom}]",
+        roof = {"bound": "mfma" if mfma_bound else "hbm", "kernel": f"{CLASS_REP.get(dom, dom)} [{dom}]",
                 "achieved": d["TFLOPs"] if mfma_bound else d["GBs"], "peak": MFMA_PEAK_TF if mfma_bound else HBM_PEAK_GBS,
                 "unit": "TFLOP/s" if mfma_bound else "GB/s", "frac": d["frac_mfma"] if mfma_bound else d["frac_hbm"],
                 "frac_binding_roof": d["frac"], "traffic": pmc_traffic(dom), "heaviest_instantiation": heaviest_instantiation(dom),
