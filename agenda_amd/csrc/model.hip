@@ -296,7 +296,7 @@ static int resnet(agd_ctx* c, hipStream_t st, const std::string& pre, const Act&
   // (those launches are one workgroup per CU or fewer on the small maps); unsplit launches only -- the split-K workspace is the main stream's
   bf16_t* side_out = nullptr;
   const bool has_sc = c->W.count(pre + "conv_shortcut.weight") != 0;
-  if (has_sc && c->opt_side) {
+  if (has_sc && c->opt_side && (c->opt_side == 1 || HW <= c->opt_side)) {        // 1: every level; else: maps of at most that many pixels
     GETW(ws, pre + "conv_shortcut.weight"); GETV(bs, pre + "conv_shortcut.bias");
     GemmOpt os; os.bias = bs; int cfg[3] = {0, 0, 0}; os.query_cfg = cfg;
     CK(run_conv(c, st, x0.p, x0.C, x1 ? x1->p : nullptr, C1, B, H, Wd, *ws, 1, nullptr, os, c->zero_page));
@@ -1306,7 +1306,7 @@ AGD_API int agd_set_option(agd_ctx* c, const char* name, int value) {
   if (!strcmp(name, "tblock_fuse")) { c->opt_tb_fuse = value < 0 ? 0 : value; return 0; }   // bit 0: fused feed-forward, bit 1: fused attn2 chain (C = 320 blocks)
   if (!strcmp(name, "reduce_gn")) { c->opt_reduce_gn = value != 0; return 0; }
   if (!strcmp(name, "conv_smap")) { c->opt_smap = value != 0; return 0; }
-  if (!strcmp(name, "side_stream")) { c->opt_side = value != 0; return 0; }
+  if (!strcmp(name, "side_stream")) { c->opt_side = value < 0 ? 0 : value; return 0; }
   if (!strcmp(name, "igemm_kgroups")) { c->opt_kg2 = value != 0; return 0; }
   if (!strcmp(name, "wreg_mask")) { c->opt_wreg = value & 2; return 0; }
   if (!strcmp(name, "igemm8p")) { c->opt_p8 = value < 0 ? 0 : value; return 0; }   // 0 off, 1 on (the launcher decides per launch); tests: 2 / 3 / 4 force the 256-wide / 160-wide / any legal tile
