@@ -580,6 +580,7 @@ static int launch_cfg(const IgemmP& p, int splits, hipStream_t st) {
                      p.stride, p.up, p.geglu, p.residual ? 1 : 0, BM, BN, splits, p.batch > 0 ? p.batch : 1);
 #endif
   constexpr bool HALO_TILE = BM == 128 && WM == 2 && WN == 2 && (BN == 128 || BN == 160);
+  if (p.sc0 && (splits > 1 || !HALO_TILE)) { agd_set_error("igemm: shortcut fusion on a launch that is not an unsplit row-halo launch (tile %dx%d, %d K slices)", BM, BN, splits); return -1; }
   if (splits > 1) {
     int rc;
     if constexpr (HALO_TILE) { rc = halo_ok(p) ? launch_halo<BN, 1, STAGES == 4 ? 4 : 2>(p, splits, st) : (p.ksize == 3) ? launch_one<BM, BN, WM, WN, 3, STAGES, 0, 1>(p, splits, st) : launch_one<BM, BN, WM, WN, 1, STAGES, 0, 1>(p, splits, st); }
@@ -700,7 +701,11 @@ int launch_igemm(const IgemmP& p_in, hipStream_t st) {
   { static int stg = -1; if (stg < 0) { const char* e = getenv("AGD_IGEMM_STAGGER"); stg = e ? atoi(e) : 0; } p.stagger = stg; }
 #endif
   if (p.K & 63 || p.C0 & 63 || p.C1 & 63) { agd_set_error("igemm: K/C0/C1 must be multiples of 64 (K=%d C0=%d C1=%d)", p.K, p.C0, p.C1); return -1; }
-  if (p.K != p.ksize * p.ksize * (p.C0 + p.C1)) { agd_set_error("igemm: K=%d != ks^2*(C0+C1)=%d", p.K, p.ksize * p.ksize * (p.C0 + p.C1)); return -1; }
+  if (p.K != p.ksize * p.ksize * (p.C0 + p.C1) + p.sc_C0 + p.sc_C1) { agd_set_error("igemm: K=%d != ks^2*(C0+C1)+shortcut=%d", p.K, p.ksize * p.ksize * (p.C0 + p.C1) + p.sc_C0 + p.sc_C1); return -1; }
+  if (p.sc0) {          // conv_shortcut folded into a 3x3 launch: the unsplit row-halo kernel only (igemm_can_fuse_shortcut tells the caller beforehand)
+    if (p.ksize != 3 || (p.sc_C0 & 63) || (p.sc_C1 & 63) || p.sc_C0 < 64 || (p.sc_C1 && !p.sc1) || !halo_ok(p) || p.w_per_image || p.geglu) { agd_set_error("igemm: shortcut fusion needs a row-halo 3x3 launch and 64-channel multiples"); return -1; }
+    p.p8 = 0; p.smap = 0;
+  }
   if (p.ksize != 1 && p.ksize != 3) { agd_set_error("igemm: ksize %d", p.ksize); return -1; }
   if (p.M < 1 || p.N < 1) { agd_set_error("igemm: empty problem M=%d N=%d", p.M, p.N); return -1; }
   if (p.rowadd && p.M >= (1 << 24)) { agd_set_error("igemm: rowadd needs M < 2^24"); return -1; }
@@ -879,6 +884,16 @@ int launch_igemm(const IgemmP& p_in, hipStream_t st) {
   if (t128 >= 128 && nk >= 16 && !KNOB(13)) return launch_cfg<128, 128, 2, 2, 4>(p, 1, st);
   if (p.kg2 && p.ksize == 1 && nk >= 8 && (long long)((p.M + 63) / 64) * ((p.N + 63) / 64) <= 256) return launch_cfg<64, 64, 2, 2, 4, 2, 4>(p, 1, st);
   return launch_cfg<64, 64, 2, 2, 4>(p, 1, st);
+}
+
+// can this 3x3 launch take its block's 1x1 conv_shortcut as extra K (IgemmP::sc0)?  True when the launcher picks the unsplit row-halo kernel for it.
+bool igemm_can_fuse_shortcut(const IgemmP& p_in) {
+  IgemmP p = p_in;
+  int cfg[3] = {0, 0, 0};
+  p.cfg_out = cfg; p.p8 = 0; p.smap = 0; p.sc0 = p.sc1 = nullptr; p.sc_C0 = p.sc_C1 = 0;
+  if (p.ksize != 3 || !halo_ok(p)) return false;
+  if (launch_igemm(p, nullptr) != 0) return false;
+  return cfg[0] == 128 && (cfg[1] == 128 || cfg[1] == 160) && cfg[2] == 1;
 }
 
 // the tile configuration launch_igemm would pick for this problem: cfg3 = {BM, BN, K splits} (nothing is launched)

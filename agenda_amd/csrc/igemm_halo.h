@@ -124,9 +124,13 @@ __global__ __launch_bounds__(256, BST == 2 ? 2 : 1) void igemm_halo_kernel(const
   // one K step (tap kx of group g): barrier, kk0 fragment reads | (2 MFMA, 1 LDS-DMA piece, 1 kk1 read) x n | remaining MFMAs.
   // Step kx = 0 also issues the NEXT group's A image (5 pieces, after the weight pieces: the next step waits with vmcnt(5), so
   // the image has two steps to land).  Dead pieces (past the K range) go through a zero-record descriptor: no branch in the body.
+  // (kx_tag: the tap whose fragments are read; values >= 4 = tap (value - 4) AND the next A image issued in this step -- the 3x3 loop issues it in its kx = 0
+  //  step (tag 4), the 1x1 shortcut loop in every step (tag 5: centre tap))
   auto kstep = [&](auto kx_tag, int aslot, int bslot, int bdst, unsigned bso, unsigned nrB, unsigned nrA) {
-    constexpr int KX = decltype(kx_tag)::value;
-    constexpr int NF = MI + NI, ND = B_IT + (KX == 0 ? A_ITH : 0), NG = NF > ND ? NF : ND;
+    constexpr int KXT = decltype(kx_tag)::value;
+    constexpr int KX = KXT >= 4 ? KXT - 4 : KXT;
+    constexpr bool ISSUE_A = KXT >= 4;
+    constexpr int NF = MI + NI, ND = B_IT + (ISSUE_A ? A_ITH : 0), NG = NF > ND ? NF : ND;
     const char* sA = sAr + aslot * A_BYTES;
     const char* sB = sBr + bslot * B_BYTES + wn * WTN * 128;
     char* dB = sBr + bdst * B_BYTES;
@@ -167,7 +171,8 @@ __global__ __launch_bounds__(256, BST == 2 ? 2 : 1) void igemm_halo_kernel(const
   };
   static_assert(2 * (MI + NI > B_IT + A_ITH ? MI + NI : B_IT + A_ITH) <= 2 * MI * NI, "interleave needs enough MFMAs");
 
-  using K0 = std::integral_constant<int, 0>; using K1 = std::integral_constant<int, 1>; using K2 = std::integral_constant<int, 2>;
+  using K0 = std::integral_constant<int, 4>; using K1 = std::integral_constant<int, 1>; using K2 = std::integral_constant<int, 2>;
+  using KS1 = std::integral_constant<int, 5>;          // shortcut loop: centre tap, next A image issued
   constexpr unsigned LIVE = 0x7FFFFFF0u;
   if (p.warm == 2) {                                    // cold-weight warm-up (see igemm.hip): the first workgroups stream W once
     const int lin = blockIdx.z * gridDim.x + blockIdx.x;
@@ -226,5 +231,41 @@ __global__ __launch_bounds__(256, BST == 2 ? 2 : 1) void igemm_halo_kernel(const
     ky = kyn; r = rn; bso = bson;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // dead tail pieces still write zeros: let them land before the epilogue reuses LDS
+  if constexpr (!SPLITK) {
+    if (p.sc0) {
+      // ---- the block's 1x1 conv_shortcut, same accumulators: chunks of 64 channels of the raw block input (one or two sources), weight columns 9 Ct + 64 r ...;
+      // two-slot rings (A images 0 / 1, weight slots 0 / 1), everything of a step requested one step ahead and waited for in full
+      asm volatile("s_barrier" ::: "memory");          // every wave has left the 3x3 loop: the rings are free
+      const int nsc = (p.sc_C0 + p.sc_C1) >> 6, sc0n = p.sc_C0 >> 6;
+      auto setS = [&](int r) {                           // A image of shortcut chunk r: the tile's own pixel rows (ky = 1), source sc0 / sc1
+        const bool s1 = r >= sc0n;
+        const int Cs = s1 ? p.sc_C1 : p.sc_C0;
+        aso = (unsigned)((s1 ? r - sc0n : r) * 128);
+        abase = s1 ? p.sc1 : p.sc0;
+#pragma unroll
+        for (int i = 0; i < A_ITH; ++i) {
+          const bool ok = ((a_ok >> i) & 1) && (unsigned)(a_y[i] + 1) < (unsigned)H;
+          const int pix = (a_brow[i] + ((a_y[i] + 1) >> ush)) * p.Win + a_ix[i];
+          avoff[i] = ok ? (unsigned)(pix * Cs + lchunk * 8) * 2u : 0x80000000u;
+        }
+      };
+      const unsigned scb = (unsigned)(9 * Ct * 2);      // byte offset of the shortcut columns inside a weight row
+      if (nsc > 0) {
+        setS(0);
+        const unsigned aso_u = __builtin_amdgcn_readfirstlane(aso);
+#pragma unroll
+        for (int i = 0; i < A_ITH; ++i) { const int pc = i * NW + wid; bufdma16(abase, pc * 8 < HRP ? sAr + pc * 1024 : scr + wid * 1024, avoff[i], aso_u); }
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i) bufdma16(p.W, sBr + (i * NW + wid) * 1024, bvoff[i], __builtin_amdgcn_readfirstlane(scb));
+      }
+      for (int r = 0; r < nsc; ++r) {
+        const bool more = r + 1 < nsc;
+        if (more) setS(r + 1);
+        wait_vm<0>(); asm volatile("s_barrier" ::: "memory");
+        kstep(KS1{}, r & 1, r & 1, (r & 1) ^ 1, scb + (unsigned)(r + 1) * 128u, more ? LIVE : 0u, more ? LIVE : 0u);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+  }
   igemm_epilogue<BM, BN, WM, WN, 0, SPLITK>(p, acc, smem, lane, wm, wn, m0, n0, tn, 0);
 }

@@ -26,6 +26,7 @@ extern "C" void agd_set_error(const char* fmt, ...) {
 #define FAIL(...) do { agd_set_error(__VA_ARGS__); return -1; } while (0)
 
 struct WMat { bf16_t* w = nullptr; int N = 0, Cin = 0, Cpad = 0, taps = 0;
+              int sc_cols = 0;                                   // conv2 with its block's conv_shortcut appended: rows are [taps x Cpad | sc_cols] (igemm_halo.h shortcut loop)
               bf16_t* wfrag = nullptr; int wfrag_ni = 0; };   // the matrix once more in MFMA fragment order (igemm_wreg.h), column ranges of wfrag_ni x 16
 // cpart: per-(M tile, channel) partial sums the producing igemm launch leaves for a following GroupNorm
 // ([B*H*W / cpart_bm][C] float2; cpart_bm = 0: none were produced -> the GroupNorm runs its own statistics pass)
@@ -117,6 +118,7 @@ struct agd_ctx {
   int opt_halo = 1;                                   // agd_set_option("conv_halo"): 3x3 stride-1 convs through the row-halo kernel (igemm_halo.h)
   int opt_tb_fuse = 255;                               // agd_set_option("tblock_fuse"): fused row-panel kernels of the C = 320 transformer blocks (tblock.hip): bit 0 = feed-forward (bit 3: + proj_out),
                                                       // bit 1 = attn2 chain (bit 2: + attn1.to_out in front of it), bit 4 = proj_in -> norm1 -> qkv, bit 5 = the attn2 chain for the C = 640 blocks too, bit 6 = the CFG-shared prefix's duplication inside the fused kernels, bit 7 = the GroupNorm applied inside the bit-4 launch (no fold launch), bit 8 (off) = the bit-4 launch with the GroupNorm inside for the C = 640 blocks
+  int opt_sc_fuse = 1;                                // agd_set_option("shortcut_fuse"): a UNet resnet's 1x1 conv_shortcut runs as extra K of its conv2 launch where that is an unsplit row-halo launch
   int opt_wreg = 2;                                   // agd_set_option("wreg_mask"): weight-streaming kernel (igemm_wreg.h) for bit 1: proj_in / proj_out of the C = 640 blocks (bit 0, the C = 1280 GEGLU at M = 2048: measured slower in situ, removed)
   int opt_kg2 = 1;                                    // agd_set_option("igemm_kgroups"): two K groups of waves per workgroup on the one-workgroup-per-CU 1x1 launches of the small maps
   int opt_side = 0;                                   // agd_set_option("side_stream"): a resnet's 1x1 conv_shortcut runs on a second stream beside norm1 / conv1 / norm2
@@ -186,6 +188,8 @@ struct GemmOpt {
   int kg2 = 0;                  // benches / tests: two K groups of waves per workgroup on the 64-row 1x1 tiles (the walk sets it through the ctx option)
   int smap = 0;                 // benches / tests: allow the 8 x 8 whole-images-resident 3x3 kernel (the walk sets it through the ctx option)
   int wreg = 0;                 // benches / tests: weight-streaming kernel for this launch when the WMat carries a fragment-order copy (bit 0 plain, bit 1 GEGLU)
+  const bf16_t* sc0 = nullptr; const bf16_t* sc1 = nullptr; int sc_C0 = 0, sc_C1 = 0;   // the block's 1x1 conv_shortcut as extra K of this 3x3 launch (WMat::sc_cols)
+  int* can_fuse_sc = nullptr;   // query only: *can_fuse_sc = 1 when this launch could take a shortcut that way (nothing is launched)
   int pad = -1;                 // -1: 1 for 3x3, 0 for 1x1
   int hout = 0, wout = 0;       // >0: override (asymmetric (0,1,0,1) padding of the VAE encoder's stride-2 convs)
 };
@@ -206,6 +210,10 @@ static int run_conv(agd_ctx* c, hipStream_t st, const bf16_t* s0, int C0, const 
   p.Wout = o.wout > 0 ? o.wout : (Win * o.up + 2 * p.pad - ksize) / o.stride + 1;
   p.W = w.w; p.bias = o.bias; p.bias_mode = o.bias ? 1 : 0; p.rowadd = o.rowadd; p.rowadd_ld = o.rowadd_ld;
   p.residual = o.residual; p.N = w.N; p.K = w.taps * w.Cpad; p.M = B * p.Hout * p.Wout;
+  if (o.sc0) {
+    if (w.sc_cols != o.sc_C0 + o.sc_C1 || w.sc_cols < 64) FAIL("conv: weight carries %d shortcut columns, the launch %d + %d", w.sc_cols, o.sc_C0, o.sc_C1);
+    p.sc0 = o.sc0; p.sc1 = o.sc1; p.sc_C0 = o.sc_C0; p.sc_C1 = o.sc_C1; p.K += w.sc_cols;
+  }
   const int nout = o.geglu ? w.N / 2 : w.N;
   p.ldr = o.ldr ? o.ldr : nout; p.out = out; p.out_f32 = o.out_f32; p.ldo = o.ldo ? o.ldo : nout;
   p.alpha = o.alpha; p.geglu = o.geglu; p.act = o.act; p.batch = 1; p.zero_page = zero_page; p.ws = c ? &c->splitk : nullptr;
@@ -219,6 +227,7 @@ static int run_conv(agd_ctx* c, hipStream_t st, const bf16_t* s0, int C0, const 
   p.smap = (c && c->opt_smap) || o.smap;
   p.kg2 = (c && c->opt_kg2) || o.kg2;
   p.p8 = o.p8 ? o.p8 : c ? c->opt_p8 : 0;          // before any igemm_query: the tile shape depends on it
+  if (o.can_fuse_sc) { *o.can_fuse_sc = igemm_can_fuse_shortcut(p) ? 1 : 0; return 0; }
   if (o.query_cfg) { if (o.want_rowstat && !p.rowstat_out) { p.rowstat_out = (float*)16; p.rowstat_slots = 0; } return igemm_query(p, o.query_cfg); }   // (nothing is launched)
   if (o.out_act) {
     o.out_act->cpart_bm = 0;
@@ -247,7 +256,7 @@ static int run_conv(agd_ctx* c, hipStream_t st, const bf16_t* s0, int C0, const 
     if (c->touch_sink) { ProfScope pt(c, st, PC_TOUCH, 0, w_b);
       hipLaunchKernelGGL(touch_kernel, dim3(1024), dim3(256), 0, st, (const u32x4*)w.w, (long long)(w_b / 16), c->touch_sink); }
   }
-  ProfScope ps(c, st, ksize == 3 ? PC_CONV3 : PC_GEMM, 2.0 * p.M * (double)p.N * p.K, in_b + w_b + out_b);
+  ProfScope ps(c, st, ksize == 3 ? PC_CONV3 : PC_GEMM, 2.0 * p.M * (double)p.N * p.K, in_b + w_b + out_b + 2.0 * B * Hin * Win * (double)(o.sc_C0 + o.sc_C1));
   return launch_igemm(p, st);
 }
 
@@ -333,6 +342,21 @@ static int resnet(agd_ctx* c, hipStream_t st, const std::string& pre, const Act&
   CK(run_conv(c, st, n1p, Cin, nullptr, 0, B, H, Wd, *w1, 3, h.p, o1, c->zero_page));
   if (!gn_done) CK(run_gn(c, st, h.p, Cout, nullptr, 0, B, HW, g2, b2, groups, eps, 1, n2.p, &h));
   const bf16_t* res = x0.p;
+  // conv_shortcut as extra K of conv2 (igemm_halo.h shortcut loop): one launch, the shortcut's output never exists -- where conv2 is an unsplit row-halo launch
+  bool fuse_sc = false;
+  if (has_sc && !side_out && c->opt_sc_fuse && c->W.count(pre + "conv2.sc")) {
+    GETW(w2q, pre + "conv2.weight");
+    int can = 0; GemmOpt q; q.can_fuse_sc = &can;
+    CK(run_conv(c, st, n2.p, Cout, nullptr, 0, B, H, Wd, *w2q, 3, nullptr, q, c->zero_page));
+    fuse_sc = can != 0;
+  }
+  if (fuse_sc) {
+    GETW(w2s, pre + "conv2.sc"); GETV(cbs, pre + "conv2.sc.bias");
+    GemmOpt o2; o2.bias = cbs; o2.out_act = &out; o2.sc0 = x0.p; o2.sc_C0 = x0.C; o2.sc1 = x1 ? x1->p : nullptr; o2.sc_C1 = C1;
+    CK(run_conv(c, st, n2.p, Cout, nullptr, 0, B, H, Wd, *w2s, 3, out.p, o2, c->zero_page));
+    c->arena.release(mk);
+    return 0;
+  }
   if (side_out) {
     if (hipStreamWaitEvent(st, c->ev_join, 0) != hipSuccess) FAIL("side stream wait");
     res = side_out;
@@ -1082,6 +1106,28 @@ AGD_API int agd_finalize(agd_ctx* c) {
       }
     }
   }
+  // ---- UNet resnets with a conv_shortcut: conv2's matrix once more with the shortcut's columns appended to every row, and the two biases summed
+  { std::vector<std::string> pres;
+    const std::string tail = "conv_shortcut.weight";
+    for (auto& kv : c->W) if (kv.first.compare(0, 5, "unet.") == 0 && kv.first.size() > tail.size() && kv.first.compare(kv.first.size() - tail.size(), tail.size(), tail) == 0)
+      pres.push_back(kv.first.substr(0, kv.first.size() - tail.size()));
+    for (const std::string& pre : pres) {
+      const WMat* w2 = getW(c, pre + "conv2.weight"); const WMat* ws = getW(c, pre + "conv_shortcut.weight");
+      auto b2 = c->V.find(pre + "conv2.bias"); auto bs = c->V.find(pre + "conv_shortcut.bias");
+      if (!w2 || !ws || b2 == c->V.end() || bs == c->V.end()) return fail_ctx(c);
+      if (w2->taps != 9 || ws->taps != 1 || w2->N != ws->N || (ws->Cpad & 63) || (w2->Cpad & 63)) continue;
+      const size_t k2 = (size_t)9 * w2->Cpad, ks = (size_t)ws->Cpad;
+      WMat f = *w2; f.sc_cols = (int)ks; f.wfrag = nullptr; f.wfrag_ni = 0;
+      f.w = dmalloc<bf16_t>(c, (size_t)f.N * (k2 + ks)); float* fb = dmalloc<float>(c, f.N);
+      if (!f.w || !fb) return fail_ctx(c);
+      if (hipMemcpy2D(f.w, (k2 + ks) * 2, w2->w, k2 * 2, k2 * 2, f.N, hipMemcpyDeviceToDevice) != hipSuccess ||
+          hipMemcpy2D(f.w + k2, (k2 + ks) * 2, ws->w, ks * 2, ks * 2, f.N, hipMemcpyDeviceToDevice) != hipSuccess) { agd_set_error("finalize: shortcut weight concat failed"); return fail_ctx(c); }
+      std::vector<float> ha(f.N), hb(f.N);
+      if (hipMemcpy(ha.data(), b2->second, f.N * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(hb.data(), bs->second, f.N * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) { agd_set_error("finalize: bias read failed"); return fail_ctx(c); }
+      for (int i = 0; i < f.N; ++i) ha[i] += hb[i];
+      if (hipMemcpy(fb, ha.data(), f.N * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) { agd_set_error("finalize: bias write failed"); return fail_ctx(c); }
+      c->W[pre + "conv2.sc"] = f; c->V[pre + "conv2.sc.bias"] = fb; c->Vn[pre + "conv2.sc.bias"] = f.N;
+    } }
   // ---- all time_emb_proj stacked into one [sum Cout][4*dim] matrix
   { std::vector<const WMat*> parts; std::vector<std::string> pres; int total = 0;
     for (auto& kv : c->W) if (ends_with(kv.first, "time_emb_proj.weight")) pres.push_back(kv.first.substr(0, kv.first.size() - strlen("time_emb_proj.weight")));
@@ -1308,6 +1354,7 @@ AGD_API int agd_set_option(agd_ctx* c, const char* name, int value) {
   if (!strcmp(name, "conv_smap")) { c->opt_smap = value != 0; return 0; }
   if (!strcmp(name, "side_stream")) { c->opt_side = value < 0 ? 0 : value; return 0; }
   if (!strcmp(name, "igemm_kgroups")) { c->opt_kg2 = value != 0; return 0; }
+  if (!strcmp(name, "shortcut_fuse")) { c->opt_sc_fuse = value != 0; return 0; }
   if (!strcmp(name, "wreg_mask")) { c->opt_wreg = value & 2; return 0; }
   if (!strcmp(name, "igemm8p")) { c->opt_p8 = value < 0 ? 0 : value; return 0; }   // 0 off, 1 on (the launcher decides per launch); tests: 2 / 3 / 4 force the 256-wide / 160-wide / any legal tile
   agd_set_error("set_option: unknown option '%s'", name);

@@ -282,8 +282,14 @@ def test_sd15_unet_forward_512px_batch4_matches_oracle(sd15_host_weights, sd15_p
         pipe.engine.record_reset(B, L)
         got8 = pipe.engine.unet_forward(x, 601.0).clone()
         hm8 = torch.stack([pipe.engine.daam_global(i, 77, L).cpu() for i in range(B)])
+        # shortcut_fuse off: the resnets' 1x1 conv_shortcut as its own launch (its bf16-rounded output added as conv2's residual) instead of extra K of conv2
+        pipe.engine.set_option("tblock_fuse", 255)
+        pipe.engine.set_option("shortcut_fuse", 0)
+        pipe.engine.record_reset(B, L)
+        got_s = pipe.engine.unet_forward(x, 601.0).clone()
     finally:
         pipe.engine.set_option("tblock_fuse", 255)
+        pipe.engine.set_option("shortcut_fuse", 1)
         pipe.engine.record_config(0)
     err = _rms_rel(got, want)
     hm_err = float((hm - whm).abs().max() / whm.abs().max())
@@ -292,6 +298,9 @@ def test_sd15_unet_forward_512px_batch4_matches_oracle(sd15_host_weights, sd15_p
     assert err < 2.0 ** -6, err
     assert hm_err < 0.02, hm_err
     assert err8 < 2.0 ** -6 and hm_err8 < 0.02 and 0 < d8 < 2.0 ** -5, (err8, hm_err8, d8)
+    err_s, d_s = _rms_rel(got_s, want), _rms_rel(got_s, got.cpu())
+    print(f"  conv_shortcut as its own launch: {err_s:.5f} vs the oracle, {d_s:.5f} vs the fused form")
+    assert err_s < 2.0 ** -6 and 0 < d_s < 2.0 ** -5, (err_s, d_s)
 
 
 @pytest.mark.parametrize("p8", [1, 4])
