@@ -580,7 +580,7 @@ static int launch_cfg(const IgemmP& p, int splits, hipStream_t st) {
                      p.stride, p.up, p.geglu, p.residual ? 1 : 0, BM, BN, splits, p.batch > 0 ? p.batch : 1);
 #endif
   constexpr bool HALO_TILE = BM == 128 && WM == 2 && WN == 2 && (BN == 128 || BN == 160);
-  if (p.sc0 && (splits > 1 || !HALO_TILE)) { agd_set_error("igemm: shortcut fusion on a launch that is not an unsplit row-halo launch (tile %dx%d, %d K slices)", BM, BN, splits); return -1; }
+  if (p.sc0 && !HALO_TILE) { agd_set_error("igemm: shortcut fusion on a launch that is not a row-halo launch (tile %dx%d, %d K slices)", BM, BN, splits); return -1; }
   if (splits > 1) {
     int rc;
     if constexpr (HALO_TILE) { rc = halo_ok(p) ? launch_halo<BN, 1, STAGES == 4 ? 4 : 2>(p, splits, st) : (p.ksize == 3) ? launch_one<BM, BN, WM, WN, 3, STAGES, 0, 1>(p, splits, st) : launch_one<BM, BN, WM, WN, 1, STAGES, 0, 1>(p, splits, st); }
@@ -886,14 +886,14 @@ int launch_igemm(const IgemmP& p_in, hipStream_t st) {
   return launch_cfg<64, 64, 2, 2, 4>(p, 1, st);
 }
 
-// can this 3x3 launch take its block's 1x1 conv_shortcut as extra K (IgemmP::sc0)?  True when the launcher picks the unsplit row-halo kernel for it.
+// can this 3x3 launch take its block's 1x1 conv_shortcut as extra K (IgemmP::sc0)?  True when the launcher picks the row-halo kernel for it.
 bool igemm_can_fuse_shortcut(const IgemmP& p_in) {
-  IgemmP p = p_in;
+  IgemmP p = p_in;                       // WITH the shortcut fields and the widened K: the launcher's decision for exactly the launch that would follow
   int cfg[3] = {0, 0, 0};
-  p.cfg_out = cfg; p.p8 = 0; p.smap = 0; p.sc0 = p.sc1 = nullptr; p.sc_C0 = p.sc_C1 = 0;
-  if (p.ksize != 3 || !halo_ok(p)) return false;
+  p.cfg_out = cfg;
+  if (!p.sc0 || p.ksize != 3 || !halo_ok(p)) return false;
   if (launch_igemm(p, nullptr) != 0) return false;
-  return cfg[0] == 128 && (cfg[1] == 128 || cfg[1] == 160) && cfg[2] == 1;
+  return cfg[0] == 128 && (cfg[1] == 128 || cfg[1] == 160);      // the row-halo tiles (split-K or not)
 }
 
 // the tile configuration launch_igemm would pick for this problem: cfg3 = {BM, BN, K splits} (nothing is launched)

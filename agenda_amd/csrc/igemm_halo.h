@@ -231,12 +231,14 @@ __global__ __launch_bounds__(256, BST == 2 ? 2 : 1) void igemm_halo_kernel(const
     ky = kyn; r = rn; bso = bson;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // dead tail pieces still write zeros: let them land before the epilogue reuses LDS
-  if constexpr (!SPLITK) {
+  {
     if (p.sc0) {
       // ---- the block's 1x1 conv_shortcut, same accumulators: chunks of 64 channels of the raw block input (one or two sources), weight columns 9 Ct + 64 r ...;
       // two-slot rings (A images 0 / 1, weight slots 0 / 1), everything of a step requested one step ahead and waited for in full
       asm volatile("s_barrier" ::: "memory");          // every wave has left the 3x3 loop: the rings are free
       const int nsc = (p.sc_C0 + p.sc_C1) >> 6, sc0n = p.sc_C0 >> 6;
+      int r0 = 0, r1 = nsc;                              // split-K: the chunks are dealt to the K slices like the 3x3 groups
+      if constexpr (SPLITK) { const int per = (nsc + (int)gridDim.z - 1) / (int)gridDim.z; r0 = (int)blockIdx.z * per; r1 = r0 + per < nsc ? r0 + per : nsc; if (r1 < r0) r1 = r0; }
       auto setS = [&](int r) {                           // A image of shortcut chunk r: the tile's own pixel rows (ky = 1), source sc0 / sc1
         const bool s1 = r >= sc0n;
         const int Cs = s1 ? p.sc_C1 : p.sc_C0;
@@ -250,19 +252,20 @@ __global__ __launch_bounds__(256, BST == 2 ? 2 : 1) void igemm_halo_kernel(const
         }
       };
       const unsigned scb = (unsigned)(9 * Ct * 2);      // byte offset of the shortcut columns inside a weight row
-      if (nsc > 0) {
-        setS(0);
+      if (r1 > r0) {
+        setS(r0);
         const unsigned aso_u = __builtin_amdgcn_readfirstlane(aso);
 #pragma unroll
         for (int i = 0; i < A_ITH; ++i) { const int pc = i * NW + wid; bufdma16(abase, pc * 8 < HRP ? sAr + pc * 1024 : scr + wid * 1024, avoff[i], aso_u); }
 #pragma unroll
-        for (int i = 0; i < B_IT; ++i) bufdma16(p.W, sBr + (i * NW + wid) * 1024, bvoff[i], __builtin_amdgcn_readfirstlane(scb));
+        for (int i = 0; i < B_IT; ++i) bufdma16(p.W, sBr + (i * NW + wid) * 1024, bvoff[i], __builtin_amdgcn_readfirstlane(scb + (unsigned)r0 * 128u));
       }
-      for (int r = 0; r < nsc; ++r) {
-        const bool more = r + 1 < nsc;
+      for (int r = r0; r < r1; ++r) {
+        const bool more = r + 1 < r1;
+        const int sl = (r - r0) & 1;
         if (more) setS(r + 1);
         wait_vm<0>(); asm volatile("s_barrier" ::: "memory");
-        kstep(KS1{}, r & 1, r & 1, (r & 1) ^ 1, scb + (unsigned)(r + 1) * 128u, more ? LIVE : 0u, more ? LIVE : 0u);
+        kstep(KS1{}, sl, sl, sl ^ 1, scb + (unsigned)(r + 1) * 128u, more ? LIVE : 0u, more ? LIVE : 0u);
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }

@@ -345,15 +345,21 @@ static int resnet(agd_ctx* c, hipStream_t st, const std::string& pre, const Act&
   // conv_shortcut as extra K of conv2 (igemm_halo.h shortcut loop): one launch, the shortcut's output never exists -- where conv2 is an unsplit row-halo launch
   bool fuse_sc = false;
   if (has_sc && !side_out && c->opt_sc_fuse && c->W.count(pre + "conv2.sc")) {
-    GETW(w2q, pre + "conv2.weight");
-    int can = 0; GemmOpt q; q.can_fuse_sc = &can;
+    GETW(w2q, pre + "conv2.sc");
+    int can = 0; GemmOpt q; q.can_fuse_sc = &can; q.sc0 = x0.p; q.sc_C0 = x0.C; q.sc1 = x1 ? x1->p : nullptr; q.sc_C1 = C1;
     CK(run_conv(c, st, n2.p, Cout, nullptr, 0, B, H, Wd, *w2q, 3, nullptr, q, c->zero_page));
     fuse_sc = can != 0;
   }
   if (fuse_sc) {
     GETW(w2s, pre + "conv2.sc"); GETV(cbs, pre + "conv2.sc.bias");
     GemmOpt o2; o2.bias = cbs; o2.out_act = &out; o2.sc0 = x0.p; o2.sc_C0 = x0.C; o2.sc1 = x1 ? x1->p : nullptr; o2.sc_C1 = C1;
+    int gn2_done = 0;
+    if (out_normed) {      // (as below: a split-K launch's slab pass also applies the GroupNorm that reads this output next)
+      o2.gn_gamma = next->gamma; o2.gn_beta = next->beta; o2.gn_y = out_normed; o2.gn_groups = groups; o2.gn_eps = next->eps; o2.gn_silu = next->silu;
+      o2.gn_keep_out = 1; o2.gn_fused = &gn2_done;
+    }
     CK(run_conv(c, st, n2.p, Cout, nullptr, 0, B, H, Wd, *w2s, 3, out.p, o2, c->zero_page));
+    if (gn2_done) { out.normed = out_normed; out.normed_gamma = next->gamma; }
     c->arena.release(mk);
     return 0;
   }
