@@ -118,6 +118,7 @@ struct agd_ctx {
   int opt_halo = 1;                                   // agd_set_option("conv_halo"): 3x3 stride-1 convs through the row-halo kernel (igemm_halo.h)
   int opt_tb_fuse = 255;                               // agd_set_option("tblock_fuse"): fused row-panel kernels of the C = 320 transformer blocks (tblock.hip): bit 0 = feed-forward (bit 3: + proj_out),
                                                       // bit 1 = attn2 chain (bit 2: + attn1.to_out in front of it), bit 4 = proj_in -> norm1 -> qkv, bit 5 = the attn2 chain for the C = 640 blocks too, bit 6 = the CFG-shared prefix's duplication inside the fused kernels, bit 7 = the GroupNorm applied inside the bit-4 launch (no fold launch), bit 8 (off) = the bit-4 launch with the GroupNorm inside for the C = 640 blocks
+  int opt_ffproj = 1;                                 // agd_set_option("ff_proj_fuse"): ff.net.2 and proj_out as ONE GEMM with the pre-multiplied matrix [Wp W2 | Wp] over [hidden | h] (blocks whose feed-forward is not the fused row-panel kernel)
   int opt_sc_fuse = 1;                                // agd_set_option("shortcut_fuse"): a UNet resnet's 1x1 conv_shortcut runs as extra K of its conv2 launch where that is an unsplit row-halo launch
   int opt_wreg = 2;                                   // agd_set_option("wreg_mask"): weight-streaming kernel (igemm_wreg.h) for bit 1: proj_in / proj_out of the C = 640 blocks (bit 0, the C = 1280 GEGLU at M = 2048: measured slower in situ, removed)
   int opt_kg2 = 1;                                    // agd_set_option("igemm_kgroups"): two K groups of waves per workgroup on the one-workgroup-per-CU 1x1 launches of the small maps
@@ -680,9 +681,17 @@ static int transformer(agd_ctx* c, hipStream_t st, const std::string& pre, const
   { bf16_t* ff = (bf16_t*)c->arena.alloc((size_t)M * 4 * C * 2); if (!ff) return -1;
     GETV(b1, t + "ff.net.0.proj.bias");
     CK(consume(t + "norm3", t + "ff.net.0.proj.weight", b1, 1, ff));
+    if (c->opt_ffproj && c->W.count(pre + "ffproj.weight")) {
+      // proj_out(ff.net.2(g) + h) + x = [Wp W2 | Wp] . [g | h] + (Wp b2 + bp) + x: one launch over the channel concat of the hidden activation and the residual stream
+      // with the matrix pre-multiplied at load time -- h3 is never formed, the proj_out launch (its 5 - 10 MB output pass and epilogue) disappears
+      GETW(wc, pre + "ffproj.weight"); GETV(bc, pre + "ffproj.bias");
+      GemmOpt o; o.bias = bc; o.residual = xres; o.out_act = &out; o.rows_per_image = HW;
+      CK(run_conv(c, st, ff, 4 * C, h.p, C, 1, 1, M, *wc, 1, out.p, o, c->zero_page));
+      proj_done = true;
+    } else {
     GETW(w2, t + "ff.net.2.weight"); GETV(b2, t + "ff.net.2.bias");
     GemmOpt o2; o2.bias = b2; o2.residual = h.p;
-    CK(run_conv(c, st, ff, 4 * C, nullptr, 0, 1, 1, M, *w2, 1, h.p, o2, c->zero_page)); }
+    CK(run_conv(c, st, ff, 4 * C, nullptr, 0, 1, 1, M, *w2, 1, h.p, o2, c->zero_page)); } }
   if (!proj_done)
   { GETW(w, pre + "proj_out.weight"); GETV(b, pre + "proj_out.bias"); GemmOpt o; o.bias = b; o.residual = xres; o.out_act = &out; o.rows_per_image = HW;
     if (C == 640 && (c->opt_wreg & 2)) o.wreg = 1;
@@ -1049,6 +1058,31 @@ AGD_API int agd_finalize(agd_ctx* c) {
       const std::string k = t + f.w + ".lnfold";
       c->W[k] = wf; c->V[k + ".cs"] = cs; c->V[k + ".bias"] = bf; c->Vn[k + ".cs"] = w->N; c->Vn[k + ".bias"] = w->N;
     }
+    // ff.net.2 and proj_out pre-multiplied: [Wp W2 | Wp] (rows of 5 C) and Wp b2 + bp, for the blocks whose feed-forward runs as separate launches
+    { const WMat* w2 = getW(c, t + "ff.net.2.weight"); const WMat* wp = getW(c, pr.first + "proj_out.weight");
+      auto b2 = c->V.find(t + "ff.net.2.bias"); auto bp = c->V.find(pr.first + "proj_out.bias");
+      if (w2 && wp && b2 != c->V.end() && bp != c->V.end() && w2->taps == 1 && wp->taps == 1 && wp->N == q->N && wp->Cpad == q->N && w2->N == q->N && w2->Cpad == 4 * q->N) {
+        const int C = q->N;
+        bf16_t* w2t = dmalloc<bf16_t>(c, (size_t)4 * C * C);
+        WMat wc = *wp; wc.N = C; wc.taps = 1; wc.Cpad = 5 * C; wc.Cin = 5 * C; wc.wfrag = nullptr; wc.wfrag_ni = 0; wc.sc_cols = 0;
+        wc.w = dmalloc<bf16_t>(c, (size_t)C * 5 * C); float* bc = dmalloc<float>(c, C);
+        if (!w2t || !wc.w || !bc) return fail_ctx(c);
+        API_CK(c, launch_transpose_bf16(w2->w, C, 4 * C, w2t, 0));                       // W2 [C][4C] -> [4C][C]
+        { WMat wt; wt.w = w2t; wt.N = 4 * C; wt.Cin = C; wt.Cpad = C; wt.taps = 1;        // (Wp W2)[n][k] = sum_j Wp[n][j] W2T[k][j]: Wp's rows as the activation rows
+          GemmOpt o; o.ldo = 5 * C;
+          API_CK(c, run_conv(c, 0, wp->w, C, nullptr, 0, 1, 1, C, wt, 1, wc.w, o, c->zero_page)); }
+        if (hipMemcpy2D(wc.w + 4 * C, (size_t)5 * C * 2, wp->w, (size_t)C * 2, (size_t)C * 2, C, hipMemcpyDeviceToDevice) != hipSuccess) { agd_set_error("finalize: ff/proj matrix assembly failed"); return fail_ctx(c); }
+        std::vector<unsigned short> hw((size_t)C * C); std::vector<float> hb2(C), hbp(C);
+        if (hipMemcpy(hw.data(), wp->w, (size_t)C * C * 2, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(hb2.data(), b2->second, C * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess ||
+            hipMemcpy(hbp.data(), bp->second, C * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) { agd_set_error("finalize: ff/proj bias read failed"); return fail_ctx(c); }
+        for (int n = 0; n < C; ++n) {
+          double a = hbp[n];
+          for (int j = 0; j < C; ++j) { unsigned u = (unsigned)hw[(size_t)n * C + j] << 16; float f; memcpy(&f, &u, 4); a += (double)f * hb2[j]; }
+          hbp[n] = (float)a;
+        }
+        if (hipMemcpy(bc, hbp.data(), C * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) { agd_set_error("finalize: ff/proj bias write failed"); return fail_ctx(c); }
+        c->W[pr.first + "ffproj.weight"] = wc; c->V[pr.first + "ffproj.bias"] = bc; c->Vn[pr.first + "ffproj.bias"] = C;
+      } }
     // fused row-panel kernels (tblock.hip, C = 320 blocks): the matrices once more in MFMA fragment order
     if (q->N == 320 || q->N == 640) {                 // (C = 640: the attn2 chain only -- a wave's GEMM tile is 80 columns whatever C: NI = 5)
       const int C = q->N;
@@ -1360,6 +1394,7 @@ AGD_API int agd_set_option(agd_ctx* c, const char* name, int value) {
   if (!strcmp(name, "conv_smap")) { c->opt_smap = value != 0; return 0; }
   if (!strcmp(name, "side_stream")) { c->opt_side = value < 0 ? 0 : value; return 0; }
   if (!strcmp(name, "igemm_kgroups")) { c->opt_kg2 = value != 0; return 0; }
+  if (!strcmp(name, "ff_proj_fuse")) { c->opt_ffproj = value != 0; return 0; }
   if (!strcmp(name, "shortcut_fuse")) { c->opt_sc_fuse = value != 0; return 0; }
   if (!strcmp(name, "wreg_mask")) { c->opt_wreg = value & 2; return 0; }
   if (!strcmp(name, "igemm8p")) { c->opt_p8 = value < 0 ? 0 : value; return 0; }   // 0 off, 1 on (the launcher decides per launch); tests: 2 / 3 / 4 force the 256-wide / 160-wide / any legal tile

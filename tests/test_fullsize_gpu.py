@@ -287,9 +287,15 @@ def test_sd15_unet_forward_512px_batch4_matches_oracle(sd15_host_weights, sd15_p
         pipe.engine.set_option("shortcut_fuse", 0)
         pipe.engine.record_reset(B, L)
         got_s = pipe.engine.unet_forward(x, 601.0).clone()
+        # ff_proj_fuse off: ff.net.2 (+ residual) and proj_out (+ block residual) as two launches instead of one GEMM with the pre-multiplied matrix [Wp W2 | Wp]
+        pipe.engine.set_option("shortcut_fuse", 1)
+        pipe.engine.set_option("ff_proj_fuse", 0)
+        pipe.engine.record_reset(B, L)
+        got_f = pipe.engine.unet_forward(x, 601.0).clone()
     finally:
         pipe.engine.set_option("tblock_fuse", 255)
         pipe.engine.set_option("shortcut_fuse", 1)
+        pipe.engine.set_option("ff_proj_fuse", 1)
         pipe.engine.record_config(0)
     err = _rms_rel(got, want)
     hm_err = float((hm - whm).abs().max() / whm.abs().max())
@@ -301,6 +307,9 @@ def test_sd15_unet_forward_512px_batch4_matches_oracle(sd15_host_weights, sd15_p
     err_s, d_s = _rms_rel(got_s, want), _rms_rel(got_s, got.cpu())
     print(f"  conv_shortcut as its own launch: {err_s:.5f} vs the oracle, {d_s:.5f} vs the fused form")
     assert err_s < 2.0 ** -6 and 0 < d_s < 2.0 ** -5, (err_s, d_s)
+    err_f, d_f = _rms_rel(got_f, want), _rms_rel(got_f, got.cpu())
+    print(f"  ff.net.2 and proj_out as two launches: {err_f:.5f} vs the oracle, {d_f:.5f} vs the pre-multiplied form")
+    assert err_f < 2.0 ** -6 and 0 < d_f < 2.0 ** -5, (err_f, d_f)
 
 
 @pytest.mark.parametrize("p8", [1, 4])
