@@ -703,8 +703,9 @@ int launch_igemm(const IgemmP& p_in, hipStream_t st) {
   if (p.K & 63 || p.C0 & 63 || p.C1 & 63) { agd_set_error("igemm: K/C0/C1 must be multiples of 64 (K=%d C0=%d C1=%d)", p.K, p.C0, p.C1); return -1; }
   if (p.K != p.ksize * p.ksize * (p.C0 + p.C1) + p.sc_C0 + p.sc_C1) { agd_set_error("igemm: K=%d != ks^2*(C0+C1)+shortcut=%d", p.K, p.ksize * p.ksize * (p.C0 + p.C1) + p.sc_C0 + p.sc_C1); return -1; }
   if (p.sc0) {          // conv_shortcut folded into a 3x3 launch: the unsplit row-halo kernel only (igemm_can_fuse_shortcut tells the caller beforehand)
-    if (p.ksize != 3 || (p.sc_C0 & 63) || (p.sc_C1 & 63) || p.sc_C0 < 64 || (p.sc_C1 && !p.sc1) || !halo_ok(p) || p.w_per_image || p.geglu) { agd_set_error("igemm: shortcut fusion needs a row-halo 3x3 launch and 64-channel multiples"); return -1; }
-    p.p8 = 0; p.smap = 0;
+    const bool smap8 = p.smap && p.stride == 1 && p.pad == 1 && p.up == 1 && p.Hin == 8 && p.Win == 8 && p.Hout == 8 && p.Wout == 8;      // the 8 x 8 whole-images kernel walks the chunks too
+    if (p.ksize != 3 || (p.sc_C0 & 63) || (p.sc_C1 & 63) || p.sc_C0 < 64 || (p.sc_C1 && !p.sc1) || !(halo_ok(p) || smap8) || p.w_per_image || p.geglu) { agd_set_error("igemm: shortcut fusion needs a row-halo or 8 x 8 whole-images 3x3 launch and 64-channel multiples"); return -1; }
+    p.p8 = 0; if (!smap8) p.smap = 0;
   }
   if (p.ksize != 1 && p.ksize != 3) { agd_set_error("igemm: ksize %d", p.ksize); return -1; }
   if (p.M < 1 || p.N < 1) { agd_set_error("igemm: empty problem M=%d N=%d", p.M, p.N); return -1; }
@@ -891,9 +892,11 @@ bool igemm_can_fuse_shortcut(const IgemmP& p_in) {
   IgemmP p = p_in;                       // WITH the shortcut fields and the widened K: the launcher's decision for exactly the launch that would follow
   int cfg[3] = {0, 0, 0};
   p.cfg_out = cfg;
-  if (!p.sc0 || p.ksize != 3 || !halo_ok(p)) return false;
+  if (!p.sc0 || p.ksize != 3) return false;
+  const bool smap8 = p.smap && p.stride == 1 && p.pad == 1 && p.up == 1 && p.Hin == 8 && p.Win == 8 && p.Hout == 8 && p.Wout == 8;
+  if (!halo_ok(p) && !smap8) return false;
   if (launch_igemm(p, nullptr) != 0) return false;
-  return cfg[0] == 128 && (cfg[1] == 128 || cfg[1] == 160);      // the row-halo tiles (split-K or not)
+  return (cfg[0] == 128 && (cfg[1] == 128 || cfg[1] == 160) && halo_ok(p)) || (cfg[0] == 512 && cfg[1] == 64);      // the row-halo tiles (split-K or not), or the 8 x 8 whole-images kernel
 }
 
 // the tile configuration launch_igemm would pick for this problem: cfg3 = {BM, BN, K splits} (nothing is launched)

@@ -137,5 +137,45 @@ __global__ __launch_bounds__(512, 2) void igemm_smap_kernel(const IgemmP p) {
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // dead tail pieces still write zeros to LDS: let them land
+  if (p.sc0) {
+    // ---- the block's 1x1 conv_shortcut as extra K (IgemmP::sc0, as in igemm_halo.h): 64-channel chunks of the raw block input (one or two sources), dealt to the K
+    // slices like the 3x3 chunks; per chunk one LDS image (the centre tap reads it) and ONE weight tile (columns 9 Ct + 64 r ... of the rows) into ring slot 0
+    const int nsc = (p.sc_C0 + p.sc_C1) >> 6, sc0n = p.sc_C0 >> 6;
+    int r0 = 0, r1 = nsc;
+    if constexpr (SPLITK) { const int per = (nsc + (int)gridDim.z - 1) / (int)gridDim.z; r0 = (int)blockIdx.z * per; r1 = r0 + per < nsc ? r0 + per : nsc; if (r1 < r0) r1 = r0; }
+    const int aoff = abase + (1 * HP + 1) * 128, akey = (fx + 1) & 7;
+    for (int r = r0; r < r1; ++r) {
+      asm volatile("s_barrier" ::: "memory");                      // every wave has left the previous image and weight slot 0
+      const bool s1 = r >= sc0n;
+      const int Cs = s1 ? p.sc_C1 : p.sc_C0;
+      const bf16_t* base = s1 ? p.sc1 : p.sc0;
+      const unsigned so = (unsigned)((s1 ? r - sc0n : r) * 128);
+#pragma unroll
+      for (int i = 0; i < A_IT; ++i) {
+        const int piece = i * NW + wid;
+        const unsigned voff = ((a_live >> i) & 1) ? (unsigned)(a_pix[i] * Cs + (((lane & 7) ^ a_key[i]) << 3)) * 2u : 0x80000000u;
+        char* dst = piece < A_ROWS / 8 ? sA + piece * 1024 : scr + wid * 1024;
+        bufdma16(base, dst, voff, so);
+      }
+      bufdma16(p.W, sBr + wid * 1024, bvoff, __builtin_amdgcn_readfirstlane((unsigned)((9 * Ct + r * 64) * 2)));
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asm volatile("s_barrier" ::: "memory");
+      const char* sB = sBr + wn * WTN * 128;
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        bf16x8 b[NI], a[MI];
+#pragma unroll
+        for (int j = 0; j < NI; ++j) b[j] = *(const bf16x8*)(sB + j * 512 + foffB[kk]);
+        const int ach = (((kk << 2) + q) ^ akey) << 4;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) a[i] = *(const bf16x8*)(sA + aoff + ((i >> 2) * IMG + 2 * (i & 3) * HP) * 128 + ach);
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
+      }
+    }
+    asm volatile("s_barrier" ::: "memory");                        // (the epilogue's LDS-staged paths start behind their own barriers; the register path touches no LDS)
+  }
   igemm_epilogue<BM, BN, WM, WN, 0, SPLITK>(p, acc, smem, lane, wm, wn, m0, n0, tn, 0, nullptr);
 }

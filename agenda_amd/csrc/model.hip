@@ -119,7 +119,7 @@ struct agd_ctx {
   int opt_tb_fuse = 255;                               // agd_set_option("tblock_fuse"): fused row-panel kernels of the C = 320 transformer blocks (tblock.hip): bit 0 = feed-forward (bit 3: + proj_out),
                                                       // bit 1 = attn2 chain (bit 2: + attn1.to_out in front of it), bit 4 = proj_in -> norm1 -> qkv, bit 5 = the attn2 chain for the C = 640 blocks too, bit 6 = the CFG-shared prefix's duplication inside the fused kernels, bit 7 = the GroupNorm applied inside the bit-4 launch (no fold launch), bit 8 (off) = the bit-4 launch with the GroupNorm inside for the C = 640 blocks
   int opt_ffproj = 1;                                 // agd_set_option("ff_proj_fuse"): ff.net.2 and proj_out as ONE GEMM with the pre-multiplied matrix [Wp W2 | Wp] over [hidden | h] (blocks whose feed-forward is not the fused row-panel kernel)
-  int opt_sc_fuse = 1;                                // agd_set_option("shortcut_fuse"): a UNet resnet's 1x1 conv_shortcut runs as extra K of its conv2 launch where that is an unsplit row-halo launch
+  int opt_sc_fuse = 3;                                // agd_set_option("shortcut_fuse"): a UNet resnet's 1x1 conv_shortcut runs as extra K of its conv2 launch where that is an unsplit row-halo launch
   int opt_wreg = 2;                                   // agd_set_option("wreg_mask"): weight-streaming kernel (igemm_wreg.h) for bit 1: proj_in / proj_out of the C = 640 blocks (bit 0, the C = 1280 GEGLU at M = 2048: measured slower in situ, removed)
   int opt_kg2 = 1;                                    // agd_set_option("igemm_kgroups"): two K groups of waves per workgroup on the one-workgroup-per-CU 1x1 launches of the small maps
   int opt_side = 0;                                   // agd_set_option("side_stream"): a resnet's 1x1 conv_shortcut runs on a second stream beside norm1 / conv1 / norm2
@@ -345,7 +345,7 @@ static int resnet(agd_ctx* c, hipStream_t st, const std::string& pre, const Act&
   const bf16_t* res = x0.p;
   // conv_shortcut as extra K of conv2 (igemm_halo.h shortcut loop): one launch, the shortcut's output never exists -- where conv2 is an unsplit row-halo launch
   bool fuse_sc = false;
-  if (has_sc && !side_out && c->opt_sc_fuse && c->W.count(pre + "conv2.sc")) {
+  if (has_sc && !side_out && (c->opt_sc_fuse & (H == 8 && Wd == 8 ? 2 : 1)) && c->W.count(pre + "conv2.sc")) {
     GETW(w2q, pre + "conv2.sc");
     int can = 0; GemmOpt q; q.can_fuse_sc = &can; q.sc0 = x0.p; q.sc_C0 = x0.C; q.sc1 = x1 ? x1->p : nullptr; q.sc_C1 = C1;
     CK(run_conv(c, st, n2.p, Cout, nullptr, 0, B, H, Wd, *w2q, 3, nullptr, q, c->zero_page));
@@ -1395,7 +1395,7 @@ AGD_API int agd_set_option(agd_ctx* c, const char* name, int value) {
   if (!strcmp(name, "side_stream")) { c->opt_side = value < 0 ? 0 : value; return 0; }
   if (!strcmp(name, "igemm_kgroups")) { c->opt_kg2 = value != 0; return 0; }
   if (!strcmp(name, "ff_proj_fuse")) { c->opt_ffproj = value != 0; return 0; }
-  if (!strcmp(name, "shortcut_fuse")) { c->opt_sc_fuse = value != 0; return 0; }
+  if (!strcmp(name, "shortcut_fuse")) { c->opt_sc_fuse = value & 3; return 0; }      // bit 0: row-halo launches (64 x 64 .. 16 x 16 maps), bit 1: the 8 x 8 whole-images launches
   if (!strcmp(name, "wreg_mask")) { c->opt_wreg = value & 2; return 0; }
   if (!strcmp(name, "igemm8p")) { c->opt_p8 = value < 0 ? 0 : value; return 0; }   // 0 off, 1 on (the launcher decides per launch); tests: 2 / 3 / 4 force the 256-wide / 160-wide / any legal tile
   agd_set_error("set_option: unknown option '%s'", name);

@@ -288,13 +288,13 @@ def test_sd15_unet_forward_512px_batch4_matches_oracle(sd15_host_weights, sd15_p
         pipe.engine.record_reset(B, L)
         got_s = pipe.engine.unet_forward(x, 601.0).clone()
         # ff_proj_fuse off: ff.net.2 (+ residual) and proj_out (+ block residual) as two launches instead of one GEMM with the pre-multiplied matrix [Wp W2 | Wp]
-        pipe.engine.set_option("shortcut_fuse", 1)
+        pipe.engine.set_option("shortcut_fuse", 3)
         pipe.engine.set_option("ff_proj_fuse", 0)
         pipe.engine.record_reset(B, L)
         got_f = pipe.engine.unet_forward(x, 601.0).clone()
     finally:
         pipe.engine.set_option("tblock_fuse", 255)
-        pipe.engine.set_option("shortcut_fuse", 1)
+        pipe.engine.set_option("shortcut_fuse", 3)
         pipe.engine.set_option("ff_proj_fuse", 1)
         pipe.engine.record_config(0)
     err = _rms_rel(got, want)
