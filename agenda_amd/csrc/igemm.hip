@@ -106,6 +106,9 @@ __global__ __launch_bounds__(WM * WN * 64 * KG, 2) void igemm_kernel(const Igemm
   int a_b[A_IT], a_y[A_IT], a_x[A_IT];
   unsigned a_rowok = 0;
   const bool lin = KS == 1 && p.stride == 1 && p.up == 1 && p.pad == 0 && p.Hin == p.Hout && p.Win == p.Wout;
+  // (phase convs of an upsampling conv, IgemmP::ups4: this tile's phase (a, b) = n0 / Cout pads (1 - a) rows above and (1 - b) columns left of its 2x2 window)
+  const int ph4 = (KS == 2 && p.ups4) ? n0 / p.ups4 : 0;
+  const int pad_y = (KS == 2 && p.ups4) ? 1 - (ph4 >> 1) : p.pad, pad_x = (KS == 2 && p.ups4) ? 1 - (ph4 & 1) : p.pad;
   const bool small_m = p.M < (1 << 24);
   const float inv_hwo = 1.0f / (float)HWo, inv_wo = 1.0f / (float)p.Wout;
 #pragma unroll
@@ -119,7 +122,7 @@ __global__ __launch_bounds__(WM * WN * 64 * KG, 2) void igemm_kernel(const Igemm
       if (small_m) { b = fast_udiv(mm, HWo, inv_hwo); const int rem_ = mm - b * HWo; oy = fast_udiv(rem_, p.Wout, inv_wo); }
       else { b = mm / HWo; oy = (mm - b * HWo) / p.Wout; }
       const int ox = mm - b * HWo - oy * p.Wout;
-      a_b[i] = b; a_y[i] = oy * p.stride - p.pad; a_x[i] = ox * p.stride - p.pad;
+      a_b[i] = b; a_y[i] = oy * p.stride - pad_y; a_x[i] = ox * p.stride - pad_x;
     }
     a_rowok |= (ok ? 1u : 0u) << i;
   }
@@ -142,7 +145,7 @@ __global__ __launch_bounds__(WM * WN * 64 * KG, 2) void igemm_kernel(const Igemm
   const int nk_total = p.K >> 6;
   int ks0 = kg, nk = KG == 1 ? nk_total : (nk_total - kg + KG - 1) / KG;      // K groups: steps kg, kg + KG, ...
   if constexpr (SPLITK) {
-    constexpr int Q = (KS == 3) ? 9 : 1;             // 3x3: slice on whole channel chunks (9 taps each)
+    constexpr int Q = KS * KS;                       // 3x3: slice on whole channel chunks (9 taps each)
     const int per = ((nk_total / Q + (int)gridDim.z - 1) / (int)gridDim.z) * Q;
     ks0 = (int)blockIdx.z * per;
     nk = nk_total - ks0 < per ? nk_total - ks0 : per;
@@ -151,7 +154,7 @@ __global__ __launch_bounds__(WM * WN * 64 * KG, 2) void igemm_kernel(const Igemm
 
   auto set_segment = [&](int tap_, int src_, int off_steps) {
     tap = tap_; cursrc = src_;
-    const int kh = (KS == 3) ? tap / 3 : 0, kw = (KS == 3) ? tap - kh * 3 : 0;
+    const int kh = (KS > 1) ? tap / KS : 0, kw = (KS > 1) ? tap - kh * KS : 0;
     const int Cs = cursrc ? p.C1 : p.C0;
     seg_left = KG == 1 ? (Cs >> 6) - off_steps : (1 << 30);     // K groups: one source, one tap (launcher) -- the segment never ends
     asoff = (unsigned)off_steps * 128u;
@@ -594,6 +597,7 @@ static int launch_cfg(const IgemmP& p, int splits, hipStream_t st) {
   }
   if constexpr (HALO_TILE) { if (halo_ok(p)) return launch_halo<BN, 0, STAGES == 4 ? 4 : 2>(p, 1, st); }
   if (p.ksize == 3) return launch_one<BM, BN, WM, WN, 3, STAGES, 0, 0>(p, 1, st);
+  if (p.ksize == 2) { if constexpr (BM == 128 && STAGES == 2 && KG == 1) return launch_one<BM, BN, WM, WN, 2, 2, 0, 0>(p, 1, st); agd_set_error("igemm: 2x2 phase convs run on the 128-row two-stage tiles"); return -1; }
   if constexpr (KG == 2) {
     // two K groups of waves per workgroup: plain single-source 1x1 launches (the kernel's K walk has one segment)
     if (p.C1 == 0 && p.stride == 1 && p.up == 1 && p.pad == 0 && p.Hin == p.Hout && p.Win == p.Wout && (p.batch <= 1) && !p.w_per_image)
@@ -707,7 +711,13 @@ int launch_igemm(const IgemmP& p_in, hipStream_t st) {
     if (p.ksize != 3 || (p.sc_C0 & 63) || (p.sc_C1 & 63) || p.sc_C0 < 64 || (p.sc_C1 && !p.sc1) || !(halo_ok(p) || smap8) || p.w_per_image || p.geglu) { agd_set_error("igemm: shortcut fusion needs a row-halo or 8 x 8 whole-images 3x3 launch and 64-channel multiples"); return -1; }
     p.p8 = 0; if (!smap8) p.smap = 0;
   }
-  if (p.ksize != 1 && p.ksize != 3) { agd_set_error("igemm: ksize %d", p.ksize); return -1; }
+  if (p.ksize != 1 && p.ksize != 3 && !(p.ksize == 2 && p.ups4)) { agd_set_error("igemm: ksize %d", p.ksize); return -1; }
+  if (p.ups4) {          // phase-decomposed upsampling conv: the general 4-wave kernel on 128-row tiles that stay inside one phase
+    if (p.ksize != 2 || p.stride != 1 || p.up != 1 || p.Hin != p.Hout || p.Win != p.Wout || p.N != 4 * p.ups4 || p.C1 || p.geglu || p.residual || p.rowadd || p.out_f32 || p.w_per_image ||
+        p.sc0 || (p.batch > 1) || p.ldo != p.ups4 || (p.ups4 % 160 && p.ups4 % 128) || p.rowstat_out || p.ln_stats) { agd_set_error("igemm: unsupported phase-conv launch"); return -1; }
+    p.p8 = 0; p.smap = 0; p.halo = 0; p.warm = 0;
+    return (p.ups4 % 160) == 0 ? launch_cfg<128, 160, 2, 2>(p, 1, st) : launch_cfg<128, 128, 2, 2>(p, 1, st);
+  }
   if (p.M < 1 || p.N < 1) { agd_set_error("igemm: empty problem M=%d N=%d", p.M, p.N); return -1; }
   if (p.rowadd && p.M >= (1 << 24)) { agd_set_error("igemm: rowadd needs M < 2^24"); return -1; }
   if (p.geglu && (p.N % 128)) { agd_set_error("igemm: geglu needs N %% 128 == 0"); return -1; }

@@ -217,7 +217,13 @@ AGD_DEV void igemm_epilogue(const IgemmP& p, f32x4 (&acc)[BM / WM / 16][BN / WN 
 #pragma unroll
           for (int c = 0; c < CW / 4; ++c) *(f32x4*)(op + 4 * c) = f32x4{v[4 * c], v[4 * c + 1], v[4 * c + 2], v[4 * c + 3]};
         } else {
-          bf16_t* op = (bf16_t*)p.out + bz * p.sO + (long long)m * p.ldo + no;
+          long long orow = m; int ocol = no;
+          if (p.ups4) {      // phase conv of an upsampling conv: source pixel (b, i, j), phase (a, b') = no / Cout -> output pixel (b, 2 i + a, 2 j + b') of the 2x map, channel no % Cout
+            const int ph = no / p.ups4, bimg = fast_udiv(m, HWo, inv_hwo), rem = m - bimg * HWo, ii = rem / p.Wout, jj = rem - ii * p.Wout;
+            orow = ((long long)bimg * 2 * p.Hout + 2 * ii + (ph >> 1)) * (2 * p.Wout) + 2 * jj + (ph & 1);
+            ocol = no - ph * p.ups4;
+          }
+          bf16_t* op = (bf16_t*)p.out + bz * p.sO + orow * p.ldo + ocol;
           bf16_t* lp = ctile ? ctile + (i * 16 + px) * WTN + q * CA : nullptr;
           if constexpr (SV == 4 && CW % 8 == 4) {
 #pragma unroll

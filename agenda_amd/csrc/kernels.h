@@ -15,6 +15,9 @@ struct IgemmP {
   // ResnetBlock2D.conv_shortcut folded into conv2's launch (row-halo kernel, unsplit): after the 3x3 groups the K loop walks the 1x1 shortcut's channel chunks over
   // its own sources (the block's raw input, possibly a skip concat) with the weight rows' trailing sc_C0 + sc_C1 columns; K = 9 (C0 + C1) + sc_C0 + sc_C1
   const bf16_t* sc0 = nullptr; const bf16_t* sc1 = nullptr; int sc_C0 = 0, sc_C1 = 0;
+  // Upsample2D.conv (3x3 on the nearest-2x upsampled map) as four 2x2 phase convs on the un-upsampled map in ONE launch: ups4 = Cout; ksize = 2, N = 4 Cout, the weight
+  // rows [phase a b][co] hold the taps that coincide pre-summed; a tile's phase = n0 / ups4 sets its padding (1 - a, 1 - b) and its output rows (2 i + a, 2 j + b)
+  int ups4 = 0;
   const bf16_t* src0; const bf16_t* src1;
   int C0, C1;
   int Hin, Win, Hout, Wout;
@@ -167,6 +170,7 @@ int launch_convert_weight(const float* w, bf16_t* out, int N, int Cin, int taps,
 int launch_f32_to_bf16(const float* x, bf16_t* y, long long n, hipStream_t st);
 int launch_bf16_to_f32(const bf16_t* x, float* y, long long n, hipStream_t st);
 bool igemm_can_fuse_shortcut(const IgemmP& p);
+int launch_upsample_phase_weight(const bf16_t* w, bf16_t* out, int Cout, int Cin, hipStream_t st);   // [Cout][9][Cin] -> [4 Cout][4][Cin]
 int launch_prep_latents(const float* lat_nchw, bf16_t* out_nhwc, int B, int C, int HW, int Cpad, int dup, float scale, hipStream_t st);
 int launch_timestep_embed(float t, float* out, int dim, hipStream_t st);
 int launch_small_linear(const float* x, const bf16_t* W, const float* bias, float* out, int M, int N, int K, int silu_in,

@@ -65,6 +65,29 @@ int launch_prep_latents(const float* lat, bf16_t* out, int B, int C, int HW, int
   HIP_CHECK_RET(hipGetLastError()); return 0;
 }
 
+// Upsample2D.conv as four 2x2 phase convs on the un-upsampled map (IgemmP::ups4): output pixel (2 i + a, 2 j + b) of conv3x3(nearest2x(x)) sees source rows {i - 1 + a, i + a}: for a = 0
+// tap kh = 0 on the upper row and kh = 1, 2 on the lower one, for a = 1 kh = 0, 1 on the upper and kh = 2 on the lower (columns alike).  [Cout][9][Cin] -> [4 Cout][4][Cin]: row (2 a + b) Cout + co,
+// tap 2 r + s = the fp32 sum of the coinciding taps, rounded to bf16 once.
+__global__ void upsample_phase_weight_kernel(const bf16_t* __restrict__ w, bf16_t* __restrict__ out, int Cout, int Cin) {
+  const long long total = (long long)4 * Cout * 4 * Cin;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % Cin);
+    const int lt = (int)((i / Cin) % 4);
+    const int n = (int)(i / ((long long)4 * Cin));
+    const int ph = n / Cout, co = n - ph * Cout, a = ph >> 1, b = ph & 1, r = lt >> 1, sx = lt & 1;
+    const int kh0 = a == 0 ? (r == 0 ? 0 : 1) : (r == 0 ? 0 : 2), kh1 = a == 0 ? (r == 0 ? 0 : 2) : (r == 0 ? 1 : 2);
+    const int kw0 = b == 0 ? (sx == 0 ? 0 : 1) : (sx == 0 ? 0 : 2), kw1 = b == 0 ? (sx == 0 ? 0 : 2) : (sx == 0 ? 1 : 2);
+    float acc = 0.f;
+    for (int kh = kh0; kh <= kh1; ++kh)
+      for (int kw = kw0; kw <= kw1; ++kw) acc += bf2f(w[((long long)co * 9 + kh * 3 + kw) * Cin + c]);
+    out[i] = f2bf(acc);
+  }
+}
+int launch_upsample_phase_weight(const bf16_t* w, bf16_t* out, int Cout, int Cin, hipStream_t st) {
+  hipLaunchKernelGGL(upsample_phase_weight_kernel, dim3(grid_for((long long)16 * Cout * Cin)), dim3(256), 0, st, w, out, Cout, Cin);
+  HIP_CHECK_RET(hipGetLastError()); return 0;
+}
+
 // diffusers Timesteps(dim, flip_sin_to_cos=True, downscale_freq_shift=0): [cos | sin], fp32
 __global__ void timestep_embed_kernel(float t, float* __restrict__ out, int dim) {
   const int half = dim / 2;

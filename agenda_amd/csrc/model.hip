@@ -118,6 +118,7 @@ struct agd_ctx {
   int opt_halo = 1;                                   // agd_set_option("conv_halo"): 3x3 stride-1 convs through the row-halo kernel (igemm_halo.h)
   int opt_tb_fuse = 255;                               // agd_set_option("tblock_fuse"): fused row-panel kernels of the C = 320 transformer blocks (tblock.hip): bit 0 = feed-forward (bit 3: + proj_out),
                                                       // bit 1 = attn2 chain (bit 2: + attn1.to_out in front of it), bit 4 = proj_in -> norm1 -> qkv, bit 5 = the attn2 chain for the C = 640 blocks too, bit 6 = the CFG-shared prefix's duplication inside the fused kernels, bit 7 = the GroupNorm applied inside the bit-4 launch (no fold launch), bit 8 (off) = the bit-4 launch with the GroupNorm inside for the C = 640 blocks
+  int opt_ups4 = 1;                                   // agd_set_option("upsample_phases"): the UNet's nearest-2x upsampling convs as four 2x2 phase convs on the un-upsampled map (one launch, 4/9 of the MACs)
   int opt_ffproj = 1;                                 // agd_set_option("ff_proj_fuse"): ff.net.2 and proj_out as ONE GEMM with the pre-multiplied matrix [Wp W2 | Wp] over [hidden | h] (blocks whose feed-forward is not the fused row-panel kernel)
   int opt_sc_fuse = 3;                                // agd_set_option("shortcut_fuse"): a UNet resnet's 1x1 conv_shortcut runs as extra K of its conv2 launch where that is an unsplit row-halo launch
   int opt_wreg = 2;                                   // agd_set_option("wreg_mask"): weight-streaming kernel (igemm_wreg.h) for bit 1: proj_in / proj_out of the C = 640 blocks (bit 0, the C = 1280 GEGLU at M = 2048: measured slower in situ, removed)
@@ -190,6 +191,7 @@ struct GemmOpt {
   int smap = 0;                 // benches / tests: allow the 8 x 8 whole-images-resident 3x3 kernel (the walk sets it through the ctx option)
   int wreg = 0;                 // benches / tests: weight-streaming kernel for this launch when the WMat carries a fragment-order copy (bit 0 plain, bit 1 GEGLU)
   const bf16_t* sc0 = nullptr; const bf16_t* sc1 = nullptr; int sc_C0 = 0, sc_C1 = 0;   // the block's 1x1 conv_shortcut as extra K of this 3x3 launch (WMat::sc_cols)
+  int ups4 = 0;                 // > 0: phase-decomposed upsampling conv (IgemmP::ups4 = Cout; ksize 2, the merged [4 Cout][4][Cin] matrix, hout / wout = the input size)
   int* can_fuse_sc = nullptr;   // query only: *can_fuse_sc = 1 when this launch could take a shortcut that way (nothing is launched)
   int pad = -1;                 // -1: 1 for 3x3, 0 for 1x1
   int hout = 0, wout = 0;       // >0: override (asymmetric (0,1,0,1) padding of the VAE encoder's stride-2 convs)
@@ -210,7 +212,7 @@ static int run_conv(agd_ctx* c, hipStream_t st, const bf16_t* s0, int C0, const 
   p.Hout = o.hout > 0 ? o.hout : (Hin * o.up + 2 * p.pad - ksize) / o.stride + 1;
   p.Wout = o.wout > 0 ? o.wout : (Win * o.up + 2 * p.pad - ksize) / o.stride + 1;
   p.W = w.w; p.bias = o.bias; p.bias_mode = o.bias ? 1 : 0; p.rowadd = o.rowadd; p.rowadd_ld = o.rowadd_ld;
-  p.residual = o.residual; p.N = w.N; p.K = w.taps * w.Cpad; p.M = B * p.Hout * p.Wout;
+  p.residual = o.residual; p.N = w.N; p.K = w.taps * w.Cpad; p.M = B * p.Hout * p.Wout; p.ups4 = o.ups4;
   if (o.sc0) {
     if (w.sc_cols != o.sc_C0 + o.sc_C1 || w.sc_cols < 64) FAIL("conv: weight carries %d shortcut columns, the launch %d + %d", w.sc_cols, o.sc_C0, o.sc_C1);
     p.sc0 = o.sc0; p.sc1 = o.sc1; p.sc_C0 = o.sc_C0; p.sc_C1 = o.sc_C1; p.K += w.sc_cols;
@@ -794,8 +796,15 @@ static int unet_walk(agd_ctx* c, hipStream_t st, const bf16_t* xin, int B2, int 
       const std::string k = u + "up_blocks." + std::to_string(i) + ".upsamplers.0.conv.";
       GETW(w, k + "weight"); GETV(b, k + "bias");
       Act d = alloc_act(c, B2, h.H * 2, h.W * 2, co, true); if (!d.p) return -1;
+      if (c->opt_ups4 && c->W.count(k + "phases") && (long long)B2 * h.H * h.W >= 2048) {
+        // conv3x3(nearest2x(x)) = four 2x2 convs on x, one per output phase, with the taps that coincide pre-summed (misc.hip upsample_phase_weight_kernel): 4/9 of the MACs
+        GETW(w4, k + "phases"); GETV(b4, k + "phases.bias");
+        GemmOpt o; o.bias = b4; o.out_act = &d; o.ups4 = co; o.hout = h.H; o.wout = h.W; o.ldo = co; o.pad = 0;
+        CK(run_conv(c, st, h.p, co, nullptr, 0, B2, h.H, h.W, *w4, 2, d.p, o, c->zero_page));
+      } else {
       GemmOpt o; o.bias = b; o.up = 2; o.out_act = &d;
       CK(run_conv(c, st, h.p, co, nullptr, 0, B2, h.H, h.W, *w, 3, d.p, o, c->zero_page));
+      }
       h = d;
     }
   }
@@ -1146,6 +1155,23 @@ AGD_API int agd_finalize(agd_ctx* c) {
       }
     }
   }
+  // ---- the UNet's upsampling convs once more as the merged phase matrices [4 Cout][4 taps][Cin] (+ the bias four times)
+  { std::vector<std::string> keys;
+    const std::string tail = "upsamplers.0.conv.weight";
+    for (auto& kv : c->W) if (kv.first.compare(0, 5, "unet.") == 0 && kv.first.size() > tail.size() && kv.first.compare(kv.first.size() - tail.size(), tail.size(), tail) == 0)
+      keys.push_back(kv.first.substr(0, kv.first.size() - 6));                 // "... .conv."
+    for (const std::string& k : keys) {
+      const WMat* w = getW(c, k + "weight"); auto bi = c->V.find(k + "bias");
+      if (!w || bi == c->V.end()) return fail_ctx(c);
+      if (w->taps != 9 || (w->Cpad & 63) || (w->N % 160 && w->N % 128)) continue;
+      WMat w4 = *w; w4.N = 4 * w->N; w4.taps = 4; w4.wfrag = nullptr; w4.wfrag_ni = 0; w4.sc_cols = 0;
+      w4.w = dmalloc<bf16_t>(c, (size_t)w4.N * 4 * w->Cpad); float* b4 = dmalloc<float>(c, w4.N);
+      if (!w4.w || !b4) return fail_ctx(c);
+      API_CK(c, launch_upsample_phase_weight(w->w, w4.w, w->N, w->Cpad, 0));
+      for (int ph = 0; ph < 4; ++ph)
+        if (hipMemcpy(b4 + (size_t)ph * w->N, bi->second, w->N * sizeof(float), hipMemcpyDeviceToDevice) != hipSuccess) { agd_set_error("finalize: phase bias copy failed"); return fail_ctx(c); }
+      c->W[k + "phases"] = w4; c->V[k + "phases.bias"] = b4; c->Vn[k + "phases.bias"] = w4.N;
+    } }
   // ---- UNet resnets with a conv_shortcut: conv2's matrix once more with the shortcut's columns appended to every row, and the two biases summed
   { std::vector<std::string> pres;
     const std::string tail = "conv_shortcut.weight";
@@ -1394,6 +1420,7 @@ AGD_API int agd_set_option(agd_ctx* c, const char* name, int value) {
   if (!strcmp(name, "conv_smap")) { c->opt_smap = value != 0; return 0; }
   if (!strcmp(name, "side_stream")) { c->opt_side = value < 0 ? 0 : value; return 0; }
   if (!strcmp(name, "igemm_kgroups")) { c->opt_kg2 = value != 0; return 0; }
+  if (!strcmp(name, "upsample_phases")) { c->opt_ups4 = value != 0; return 0; }
   if (!strcmp(name, "ff_proj_fuse")) { c->opt_ffproj = value != 0; return 0; }
   if (!strcmp(name, "shortcut_fuse")) { c->opt_sc_fuse = value & 3; return 0; }      // bit 0: row-halo launches (64 x 64 .. 16 x 16 maps), bit 1: the 8 x 8 whole-images launches
   if (!strcmp(name, "wreg_mask")) { c->opt_wreg = value & 2; return 0; }
@@ -1707,6 +1734,19 @@ AGD_API int agd_op_conv2d_ex(const float* x, const float* w, const float* bias, 
   WMat wm; wm.w = wb; wm.N = Cout; wm.Cin = Cin; wm.Cpad = Cpad; wm.taps = taps;
   GemmOpt o; o.bias = bias; o.stride = stride; o.up = up; o.out_f32 = 1; o.halo = flags & 1; o.p8 = (flags & 4) ? 2 : (flags & 8) ? 3 : (flags & 2) ? 1 : 0;
   o.smap = (flags & 16) ? 1 : 0;
+  if ((flags & 64) && upsample && ksize == 3 && stride == 1) {     // the upsampling conv as four 2x2 phase convs (IgemmP::ups4); bf16 output (that form's only one), widened afterwards
+    bf16_t* w4 = tmp.get<bf16_t>((size_t)4 * Cout * 4 * Cpad); float* b4 = tmp.get<float>((size_t)4 * Cout); bf16_t* yb = tmp.get<bf16_t>((size_t)B * Ho * Wo * Cout);
+    if (!w4 || !b4 || !yb) return -1;
+    CK(launch_upsample_phase_weight(wb, w4, Cout, Cpad, st));
+    for (int ph = 0; ph < 4; ++ph) {
+      if (bias) { if (hipMemcpyAsync(b4 + (size_t)ph * Cout, bias, Cout * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) { agd_set_error("op_conv2d: bias copy"); return -1; } }
+      else if (hipMemsetAsync(b4 + (size_t)ph * Cout, 0, Cout * sizeof(float), st) != hipSuccess) { agd_set_error("op_conv2d: bias clear"); return -1; }
+    }
+    WMat wm4; wm4.w = w4; wm4.N = 4 * Cout; wm4.Cin = Cin; wm4.Cpad = Cpad; wm4.taps = 4;
+    GemmOpt o4; o4.bias = b4; o4.ups4 = Cout; o4.hout = H; o4.wout = W; o4.ldo = Cout; o4.pad = 0;
+    CK(run_conv(nullptr, st, xb, Cpad, nullptr, 0, B, H, W, wm4, 2, yb, o4, op_zero_page()));
+    CK(launch_bf16_to_f32(yb, yn, (long long)B * Ho * Wo * Cout, st));
+  } else
   CK(run_conv(nullptr, st, xb, Cpad, nullptr, 0, B, H, W, wm, ksize, yn, o, op_zero_page()));
   CK(launch_nchw_from_nhwc_f32(yn, Cout, y, B, Cout, Ho * Wo, st));
   hipStreamSynchronize(st);

@@ -16,7 +16,7 @@ def _f32c(t):
 _P8 = {0: 0, 1: 2, 2: 4, 3: 8}      # igemm8p.h: 1 = where the launcher would pick it, 2 / 3 = force the 256- / 160-wide tile
 
 
-def conv2d(x, w, bias=None, stride=1, padding=None, upsample=False, halo=False, p8=0, smap=False):
+def conv2d(x, w, bias=None, stride=1, padding=None, upsample=False, halo=False, p8=0, smap=False, phases=False):
     lib = _lib.load()
     x, w = _f32c(x), _f32c(w)
     b = _f32c(bias) if bias is not None else None
@@ -28,7 +28,7 @@ def conv2d(x, w, bias=None, stride=1, padding=None, upsample=False, halo=False, 
     Wo = (W * up + 2 * pad - k) // stride + 1
     y = torch.empty(B, Cout, Ho, Wo, device=x.device, dtype=torch.float32)
     _lib.check(lib.agd_op_conv2d_ex(_lib.ptr(x), _lib.ptr(w), _lib.ptr(b), _lib.ptr(y), B, Cin, H, W, Cout, k, stride,
-                                    pad, int(upsample), (1 if halo else 0) | _P8[p8] | (16 if smap else 0), _lib.current_stream_ptr()), None, "agd_op_conv2d")
+                                    pad, int(upsample), (1 if halo else 0) | _P8[p8] | (16 if smap else 0) | (64 if phases else 0), _lib.current_stream_ptr()), None, "agd_op_conv2d")
     return y
 
 

@@ -292,7 +292,13 @@ def test_sd15_unet_forward_512px_batch4_matches_oracle(sd15_host_weights, sd15_p
         pipe.engine.set_option("ff_proj_fuse", 0)
         pipe.engine.record_reset(B, L)
         got_f = pipe.engine.unet_forward(x, 601.0).clone()
+        # upsample_phases off: the nearest-2x upsampling convs as 3x3 convs on the upsampled map (the gather folds the upsample) instead of four 2x2 phase convs on the source map
+        pipe.engine.set_option("ff_proj_fuse", 1)
+        pipe.engine.set_option("upsample_phases", 0)
+        pipe.engine.record_reset(B, L)
+        got_u = pipe.engine.unet_forward(x, 601.0).clone()
     finally:
+        pipe.engine.set_option("upsample_phases", 1)
         pipe.engine.set_option("tblock_fuse", 255)
         pipe.engine.set_option("shortcut_fuse", 3)
         pipe.engine.set_option("ff_proj_fuse", 1)
@@ -310,6 +316,9 @@ def test_sd15_unet_forward_512px_batch4_matches_oracle(sd15_host_weights, sd15_p
     err_f, d_f = _rms_rel(got_f, want), _rms_rel(got_f, got.cpu())
     print(f"  ff.net.2 and proj_out as two launches: {err_f:.5f} vs the oracle, {d_f:.5f} vs the pre-multiplied form")
     assert err_f < 2.0 ** -6 and 0 < d_f < 2.0 ** -5, (err_f, d_f)
+    err_u, d_u = _rms_rel(got_u, want), _rms_rel(got_u, got.cpu())
+    print(f"  upsampling convs on the upsampled map: {err_u:.5f} vs the oracle, {d_u:.5f} vs the phase form")
+    assert err_u < 2.0 ** -6 and 0 < d_u < 2.0 ** -5, (err_u, d_u)
 
 
 @pytest.mark.parametrize("p8", [1, 4])
