@@ -118,7 +118,7 @@ struct agd_ctx {
   int opt_halo = 1;                                   // agd_set_option("conv_halo"): 3x3 stride-1 convs through the row-halo kernel (igemm_halo.h)
   int opt_tb_fuse = 255;                               // agd_set_option("tblock_fuse"): fused row-panel kernels of the C = 320 transformer blocks (tblock.hip): bit 0 = feed-forward (bit 3: + proj_out),
                                                       // bit 1 = attn2 chain (bit 2: + attn1.to_out in front of it), bit 4 = proj_in -> norm1 -> qkv, bit 5 = the attn2 chain for the C = 640 blocks too, bit 6 = the CFG-shared prefix's duplication inside the fused kernels, bit 7 = the GroupNorm applied inside the bit-4 launch (no fold launch), bit 8 (off) = the bit-4 launch with the GroupNorm inside for the C = 640 blocks
-  int opt_ups4 = 1;                                   // agd_set_option("upsample_phases"): the UNet's nearest-2x upsampling convs as four 2x2 phase convs on the un-upsampled map (one launch, 4/9 of the MACs)
+  int opt_ups4 = 3; /* see agd_set_option */                                   // agd_set_option("upsample_phases"): the UNet's nearest-2x upsampling convs as four 2x2 phase convs on the un-upsampled map (one launch, 4/9 of the MACs)
   int opt_ffproj = 1;                                 // agd_set_option("ff_proj_fuse"): ff.net.2 and proj_out as ONE GEMM with the pre-multiplied matrix [Wp W2 | Wp] over [hidden | h] (blocks whose feed-forward is not the fused row-panel kernel)
   int opt_sc_fuse = 3;                                // agd_set_option("shortcut_fuse"): a UNet resnet's 1x1 conv_shortcut runs as extra K of its conv2 launch where that is an unsplit row-halo launch
   int opt_wreg = 2;                                   // agd_set_option("wreg_mask"): weight-streaming kernel (igemm_wreg.h) for bit 1: proj_in / proj_out of the C = 640 blocks (bit 0, the C = 1280 GEGLU at M = 2048: measured slower in situ, removed)
@@ -796,7 +796,7 @@ static int unet_walk(agd_ctx* c, hipStream_t st, const bf16_t* xin, int B2, int 
       const std::string k = u + "up_blocks." + std::to_string(i) + ".upsamplers.0.conv.";
       GETW(w, k + "weight"); GETV(b, k + "bias");
       Act d = alloc_act(c, B2, h.H * 2, h.W * 2, co, true); if (!d.p) return -1;
-      if (c->opt_ups4 && c->W.count(k + "phases") && (long long)B2 * h.H * h.W >= 2048) {
+      if ((c->opt_ups4 & 1) && c->W.count(k + "phases") && (long long)B2 * h.H * h.W >= ((c->opt_ups4 & 4) ? 512 : 2048)) {
         // conv3x3(nearest2x(x)) = four 2x2 convs on x, one per output phase, with the taps that coincide pre-summed (misc.hip upsample_phase_weight_kernel): 4/9 of the MACs
         GETW(w4, k + "phases"); GETV(b4, k + "phases.bias");
         GemmOpt o; o.bias = b4; o.out_act = &d; o.ups4 = co; o.hout = h.H; o.wout = h.W; o.ldo = co; o.pad = 0;
@@ -883,8 +883,14 @@ static int vae_walk(agd_ctx* c, hipStream_t st, const bf16_t* zin, int B, int L,
       const std::string k = v + "decoder.up_blocks." + std::to_string(i) + ".upsamplers.0.conv.";
       GETW(w, k + "weight"); GETV(b, k + "bias");
       Act d = alloc_act(c, B, h.H * 2, h.W * 2, co, true); if (!d.p) return -1;
+      if ((c->opt_ups4 & 2) && c->W.count(k + "phases")) {              // four 2x2 phase convs on the un-upsampled map (as in the UNet walk)
+        GETW(w4, k + "phases"); GETV(b4, k + "phases.bias");
+        GemmOpt o; o.bias = b4; o.out_act = &d; o.ups4 = co; o.hout = h.H; o.wout = h.W; o.ldo = co; o.pad = 0;
+        CK(run_conv(c, st, h.p, co, nullptr, 0, B, h.H, h.W, *w4, 2, d.p, o, c->zero_page));
+      } else {
       GemmOpt o; o.bias = b; o.up = 2; o.out_act = &d;
       CK(run_conv(c, st, h.p, co, nullptr, 0, B, h.H, h.W, *w, 3, d.p, o, c->zero_page));
+      }
       h = d;
     }
   }
@@ -1158,8 +1164,8 @@ AGD_API int agd_finalize(agd_ctx* c) {
   // ---- the UNet's upsampling convs once more as the merged phase matrices [4 Cout][4 taps][Cin] (+ the bias four times)
   { std::vector<std::string> keys;
     const std::string tail = "upsamplers.0.conv.weight";
-    for (auto& kv : c->W) if (kv.first.compare(0, 5, "unet.") == 0 && kv.first.size() > tail.size() && kv.first.compare(kv.first.size() - tail.size(), tail.size(), tail) == 0)
-      keys.push_back(kv.first.substr(0, kv.first.size() - 6));                 // "... .conv."
+    for (auto& kv : c->W) if (kv.first.size() > tail.size() && kv.first.compare(kv.first.size() - tail.size(), tail.size(), tail) == 0)
+      keys.push_back(kv.first.substr(0, kv.first.size() - 6));                 // "... .conv." (UNet and VAE decoder)
     for (const std::string& k : keys) {
       const WMat* w = getW(c, k + "weight"); auto bi = c->V.find(k + "bias");
       if (!w || bi == c->V.end()) return fail_ctx(c);
@@ -1420,7 +1426,7 @@ AGD_API int agd_set_option(agd_ctx* c, const char* name, int value) {
   if (!strcmp(name, "conv_smap")) { c->opt_smap = value != 0; return 0; }
   if (!strcmp(name, "side_stream")) { c->opt_side = value < 0 ? 0 : value; return 0; }
   if (!strcmp(name, "igemm_kgroups")) { c->opt_kg2 = value != 0; return 0; }
-  if (!strcmp(name, "upsample_phases")) { c->opt_ups4 = value != 0; return 0; }
+  if (!strcmp(name, "upsample_phases")) { c->opt_ups4 = value & 7; return 0; }      // bit 0: the UNet's upsamplers from 16 x 16 maps up, bit 1: the VAE decoder's, bit 2: the UNet's 8 x 8 -> 16 x 16 one too
   if (!strcmp(name, "ff_proj_fuse")) { c->opt_ffproj = value != 0; return 0; }
   if (!strcmp(name, "shortcut_fuse")) { c->opt_sc_fuse = value & 3; return 0; }      // bit 0: row-halo launches (64 x 64 .. 16 x 16 maps), bit 1: the 8 x 8 whole-images launches
   if (!strcmp(name, "wreg_mask")) { c->opt_wreg = value & 2; return 0; }
