@@ -645,11 +645,11 @@ static int launch_8p(const IgemmP& p, hipStream_t st) {
   if (p.geglu) {
     if constexpr (G::NI == 4) kfn = (const void*)igemm8p_kernel<WM, WN, MI, NI0, NI1, 1, 1>;
     if (!kfn || p.ksize != 1) { agd_set_error("igemm8p: geglu only on 1x1 with the 256-wide tile"); return -1; }
-  } else kfn = p.ksize == 3 ? (const void*)igemm8p_kernel<WM, WN, MI, NI0, NI1, 3, 0> : (const void*)igemm8p_kernel<WM, WN, MI, NI0, NI1, 1, 0>;
-  static bool attr[AGD_MAX_DEVICES][3] = {};
+  } else kfn = p.ksize == 3 ? (const void*)igemm8p_kernel<WM, WN, MI, NI0, NI1, 3, 0> : p.ksize == 2 ? (const void*)igemm8p_kernel<WM, WN, MI, NI0, NI1, 2, 0> : (const void*)igemm8p_kernel<WM, WN, MI, NI0, NI1, 1, 0>;
+  static bool attr[AGD_MAX_DEVICES][4] = {};
   int dev = 0; HIP_CHECK_RET(hipGetDevice(&dev));
   if (dev < 0 || dev >= AGD_MAX_DEVICES) { agd_set_error("igemm8p: device ordinal %d out of range", dev); return -1; }
-  const int slot = p.geglu ? 2 : p.ksize == 3 ? 1 : 0;
+  const int slot = p.geglu ? 2 : p.ksize == 3 ? 1 : p.ksize == 2 ? 3 : 0;
   if (!attr[dev][slot]) { HIP_CHECK_RET(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS)); attr[dev][slot] = true; }
   IgemmP pp = p;
   void* args[] = {&pp};
@@ -715,7 +715,13 @@ int launch_igemm(const IgemmP& p_in, hipStream_t st) {
   if (p.ups4) {          // phase-decomposed upsampling conv: the general 4-wave kernel on 128-row tiles that stay inside one phase
     if (p.ksize != 2 || p.stride != 1 || p.up != 1 || p.Hin != p.Hout || p.Win != p.Wout || p.N != 4 * p.ups4 || p.C1 || p.geglu || p.residual || p.rowadd || p.out_f32 || p.w_per_image ||
         p.sc0 || (p.batch > 1) || p.ldo != p.ups4 || (p.ups4 % 160 && p.ups4 % 128) || p.rowstat_out || p.ln_stats) { agd_set_error("igemm: unsupported phase-conv launch"); return -1; }
+    const int p8 = p.p8;
     p.p8 = 0; p.smap = 0; p.halo = 0; p.warm = 0;
+    // the 8-phase kernel where its 256-row tiles fill the chip and stay inside one phase (160- or 256-wide), else the 4-wave general kernel
+    if (p8 && p.M % 256 == 0 && p.M < (1 << 24) && (long long)p.N * p.K * 2 < (1LL << 31) && (long long)p.Hin * p.Win * p.C0 * 2 * (p.M / (p.Hout * p.Wout) + 1) < (1LL << 31)) {
+      if (p.ups4 % 256 == 0 && (long long)(p.M / 256) * (p.N / 256) >= 256) return launch_8p<2, 4, 8, 2, 2>(p, st);
+      if (p.ups4 % 160 == 0 && (long long)(p.M / 256) * (p.N / 160) >= 256) return launch_8p<4, 2, 4, 3, 2>(p, st);
+    }
     return (p.ups4 % 160) == 0 ? launch_cfg<128, 160, 2, 2>(p, 1, st) : launch_cfg<128, 128, 2, 2>(p, 1, st);
   }
   if (p.M < 1 || p.N < 1) { agd_set_error("igemm: empty problem M=%d N=%d", p.M, p.N); return -1; }

@@ -96,6 +96,9 @@ __global__ __launch_bounds__(512, 2) void igemm8p_kernel(const IgemmP p) {
   // Their im2col offsets are fixed within a (tap, source) segment and recomputed from the row index when the segment changes (nothing
   // but the four offsets lives across the loop).
   const bool lin = KS == 1;                           // the launcher routes only stride-1 / pad-0 1x1 launches here: im2col row = pixel
+  // KS = 2: the phase convs of an upsampling conv (IgemmP::ups4, see igemm.hip): this tile's phase (a, b) = n0 / Cout pads (1 - a) rows above, (1 - b) columns left
+  const int ph4 = (KS == 2 && p.ups4) ? n0 / p.ups4 : 0;
+  const int pad_y = (KS == 2 && p.ups4) ? 1 - (ph4 >> 1) : p.pad, pad_x = (KS == 2 && p.ups4) ? 1 - (ph4 & 1) : p.pad;
   const int HWo = p.Hout * p.Wout;
   const int ush = (p.up == 2) ? 1 : 0;
   const float inv_hwo = 1.0f / (float)HWo, inv_wo = 1.0f / (float)p.Wout;
@@ -104,7 +107,7 @@ __global__ __launch_bounds__(512, 2) void igemm8p_kernel(const IgemmP p) {
   unsigned asoff = 0, bsoff = 0;
   auto set_segment = [&](int tap_, int src_) {
     tap = tap_; cursrc = src_;
-    const int kh = (KS == 3) ? tap / 3 : 0, kw = (KS == 3) ? tap - kh * 3 : 0;
+    const int kh = (KS > 1) ? tap / KS : 0, kw = (KS > 1) ? tap - kh * KS : 0;
     const int Cs = cursrc ? p.C1 : p.C0;
     seg_left = Cs >> 6; asoff = 0;
 #pragma unroll
@@ -119,7 +122,7 @@ __global__ __launch_bounds__(512, 2) void igemm8p_kernel(const IgemmP p) {
           const int mm = ok ? m : 0;
           const int b = fast_udiv(mm, HWo, inv_hwo); const int rem = mm - b * HWo;
           const int oy = fast_udiv(rem, p.Wout, inv_wo), ox = rem - oy * p.Wout;
-          const int iy = oy * p.stride - p.pad + kh, ix = ox * p.stride - p.pad + kw;
+          const int iy = oy * p.stride - pad_y + kh, ix = ox * p.stride - pad_x + kw;
           ok = ok && (unsigned)iy < (unsigned)(p.Hin << ush) && (unsigned)ix < (unsigned)(p.Win << ush);
           pix = (b * p.Hin + (iy >> ush)) * p.Win + (ix >> ush);
         }

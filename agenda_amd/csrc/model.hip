@@ -229,7 +229,7 @@ static int run_conv(agd_ctx* c, hipStream_t st, const bf16_t* s0, int C0, const 
   p.halo = (c && c->opt_halo) || o.halo;
   p.smap = (c && c->opt_smap) || o.smap;
   p.kg2 = (c && c->opt_kg2) || o.kg2;
-  p.p8 = o.p8 ? o.p8 : c ? c->opt_p8 : 0;          // before any igemm_query: the tile shape depends on it
+  p.p8 = o.p8 < 0 ? 0 : o.p8 ? o.p8 : c ? c->opt_p8 : 0;          // before any igemm_query: the tile shape depends on it (-1: not for this launch)
   if (o.can_fuse_sc) { *o.can_fuse_sc = igemm_can_fuse_shortcut(p) ? 1 : 0; return 0; }
   if (o.query_cfg) { if (o.want_rowstat && !p.rowstat_out) { p.rowstat_out = (float*)16; p.rowstat_slots = 0; } return igemm_query(p, o.query_cfg); }   // (nothing is launched)
   if (o.out_act) {
@@ -800,6 +800,7 @@ static int unet_walk(agd_ctx* c, hipStream_t st, const bf16_t* xin, int B2, int 
         // conv3x3(nearest2x(x)) = four 2x2 convs on x, one per output phase, with the taps that coincide pre-summed (misc.hip upsample_phase_weight_kernel): 4/9 of the MACs
         GETW(w4, k + "phases"); GETV(b4, k + "phases.bias");
         GemmOpt o; o.bias = b4; o.out_act = &d; o.ups4 = co; o.hout = h.H; o.wout = h.W; o.ldo = co; o.pad = 0;
+        if (c->opt_ups4 & 8) o.p8 = -1;                    // (A/B: keep the phase convs on the 4-wave kernel)
         CK(run_conv(c, st, h.p, co, nullptr, 0, B2, h.H, h.W, *w4, 2, d.p, o, c->zero_page));
       } else {
       GemmOpt o; o.bias = b; o.up = 2; o.out_act = &d;
@@ -886,6 +887,7 @@ static int vae_walk(agd_ctx* c, hipStream_t st, const bf16_t* zin, int B, int L,
       if ((c->opt_ups4 & 2) && c->W.count(k + "phases")) {              // four 2x2 phase convs on the un-upsampled map (as in the UNet walk)
         GETW(w4, k + "phases"); GETV(b4, k + "phases.bias");
         GemmOpt o; o.bias = b4; o.out_act = &d; o.ups4 = co; o.hout = h.H; o.wout = h.W; o.ldo = co; o.pad = 0;
+        if (c->opt_ups4 & 8) o.p8 = -1;
         CK(run_conv(c, st, h.p, co, nullptr, 0, B, h.H, h.W, *w4, 2, d.p, o, c->zero_page));
       } else {
       GemmOpt o; o.bias = b; o.up = 2; o.out_act = &d;
@@ -1426,7 +1428,7 @@ AGD_API int agd_set_option(agd_ctx* c, const char* name, int value) {
   if (!strcmp(name, "conv_smap")) { c->opt_smap = value != 0; return 0; }
   if (!strcmp(name, "side_stream")) { c->opt_side = value < 0 ? 0 : value; return 0; }
   if (!strcmp(name, "igemm_kgroups")) { c->opt_kg2 = value != 0; return 0; }
-  if (!strcmp(name, "upsample_phases")) { c->opt_ups4 = value & 7; return 0; }      // bit 0: the UNet's upsamplers from 16 x 16 maps up, bit 1: the VAE decoder's, bit 2: the UNet's 8 x 8 -> 16 x 16 one too
+  if (!strcmp(name, "upsample_phases")) { c->opt_ups4 = value & 15; return 0; }      // bit 0: the UNet's upsamplers from 16 x 16 maps up, bit 1: the VAE decoder's, bit 2: the UNet's 8 x 8 -> 16 x 16 one too
   if (!strcmp(name, "ff_proj_fuse")) { c->opt_ffproj = value != 0; return 0; }
   if (!strcmp(name, "shortcut_fuse")) { c->opt_sc_fuse = value & 3; return 0; }      // bit 0: row-halo launches (64 x 64 .. 16 x 16 maps), bit 1: the 8 x 8 whole-images launches
   if (!strcmp(name, "wreg_mask")) { c->opt_wreg = value & 2; return 0; }
@@ -1749,7 +1751,7 @@ AGD_API int agd_op_conv2d_ex(const float* x, const float* w, const float* bias, 
       else if (hipMemsetAsync(b4 + (size_t)ph * Cout, 0, Cout * sizeof(float), st) != hipSuccess) { agd_set_error("op_conv2d: bias clear"); return -1; }
     }
     WMat wm4; wm4.w = w4; wm4.N = 4 * Cout; wm4.Cin = Cin; wm4.Cpad = Cpad; wm4.taps = 4;
-    GemmOpt o4; o4.bias = b4; o4.ups4 = Cout; o4.hout = H; o4.wout = W; o4.ldo = Cout; o4.pad = 0;
+    GemmOpt o4; o4.bias = b4; o4.ups4 = Cout; o4.hout = H; o4.wout = W; o4.ldo = Cout; o4.pad = 0; o4.p8 = o.p8;
     CK(run_conv(nullptr, st, xb, Cpad, nullptr, 0, B, H, W, wm4, 2, yb, o4, op_zero_page()));
     CK(launch_bf16_to_f32(yb, yn, (long long)B * Ho * Wo * Cout, st));
   } else

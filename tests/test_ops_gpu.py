@@ -383,8 +383,8 @@ def test_conv3x3_row_halo_kernel_upsampled(ops, B, C, H, Co):
     assert float((got - ref).abs().max()) / scale < 1e-5
 
 
-@pytest.mark.parametrize("B,C,H,Co", [(8, 640, 32, 640), (8, 1280, 16, 1280), (2, 128, 32, 160), (3, 192, 24, 256), (1, 64, 16, 128)])
-def test_upsampling_conv_as_four_phase_convs(ops, B, C, H, Co):
+@pytest.mark.parametrize("B,C,H,Co,p8", [(8, 640, 32, 640, 0), (8, 640, 32, 640, 1), (8, 1280, 16, 1280, 1), (4, 256, 64, 256, 1), (2, 128, 32, 160, 0), (3, 192, 24, 256, 0), (1, 64, 16, 128, 1)])
+def test_upsampling_conv_as_four_phase_convs(ops, B, C, H, Co, p8):
     """Upsample2D.conv -- conv3x3(nearest2x(x)) -- as four 2x2 convs on the un-upsampled map, one per output phase (2 i + a, 2 j + b), with the taps that coincide
     pre-summed (IgemmP::ups4: one launch of the general igemm over N = 4 Cout, the epilogue writes the pixel-shuffled rows): 4/9 of the MACs.  vs F.conv2d on the
     upsampled input (bf16 output and bf16-rounded merged weights: 2^-7) and vs the production upsampling kernel; an M tail (B = 3, 24 x 24) and the borders of every phase."""
@@ -393,12 +393,12 @@ def test_upsampling_conv_as_four_phase_convs(ops, B, C, H, Co):
     w = bfr(torch.randn(Co, C, 3, 3, generator=g) / (3 * C ** 0.5))
     b = torch.randn(Co, generator=g)
     want = F.conv2d(F.interpolate(x, scale_factor=2.0, mode="nearest"), w, b, padding=1)
-    got = ops.conv2d(x.cuda(), w.cuda(), b.cuda(), upsample=True, phases=True).cpu()
+    got = ops.conv2d(x.cuda(), w.cuda(), b.cuda(), upsample=True, phases=True, p8=p8).cpu()      # p8 = 1: the 8-phase kernel where the launcher takes it (256-row tiles inside one phase, >= 256 of them)
     ref = ops.conv2d(x.cuda(), w.cuda(), b.cuda(), upsample=True, halo=True).cpu()
     scale = float(want.abs().max())
     assert float((got - want).abs().max()) / scale < REL, float((got - want).abs().max()) / scale
     assert float((got - ref).abs().max()) / scale < REL
-    assert torch.equal(got, ops.conv2d(x.cuda(), w.cuda(), b.cuda(), upsample=True, phases=True).cpu())
+    assert torch.equal(got, ops.conv2d(x.cuda(), w.cuda(), b.cuda(), upsample=True, phases=True, p8=p8).cpu())
 
 
 def test_igemm_random_shape_sweep(ops):
