@@ -216,6 +216,38 @@ def test_fused_transformer_block_kernels_match_the_kernel_chain_512px(sd15_host_
         assert h_o < 0.02, (key, h_o)
 
 
+@pytest.mark.parametrize("side,B", [(384, 3), (640, 1), (256, 5)])
+def test_merged_launches_at_odd_sizes_match_the_unmerged_walk(sd15_pipe, side, B):
+    """Shapes the bench never runs -- 48 / 80 / 32-pixel latent maps, batches 3 / 1 / 5 -- through every round-4 merge at its default (fused row-panel kernels, slab pass + GroupNorm,
+    shortcut / ff-proj / upsampling merges, K groups, weight-streaming kernel) against the same two denoise steps with all of them off: each merge decides from the launch's
+    shape whether it applies (row-halo geometry, tiles inside one image or phase, partial sums present), so an odd size must fall back cleanly, never fault or diverge.  Two valid
+    realisations of the same steps: classifier-free guidance multiplies their bf16 noise (cf. the shared-prefix test), the bound is calibrated there."""
+    from agenda_amd import synthetic
+    pipe = sd15_pipe
+    cfg = pipe.cfg
+    L = side // 8
+    ctx = synthetic.make_context(cfg, B, seed=side)
+    lat = synthetic.make_latents(cfg, list(range(B)), L)
+    off = {"tblock_fuse": 0, "reduce_gn": 0, "shortcut_fuse": 0, "ff_proj_fuse": 0, "upsample_phases": 0, "igemm_kgroups": 0, "wreg_mask": 0, "conv_smap": 0}
+    on = {"tblock_fuse": 255, "reduce_gn": 1, "shortcut_fuse": 3, "ff_proj_fuse": 1, "upsample_phases": 3, "igemm_kgroups": 1, "wreg_mask": 2, "conv_smap": 1}
+
+    def run():
+        return pipe(prompt_embeds=ctx, latents=lat, num_inference_steps=2, height=side, width=side, output_type="latent").latents.clone()
+
+    try:
+        a = run()
+        for k, v in off.items():
+            pipe.engine.set_option(k, v)
+        b = run()
+    finally:
+        for k, v in on.items():
+            pipe.engine.set_option(k, v)
+    assert torch.isfinite(a).all() and torch.isfinite(b).all()
+    e = _rms_rel(a, b.cpu())
+    print(f"{side} px, batch {B}: merged vs unmerged walk, two steps: latents rms rel {e:.5f}")
+    assert e < 0.08, e
+
+
 def test_cfg_shared_prefix_inside_the_fused_kernels_512px(sd15_pipe):
     """`cfg_shared_prefix` with the fused block kernels behind it (tblock_fuse bit 6): the B' shared rows are not copied -- the attn2 chain reads input
     row m % M' (and starts at attn1.to_out), the feed-forward's proj_out stage adds block-input row m % M'.  Two denoise steps at 512 px against the
