@@ -826,7 +826,7 @@ int launch_igemm(const IgemmP& p_in, hipStream_t st) {
       const int wn = w160 ? 5 : 4, kgn = kg2 ? 2 : 1;
       IgemmP pp = p;
       void* args[] = {&pp};
-      HIP_CHECK_RET(hipLaunchKernel(kfn, dim3((unsigned)tiles), dim3(wn * 64 * kgn), args, kgn * (3 * 64 * 128 + wn * 1024), st));
+      HIP_CHECK_RET(hipLaunchKernel(kfn, dim3((unsigned)tiles), dim3(wn * 64 * kgn), args, kgn * (3 * 64 * 128 + wn * 1024) + 64 * 8, st));
       return 0;
     }
   }

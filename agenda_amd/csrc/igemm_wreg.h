@@ -12,8 +12,10 @@
 #pragma once
 #include "igemm_epilogue.h"
 
-#define WR_F 8      // weight-fragment ring (registers), filled WR_D fragments ahead
-#define WR_D 6
+// weight-fragment ring (registers), filled WR_D fragments ahead: 8 / 6 for the plain kernels; the GEGLU form (NI = 4: eight fragments per stage) keeps two stages of
+// fragments (16 / 14) in flight -- its 26 MB matrices arrive cold from HBM in situ
+#define WR_F (NI == 4 ? 16 : 8)
+#define WR_D (NI == 4 ? 14 : 6)
 // WN = 5: 160-wide tiles (N = 1280 at M = 2048: exactly 256 workgroups); waves 0 - 3 of a group stage the activations.
 // KG = 2: two K groups of WN waves per workgroup -- group g walks the 64-deep stages g, g + 2, ... with its own activation ring, weight-fragment ring and
 // accumulators and hands its sums to group 0 through LDS before the epilogue (igemm_kernel's KG = 2, where the LDS-DMA path made it lose on these tiles;
@@ -85,6 +87,17 @@ __global__ __launch_bounds__(WN * 64 * KG, 2) void igemm_wreg_kernel(const Igemm
 #pragma unroll
     for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  // LayerNorm-fold consumer (as igemm_kernel): one thread per tile row sums the producer's partial sums while the prologue loads are in flight and leaves (mean, rstd)
+  // in LDS behind the rings -- the epilogue then reads two floats per row instead of chasing `slots` loads per row
+  float* const lnst = (float*)(smem_all + KG * STG * A_BYTES + KG * WN * 1024);
+  if (p.ln_stats && threadIdx.x < BM) {
+    const int m = m0 + (int)threadIdx.x;
+    float S = 0.f, Q = 0.f;
+    if (m < p.M) for (int k = 0; k < p.ln_slots; ++k) { const f32x2 v = *(const f32x2*)(p.ln_stats + ((long long)m * p.ln_slots + k) * 2); S += v[0]; Q += v[1]; }
+    const float mu = S * p.ln_invC;
+    float var = Q * p.ln_invC - mu * mu; var = var < 0.f ? 0.f : var;
+    *(f32x2*)(lnst + threadIdx.x * 2) = f32x2{mu, rsqrtf(var + p.ln_eps)};
+  }
   // prologue: activation stages 0, 1 requested, the ring's head in flight, stage 0 into LDS
   a_load(0, 0);
   if (nk > 1) a_load(1, 1);
@@ -152,5 +165,5 @@ __global__ __launch_bounds__(WN * 64 * KG, 2) void igemm_wreg_kernel(const Igemm
 #pragma unroll
       for (int j = 0; j < NI; ++j) acc[i][j] += xch[(i * NI + j) * 64];
   }
-  igemm_epilogue<BM, BN, 1, WN, GEGLU, 0>(p, acc, smem_all, lane, 0, wid, m0, n0, tn, 0, nullptr);
+  igemm_epilogue<BM, BN, 1, WN, GEGLU, 0>(p, acc, smem_all, lane, 0, wid, m0, n0, tn, 0, p.ln_stats ? lnst : nullptr);
 }

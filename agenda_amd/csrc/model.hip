@@ -121,7 +121,7 @@ struct agd_ctx {
   int opt_ups4 = 3; /* see agd_set_option */                                   // agd_set_option("upsample_phases"): the UNet's nearest-2x upsampling convs as four 2x2 phase convs on the un-upsampled map (one launch, 4/9 of the MACs)
   int opt_ffproj = 1;                                 // agd_set_option("ff_proj_fuse"): ff.net.2 and proj_out as ONE GEMM with the pre-multiplied matrix [Wp W2 | Wp] over [hidden | h] (blocks whose feed-forward is not the fused row-panel kernel)
   int opt_sc_fuse = 3;                                // agd_set_option("shortcut_fuse"): a UNet resnet's 1x1 conv_shortcut runs as extra K of its conv2 launch where that is an unsplit row-halo launch
-  int opt_wreg = 2;                                   // agd_set_option("wreg_mask"): weight-streaming kernel (igemm_wreg.h) for bit 1: proj_in / proj_out of the C = 640 blocks (bit 0, the C = 1280 GEGLU at M = 2048: measured slower in situ, removed)
+  int opt_wreg = 3;                                   // agd_set_option("wreg_mask"): weight-streaming kernel (igemm_wreg.h) for bit 0: the C = 1280 GEGLU at 1024 <= M <= 4096 (the 16 x 16 blocks), bit 1: proj_in / proj_out of the C = 640 blocks
   int opt_kg2 = 1;                                    // agd_set_option("igemm_kgroups"): two K groups of waves per workgroup on the one-workgroup-per-CU 1x1 launches of the small maps
   int opt_side = 0;                                   // agd_set_option("side_stream"): a resnet's 1x1 conv_shortcut runs on a second stream beside norm1 / conv1 / norm2
   hipStream_t side = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -528,6 +528,7 @@ static int transformer(agd_ctx* c, hipStream_t st, const std::string& pre, const
       const std::string k = wkey + ".lnfold";
       GETW(wf, k); GETV(cs, k + ".cs"); GETV(bf, k + ".bias");
       GemmOpt o; o.bias = bf; o.geglu = geglu; o.ln_stats = stats; o.ln_slots = slots; o.ln_cs = cs; o.ln_invC = 1.0f / (float)C; o.ln_eps = lneps;
+      if (geglu && C == 1280 && M >= 1024 && M <= 4096 && (c->opt_wreg & 1) && wf->wfrag) o.wreg = 2;
       return run_conv(c, st, h.p, C, nullptr, 0, 1, 1, M, *wf, 1, outp, o, c->zero_page);
     }
     GETV(g, lnkey + ".weight"); GETV(b, lnkey + ".bias");
@@ -1075,6 +1076,14 @@ AGD_API int agd_finalize(agd_ctx* c) {
       const std::string k = t + f.w + ".lnfold";
       c->W[k] = wf; c->V[k + ".cs"] = cs; c->V[k + ".bias"] = bf; c->Vn[k + ".cs"] = w->N; c->Vn[k + ".bias"] = w->N;
     }
+    if (q->N == 1280) {                                 // the C = 1280 GEGLU matrix once more in igemm_wreg.h's fragment order (option wreg_mask bit 0)
+      auto it = c->W.find(t + "ff.net.0.proj.weight.lnfold");
+      if (it != c->W.end() && it->second.taps == 1 && it->second.N % 256 == 0) {
+        WMat& wm_ = it->second;
+        wm_.wfrag = dmalloc<bf16_t>(c, (size_t)wm_.N * wm_.Cpad); if (!wm_.wfrag) return fail_ctx(c);
+        API_CK(c, launch_frag_order_w(wm_.w, wm_.wfrag, wm_.N, wm_.Cpad, 4, wm_.Cpad, 0)); wm_.wfrag_ni = 4;
+      }
+    }
     // ff.net.2 and proj_out pre-multiplied: [Wp W2 | Wp] (rows of 5 C) and Wp b2 + bp, for the blocks whose feed-forward runs as separate launches
     { const WMat* w2 = getW(c, t + "ff.net.2.weight"); const WMat* wp = getW(c, pr.first + "proj_out.weight");
       auto b2 = c->V.find(t + "ff.net.2.bias"); auto bp = c->V.find(pr.first + "proj_out.bias");
@@ -1431,7 +1440,7 @@ AGD_API int agd_set_option(agd_ctx* c, const char* name, int value) {
   if (!strcmp(name, "upsample_phases")) { c->opt_ups4 = value & 15; return 0; }      // bit 0: the UNet's upsamplers from 16 x 16 maps up, bit 1: the VAE decoder's, bit 2: the UNet's 8 x 8 -> 16 x 16 one too
   if (!strcmp(name, "ff_proj_fuse")) { c->opt_ffproj = value != 0; return 0; }
   if (!strcmp(name, "shortcut_fuse")) { c->opt_sc_fuse = value & 3; return 0; }      // bit 0: row-halo launches (64 x 64 .. 16 x 16 maps), bit 1: the 8 x 8 whole-images launches
-  if (!strcmp(name, "wreg_mask")) { c->opt_wreg = value & 2; return 0; }
+  if (!strcmp(name, "wreg_mask")) { c->opt_wreg = value & 3; return 0; }
   if (!strcmp(name, "igemm8p")) { c->opt_p8 = value < 0 ? 0 : value; return 0; }   // 0 off, 1 on (the launcher decides per launch); tests: 2 / 3 / 4 force the 256-wide / 160-wide / any legal tile
   agd_set_error("set_option: unknown option '%s'", name);
   return fail_ctx(c);

@@ -130,7 +130,8 @@ int agd_vae_encode(agd_ctx* ctx, const float* image, int batch, int side, float*
  * blocks whose feed-forward is not the fused row-panel kernel; 0 = two launches.
  * "shortcut_fuse" (default 3): a UNet ResnetBlock2D's 1x1 conv_shortcut runs as extra K of its conv2 launch (the shortcut's output is never stored) -- bit 0: where conv2 is a
  * row-halo launch (the 64 x 64 .. 16 x 16 maps), bit 1: the 8 x 8 whole-images launches; 0 = its own launch, added as conv2's residual.
- * "wreg_mask" (default 2): bit 1 = proj_in / proj_out of the C = 640 transformer blocks run the weight-streaming kernel (igemm_wreg.h: weight fragments straight to registers).
+ * "wreg_mask" (default 3): the weight-streaming kernel (igemm_wreg.h: weight fragments straight to registers) for bit 0 = the GEGLU projection of the C = 1280 blocks at 16 x 16,
+ * bit 1 = proj_in / proj_out of the C = 640 transformer blocks.
  * "igemm_kgroups" (default 1): the unsplit 1x1 launches on 64 x 64 tiles (8 x 8 maps: at most one workgroup per CU) run two K groups of four waves per workgroup.
  * "side_stream" (default 0; measured slower, kept for the A/B): a resnet's 1x1 conv_shortcut runs on a second stream beside norm1 / conv1 / norm2. */
 int agd_set_option(agd_ctx* ctx, const char* name, int value);
