@@ -104,6 +104,7 @@ struct FFusedP {
   // colstat (optional): [M / 128][C] float2 per-(tile, channel) sums of the bf16 outputs for the GroupNorm that reads pout
   const bf16_t* wpf; const float* bp; const bf16_t* xres; bf16_t* pout; float* colstat;
   int xres_rows;                    // > 0: xres holds xres_rows rows, output row m adds row m % xres_rows (CFG-shared prefix)
+  int premul;                       // 1 (with wpf): w2f holds Wp W2 and bp holds Wp b2 + bp (pre-multiplied at load time); the proj_out stage adds Wp . h on top of GEMM2's sums
 };
 int launch_ff_fused(const FFusedP& p, int C, hipStream_t st);
 // norm2 -> to_q -> cross-attention (77 keys, recorder optional) -> to_out + bias + residual in one launch; 8 heads of 40

@@ -116,8 +116,8 @@ struct agd_ctx {
   int opt_gn_proj_fold = 1;                           // agd_set_option("gn_proj_fold"): the transformers' GroupNorm folded into per-image proj_in matrices (1: C <= 320, 2: C <= 640)
   int opt_p8 = 1;                                     // agd_set_option("igemm8p"): 256-row 8-wave / 8-phase igemm for launches with enough tiles (igemm8p.h)
   int opt_halo = 1;                                   // agd_set_option("conv_halo"): 3x3 stride-1 convs through the row-halo kernel (igemm_halo.h)
-  int opt_tb_fuse = 255;                               // agd_set_option("tblock_fuse"): fused row-panel kernels of the C = 320 transformer blocks (tblock.hip): bit 0 = feed-forward (bit 3: + proj_out),
-                                                      // bit 1 = attn2 chain (bit 2: + attn1.to_out in front of it), bit 4 = proj_in -> norm1 -> qkv, bit 5 = the attn2 chain for the C = 640 blocks too, bit 6 = the CFG-shared prefix's duplication inside the fused kernels, bit 7 = the GroupNorm applied inside the bit-4 launch (no fold launch), bit 8 (off) = the bit-4 launch with the GroupNorm inside for the C = 640 blocks
+  int opt_tb_fuse = 255 | 512;                               // agd_set_option("tblock_fuse"): fused row-panel kernels of the C = 320 transformer blocks (tblock.hip): bit 0 = feed-forward (bit 3: + proj_out),
+                                                      // bit 1 = attn2 chain (bit 2: + attn1.to_out in front of it), bit 4 = proj_in -> norm1 -> qkv, bit 5 = the attn2 chain for the C = 640 blocks too, bit 6 = the CFG-shared prefix's duplication inside the fused kernels, bit 7 = the GroupNorm applied inside the bit-4 launch (no fold launch), bit 8 (off) = the bit-4 launch with the GroupNorm inside for the C = 640 blocks, bit 9 = ff.net.2 / proj_out pre-multiplied inside the feed-forward kernel
   int opt_ups4 = 3; /* see agd_set_option */                                   // agd_set_option("upsample_phases"): the UNet's nearest-2x upsampling convs as four 2x2 phase convs on the un-upsampled map (one launch, 4/9 of the MACs)
   int opt_ffproj = 1;                                 // agd_set_option("ff_proj_fuse"): ff.net.2 and proj_out as ONE GEMM with the pre-multiplied matrix [Wp W2 | Wp] over [hidden | h] (blocks whose feed-forward is not the fused row-panel kernel)
   int opt_sc_fuse = 3;                                // agd_set_option("shortcut_fuse"): a UNet resnet's 1x1 conv_shortcut runs as extra K of its conv2 launch where that is an unsplit row-halo launch
@@ -673,6 +673,10 @@ static int transformer(agd_ctx* c, hipStream_t st, const std::string& pre, const
     if ((c->opt_tb_fuse & 8) && c->W.count(pre + "proj_out.frag")) {      // proj_out + residual (+ the next GroupNorm's partial sums) behind it, same launch
       GETW(fpw, pre + "proj_out.frag"); GETV(bp, pre + "proj_out.bias");
       fp.wpf = fpw->w; fp.bp = bp; fp.xres = xres; fp.pout = out.p;
+      if ((c->opt_tb_fuse & 512) && c->W.count(t + "ff.w2p.frag")) {      // ff.net.2 and proj_out pre-multiplied (as ff_proj_fuse does for the other blocks): no intermediate h3
+        GETW(f2p, t + "ff.w2p.frag"); GETV(bcp, pre + "ffproj.bias");
+        fp.w2f = f2p->w; fp.bp = bcp; fp.premul = 1;
+      }
       if (lazy_dup) fp.xres_rows = Mshared;             // xres is still the B'-row block input
       out.cpart_bm = 0;
       if (out.cpart && c->opt_gn_fused && HW % 128 == 0) { fp.colstat = out.cpart; out.cpart_bm = 128; }
@@ -1108,6 +1112,14 @@ AGD_API int agd_finalize(agd_ctx* c) {
         }
         if (hipMemcpy(bc, hbp.data(), C * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) { agd_set_error("finalize: ff/proj bias write failed"); return fail_ctx(c); }
         c->W[pr.first + "ffproj.weight"] = wc; c->V[pr.first + "ffproj.bias"] = bc; c->Vn[pr.first + "ffproj.bias"] = C;
+        if (C == 320) {                                   // the fused feed-forward kernel's form of it: Wp W2 alone, in ff.net.2's fragment order
+          bf16_t* tmpc = dmalloc<bf16_t>(c, (size_t)C * 4 * C); WMat f2p = *w2; f2p.wfrag = nullptr; f2p.wfrag_ni = 0;
+          f2p.w = dmalloc<bf16_t>(c, (size_t)C * 4 * C);
+          if (!tmpc || !f2p.w) return fail_ctx(c);
+          if (hipMemcpy2D(tmpc, (size_t)4 * C * 2, wc.w, (size_t)5 * C * 2, (size_t)4 * C * 2, C, hipMemcpyDeviceToDevice) != hipSuccess) { agd_set_error("finalize: Wp W2 copy failed"); return fail_ctx(c); }
+          API_CK(c, launch_frag_order_w(tmpc, f2p.w, C, 4 * C, C / 64, 128, 0));
+          c->W[t + "ff.w2p.frag"] = f2p;
+        }
       } }
     // fused row-panel kernels (tblock.hip, C = 320 blocks): the matrices once more in MFMA fragment order
     if (q->N == 320 || q->N == 640) {                 // (C = 640: the attn2 chain only -- a wave's GEMM tile is 80 columns whatever C: NI = 5)

@@ -168,15 +168,17 @@ AGD_DEV void panel_gemm_head(u32x4 (&ring)[TB_F], const bf16_t* wf, unsigned wba
 #pragma unroll
   for (int f = 0; f < TB_D; ++f) ring[f % TB_F] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, lane16, wbase + (unsigned)f * 1024u, 0));
 }
-template <int C>
+template <int C, bool ZERO = true>     // ZERO = false: accumulate on top of what acc holds
 AGD_DEV void panel_gemm_body(u32x4 (&ring)[TB_F], f32x4 (&acc)[4][5], const bf16_t* wf, unsigned wbase, unsigned lane16, const char* xrow, const XOff<C>& xo,
                              unsigned wbytes = C * C * 2) {
   constexpr int NI = 5, KS = C / 32, NFR = KS * NI, PITCH = C * 2;       // a wave's tile is 64 rows x 80 columns whatever C
   const auto wrs = __builtin_amdgcn_make_buffer_rsrc((void*)wf, 0, wbytes, 0x00020000);
+  if constexpr (ZERO) {
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
   bf16x8 xf[4];
 #pragma unroll
   for (int f = 0; f < NFR; ++f) {
@@ -369,9 +371,13 @@ __global__ __launch_bounds__(512, 2) void ff_fused_kernel(const FFusedP p) {
   // GroupNorm reads (IgemmP::colstat_out's layout).
   const int ncol0 = (C / 4) * nq + 4 * NI2 * q;
   constexpr bool post = POST != 0;
+  // POST = 2: ff.net.2 and proj_out pre-multiplied (model.hip, ff_proj_fuse): w2f holds Wp W2, bp holds Wp b2 + bp, and the proj_out stage is the REST of the product,
+  // Wp . h, accumulated on top of GEMM2's sums straight from the raw rows in the panel -- no intermediate h3, no rounding, no panel rewrite, no barrier
+  constexpr bool premul = POST == 2;
   static_assert(F == TB_F, "the proj_out stage reuses the weight ring");
   const unsigned pwbase = __builtin_amdgcn_readfirstlane((unsigned)(nq * KS1 * NI2) * 1024u);
   if (post) panel_gemm_head<C>(ring, p.wpf, pwbase, lane16);
+  if constexpr (!premul) {
   float b2v[NI2 * 4];
 #pragma unroll
   for (int t = 0; t < NI2; ++t) *(f32x4*)&b2v[4 * t] = *(const f32x4*)(p.b2 + ncol0 + 4 * t);
@@ -391,12 +397,13 @@ __global__ __launch_bounds__(512, 2) void ff_fused_kernel(const FFusedP p) {
     }
     if (!post) store_row_chunk<NI2>(p.out + (long long)m * C + ncol0, pk);
   }
+  }
   if constexpr (post) {
-  __syncthreads();                                       // h3 complete in the panel (every GEMM1 read of the raw rows is long done)
+  if constexpr (!premul) __syncthreads();                // h3 complete in the panel (every GEMM1 read of the raw rows is long done)
   u32x2 xr[4][NI2];                                      // the residual rows (HBM-cold) are requested ahead of the GEMM, not in its epilogue
 #pragma unroll
   for (int i = 0; i < 4; ++i) { const int m = m0 + rbase + 16 * i, ms = m < p.M ? (p.xres_rows > 0 ? m % p.xres_rows : m) : 0; load_row_chunk<NI2>(p.xres + (long long)ms * C + ncol0, xr[i]); }
-  panel_gemm_body<C>(ring, acc2, p.wpf, pwbase, lane16, xrow, XOff<C>(q, px));
+  panel_gemm_body<C, !premul>(ring, acc2, p.wpf, pwbase, lane16, xrow, XOff<C>(q, px));
   float bpv[NI2 * 4];
 #pragma unroll
   for (int t = 0; t < NI2; ++t) *(f32x4*)&bpv[4 * t] = *(const f32x4*)(p.bp + ncol0 + 4 * t);
@@ -448,8 +455,9 @@ int launch_ff_fused(const FFusedP& p, int C, hipStream_t st) {
   if (p.M < 1 || !p.h || !p.out || !p.w1f || !p.w2f || !p.cs1 || !p.b1 || !p.b2) { agd_set_error("ff_fused: bad arguments"); return -1; }
   if ((long long)p.M * C * 2 >= (1LL << 31)) { agd_set_error("ff_fused: activation too large for 32-bit offsets"); return -1; }
   constexpr int lds = 128 * 320 * 2 + 2 * 128 * 128 * 2 + 128 * 8;
-  const void* kfn = p.wpf ? (const void*)ff_fused_kernel<320, 0, 1> : (const void*)ff_fused_kernel<320>;
+  const void* kfn = p.wpf ? (p.premul ? (const void*)ff_fused_kernel<320, 0, 2> : (const void*)ff_fused_kernel<320, 0, 1>) : (const void*)ff_fused_kernel<320>;
   if (p.wpf && (!p.bp || !p.xres || !p.pout)) { agd_set_error("ff_fused: the proj_out stage needs bias, residual and output"); return -1; }
+  if (p.premul && !p.wpf) { agd_set_error("ff_fused: the pre-multiplied form is the proj_out stage's"); return -1; }
 #ifdef AGD_EXPERIMENTS
   static const void* const vars[16] = {(const void*)ff_fused_kernel<320, 0>, (const void*)ff_fused_kernel<320, 1>, (const void*)ff_fused_kernel<320, 2>, (const void*)ff_fused_kernel<320, 3>,
                                        (const void*)ff_fused_kernel<320, 4>, nullptr, (const void*)ff_fused_kernel<320, 6>, (const void*)ff_fused_kernel<320, 7>,

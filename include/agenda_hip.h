@@ -117,10 +117,10 @@ int agd_vae_encode(agd_ctx* ctx, const float* image, int batch, int side, float*
  * "igemm8p" (default 1): launches with enough 256-row tiles (wide 1x1 projections, 3x3 convs with N a multiple of 256, the
  * upsampling convs) run the 8-wave / 8-phase implicit-GEMM kernel (igemm8p.h); 0 = the 4-wave kernels everywhere; tests: 2 / 3 / 4
  * force its 256-wide / 160-wide / any legal tile.
- * "tblock_fuse" (default 255): fused row-panel kernels of the transformer blocks at C = 320 (tblock.hip) -- bit 0: norm3 -> GEGLU ->
+ * "tblock_fuse" (default 767): fused row-panel kernels of the transformer blocks at C = 320 (tblock.hip) -- bit 0: norm3 -> GEGLU ->
  * ff.net.2 + residual as one launch, bit 1: norm2 -> to_q -> cross-attention (+ recorder) -> to_out + residual as one launch, bit 2: that
  * launch starts at attn1.to_out + residual, bit 3: the feed-forward launch ends with proj_out + residual (+ the next GroupNorm's sums), bit 4: proj_in (GroupNorm folded) -> norm1 ->
- * q / k / v projections as one launch, bit 5: the attn2 chain (bits 1, 2) for the C = 640 blocks of the 32 x 32 maps as well (64-row panels), bit 6: under `cfg_shared_prefix` the duplication of the shared rows happens inside the fused kernels (no copy launches), bit 7: the bit-4 launch applies the transformer's GroupNorm itself (statistics from the producer's partial sums, rows normalised in its LDS panel) instead of reading per-image folded matrices from a fold launch, bit 8 (not in the default: measured slower): that launch, GroupNorm inside, for the C = 640 blocks too.
+ * q / k / v projections as one launch, bit 5: the attn2 chain (bits 1, 2) for the C = 640 blocks of the 32 x 32 maps as well (64-row panels), bit 6: under `cfg_shared_prefix` the duplication of the shared rows happens inside the fused kernels (no copy launches), bit 7: the bit-4 launch applies the transformer's GroupNorm itself (statistics from the producer's partial sums, rows normalised in its LDS panel) instead of reading per-image folded matrices from a fold launch, bit 8 (not in the default: measured slower): that launch, GroupNorm inside, for the C = 640 blocks too, bit 9: inside the feed-forward launch (bits 0, 3) ff.net.2 and proj_out are pre-multiplied (Wp W2 at load time; the proj_out stage adds Wp . h on the same accumulators -- no intermediate h3).
  * "reduce_gn" (default 1): the slab-sum pass of a split-K conv also applies the GroupNorm (+ SiLU) that reads its output next (conv1 -> norm2 of a
  * ResnetBlock2D; conv2 -> the following module's norm where that reads this output alone); 0 = separate statistics / apply launches.
  * "conv_smap" (default 1): 3x3 convs of the 8 x 8 maps run the whole-images-resident kernel (igemm_smap.h).

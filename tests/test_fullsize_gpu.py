@@ -171,7 +171,7 @@ def test_sd15_unet_forward_512px_matches_oracle(sd15_host_weights, sd15_pipe, p8
 def test_fused_transformer_block_kernels_match_the_kernel_chain_512px(sd15_host_weights, sd15_pipe):
     """opt "tblock_fuse" (tblock.hip, the C = 320 blocks of the 64 x 64 maps): bit 0 norm3 -> GEGLU -> ff.net.2 + residual in one launch, bit 1
     norm2 -> to_q -> cross-attention (+ DAAM record) -> to_out + residual in one launch, bit 2 that launch starting at attn1.to_out, bit 3 the
-    feed-forward launch ending with proj_out (+ the next GroupNorm's partial sums), bit 4 proj_in -> norm1 -> q / k / v in one launch, bit 5 the attn2 chain for the C = 640 blocks (32 x 32 maps) too, bit 7 the transformer's GroupNorm applied inside the bit-4 launch (no fold launch); opt "reduce_gn": split-K slab sum + GroupNorm in one launch.
+    feed-forward launch ending with proj_out (+ the next GroupNorm's partial sums), bit 4 proj_in -> norm1 -> q / k / v in one launch, bit 5 the attn2 chain for the C = 640 blocks (32 x 32 maps) too, bit 7 the transformer's GroupNorm applied inside the bit-4 launch (no fold launch), bit 9 ff.net.2 / proj_out pre-multiplied inside the feed-forward launch; opt "reduce_gn": split-K slab sum + GroupNorm in one launch.
     Every combination against the fp32 oracle (UNet output and DAAM heat maps) and against the unfused kernel chain: the same fp32 function
     with bf16 roundings at different points, so within bf16 noise of each other, each within the oracle bound."""
     from agenda_amd import synthetic
@@ -189,7 +189,7 @@ def test_fused_transformer_block_kernels_match_the_kernel_chain_512px(sd15_host_
     want, whm, _ = _ORACLE_CACHE["unet512"]
     outs = {}
     try:
-        for fuse, rg in ((0, 0), (1, 1), (2, 1), (6, 1), (9, 1), (16, 1), (31, 1), (34, 1), (63, 1), (63, 0), (144, 1), (176, 1), (255, 1)):
+        for fuse, rg in ((0, 0), (1, 1), (2, 1), (6, 1), (9, 1), (16, 1), (31, 1), (34, 1), (63, 1), (63, 0), (144, 1), (176, 1), (255, 1), (767, 1)):
             pipe.engine.set_option("tblock_fuse", fuse)
             pipe.engine.set_option("reduce_gn", rg)
             pipe.engine.set_context(ctx)
@@ -203,7 +203,7 @@ def test_fused_transformer_block_kernels_match_the_kernel_chain_512px(sd15_host_
                 again = pipe.engine.unet_forward(x, 981.0)
                 assert torch.equal(got, again) and torch.equal(hm, pipe.engine.daam_global(0, 77, L).cpu())
     finally:
-        pipe.engine.set_option("tblock_fuse", 255)
+        pipe.engine.set_option("tblock_fuse", 767)
         pipe.engine.set_option("reduce_gn", 1)
         pipe.engine.record_config(0)
     base, bhm = outs[(0, 0)]
@@ -229,7 +229,7 @@ def test_merged_launches_at_odd_sizes_match_the_unmerged_walk(sd15_pipe, side, B
     ctx = synthetic.make_context(cfg, B, seed=side)
     lat = synthetic.make_latents(cfg, list(range(B)), L)
     off = {"tblock_fuse": 0, "reduce_gn": 0, "shortcut_fuse": 0, "ff_proj_fuse": 0, "upsample_phases": 0, "igemm_kgroups": 0, "wreg_mask": 0, "conv_smap": 0}
-    on = {"tblock_fuse": 255, "reduce_gn": 1, "shortcut_fuse": 3, "ff_proj_fuse": 1, "upsample_phases": 3, "igemm_kgroups": 1, "wreg_mask": 3, "conv_smap": 1}
+    on = {"tblock_fuse": 767, "reduce_gn": 1, "shortcut_fuse": 3, "ff_proj_fuse": 1, "upsample_phases": 3, "igemm_kgroups": 1, "wreg_mask": 3, "conv_smap": 1}
 
     def run():
         return pipe(prompt_embeds=ctx, latents=lat, num_inference_steps=2, height=side, width=side, output_type="latent").latents.clone()
@@ -268,12 +268,12 @@ def test_cfg_shared_prefix_inside_the_fused_kernels_512px(sd15_pipe):
 
     try:
         a = run(); a2 = run()
-        pipe.engine.set_option("tblock_fuse", 255 & ~64)
+        pipe.engine.set_option("tblock_fuse", 767 & ~64)
         b = run()
         pipe.engine.set_option("cfg_shared_prefix", 0)
         c0 = run()
     finally:
-        pipe.engine.set_option("tblock_fuse", 255)
+        pipe.engine.set_option("tblock_fuse", 767)
         pipe.engine.set_option("cfg_shared_prefix", 1)
     assert torch.equal(a[0], a2[0]) and torch.equal(a[1], a2[1])
     # calibration: how far two VALID realisations of the same two steps drift apart (classifier-free guidance multiplies the bf16 noise of eps by ~10)
@@ -310,12 +310,12 @@ def test_sd15_unet_forward_512px_batch4_matches_oracle(sd15_host_weights, sd15_p
         hm = torch.stack([pipe.engine.daam_global(i, 77, L).cpu() for i in range(B)])
         # tblock_fuse bit 8 (off by default: measured slower): proj_in -> norm1 -> q / k / v with the GroupNorm inside for the C = 640 blocks too
         # (only at this batch do the 32 x 32 convs leave the partial sums the kernel needs)
-        pipe.engine.set_option("tblock_fuse", 255 | 256)
+        pipe.engine.set_option("tblock_fuse", 767 | 256)
         pipe.engine.record_reset(B, L)
         got8 = pipe.engine.unet_forward(x, 601.0).clone()
         hm8 = torch.stack([pipe.engine.daam_global(i, 77, L).cpu() for i in range(B)])
         # shortcut_fuse off: the resnets' 1x1 conv_shortcut as its own launch (its bf16-rounded output added as conv2's residual) instead of extra K of conv2
-        pipe.engine.set_option("tblock_fuse", 255)
+        pipe.engine.set_option("tblock_fuse", 767)
         pipe.engine.set_option("shortcut_fuse", 0)
         pipe.engine.record_reset(B, L)
         got_s = pipe.engine.unet_forward(x, 601.0).clone()
@@ -331,7 +331,7 @@ def test_sd15_unet_forward_512px_batch4_matches_oracle(sd15_host_weights, sd15_p
         got_u = pipe.engine.unet_forward(x, 601.0).clone()
     finally:
         pipe.engine.set_option("upsample_phases", 1)
-        pipe.engine.set_option("tblock_fuse", 255)
+        pipe.engine.set_option("tblock_fuse", 767)
         pipe.engine.set_option("shortcut_fuse", 3)
         pipe.engine.set_option("ff_proj_fuse", 1)
         pipe.engine.record_config(0)
