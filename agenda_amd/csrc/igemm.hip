@@ -597,7 +597,11 @@ static int launch_cfg(const IgemmP& p, int splits, hipStream_t st) {
   }
   if constexpr (HALO_TILE) { if (halo_ok(p)) return launch_halo<BN, 0, STAGES == 4 ? 4 : 2>(p, 1, st); }
   if (p.ksize == 3) return launch_one<BM, BN, WM, WN, 3, STAGES, 0, 0>(p, 1, st);
-  if (p.ksize == 2) { if constexpr (BM == 128 && STAGES == 2 && KG == 1) return launch_one<BM, BN, WM, WN, 2, 2, 0, 0>(p, 1, st); agd_set_error("igemm: 2x2 phase convs run on the 128-row two-stage tiles"); return -1; }
+  if (p.ksize == 2) {
+    if constexpr (BM == 128 && STAGES == 2 && KG == 1) return launch_one<BM, BN, WM, WN, 2, 2, 0, 0>(p, 1, st);
+    if constexpr (BM == 64 && BN == 160 && STAGES == 4 && KG == 1) return launch_one<64, 160, WM, WN, 2, 4, 0, 0>(p, 1, st);
+    agd_set_error("igemm: 2x2 phase convs run on the 128-row two-stage tiles or the 64 x 160 deep-ring tile"); return -1;
+  }
   if constexpr (KG == 2) {
     // two K groups of waves per workgroup: plain single-source 1x1 launches (the kernel's K walk has one segment)
     if (p.C1 == 0 && p.stride == 1 && p.up == 1 && p.pad == 0 && p.Hin == p.Hout && p.Win == p.Wout && (p.batch <= 1) && !p.w_per_image)
@@ -722,6 +726,8 @@ int launch_igemm(const IgemmP& p_in, hipStream_t st) {
       if (p.ups4 % 256 == 0 && (long long)(p.M / 256) * (p.N / 256) >= 256) return launch_8p<2, 4, 8, 2, 2>(p, st);
       if (p.ups4 % 160 == 0 && (long long)(p.M / 256) * (p.N / 160) >= 256) return launch_8p<4, 2, 4, 3, 2>(p, st);
     }
+    // few source rows (the 8 x 8 -> 16 x 16 upsampler: M = 512): 64 x 160 tiles on the deep ring give one workgroup per CU where the 128-row tiles give half a wave
+    if (p.ups4 % 160 == 0 && p.M % 64 == 0 && (long long)(p.M / 128) * (p.N / 160) < 192 && (long long)(p.M / 64) * (p.N / 160) <= 512) return launch_cfg<64, 160, 2, 2, 4>(p, 1, st);
     return (p.ups4 % 160) == 0 ? launch_cfg<128, 160, 2, 2>(p, 1, st) : launch_cfg<128, 128, 2, 2>(p, 1, st);
   }
   if (p.M < 1 || p.N < 1) { agd_set_error("igemm: empty problem M=%d N=%d", p.M, p.N); return -1; }

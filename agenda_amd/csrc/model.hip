@@ -118,7 +118,7 @@ struct agd_ctx {
   int opt_halo = 1;                                   // agd_set_option("conv_halo"): 3x3 stride-1 convs through the row-halo kernel (igemm_halo.h)
   int opt_tb_fuse = 255 | 512;                               // agd_set_option("tblock_fuse"): fused row-panel kernels of the C = 320 transformer blocks (tblock.hip): bit 0 = feed-forward (bit 3: + proj_out),
                                                       // bit 1 = attn2 chain (bit 2: + attn1.to_out in front of it), bit 4 = proj_in -> norm1 -> qkv, bit 5 = the attn2 chain for the C = 640 blocks too, bit 6 = the CFG-shared prefix's duplication inside the fused kernels, bit 7 = the GroupNorm applied inside the bit-4 launch (no fold launch), bit 8 (off) = the bit-4 launch with the GroupNorm inside for the C = 640 blocks, bit 9 = ff.net.2 / proj_out pre-multiplied inside the feed-forward kernel
-  int opt_ups4 = 3; /* see agd_set_option */                                   // agd_set_option("upsample_phases"): the UNet's nearest-2x upsampling convs as four 2x2 phase convs on the un-upsampled map (one launch, 4/9 of the MACs)
+  int opt_ups4 = 7; /* see agd_set_option */                                   // agd_set_option("upsample_phases"): the UNet's nearest-2x upsampling convs as four 2x2 phase convs on the un-upsampled map (one launch, 4/9 of the MACs)
   int opt_ffproj = 1;                                 // agd_set_option("ff_proj_fuse"): ff.net.2 and proj_out as ONE GEMM with the pre-multiplied matrix [Wp W2 | Wp] over [hidden | h] (blocks whose feed-forward is not the fused row-panel kernel)
   int opt_sc_fuse = 3;                                // agd_set_option("shortcut_fuse"): a UNet resnet's 1x1 conv_shortcut runs as extra K of its conv2 launch where that is an unsplit row-halo launch
   int opt_wreg = 3;                                   // agd_set_option("wreg_mask"): weight-streaming kernel (igemm_wreg.h) for bit 0: the C = 1280 GEGLU at 1024 <= M <= 4096 (the 16 x 16 blocks), bit 1: proj_in / proj_out of the C = 640 blocks

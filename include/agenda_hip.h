@@ -124,7 +124,7 @@ int agd_vae_encode(agd_ctx* ctx, const float* image, int batch, int side, float*
  * "reduce_gn" (default 1): the slab-sum pass of a split-K conv also applies the GroupNorm (+ SiLU) that reads its output next (conv1 -> norm2 of a
  * ResnetBlock2D; conv2 -> the following module's norm where that reads this output alone); 0 = separate statistics / apply launches.
  * "conv_smap" (default 1): 3x3 convs of the 8 x 8 maps run the whole-images-resident kernel (igemm_smap.h).
- * "upsample_phases" (default 3; bit 0: the UNet's from 16 x 16 maps up, bit 1: the VAE decoder's, bit 2: the UNet's 8 x 8 -> 16 x 16 one): nearest-2x upsampling convs run as four 2x2 phase convs on the un-upsampled map in one launch (taps that coincide pre-summed at load
+ * "upsample_phases" (default 7; bit 0: the UNet's from 16 x 16 maps up, bit 1: the VAE decoder's, bit 2: the UNet's 8 x 8 -> 16 x 16 one): nearest-2x upsampling convs run as four 2x2 phase convs on the un-upsampled map in one launch (taps that coincide pre-summed at load
  * time, pixel-shuffled output rows: 4/9 of the MACs); 0 = the 3x3 conv with the upsample folded into its gather.
  * "ff_proj_fuse" (default 1): ff.net.2 (+ residual) and proj_out (+ block residual) as one GEMM with the pre-multiplied matrix [Wp W2 | Wp] over [hidden | h], in the transformer
  * blocks whose feed-forward is not the fused row-panel kernel; 0 = two launches.

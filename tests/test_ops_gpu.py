@@ -383,7 +383,7 @@ def test_conv3x3_row_halo_kernel_upsampled(ops, B, C, H, Co):
     assert float((got - ref).abs().max()) / scale < 1e-5
 
 
-@pytest.mark.parametrize("B,C,H,Co,p8", [(8, 640, 32, 640, 0), (8, 640, 32, 640, 1), (8, 1280, 16, 1280, 1), (4, 256, 64, 256, 1), (2, 128, 32, 160, 0), (3, 192, 24, 256, 0), (1, 64, 16, 128, 1)])
+@pytest.mark.parametrize("B,C,H,Co,p8", [(8, 640, 32, 640, 0), (8, 640, 32, 640, 1), (8, 1280, 16, 1280, 1), (4, 256, 64, 256, 1), (2, 128, 32, 160, 0), (3, 192, 24, 256, 0), (1, 64, 16, 128, 1), (8, 1280, 8, 1280, 1), (8, 320, 8, 160, 0)])      # the last two: few source rows -> 64 x 160 tiles
 def test_upsampling_conv_as_four_phase_convs(ops, B, C, H, Co, p8):
     """Upsample2D.conv -- conv3x3(nearest2x(x)) -- as four 2x2 convs on the un-upsampled map, one per output phase (2 i + a, 2 j + b), with the taps that coincide
     pre-summed (IgemmP::ups4: one launch of the general igemm over N = 4 Cout, the epilogue writes the pixel-shuffled rows): 4/9 of the MACs.  vs F.conv2d on the
