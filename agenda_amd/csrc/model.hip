@@ -150,6 +150,12 @@ struct ProfScope {
   ~ProfScope() { if (on) hipEventRecord(c->prof[idx].b, st); }
 };
 
+// frees a dmalloc'd block before agd_destroy (load-time scratch); the caller has synchronised
+static void dfree(agd_ctx* c, void* p) {
+  if (!p) return;
+  if (c) { auto it = std::find(c->owned.begin(), c->owned.end(), p); if (it != c->owned.end()) c->owned.erase(it); }
+  (void)hipFree(p);
+}
 template <typename T> static T* dmalloc(agd_ctx* c, size_t n) {
   void* p = nullptr;
   if (hipMalloc(&p, n * sizeof(T) ? n * sizeof(T) : 256) != hipSuccess) { agd_set_error("hipMalloc(%zu) failed", n * sizeof(T)); return nullptr; }
@@ -230,19 +236,24 @@ static int run_conv(agd_ctx* c, hipStream_t st, const bf16_t* s0, int C0, const 
   p.smap = (c && c->opt_smap) || o.smap;
   p.kg2 = (c && c->opt_kg2) || o.kg2;
   p.p8 = o.p8 < 0 ? 0 : o.p8 ? o.p8 : c ? c->opt_p8 : 0;          // before any igemm_query: the tile shape depends on it (-1: not for this launch)
-  if (o.can_fuse_sc) { *o.can_fuse_sc = igemm_can_fuse_shortcut(p) ? 1 : 0; return 0; }
   if (o.query_cfg) { if (o.want_rowstat && !p.rowstat_out) { p.rowstat_out = (float*)16; p.rowstat_slots = 0; } return igemm_query(p, o.query_cfg); }   // (nothing is launched)
   if (o.out_act) {
     o.out_act->cpart_bm = 0;
     if (o.out_act->cpart && !o.out_f32 && !o.geglu) {
       int cfg[3] = {0, 0, 0};
-      CK(igemm_query(p, cfg));
+      if (igemm_query(p, cfg) != 0) {                      // (a shortcut-fusion query on a launch that cannot take the shortcut: "no", not an error)
+        if (o.can_fuse_sc) { *o.can_fuse_sc = 0; return 0; }
+        return -1;
+      }
       const int rpi = o.rows_per_image > 0 ? o.rows_per_image : p.Hout * p.Wout;
       // split-K launches keep the separate statistics kernel: a reduce pass that also emits partial sums was measured
       // slower than the two it replaces (+5.7 ms per batch, tools/ab_option.py)
       if (cfg[2] == 1 && cfg[0] > 0 && rpi % cfg[0] == 0) { p.colstat_out = o.out_act->cpart; p.colstat_rows = rpi; o.out_act->cpart_bm = cfg[0]; }
     }
   }
+  // (asked AFTER the column-statistics decision above: the query must see the launch exactly as it will run -- a statistics producer never splits K,
+  //  which can change the tile the launcher picks)
+  if (o.can_fuse_sc) { *o.can_fuse_sc = igemm_can_fuse_shortcut(p) ? 1 : 0; return 0; }
   if (w.taps != ksize * ksize || w.Cpad != C0 + C1) FAIL("conv: weight [N=%d taps=%d Cpad=%d] does not match input C=%d+%d ksize=%d", w.N, w.taps, w.Cpad, C0, C1, ksize);
   // algorithmic HBM bytes: every input pixel / weight read once, the output written once (+ the residual read)
   const double in_b = 2.0 * B * Hin * Win * (double)(C0 + C1), w_b = 2.0 * p.N * (double)p.K;
@@ -259,7 +270,7 @@ static int run_conv(agd_ctx* c, hipStream_t st, const bf16_t* s0, int C0, const 
     if (c->touch_sink) { ProfScope pt(c, st, PC_TOUCH, 0, w_b);
       hipLaunchKernelGGL(touch_kernel, dim3(1024), dim3(256), 0, st, (const u32x4*)w.w, (long long)(w_b / 16), c->touch_sink); }
   }
-  ProfScope ps(c, st, ksize == 3 ? PC_CONV3 : PC_GEMM, 2.0 * p.M * (double)p.N * p.K, in_b + w_b + out_b + 2.0 * B * Hin * Win * (double)(o.sc_C0 + o.sc_C1));
+  ProfScope ps(c, st, ksize != 1 ? PC_CONV3 : PC_GEMM, 2.0 * p.M * (double)p.N * p.K, in_b + w_b + out_b + 2.0 * B * Hin * Win * (double)(o.sc_C0 + o.sc_C1));
   return launch_igemm(p, st);
 }
 
@@ -350,6 +361,7 @@ static int resnet(agd_ctx* c, hipStream_t st, const std::string& pre, const Act&
   if (has_sc && !side_out && (c->opt_sc_fuse & (H == 8 && Wd == 8 ? 2 : 1)) && c->W.count(pre + "conv2.sc")) {
     GETW(w2q, pre + "conv2.sc");
     int can = 0; GemmOpt q; q.can_fuse_sc = &can; q.sc0 = x0.p; q.sc_C0 = x0.C; q.sc1 = x1 ? x1->p : nullptr; q.sc_C1 = C1;
+    q.out_act = &out;                                    // the launch below as it will run (its output leaves GroupNorm partial sums)
     CK(run_conv(c, st, n2.p, Cout, nullptr, 0, B, H, Wd, *w2q, 3, nullptr, q, c->zero_page));
     fuse_sc = can != 0;
   }
@@ -1119,7 +1131,9 @@ AGD_API int agd_finalize(agd_ctx* c) {
           if (hipMemcpy2D(tmpc, (size_t)4 * C * 2, wc.w, (size_t)5 * C * 2, (size_t)4 * C * 2, C, hipMemcpyDeviceToDevice) != hipSuccess) { agd_set_error("finalize: Wp W2 copy failed"); return fail_ctx(c); }
           API_CK(c, launch_frag_order_w(tmpc, f2p.w, C, 4 * C, C / 64, 128, 0));
           c->W[t + "ff.w2p.frag"] = f2p;
+          hipDeviceSynchronize(); dfree(c, tmpc);          // load-time scratch
         }
+        hipDeviceSynchronize(); dfree(c, w2t);
       } }
     // fused row-panel kernels (tblock.hip, C = 320 blocks): the matrices once more in MFMA fragment order
     if (q->N == 320 || q->N == 640) {                 // (C = 640: the attn2 chain only -- a wave's GEMM tile is 80 columns whatever C: NI = 5)
@@ -1144,7 +1158,7 @@ AGD_API int agd_finalize(agd_ctx* c) {
       }
       if (C == 640) {                                   // proj_in / proj_out once more in igemm_wreg.h's fragment order (option wreg_mask bit 1)
         for (const char* nm : {"proj_in.weight", "proj_out.weight"}) {
-          auto it = c->W.find(pr.first + nm); if (it == c->W.end()) return fail_ctx(c);
+          auto it = c->W.find(pr.first + nm); if (it == c->W.end()) { agd_set_error("finalize: missing weight '%s%s'", pr.first.c_str(), nm); return fail_ctx(c); }
           WMat& wm_ = it->second;
           if (wm_.taps == 1 && wm_.N % 128 == 0 && wm_.Cpad % 64 == 0) {
             wm_.wfrag = dmalloc<bf16_t>(c, (size_t)wm_.N * wm_.Cpad); if (!wm_.wfrag) return fail_ctx(c);

@@ -119,7 +119,13 @@ def gather_outputs(images: torch.Tensor, heatmaps: torch.Tensor, seeds: Optional
     `shard_seeds`, a pure view permutation), else (seeds, images, heatmaps).  With `global_seeds` (the sorted seeds of ALL ranks in
     this round, which callers of `shard_seeds` know on the host) nothing here synchronises with the host: rows are ordered by a
     masked argsort on the device and sliced by len(global_seeds); without it the seed list is read back from the gathered ids
-    (one device -> host copy).  No-op for world size 1."""
+    (one device -> host copy).  No-op for world size 1.
+
+    Contract of `global_seeds`: it must be EXACTLY the sorted union of the seeds the ranks packed this round (what `shard_seeds`
+    hands each rank, derived from one place -- `round_seeds` in `generation.main`).  The sync-free path cannot check that: a list
+    that disagrees with the packed ids (a rank that dropped an image, a different `max_batch`) would pair seeds with the wrong rows
+    silently.  Set AGD_GATHER_CHECK=1 to verify it (one device -> host copy per round: gathered ids == global_seeds, the next id the
+    padding sentinel); the ragged tests run with it on."""
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         res = (images, heatmaps) if seeds is None else (list(seeds), images, heatmaps)
@@ -172,6 +178,12 @@ def gather_outputs(images: torch.Tensor, heatmaps: torch.Tensor, seeds: Optional
         order = torch.argsort(key)
         if global_seeds is not None:            # the caller knows every rank's seeds of this round: no host sync at all
             n = len(global_seeds)
+            if os.environ.get("AGD_GATHER_CHECK"):      # debug: the caller's list against what the ranks really packed (host sync)
+                got = key[order].tolist()
+                sentinel = torch.iinfo(torch.int64).max
+                if got[:n] != [int(s_) for s_ in global_seeds] or (n < len(got) and got[n] != sentinel):
+                    raise RuntimeError(f"gather_outputs: global_seeds {list(global_seeds)} disagree with the gathered ids "
+                                       f"{[g_ for g_ in got if g_ != sentinel]}")
             return list(global_seeds), gi[order[:n]], gh[order[:n]]
         srt = key[order].tolist()               # (device -> host: the seed list is part of the result)
         n = sum(1 for s_ in srt if s_ != torch.iinfo(torch.int64).max)

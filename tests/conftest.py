@@ -36,6 +36,16 @@ def pytest_collection_modifyitems(config, items):
             it.add_marker(skip)
 
 
+def pytest_sessionfinish(session, exitstatus):
+    """measured parity figures of this run -> gpurun_out/parity_report.json (tests/_report.py)"""
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import _report
+        _report.dump()
+    except Exception:
+        pass
+
+
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN

@@ -176,8 +176,39 @@ def main():
             out[f"seam_{tag}_cross_y_train{int(is_train)}"] = yc.numpy()
             out[f"seam_{tag}_self_y_train{int(is_train)}"] = ys.numpy()
             out[f"seam_{tag}_map_train{int(is_train)}"] = hk.cross_attn_maps[0].numpy()
+    # (5) __call__ at the PRODUCTION shapes of the fused attn2 chain kernel (tblock.hip attn_chain_kernel<320> / <640>: SD-1.5's 64 x 64 and
+    #     32 x 32 blocks -- C = 320, 8 heads of 40, hw = 1024 and C = 640, 8 heads of 80, hw = 256), inference mode.  The kernel takes the RAW
+    #     residual stream and applies norm2 itself, so the reference is called on F.layer_norm(x_raw) (diffusers' norm2 in front of the seam):
+    #     ops.attn_chain(x_raw, ...) - x_raw must equal this output, its head-summed probabilities / heads this map (hook.py:55,110-112).
+    #     Inputs and weights are bf16-exact (the kernel rounds them to bf16); x is quantised to 1/32 and the weights to 2^-8 so that the fixture compresses.
+    for name, C, N in (("chain320", 320, 1024), ("chain640", 640, 256)):
+        H, T, ctxd = 8, 77, 64
+        gw = torch.Generator().manual_seed(9000 + C)
+        cross = DuckAttn(C, ctxd, H, gw, cross=True)
+        with torch.no_grad():
+            for lin in (cross.to_q, cross.to_k, cross.to_v, cross.to_out[0]):
+                lin.weight.copy_((lin.weight * 256).round() / 256)          # multiples of 2^-8, |w| < 0.5: bf16-exact and compressible
+        # |x_raw| <= ~1.2, the size of the output: the kernel returns bf16(x_raw + y), so a large x_raw would bury y under the sum's rounding step
+        x_raw = ((torch.randn(2, N, C, generator=gw) * 0.25 + 0.05) * 32).round() / 32
+        ctx = torch.randn(2, T, ctxd, generator=gw).bfloat16().float()
+        gamma = (torch.randn(C, generator=gw) * 0.2 + 1).float()
+        beta = (torch.randn(C, generator=gw) * 0.2).float()
+        assert torch.equal(x_raw, x_raw.bfloat16().float())
+        hk = ref_hook.UNetCrossAttentionHooker(is_train=False, latent_hw=64)
+        with torch.no_grad():
+            y = hk(cross, F.layer_norm(x_raw, (C,), gamma, beta, 1e-5), encoder_hidden_states=ctx)
+        assert len(hk.cross_attn_maps) == 1
+        out[f"{name}_x_bf16bits"] = (x_raw.bfloat16().view(torch.int16).numpy()).view(np.uint16)
+        out[f"{name}_ctx"], out[f"{name}_gamma"], out[f"{name}_beta"] = ctx.numpy(), gamma.numpy(), beta.numpy()
+        for wn, lin in (("wq", cross.to_q), ("wk", cross.to_k), ("wv", cross.to_v), ("wo", cross.to_out[0])):
+            out[f"{name}_{wn}_bf16bits"] = lin.weight.detach().bfloat16().view(torch.int16).numpy().view(np.uint16)
+        out[f"{name}_bo"] = cross.to_out[0].bias.detach().numpy()
+        for lin in (cross.to_q, cross.to_k, cross.to_v, cross.to_out[0]):
+            assert torch.equal(lin.weight.detach(), lin.weight.detach().bfloat16().float())
+        out[f"{name}_y1_f16"] = y[1].numpy().astype(np.float16)             # the conditional half's rows (the ones the map belongs to); |y| = O(1): fp16 keeps 2^-11 relative, the test's bound is 2^-6
+        out[f"{name}_map"] = hk.cross_attn_maps[0].numpy()                   # [1, T, side, side]: conditional half, mean over the 8 heads
     # split to keep each fixture small
-    groups = {"hook_unravel": "unravel", "hook_global": "global", "hook_call": "call", "hook_seam": "seam"}
+    groups = {"hook_unravel": "unravel", "hook_global": "global", "hook_call": "call", "hook_seam": "seam", "hook_chain": "chain"}
     for fn, pref in groups.items():
         sub = {k: (v.astype(np.float32) if v.dtype == np.float64 else v) for k, v in out.items() if k.startswith(pref)}
         np.savez_compressed(os.path.join(OUT, fn + ".npz"), **sub)

@@ -8,6 +8,7 @@ import os
 import numpy as np
 import pytest
 import torch
+from _report import report
 
 pytestmark = pytest.mark.gpu
 
@@ -122,3 +123,4 @@ def test_config4_learned_token_heatmaps_match_the_oracle(tmp_path):
             worst = max(worst, int(d.max()))
             assert d.max() <= 12 and d.mean() < 3.0, (w, i, int(d.max()), float(d.mean()))      # bf16 path vs fp32 oracle (measured: worst 5)
     print(f"config 4 learned-token heat maps vs oracle: worst |diff| {worst}/255")
+    report("config4_learned_token_heat_maps_png", worst_abs_255=worst)

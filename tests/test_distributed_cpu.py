@@ -42,6 +42,7 @@ def _ragged_worker(rank, world, port, out_dir, num_images, batch):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from agenda_amd.generation import shard_seeds, gather_outputs
+    os.environ["AGD_GATHER_CHECK"] = "1"                      # the sync-free path verifies the caller's global_seeds against the gathered ids
     seeds = shard_seeds(num_images, rank, world)
     per_rank = (num_images + world - 1) // world
     rounds = (per_rank + batch - 1) // batch                  # every rank joins every round (generation.main)
@@ -83,6 +84,31 @@ def test_gather_handles_ragged_and_empty_last_batches(tmp_path, world, num_image
         assert sorted(s.tolist()) == list(range(num_images))
         assert gi.shape == (num_images, 4, 4, 3) and gh.shape == (num_images, 2, 8, 8)
         assert [int(x[0, 0, 0]) for x in gi] == s.tolist() and [float(x[0, 0, 0]) for x in gh] == [float(v) for v in s]
+
+
+def _mismatch_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), AGD_GATHER_CHECK="1")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from agenda_amd.generation import gather_outputs
+    chunk = [rank]                                            # the ranks packed seeds 0 and 1 ...
+    imgs, hms = torch.full((1, 4, 4, 3), rank, dtype=torch.uint8), torch.full((1, 2, 8, 8), float(rank))
+    msg = ""
+    try:
+        gather_outputs(imgs, hms, seeds=chunk, max_batch=1, global_seeds=[0, 2])      # ... the caller claims 0 and 2
+    except RuntimeError as e:
+        msg = str(e)
+    open(os.path.join(out_dir, f"m{rank}.txt"), "w").write(msg)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gather_debug_check_catches_a_global_seed_list_that_disagrees_with_the_ranks(tmp_path):
+    """with `global_seeds` nothing synchronises with the host, so a caller's list that disagrees with what the ranks packed would
+    mis-pair seeds and rows silently; AGD_GATHER_CHECK=1 turns that into an error on every rank."""
+    world, port = 2, _free_port()
+    mp.start_processes(_mismatch_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True, start_method="spawn")
+    for r in range(world):
+        assert "disagree with the gathered ids" in open(tmp_path / f"m{r}.txt").read()
 
 
 def test_bench_launcher_plans_n_ranks_before_touching_the_gpu(monkeypatch):

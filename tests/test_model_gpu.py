@@ -7,6 +7,7 @@ import math
 import numpy as np
 import pytest
 import torch
+from _report import report
 
 pytestmark = pytest.mark.gpu
 
@@ -533,6 +534,7 @@ def test_layernorm_fold_matches_the_separate_layernorm_kernels(cfgname):
     assert torch.equal(a, a2)                                  # the fold is deterministic (ordered partial sums, no atomics)
     e_a, e_b, e_ab = _rms_rel(a, want), _rms_rel(b, want), _rms_rel(a, b.cpu())
     print(f"ln_fold {cfgname}: folded vs oracle {e_a:.5f}, unfolded vs oracle {e_b:.5f}, folded vs unfolded {e_ab:.5f}")
+    report(f"ln_fold[{cfgname}]", folded_rms_rel=e_a, unfolded_rms_rel=e_b, folded_vs_unfolded=e_ab)
     # two independent bf16-noise realisations of the same fp32 function: each within 2^-6 of the oracle, ~sqrt(2) x that apart
     assert e_a < 2.0 ** -6 and e_b < 2.0 ** -6 and e_ab < 2.0 ** -5
     pipe.engine.close()
@@ -565,6 +567,7 @@ def test_groupnorm_fold_into_proj_in_matches_the_groupnorm_kernel(cfgname):
     assert not torch.equal(a, b)                               # the option really switches the path
     e_a, e_b, e_ab = _rms_rel(a, want), _rms_rel(b, want), _rms_rel(a, b.cpu())
     print(f"gn_proj_fold {cfgname}: folded vs oracle {e_a:.5f}, unfolded vs oracle {e_b:.5f}, folded vs unfolded {e_ab:.5f}")
+    report(f"gn_proj_fold[{cfgname}]", folded_rms_rel=e_a, unfolded_rms_rel=e_b, folded_vs_unfolded=e_ab)
     assert e_a < 2.0 ** -6 and e_b < 2.0 ** -6 and e_ab < 2.0 ** -5
     pipe.engine.close()
 
@@ -590,6 +593,7 @@ def test_groupnorm_statistics_from_producer_epilogues(tiny_pipe):
     assert torch.equal(a, a2)
     e, ev = _rms_rel(a, b.cpu()), _rms_rel(va, vb.cpu())
     print(f"gn_fused_stats: unet fused vs separate rms rel {e:.6f}, vae {ev:.6f}")
+    report("gn_fused_stats", unet_fused_vs_separate=e, vae_fused_vs_separate=ev)
     # a last-bit change of a group's mean / rstd flips isolated bf16 roundings, which the next ~60 layers amplify to the bf16
     # noise floor: the two paths are two realisations of that noise (exactness of the statistics: tests/test_ops_gpu.py)
     assert e < 2.0 ** -5 and ev < 2.0 ** -5

@@ -6,6 +6,7 @@ import math
 
 import pytest
 import torch
+from _report import report
 import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
@@ -186,6 +187,7 @@ def test_ff_fused_matches_torch_and_the_unfused_kernels(ops, M):
     unf = ops.linear(hid, cu(w2), cu(b2), cu(x))
     e_t, e_u = rel_err(got, want), rel_err(got, unf.cpu())
     print(f"ff_fused M={M}: vs torch {e_t:.5f}, vs unfused kernels {e_u:.5f}")
+    report(f"op_ff_fused[M={M}]", max_rel_vs_torch=e_t, max_rel_vs_unfused=e_u)
     assert e_t < REL, e_t                # bf16 hidden activation + bf16 output against fp32 torch
     assert e_u < REL, e_u
     assert torch.equal(got, ops.ff_fused(cu(x), cu(ga), cu(be), cu(w1), cu(b1), cu(w2), cu(b2)))      # run-to-run identical
@@ -214,6 +216,7 @@ def test_attn_chain_fused_matches_torch(ops, B, HW, T, C):
     got, pr = ops.attn_chain(cu(x), cu(ga), cu(be), cu(wq), cu(kv), cu(wo), cu(bo), heads=H, return_probs=True)
     e_y, e_p = rel_err(got, want), float((pr.cpu() - want_p).abs().max())
     print(f"attn_chain C={C} B={B} HW={HW} T={T}: out {e_y:.5f}, head-summed probabilities max abs {e_p:.5f}")
+    report(f"op_attn_chain[C={C},B={B},HW={HW},T={T}]", out_max_rel=e_y, head_summed_probs_max_abs=e_p)
     assert e_y < REL, e_y
     assert e_p < 8 * 2e-3, e_p                             # sum of 8 heads' probabilities (2e-3 each: bf16 Q / K operands)
     got2, pr2 = ops.attn_chain(cu(x), cu(ga), cu(be), cu(wq), cu(kv), cu(wo), cu(bo), heads=H, return_probs=True)

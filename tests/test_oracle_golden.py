@@ -80,3 +80,24 @@ def test_processor_seam_fixture_matches_reference(golden_dir, tag, is_train):
     ys = O.explicit_attention_processor(x, None, w["wq"], w["wk"], w["wv"], w["wo"], w["bo"], 2, recorder=rec, attention_mask=ms)
     np.testing.assert_allclose(ys.numpy(), z[f"seam_{tag}_self_y_train{int(is_train)}"], rtol=1e-5, atol=2e-6)
     assert len(rec.cross_attn_maps) == 1
+
+
+def _bf16bits(a):
+    """uint16 bf16 bit patterns -> the fp32 values they denote"""
+    return torch.from_numpy((a.astype(np.uint32) << 16).view(np.float32).copy())
+
+
+@pytest.mark.parametrize("name,C", [("chain320", 320), ("chain640", 640)])
+def test_processor_call_at_chain_kernel_shapes_matches_reference(golden_dir, name, C):
+    """hook.py:83-122 at the shapes of SD-1.5's 64 x 64 / 32 x 32 blocks (8 heads of 40 / 80, hw = 1024 / 256), called behind
+    diffusers' norm2 (F.layer_norm of the raw residual stream): the fixture tests/test_golden_gpu.py drives the fused attn2 chain
+    kernel with.  The oracle's restatement on the same inputs."""
+    z = _load(golden_dir, "hook_chain.npz")
+    x = _bf16bits(z[name + "_x_bf16bits"])
+    w = {k: _bf16bits(z[f"{name}_{k}_bf16bits"]) for k in ("wq", "wk", "wv", "wo")}
+    ctx, ga, be, bo = (torch.from_numpy(z[f"{name}_{k}"]) for k in ("ctx", "gamma", "beta", "bo"))
+    assert x.shape[-1] == C and w["wq"].shape == (C, C)
+    rec = O.HookRecorder(is_train=False, latent_hw=64)
+    y = O.explicit_attention_processor(torch.nn.functional.layer_norm(x, (C,), ga, be, 1e-5), ctx, w["wq"], w["wk"], w["wv"], w["wo"], bo, 8, recorder=rec)
+    np.testing.assert_allclose(y[1].numpy(), z[name + "_y1_f16"].astype(np.float32), rtol=2e-3, atol=2e-3)      # the fixture keeps fp16
+    np.testing.assert_allclose(rec.cross_attn_maps[0].numpy(), z[name + "_map"], rtol=1e-5, atol=1e-7)

@@ -4,6 +4,7 @@ HIP kernels vs torch autograd of the oracle's restatements."""
 import numpy as np
 import pytest
 import torch
+from _report import report
 
 pytestmark = pytest.mark.gpu
 
@@ -90,6 +91,7 @@ def seam_backward_check(pipe, cfg, u, name, heads, side, is_train, B2=4, tol=0.0
         pipe.unet.set_attn_processor(pipe.unet._default)
     e_h, e_c = _rel(h1.grad, h0.grad), _rel(c1.grad, c0.grad)
     print(f"seam backward {name} (C={C}, heads={heads}, N={side * side}, is_train={is_train}): d_hidden rel {e_h:.4f}, d_ctx rel {e_c:.4f}")
+    report(f"seam_backward[{name},is_train={is_train}]", d_hidden_rel=e_h, d_ctx_rel=e_c)
     # bf16 operands (Q, K, V, dO, dQ, dK, dV) / fp32 arithmetic vs fp32 autograd
     assert e_h < tol and e_c < tol, (e_h, e_c)
     if not is_train:                                           # hook.py:48-49: the unconditional half never reaches the map
