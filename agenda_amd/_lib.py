@@ -83,6 +83,7 @@ _SIGS = {
     "agd_op_layernorm": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_float, _P]),
     "agd_op_ff_fused": (C.c_int, [_P] * 8 + [C.c_int, C.c_int, C.c_float, _P]),
     "agd_op_attn_chain": (C.c_int, [_P] * 9 + [C.c_int] * 5 + [C.c_float, _P]),
+    "agd_op_xattn_premul": (C.c_int, [_P] * 9 + [C.c_int] * 5 + [C.c_float, _P]),
     "agd_op_attention": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _P, _P]),
     "agd_op_attention_headsum": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _P, _P]),
     "agd_op_bicubic_clamp_mean": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),

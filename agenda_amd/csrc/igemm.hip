@@ -30,6 +30,7 @@
 #include "igemm8p.h"
 #include "igemm_wreg.h"
 #include "igemm_smap.h"
+#include "igemm_pc.h"
 #include <type_traits>
 #include <cstdlib>
 #define CK0(expr) do { if ((expr) != 0) return -1; } while (0)
@@ -632,6 +633,41 @@ static int ensure_splitk(IgemmP& p, int S) {
   return 0;
 }
 
+// ---- producer / consumer kernel (igemm_pc.h): loader waves + consumer waves, one workgroup per CU
+static bool pc_ok(const IgemmP& p) {
+  const bool lin = p.ksize == 1 && p.stride == 1 && p.up == 1 && p.pad == 0 && p.Hin == p.Hout && p.Win == p.Wout;
+  const bool c33 = p.ksize == 3 && p.stride == 1 && p.up == 1 && p.pad == 1 && p.Hin == p.Hout && p.Win == p.Wout && !p.sc0;
+  if (!(lin || c33) || p.batch > 1 || p.geglu || p.ups4) return false;
+  const long long amax = (long long)p.M * (p.C0 > p.C1 ? p.C0 : p.C1) * 2;
+  return p.M < (1 << 24) && amax < (1LL << 31) && (long long)p.N * p.K * 2 < (1LL << 31);
+}
+template <int BM, int BN, int NLW, int STAGES>
+static int launch_pc(const IgemmP& p, int splits, hipStream_t st) {
+  using G = PcGeom<BM, BN, NLW, STAGES>;
+  if (p.cfg_out) { p.cfg_out[0] = BM; p.cfg_out[1] = BN; p.cfg_out[2] = splits; return 0; }
+  if ((p.rowstat_out || p.ln_stats) && splits > 1) { agd_set_error("igemm_pc: LayerNorm fold on a split-K launch"); return -1; }
+  if (p.colstat_out && (splits > 1 || p.colstat_rows < 1 || p.colstat_rows % BM)) { agd_set_error("igemm_pc: column statistics need an unsplit launch whose M tiles stay inside one image"); return -1; }
+  if (p.rowstat_out && p.rowstat_slots != (p.N + BN - 1) / BN) { agd_set_error("igemm_pc: rowstat_slots %d != N tiles %d", p.rowstat_slots, (p.N + BN - 1) / BN); return -1; }
+#ifdef AGD_EXPERIMENTS
+  static const bool logit = getenv("AGD_IGEMM_LOG") != nullptr;
+  if (logit) fprintf(stderr, "IGEMM M=%d N=%d K=%d ks=%d stride=%d up=%d geglu=%d res=%d tile=%dx%d splits=%d batch=1\n", p.M, p.N, p.K, p.ksize,
+                     p.stride, p.up, p.geglu, p.residual ? 1 : 0, BM, BN, splits);
+#endif
+  const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+  const void* kfn = p.ksize == 3 ? (splits > 1 ? (const void*)igemm_pc_kernel<BM, BN, NLW, STAGES, 3, 0, 1> : (const void*)igemm_pc_kernel<BM, BN, NLW, STAGES, 3, 0, 0>)
+                                 : (splits > 1 ? (const void*)igemm_pc_kernel<BM, BN, NLW, STAGES, 1, 0, 1> : (const void*)igemm_pc_kernel<BM, BN, NLW, STAGES, 1, 0, 0>);
+  static bool attr[AGD_MAX_DEVICES][4] = {};
+  int dev = 0; HIP_CHECK_RET(hipGetDevice(&dev));
+  if (dev < 0 || dev >= AGD_MAX_DEVICES) { agd_set_error("igemm_pc: device ordinal %d out of range", dev); return -1; }
+  const int slot = (p.ksize == 3 ? 2 : 0) + (splits > 1 ? 1 : 0);
+  if (!attr[dev][slot]) { HIP_CHECK_RET(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS)); attr[dev][slot] = true; }
+  IgemmP pp = p;
+  void* args[] = {&pp};
+  HIP_CHECK_RET(hipLaunchKernel(kfn, dim3((unsigned)tiles, 1, (unsigned)splits), dim3(G::THREADS), args, G::LDS, st));
+  if (splits > 1) return launch_splitk_reduce(pp, splits, st);
+  return 0;
+}
+
 // ---- 8-wave / 8-phase kernel (igemm8p.h): 256 x 256 tiles (2 x 4 waves) and 256 x 160 tiles (4 x 2 waves)
 template <int WM, int WN, int MI, int NI0, int NI1>
 static int launch_8p(const IgemmP& p, hipStream_t st) {
@@ -736,9 +772,9 @@ int launch_igemm(const IgemmP& p_in, hipStream_t st) {
   if ((p.rowstat_out || p.colstat_out) && (p.geglu || p.out_f32 || p.batch > 1)) { agd_set_error("igemm: row / column statistics only for plain bf16 launches"); return -1; }
   if (p.ln_stats && (!p.ln_cs || p.ln_slots < 1 || p.batch > 1)) { agd_set_error("igemm: LayerNorm fold needs colsum + slots"); return -1; }
   const int batch = p.batch > 0 ? p.batch : 1;
-  if (p.w_per_image) {           // image i's rows multiply with W + i * sW: plain 1x1 launches whose 128-row tiles stay inside one image, general kernel only
+  if (p.w_per_image) {           // image i's rows multiply with W + i * sW: plain 1x1 launches whose M tiles stay inside one image, general kernel only
     const int hw = p.Hout * p.Wout;
-    if (p.ksize != 1 || batch != 1 || p.geglu || hw % 128 || p.M % hw || p.sW < (long long)p.N * p.K) { agd_set_error("igemm: per-image weights need a plain 1x1 launch with Hout*Wout %% 128 == 0"); return -1; }
+    if (p.ksize != 1 || batch != 1 || p.geglu || hw % 64 || p.M % hw || p.sW < (long long)p.N * p.K) { agd_set_error("igemm: per-image weights need a plain 1x1 launch with Hout*Wout %% 64 == 0"); return -1; }
     p.p8 = 0; p.warm = 0;
   }
   {  // tile walk order: W-major when the weight matrix is the larger operand (bytes fetched once per XCD either way)
@@ -763,6 +799,16 @@ int launch_igemm(const IgemmP& p_in, hipStream_t st) {
   }
   const long long t128 = (long long)((p.M + 127) / 128) * ((p.N + 127) / 128) * batch;
   const int nk = p.K >> 6;
+  if (p.w_per_image) {
+    // per-image matrices on the small maps (the output GEMM of the pre-multiplied attn2, xattn_pre.hip: M = 2048 / 512, N = 1280, K = 640): 64 x 160 tiles on
+    // the deep ring where they make at most one wave of workgroups (256 at 16 x 16); images of fewer than 128 rows (8 x 8 maps) need 64-row tiles in any case
+    const int hw = p.Hout * p.Wout;
+    if ((p.N % 160) == 0 && (long long)(p.M / 64) * (p.N / 160) <= 256) {
+      if ((p.pc & 1) && pc_ok(p)) return launch_pc<64, 160, 4, 5>(p, 1, st);
+      return launch_cfg<64, 160, 2, 2, 4>(p, 1, st);
+    }
+    if (hw % 128) return launch_cfg<64, 64, 2, 2, 4>(p, 1, st);
+  }
   // LayerNorm-fold producers / consumers and GroupNorm-statistics producers finish in the tile's own epilogue: they never take a split-K
   // configuration (a transformer wider than SD's -- K >= 4096 at M <= 512 -- falls through to an unsplit tile instead of failing the forward)
   const bool nosplit = p.rowstat_out || p.ln_stats || p.colstat_out;
@@ -783,6 +829,17 @@ int launch_igemm(const IgemmP& p_in, hipStream_t st) {
     }
   }
 #endif
+  // 3x3 stride-1 convs of the 16 x 16 / 8 x 8 maps through the producer / consumer kernel (igemm_pc.h; IgemmP::pc bit 1: 256 unsplit tiles of 64 x 160, bit 2: 128 tiles of
+  // 128 x 160 x 2 K slices, bit 3: the 8 x 8 maps' 64 tiles of 64 x 160 x 4 K slices).  The loaders compute the im2col offsets of every (tap, chunk) step.
+  if ((p.pc & 14) && p.ksize == 3 && pc_ok(p) && (p.N % 160) == 0 && (p.M % 64) == 0 && !p.w_per_image && batch == 1) {
+    const long long t64 = (long long)(p.M / 64) * (p.N / 160);
+    if ((p.pc & 2) && t64 >= 192 && t64 <= 256) return launch_pc<64, 160, 4, 5>(p, 1, st);
+    if ((p.pc & 4) && !nosplit && (p.M % 128) == 0 && t64 >= 192 && t64 <= 256 && nk >= 32) { CK0(ensure_splitk(p, 2)); return launch_pc<128, 160, 4, 4>(p, 2, st); }
+    if ((p.pc & 8) && !nosplit && t64 <= 64 && nk >= 64) {
+      int S = (int)(256 / t64); if (S > 8) S = 8; if (S > nk / 16) S = nk / 16;
+      if (S >= 2) { CK0(ensure_splitk(p, S)); return launch_pc<64, 160, 4, 5>(p, S, st); }
+    }
+  }
   // 8 x 8 maps, 3x3 stride 1: whole images resident, every weight tile streamed once (igemm_smap.h)
   if (p.smap && p.ksize == 3 && p.stride == 1 && p.pad == 1 && p.up == 1 && p.Hin == 8 && p.Win == 8 && p.Hout == 8 && p.Wout == 8 && batch == 1 && !p.geglu &&
       !p.w_per_image && (p.N % 64) == 0 && (p.M % 64) == 0 && !nosplit_early(p) && (long long)p.N * p.K * 2 < (1LL << 32)) {
@@ -847,7 +904,11 @@ int launch_igemm(const IgemmP& p_in, hipStream_t st) {
     const long long t64 = (long long)(p.M / 64) * (p.N / 160);
     // (two K groups of waves on these tiles: 14.3 -> 17.5 us at M = 2048, K = N = 1280 -- each wave issues 7 LDS-DMA pieces per 20 MFMAs and that issue
     //  cost, not latency, is what a K step waits for; a second group doubles it.  tools/kb_m512.py)
-    if (t64 >= 192 && t64 <= 256) return launch_cfg<64, 160, 2, 2, 4>(p, 1, st);
+    if (t64 >= 192 && t64 <= 256) {
+      // producer / consumer form (igemm_pc.h): loader waves issue the ring's LDS-DMA pieces back to back, consumer waves only read fragments and run MFMAs
+      if ((p.pc & 1) && pc_ok(p)) return launch_pc<64, 160, 4, 5>(p, 1, st);
+      return launch_cfg<64, 160, 2, 2, 4>(p, 1, st);
+    }
     if (t64 <= 64 && nk >= 64 && !nosplit) {
       int S = (int)(256 / t64); if (S > nk / 16) S = nk / 16;
       if (S >= 2) { CK0(ensure_splitk(p, S)); return launch_cfg<64, 160, 2, 2, 4>(p, S, st); }

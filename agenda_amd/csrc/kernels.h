@@ -60,6 +60,7 @@ struct IgemmP {
   int smap;                         // caller: 1 = 3x3 stride-1 convs on 8 x 8 maps take the whole-images-resident kernel (igemm_smap.h)
   int wreg, wreg_mmin, wreg_mmax;   // caller: bit 0 = plain / bit 1 = GEGLU 1x1 launches with wreg_mmin <= M <= wreg_mmax take the weight-streaming kernel when Wfrag is set; bit 2 = two K groups of waves where the launch is at most one workgroup per CU
   const bf16_t* Wfrag; int wfrag_ni; // the same matrix in MFMA fragment order for the weight-streaming kernel (igemm_wreg.h): column ranges of wfrag_ni x 16, KC = K
+  int pc;                           // caller: producer / consumer kernel (igemm_pc.h) -- bit 0 = the 1x1 launches on 64 x 160 tiles (16 x 16 / 8 x 8 maps), bit 1 = 3x3 convs of the 16 x 16 maps
   int stagger;                      // timing experiments only: start delay of the CU's second workgroup, x1024 cycles
   int dbg;                          // timing experiments only (builds with -DAGD_EXPERIMENTS)
 };
@@ -142,6 +143,34 @@ struct QkvChainP {
 int launch_qkv_chain(const QkvChainP& p, int C, hipStream_t st);
 int launch_frag_order_w1(const bf16_t* src, bf16_t* dst, int C, int HID, hipStream_t st);
 int launch_frag_order_w(const bf16_t* src, bf16_t* dst, int N, int K, int NI, int KC, hipStream_t st);
+
+// ---------------------------------------------------------------------------------------
+// attn2 of the C = 1280 blocks against per-image pre-multiplied context matrices (xattn_pre.hip)
+// ---------------------------------------------------------------------------------------
+#define XATTN_TP 80                 // token rows per head in the pre-multiplied matrices (77 padded; rows >= T are zeros)
+// once per prompt batch: K''[b][(h,t)][c] = gamma[c] scale sum_d k[b][t][h,d] Wq[(h,d)][c] (bf16), cs = its row sums, bs[(h,t)] = scale k[t][h,:] . (Wq beta)[h,:],
+// V''[b][n][(h,t)] = sum_d Wo[n][(h,d)] v[b][t][h,d] (bf16)
+struct XattnPremulP {
+  const bf16_t* kv; int ldkv; long long skv;      // projected context [B][T][ldkv]: K at column 0, V at column C
+  const bf16_t* wqT;                              // attn2.to_q transposed: [c][(h,d)]
+  const bf16_t* wo;                               // attn2.to_out.0 [n][(h,d)]
+  const float* gamma; const float* wqb;           // norm2.weight [C]; Wq . norm2.bias [C]
+  int B, T, C, H; float scale;
+  bf16_t* kpp; float* kcs; float* kbs; bf16_t* vpp;   // [B][H TP][C], [B][H TP], [B][H TP], [B][C][H TP]
+};
+int launch_xattn_premul(const XattnPremulP& p, hipStream_t st);
+// per forward: P[m][(h,t)] = softmax_t(rstd_m (x[m] . K''[(h,t)] - mu_m cs[(h,t)]) + bs[(h,t)]) (bf16), recorder rows [img - rec_b0][head][t][pixel] += P
+struct XattnSP {
+  const bf16_t* x;                                // [M][C] raw residual stream (norm2 folded)
+  const float* ln_stats; int ln_slots; float ln_invC, ln_eps;   // per-row (sum, sum of squares) partials of x from its producer: [M][slots] float2
+  const bf16_t* kpp; const float* kcs; const float* kbs;
+  bf16_t* P;                                      // [M][H TP]
+  int M, HW, C, H, T;
+  float* rec; long long rec_img_stride, rec_head_stride; int rec_T, rec_b0;   // optional recorder: per-(image, head) rows [T][HW]
+};
+int launch_xattn_s(const XattnSP& p, hipStream_t st);
+int launch_matvec_bf16(const bf16_t* W, const float* v, float* out, int N, int K, hipStream_t st);      // out[j] = sum_c W[j][c] v[c]
+int launch_rowstat_bf16(const bf16_t* x, float* out, int M, int C, hipStream_t st);                    // [M] float2 (sum, sum of squares) per row
 
 // ---------------------------------------------------------------------------------------
 // Norms

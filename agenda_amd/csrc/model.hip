@@ -74,6 +74,10 @@ struct XLayer {
   WMat wkv; DBuf kvb; bf16_t* kv = nullptr; DBuf accb; float* acc = nullptr; int acc_side = 0;
   int acc_heads = 0;                                  // slices in acc per image: `heads`, or fewer = head-group sums (layers at latent resolution)
   DBuf wqTb, wkvTb, woTb; WMat wqT, wkvT, woT;        // transposed weights for the input-gradient GEMMs (built on first backward)
+  // attn2 against per-image pre-multiplied context matrices (xattn_pre.hip; the C = 1280 blocks): load-time parts (to_q transposed, Wq . norm2.bias)
+  // and the per-prompt-batch products K'' / cs / bs / V'' (agd_set_context)
+  bf16_t* pm_wqT = nullptr; float* pm_wqb = nullptr; bool pm_ready = false;
+  DBuf pm_kppb, pm_vppb, pm_csb; bf16_t* pm_kpp = nullptr; bf16_t* pm_vpp = nullptr; float* pm_kcs = nullptr; float* pm_kbs = nullptr;
 };
 
 struct ProfEv { int cls; double flops, bytes; hipEvent_t a, b; };   // algorithmic flop / HBM bytes of the launch
@@ -127,6 +131,8 @@ struct agd_ctx {
   hipStream_t side = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   int opt_smap = 1;                                   // agd_set_option("conv_smap"): 3x3 convs of the 8 x 8 maps through the whole-images-resident kernel (igemm_smap.h)
   int opt_reduce_gn = 1;                              // agd_set_option("reduce_gn"): split-K slab sum + the GroupNorm that reads it as one launch (igemm.hip splitk_reduce_gn_kernel)
+  int opt_pc = 0;                                     // agd_set_option("igemm_pc"): producer / consumer igemm (igemm_pc.h) -- bit 0: 1x1 launches on 64 x 160 tiles, bit 1: 3x3 convs of the 16 x 16 maps
+  int opt_xpre = 1;                                   // agd_set_option("attn2_premul"): attn2 of the C = 1280 blocks as two GEMMs against per-image pre-multiplied context matrices (xattn_pre.hip)
   int opt_touch = 3;                                  // agd_set_option("weight_touch"): n > 0 = stream 1x1 weight matrices of >= n MB through the caches right before their launch
   unsigned* touch_sink = nullptr;
   // profiling
@@ -195,6 +201,7 @@ struct GemmOpt {
   const float* gn_gamma = nullptr; const float* gn_beta = nullptr; bf16_t* gn_y = nullptr; int gn_groups = 0; float gn_eps = 0.f; int gn_silu = 0, gn_keep_out = 0; int* gn_fused = nullptr;
   int kg2 = 0;                  // benches / tests: two K groups of waves per workgroup on the 64-row 1x1 tiles (the walk sets it through the ctx option)
   int smap = 0;                 // benches / tests: allow the 8 x 8 whole-images-resident 3x3 kernel (the walk sets it through the ctx option)
+  int pc = 0;                   // benches / tests: producer / consumer kernel mask (IgemmP::pc; the walk sets it through the ctx option)
   int wreg = 0;                 // benches / tests: weight-streaming kernel for this launch when the WMat carries a fragment-order copy (bit 0 plain, bit 1 GEGLU)
   const bf16_t* sc0 = nullptr; const bf16_t* sc1 = nullptr; int sc_C0 = 0, sc_C1 = 0;   // the block's 1x1 conv_shortcut as extra K of this 3x3 launch (WMat::sc_cols)
   int ups4 = 0;                 // > 0: phase-decomposed upsampling conv (IgemmP::ups4 = Cout; ksize 2, the merged [4 Cout][4][Cin] matrix, hout / wout = the input size)
@@ -235,6 +242,7 @@ static int run_conv(agd_ctx* c, hipStream_t st, const bf16_t* s0, int C0, const 
   p.halo = (c && c->opt_halo) || o.halo;
   p.smap = (c && c->opt_smap) || o.smap;
   p.kg2 = (c && c->opt_kg2) || o.kg2;
+  p.pc = (c ? c->opt_pc : 0) | o.pc;
   p.p8 = o.p8 < 0 ? 0 : o.p8 ? o.p8 : c ? c->opt_p8 : 0;          // before any igemm_query: the tile shape depends on it (-1: not for this launch)
   if (o.query_cfg) { if (o.want_rowstat && !p.rowstat_out) { p.rowstat_out = (float*)16; p.rowstat_slots = 0; } return igemm_query(p, o.query_cfg); }   // (nothing is launched)
   if (o.out_act) {
@@ -666,7 +674,32 @@ static int transformer(agd_ctx* c, hipStream_t st, const std::string& pre, const
       chain_done = true;
     }
   }
-  if (!chain_done)
+  // attn2 of the C = 1280 blocks against the per-image pre-multiplied context matrices (xattn_pre.hip): S GEMM + softmax + recorder, then the output GEMM
+  // with per-image weights -- two launches instead of to_q, the attention kernel and to_out; the hook.py recorder (per-call head means) keeps the kernel chain
+  bool xpre_done = false;
+  if (!chain_done) {
+    auto it = c->xl_idx.find(t + "attn2"); XLayer& xl = c->xl[it->second];
+    const bool rec_daam = c->rec_mode == 1 && !xl.mid && xl.acc && c->rec_L / x.H != 8 && x.H == xl.acc_side && x.W == x.H && B / 2 == c->rec_B;   // daam's rule, as cross_attention()
+    if (xl.pm_ready && c->opt_xpre && fold && stats && slots > 0 && HW % 64 == 0 && c->rec_mode != 2 && c->ctx_T <= XATTN_TP && !dup && (!rec_daam || xl.acc_heads == xl.heads)) {
+      GETV(bo, t + "attn2.to_out.0.bias");
+      const int HT = heads * XATTN_TP;
+      bf16_t* P = (bf16_t*)c->arena.alloc((size_t)M * HT * 2); if (!P) return -1;
+      XattnSP sp{}; sp.x = h.p; sp.ln_stats = stats; sp.ln_slots = slots; sp.ln_invC = 1.0f / (float)C; sp.ln_eps = lneps;
+      sp.kpp = xl.pm_kpp; sp.kcs = xl.pm_kcs; sp.kbs = xl.pm_kbs; sp.P = P; sp.M = M; sp.HW = HW; sp.C = C; sp.H = heads; sp.T = c->ctx_T;
+      double rec_bytes = 0;
+      if (rec_daam) {
+        sp.rec = xl.acc; sp.rec_b0 = B / 2; sp.rec_T = c->rec_T; sp.rec_head_stride = (long long)c->rec_T * HW; sp.rec_img_stride = sp.rec_head_stride * xl.acc_heads;
+        rec_bytes = 8.0 * (B - sp.rec_b0) * heads * (double)c->rec_T * HW;
+      }
+      { ProfScope ps(c, st, PC_ATTN_CROSS, 2.0 * M * (double)HT * C, 2.0 * M * (double)C + 2.0 * B * (double)HT * C + 2.0 * M * (double)HT + rec_bytes);
+        CK(launch_xattn_s(sp, st)); }
+      WMat wv; wv.w = xl.pm_vpp; wv.N = C; wv.Cin = HT; wv.Cpad = HT; wv.taps = 1;
+      GemmOpt oo; oo.bias = bo; oo.residual = h.p; oo.w_per_image = 1;
+      CK(produce(P, HT, wv, oo, h.p, true, !ff_fused));
+      xpre_done = true;
+    }
+  }
+  if (!chain_done && !xpre_done)
   { bf16_t* q = qkv;
     CK(consume(t + "norm2", t + "attn2.to_q.weight", nullptr, 0, q));
     auto it = c->xl_idx.find(t + "attn2");
@@ -997,7 +1030,7 @@ AGD_API void agd_destroy(agd_ctx* c) {
   for (void* p : c->owned) hipFree(p);
   for (auto& xl : c->xl) { xl.kvb.release(); xl.accb.release(); }
   c->ctxb.release(); c->hook_sumb.release(); c->hook_scratchb.release(); c->hook_headsb.release(); c->hook_storeb.release(); c->bwd_wsb.release();
-  for (auto& xl : c->xl) { xl.wqTb.release(); xl.wkvTb.release(); xl.woTb.release(); }
+  for (auto& xl : c->xl) { xl.wqTb.release(); xl.wkvTb.release(); xl.woTb.release(); xl.pm_kppb.release(); xl.pm_vppb.release(); xl.pm_csb.release(); }
   c->latb.release(); c->epsb.release(); c->vae_imgb.release(); c->plmsb.release();
   if (c->side) { hipStreamDestroy(c->side); hipEventDestroy(c->ev_fork); hipEventDestroy(c->ev_join); }
   if (c->splitk.p) hipFree(c->splitk.p);
@@ -1075,6 +1108,17 @@ AGD_API int agd_finalize(agd_ctx* c) {
     xl.mid = pr.first.find("mid_block") != std::string::npos;
     API_CK(c, concat_rows(c, {ck, cv}, xl.wkv));
     if (xl.C % xl.heads) { agd_set_error("%s: C %d not divisible by heads %d", xl.name.c_str(), xl.C, xl.heads); return fail_ctx(c); }
+    // pre-multiplied attn2 (xattn_pre.hip) where it saves work: H x 80 padded token columns <= C / 2, i.e. head dim >= 160 (SD-1.x: the C = 1280 blocks)
+    { const WMat* wq2 = getW(c, t + "attn2.to_q.weight"); const WMat* wo2 = getW(c, t + "attn2.to_out.0.weight");
+      auto be2 = c->V.find(t + "norm2.bias");
+      const int C2 = xl.C, D2 = C2 / xl.heads;
+      if (wq2 && wo2 && be2 != c->V.end() && D2 % 32 == 0 && C2 % 160 == 0 && (xl.heads * XATTN_TP) % 64 == 0 && xl.heads * XATTN_TP * 2 <= C2 &&
+          wq2->taps == 1 && wq2->N == C2 && wq2->Cpad == C2 && wo2->taps == 1 && wo2->N == C2 && wo2->Cpad == C2) {
+        xl.pm_wqT = dmalloc<bf16_t>(c, (size_t)C2 * C2); xl.pm_wqb = dmalloc<float>(c, C2);
+        if (!xl.pm_wqT || !xl.pm_wqb) return fail_ctx(c);
+        API_CK(c, launch_transpose_bf16(wq2->w, C2, C2, xl.pm_wqT, 0));
+        API_CK(c, launch_matvec_bf16(wq2->w, be2->second, xl.pm_wqb, C2, C2, 0));       // (Wq beta)[(h,d)]
+      } }
     c->xl_idx[xl.name] = (int)c->xl.size(); c->xl.push_back(xl);
     // LayerNorm folded into the three GEMMs it feeds: W' = W diag(gamma), colsum(W'), bias' = bias + W beta
     struct Fold { const char* w; const char* bias; const char* ln; int geglu; };
@@ -1285,6 +1329,22 @@ AGD_API int agd_set_context(agd_ctx* c, const float* ctx_emb, int batch2, int to
   for (auto& xl : c->xl) {
     GemmOpt o;
     API_CK(c, run_conv(c, st, c->ctx_bf16, Dc, nullptr, 0, 1, 1, batch2 * tokens, xl.wkv, 1, xl.kv, o, c->zero_page));
+    // the context products of the pre-multiplied attn2 form, once per prompt batch (xattn_pre.hip)
+    xl.pm_ready = false;
+    if (c->opt_xpre && xl.pm_wqT && tokens <= XATTN_TP) {
+      const std::string t = xl.name.substr(0, xl.name.size() - 5);          // "...transformer_blocks.0."
+      const WMat* wo2 = getW(c, t + "attn2.to_out.0.weight"); const float* g2 = getV(c, t + "norm2.weight");
+      if (!wo2 || !g2) return fail_ctx(c);
+      const size_t HT = (size_t)xl.heads * XATTN_TP;
+      API_CK(c, xl.pm_kppb.ensure((size_t)batch2 * HT * xl.C * 2)); API_CK(c, xl.pm_vppb.ensure((size_t)batch2 * HT * xl.C * 2)); API_CK(c, xl.pm_csb.ensure((size_t)batch2 * HT * 2 * sizeof(float)));
+      xl.pm_kpp = xl.pm_kppb.as<bf16_t>(); xl.pm_vpp = xl.pm_vppb.as<bf16_t>(); xl.pm_kcs = xl.pm_csb.as<float>(); xl.pm_kbs = xl.pm_kcs + (size_t)batch2 * HT;
+      XattnPremulP pm{}; pm.kv = xl.kv; pm.ldkv = 2 * xl.C; pm.skv = (long long)tokens * 2 * xl.C; pm.wqT = xl.pm_wqT; pm.wo = wo2->w; pm.gamma = g2; pm.wqb = xl.pm_wqb;
+      pm.B = batch2; pm.T = tokens; pm.C = xl.C; pm.H = xl.heads; pm.scale = 1.0f / sqrtf((float)(xl.C / xl.heads));
+      pm.kpp = xl.pm_kpp; pm.kcs = xl.pm_kcs; pm.kbs = xl.pm_kbs; pm.vpp = xl.pm_vpp;
+      { ProfScope ps(c, st, PC_ATTN_CROSS, 8.0 * batch2 * (double)HT * xl.C * (xl.C / xl.heads) / 2.0, 4.0 * batch2 * (double)HT * xl.C);
+        API_CK(c, launch_xattn_premul(pm, st)); }
+      xl.pm_ready = true;
+    }
   }
   return 0;
 }
@@ -1460,6 +1520,8 @@ AGD_API int agd_set_option(agd_ctx* c, const char* name, int value) {
   if (!strcmp(name, "gn_proj_fold")) { c->opt_gn_proj_fold = value < 0 ? 0 : value; return 0; }   // 0 off, 1: blocks with C <= 320, 2: C <= 640 (A/B)
   if (!strcmp(name, "tblock_fuse")) { c->opt_tb_fuse = value < 0 ? 0 : value; return 0; }   // bit 0: fused feed-forward, bit 1: fused attn2 chain (C = 320 blocks)
   if (!strcmp(name, "reduce_gn")) { c->opt_reduce_gn = value != 0; return 0; }
+  if (!strcmp(name, "igemm_pc")) { c->opt_pc = value < 0 ? 0 : value; return 0; }
+  if (!strcmp(name, "attn2_premul")) { c->opt_xpre = value != 0; return 0; }     // takes effect at the next agd_set_context (the products are built there)
   if (!strcmp(name, "conv_smap")) { c->opt_smap = value != 0; return 0; }
   if (!strcmp(name, "side_stream")) { c->opt_side = value < 0 ? 0 : value; return 0; }
   if (!strcmp(name, "igemm_kgroups")) { c->opt_kg2 = value != 0; return 0; }
@@ -1777,6 +1839,7 @@ AGD_API int agd_op_conv2d_ex(const float* x, const float* w, const float* bias, 
   WMat wm; wm.w = wb; wm.N = Cout; wm.Cin = Cin; wm.Cpad = Cpad; wm.taps = taps;
   GemmOpt o; o.bias = bias; o.stride = stride; o.up = up; o.out_f32 = 1; o.halo = flags & 1; o.p8 = (flags & 4) ? 2 : (flags & 8) ? 3 : (flags & 2) ? 1 : 0;
   o.smap = (flags & 16) ? 1 : 0;
+  o.pc = (flags >> 7) & 15;                          // the producer / consumer kernel (igemm_pc.h): IgemmP::pc mask in bits 7..10
   if ((flags & 64) && upsample && ksize == 3 && stride == 1) {     // the upsampling conv as four 2x2 phase convs (IgemmP::ups4); bf16 output (that form's only one), widened afterwards
     bf16_t* w4 = tmp.get<bf16_t>((size_t)4 * Cout * 4 * Cpad); float* b4 = tmp.get<float>((size_t)4 * Cout); bf16_t* yb = tmp.get<bf16_t>((size_t)B * Ho * Wo * Cout);
     if (!w4 || !b4 || !yb) return -1;
@@ -1811,6 +1874,7 @@ AGD_API int agd_op_linear(const float* x, const float* w, const float* bias, con
   WMat wm; wm.w = wb; wm.N = N; wm.Cin = K; wm.Cpad = K; wm.taps = 1;
   GemmOpt o; o.bias = bias; o.residual = rb; o.geglu = geglu; o.out_f32 = 1; o.p8 = (flags & 4) ? 2 : (flags & 8) ? 3 : (flags & 2) ? 1 : 0;
   o.kg2 = (flags & 32) ? 1 : 0;                      // two K groups of waves per workgroup where the launcher's 64-row unsplit tiles apply
+  o.pc = (flags >> 7) & 15;                          // the producer / consumer kernel (igemm_pc.h): IgemmP::pc mask in bits 7..10
   if (flags & 16) {                                  // the weight-streaming kernel (igemm_wreg.h); bf16 output (that kernel's only form), widened afterwards
     const int ni = geglu ? 4 : 2;
     if (N % (ni * 64)) { agd_set_error("op_linear: the weight-streaming kernel needs N %% %d == 0", ni * 64); return -1; }
@@ -1943,6 +2007,44 @@ AGD_API int agd_op_attn_chain(const float* x, const float* gamma, const float* b
   return 0;
 }
 
+// x + to_out(attention(to_q(LayerNorm(x)), k, v)) through the pre-multiplied form (xattn_pre.hip): x [B][HW][C] fp32, wq / wo [C][C], bo [C], kv [B][T][2C];
+// probs (optional) [B][heads][T][HW] = every head's probabilities (the recorder's per-(image, head) rows, all images recording)
+AGD_API int agd_op_xattn_premul(const float* x, const float* gamma, const float* beta, const float* wq, const float* kv, const float* wo,
+                                const float* bo, float* y, float* probs, int B, int HW, int T, int C, int heads, float eps, void* stream) {
+  hipStream_t st = S(stream); Tmp tmp;
+  const long long M = (long long)B * HW;
+  if (heads < 1 || C % heads || (C / heads) % 32 || C % 160 || HW % 64 || T < 1 || T > XATTN_TP || (heads * XATTN_TP) % 64) { agd_set_error("op_xattn_premul: C %d heads %d HW %d T %d", C, heads, HW, T); return -1; }
+  const size_t HT = (size_t)heads * XATTN_TP;
+  bf16_t* xb = tmp.get<bf16_t>((size_t)M * C); bf16_t* yb = tmp.get<bf16_t>((size_t)M * C); bf16_t* kvb = tmp.get<bf16_t>((size_t)B * T * 2 * C);
+  bf16_t* wqb = tmp.get<bf16_t>((size_t)C * C); bf16_t* wqT = tmp.get<bf16_t>((size_t)C * C); bf16_t* wob = tmp.get<bf16_t>((size_t)C * C);
+  float* wqbeta = tmp.get<float>(C); float* rst = tmp.get<float>((size_t)M * 2);
+  bf16_t* kpp = tmp.get<bf16_t>((size_t)B * HT * C); bf16_t* vpp = tmp.get<bf16_t>((size_t)B * HT * C); float* kcs = tmp.get<float>((size_t)B * HT * 2);
+  bf16_t* P = tmp.get<bf16_t>((size_t)M * HT);
+  if (!xb || !yb || !kvb || !wqb || !wqT || !wob || !wqbeta || !rst || !kpp || !vpp || !kcs || !P) return -1;
+  CK(launch_f32_to_bf16(x, xb, M * C, st));
+  CK(launch_f32_to_bf16(kv, kvb, (long long)B * T * 2 * C, st));
+  CK(launch_convert_weight(wq, wqb, C, C, 1, C, 0, st)); CK(launch_transpose_bf16(wqb, C, C, wqT, st));
+  CK(launch_convert_weight(wo, wob, C, C, 1, C, 0, st));
+  CK(launch_matvec_bf16(wqb, beta, wqbeta, C, C, st));
+  CK(launch_rowstat_bf16(xb, rst, (int)M, C, st));
+  XattnPremulP pm{}; pm.kv = kvb; pm.ldkv = 2 * C; pm.skv = (long long)T * 2 * C; pm.wqT = wqT; pm.wo = wob; pm.gamma = gamma; pm.wqb = wqbeta;
+  pm.B = B; pm.T = T; pm.C = C; pm.H = heads; pm.scale = 1.0f / sqrtf((float)(C / heads)); pm.kpp = kpp; pm.kcs = kcs; pm.kbs = kcs + (size_t)B * HT; pm.vpp = vpp;
+  CK(launch_xattn_premul(pm, st));
+  XattnSP sp{}; sp.x = xb; sp.ln_stats = rst; sp.ln_slots = 1; sp.ln_invC = 1.0f / (float)C; sp.ln_eps = eps; sp.kpp = kpp; sp.kcs = pm.kcs; sp.kbs = pm.kbs; sp.P = P;
+  sp.M = (int)M; sp.HW = HW; sp.C = C; sp.H = heads; sp.T = T;
+  if (probs) {
+    if (hipMemsetAsync(probs, 0, (size_t)B * heads * T * HW * 4, st) != hipSuccess) { agd_set_error("memset probs"); return -1; }
+    sp.rec = probs; sp.rec_b0 = 0; sp.rec_T = T; sp.rec_head_stride = (long long)T * HW; sp.rec_img_stride = sp.rec_head_stride * heads;
+  }
+  CK(launch_xattn_s(sp, st));
+  WMat wv; wv.w = vpp; wv.N = C; wv.Cin = (int)HT; wv.Cpad = (int)HT; wv.taps = 1;
+  GemmOpt oo; oo.bias = bo; oo.residual = xb; oo.w_per_image = 1;
+  CK(run_conv(nullptr, st, P, (int)HT, nullptr, 0, B, 1, HW, wv, 1, yb, oo, op_zero_page()));
+  CK(launch_bf16_to_f32(yb, y, M * C, st));
+  hipStreamSynchronize(st);
+  return 0;
+}
+
 AGD_API int agd_op_attention(const float* q, const float* k, const float* v, float* o, int B, int H, int D, int Nq, int Nk,
                                 float scale, float* probs_out, void* stream) {
   hipStream_t st = S(stream); Tmp tmp;
@@ -2035,6 +2137,7 @@ AGD_API int agd_bench_conv(int B, int H, int W, int C0, int C1, int Cout, int ks
   o.p8 = (mode & 32) ? 2 : (mode & 64) ? 3 : (mode & 16) ? 1 : 0;
   o.smap = (mode & 256) ? 1 : 0;
   o.kg2 = (mode & 512) ? 1 : 0;
+  o.pc = (mode >> 11) & 15;                          // producer / consumer kernel (igemm_pc.h): IgemmP::pc mask in bits 11..14
   if (mode & 128) {                                  // weight-streaming kernel (igemm_wreg.h): the matrix once more in fragment order
     const int ni = geglu ? 4 : 2;
     wm.wfrag = tmp.get<bf16_t>((size_t)Cout * taps * Ctot); if (!wm.wfrag) return -1;

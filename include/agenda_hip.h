@@ -133,6 +133,9 @@ int agd_vae_encode(agd_ctx* ctx, const float* image, int batch, int side, float*
  * "wreg_mask" (default 3): the weight-streaming kernel (igemm_wreg.h: weight fragments straight to registers) for bit 0 = the GEGLU projection of the C = 1280 blocks at 16 x 16,
  * bit 1 = proj_in / proj_out of the C = 640 transformer blocks.
  * "igemm_kgroups" (default 1): the unsplit 1x1 launches on 64 x 64 tiles (8 x 8 maps: at most one workgroup per CU) run two K groups of four waves per workgroup.
+ * "attn2_premul" (default 1; read at the next agd_set_context): attn2 of the blocks with head dim >= 160 (SD-1.x: C = 1280, the 16 x 16 and 8 x 8 maps) runs against per-image
+ * PRE-MULTIPLIED context matrices built once per agd_set_context (csrc/xattn_pre.hip; hook.py:91-120): S = LN(h) . K'' with K'' = gamma scale (k Wq), softmax + recorder in that GEMM's
+ * epilogue, out = P . V'' + bo + h with V'' = Wo v -- two launches instead of to_q, the attention kernel and to_out; 0 = the kernel chain.  The hook.py recorder keeps the chain.
  * "side_stream" (default 0; measured slower, kept for the A/B): a resnet's 1x1 conv_shortcut runs on a second stream beside norm1 / conv1 / norm2. */
 int agd_set_option(agd_ctx* ctx, const char* name, int value);
 
@@ -209,6 +212,12 @@ int agd_op_ff_fused(const float* x, const float* gamma, const float* beta, const
  * C = 320 (HW a multiple of 128) or C = 640 (HW a multiple of 64), 8 heads, T <= 96 */
 int agd_op_attn_chain(const float* x, const float* gamma, const float* beta, const float* wq, const float* kv, const float* wo,
                       const float* bo, float* y, float* probs_sum, int B, int HW, int T, int C, int heads, float eps, void* stream);
+/* the same function through the pre-multiplied form of the C = 1280 blocks (csrc/xattn_pre.hip; hook.py:91-120 behind norm2): the context products
+ * K'' = gamma scale (k Wq), V'' = Wo v are built first, then S = LN-folded x K''^T -> softmax -> P V''^T + bo + x as two GEMMs.
+ * probs (may be NULL): [B][heads][T][HW], every head's probabilities (the recorder's per-(image, head) rows).  Needs HW % 64 == 0, T <= 80,
+ * head dim % 32 == 0, C % 160 == 0. */
+int agd_op_xattn_premul(const float* x, const float* gamma, const float* beta, const float* wq, const float* kv, const float* wo,
+                        const float* bo, float* y, float* probs, int B, int HW, int T, int C, int heads, float eps, void* stream);
 int agd_op_groupnorm(const float* x_nchw, const float* gamma, const float* beta, float* y_nchw, int B, int C, int HW,
                      int groups, float eps, int silu, void* stream);
 /* conv3x3(+bias) -> GroupNorm(+SiLU), chained as the graph walk chains them; fused != 0: the conv launch emits the per-channel

@@ -181,13 +181,15 @@ def main():
     #     residual stream and applies norm2 itself, so the reference is called on F.layer_norm(x_raw) (diffusers' norm2 in front of the seam):
     #     ops.attn_chain(x_raw, ...) - x_raw must equal this output, its head-summed probabilities / heads this map (hook.py:55,110-112).
     #     Inputs and weights are bf16-exact (the kernel rounds them to bf16); x is quantised to 1/32 and the weights to 2^-8 so that the fixture compresses.
-    for name, C, N in (("chain320", 320, 1024), ("chain640", 640, 256)):
+    # ("chain1280": the 16 x 16 blocks' shape, C = 1280, 8 heads of 160, hw = 256 -- driven through the pre-multiplied form, csrc/xattn_pre.hip)
+    for name, C, N in (("chain320", 320, 1024), ("chain640", 640, 256), ("chain1280", 1280, 256)):
         H, T, ctxd = 8, 77, 64
         gw = torch.Generator().manual_seed(9000 + C)
         cross = DuckAttn(C, ctxd, H, gw, cross=True)
         with torch.no_grad():
             for lin in (cross.to_q, cross.to_k, cross.to_v, cross.to_out[0]):
-                lin.weight.copy_((lin.weight * 256).round() / 256)          # multiples of 2^-8, |w| < 0.5: bf16-exact and compressible
+                qs = 256 if C < 1280 else 64                                  # multiples of 2^-8 (2^-6 for the 1280 x 1280 matrices): bf16-exact and compressible
+                lin.weight.copy_((lin.weight * qs).round() / qs)
         # |x_raw| <= ~1.2, the size of the output: the kernel returns bf16(x_raw + y), so a large x_raw would bury y under the sum's rounding step
         x_raw = ((torch.randn(2, N, C, generator=gw) * 0.25 + 0.05) * 32).round() / 32
         ctx = torch.randn(2, T, ctxd, generator=gw).bfloat16().float()
@@ -208,9 +210,11 @@ def main():
         out[f"{name}_y1_f16"] = y[1].numpy().astype(np.float16)             # the conditional half's rows (the ones the map belongs to); |y| = O(1): fp16 keeps 2^-11 relative, the test's bound is 2^-6
         out[f"{name}_map"] = hk.cross_attn_maps[0].numpy()                   # [1, T, side, side]: conditional half, mean over the 8 heads
     # split to keep each fixture small
-    groups = {"hook_unravel": "unravel", "hook_global": "global", "hook_call": "call", "hook_seam": "seam", "hook_chain": "chain"}
-    for fn, pref in groups.items():
-        sub = {k: (v.astype(np.float32) if v.dtype == np.float64 else v) for k, v in out.items() if k.startswith(pref)}
+    groups = [("hook_unravel", "unravel"), ("hook_global", "global"), ("hook_call", "call"), ("hook_seam", "seam"), ("hook_chain1280", "chain1280"), ("hook_chain", "chain")]
+    taken = set()
+    for fn, pref in groups:
+        sub = {k: (v.astype(np.float32) if v.dtype == np.float64 else v) for k, v in out.items() if k.startswith(pref) and k not in taken}
+        taken.update(sub)
         np.savez_compressed(os.path.join(OUT, fn + ".npz"), **sub)
         print(fn, len(sub), "arrays", os.path.getsize(os.path.join(OUT, fn + ".npz")) // 1024, "KiB")
 

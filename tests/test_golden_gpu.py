@@ -161,3 +161,31 @@ def test_attn_chain_kernel_matches_reference_hook_call_at_production_shapes(gold
     report(f"golden_attn_chain_kernel[C={C}]", out_max_rel=e_y, map_max_abs=e_m)
     assert e_y < 2.0 ** -6, e_y          # bf16 operands / fp32 accumulate + a bf16 residual stream vs the reference's fp32
     assert e_m < 2e-3, e_m
+
+
+def test_premultiplied_attn2_matches_reference_hook_call_at_the_16x16_block_shape(golden_dir):
+    """The attn2 form the C = 1280 blocks run since round 5 (csrc/xattn_pre.hip: per-image pre-multiplied context matrices, two GEMMs) pinned to the
+    reference's own outputs: hook.py:83-122 (inference mode) on F.layer_norm(x_raw) at C = 1280 / 8 heads of 160 / hw = 256
+    (tests/golden/make_golden_hook.py part 5, `chain1280`).  out - x_raw must be the reference's output, the per-head probabilities' mean its
+    recorded map (hook.py:48-55: conditional half, mean over heads)."""
+    from agenda_amd import ops
+    from _report import report
+    z = np.load(os.path.join(golden_dir, "hook_chain1280.npz"))
+    name, H = "chain1280", 8
+    x = _bf16bits(z[name + "_x_bf16bits"])
+    w = {k: _bf16bits(z[f"{name}_{k}_bf16bits"]) for k in ("wq", "wk", "wv", "wo")}
+    ctx, ga, be, bo = (torch.from_numpy(z[f"{name}_{k}"]) for k in ("ctx", "gamma", "beta", "bo"))
+    kv = torch.cat([F.linear(ctx, w["wk"]), F.linear(ctx, w["wv"])], dim=-1)               # [B, T, 2C]
+    cu = lambda t: t.cuda()
+    got, pr = ops.xattn_premul(cu(x), cu(ga), cu(be), cu(w["wq"]), cu(kv), cu(w["wo"]), cu(bo), heads=H, return_probs=True)
+    y1 = (got.cpu() - x)[1]
+    want_y1 = torch.from_numpy(z[name + "_y1_f16"].astype(np.float32))
+    e_y = float((y1 - want_y1).abs().max() / want_y1.abs().max())
+    want_m = torch.from_numpy(z[name + "_map"])                                            # [1, T, side, side]
+    side = want_m.shape[-1]
+    m = pr.cpu()[1:].mean(1).reshape(1, pr.shape[2], side, side)
+    e_m = float((m - want_m).abs().max())
+    print(f"pre-multiplied attn2 (C = 1280) vs the reference's __call__: output max rel {e_y:.5f}, map max abs {e_m:.6f}")
+    report("golden_xattn_premul[C=1280]", out_max_rel=e_y, map_max_abs=e_m)
+    assert e_y < 2.0 ** -6, e_y
+    assert e_m < 2e-3, e_m

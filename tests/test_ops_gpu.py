@@ -168,6 +168,43 @@ def test_linear_two_k_groups_per_workgroup(ops, M, K, N, res):
         assert torch.equal(g2, ops.linear(*args, wreg=True, kgroups=True))
 
 
+@pytest.mark.parametrize("M,K,N,res", [(2048, 1280, 1280, True), (2048, 1280, 1280, False), (2048, 6400, 1280, True), (2048, 640, 1280, False), (1536, 1024, 1280, True),
+                                        (2000, 1280, 1280, True)])
+def test_linear_producer_consumer_kernel(ops, M, K, N, res):
+    """igemm_pc.h (round 5): the 1x1 launches of the 16 x 16 maps (M = 2048, N = 1280: 256 tiles of 64 x 160, one workgroup per CU) with the roles split over the waves of a
+    workgroup -- four loader waves issue the ring's LDS-DMA pieces, four consumer waves read fragments and run the MFMAs.  Same tiles, fragment layout and epilogue as the
+    4-wave kernel: vs fp32 torch, and bit-identical to the 4-wave kernel's result (the same products summed in the same order); short K (fewer steps than ring stages + 1),
+    a K that is not a multiple of the ring depth, and a ragged M tail."""
+    g = torch.Generator().manual_seed(M + K + N)
+    x = bfr(torch.randn(M, K, generator=g))
+    w = bfr(torch.randn(N, K, generator=g) / math.sqrt(K))
+    b = torch.randn(N, generator=g) * 0.1
+    r = bfr(torch.randn(M, N, generator=g)) if res else None
+    y = F.linear(x, w, b) + (r if res else 0)
+    args = (x.cuda(), w.cuda(), b.cuda(), r.cuda() if res else None)
+    got = ops.linear(*args, pc=1)
+    ref = ops.linear(*args)
+    assert rel_err(got, y) < 1e-4, rel_err(got, y)            # fp32 output of bf16-exact operands
+    assert torch.equal(got, ref)
+    assert torch.equal(got, ops.linear(*args, pc=1))
+
+
+@pytest.mark.parametrize("B,H,Cin,Cout,pc", [(8, 16, 1280, 1280, 2), (8, 16, 1280, 1280, 4), (8, 16, 640, 1280, 2), (2, 32, 128, 1280, 2), (8, 8, 1280, 1280, 8), (8, 8, 2560, 1280, 8),
+                                              (6, 16, 192, 1280, 2)])
+def test_conv3x3_producer_consumer_kernel(ops, B, H, Cin, Cout, pc):
+    """igemm_pc.h on 3x3 stride-1 convs of the small maps: the loader waves compute the im2col offsets (borders through the buffer range check) of every (tap, chunk) step and
+    issue the LDS-DMA pieces, the consumer waves run the MFMAs.  pc = 2: 64 x 160 tiles unsplit (256 workgroups at 16 x 16, UNet batch 8); 4: 128 x 160 tiles x 2 K slices;
+    8: the 8 x 8 maps on 64 x 160 tiles x 4 K slices.  vs F.conv2d in fp32 on bf16-exact operands, and run-to-run identical (ordered slab sum)."""
+    g = torch.Generator().manual_seed(B + H + Cin + Cout)
+    x = bfr(torch.randn(B, Cin, H, H, generator=g))
+    w = bfr(torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(Cin * 9))
+    b = torch.randn(Cout, generator=g) * 0.1
+    want = F.conv2d(x, w, b, padding=1)
+    got = ops.conv2d(x.cuda(), w.cuda(), b.cuda(), pc=pc)
+    assert rel_err(got, want) < 1e-4, rel_err(got, want)
+    assert torch.equal(got, ops.conv2d(x.cuda(), w.cuda(), b.cuda(), pc=pc))
+
+
 @pytest.mark.parametrize("M", [128, 1000, 4096 * 2])      # one tile; ragged tail (1000 = 7 x 128 + 104); many tiles
 def test_ff_fused_matches_torch_and_the_unfused_kernels(ops, M):
     """tblock.hip ff_fused_kernel (norm3 -> GEGLU -> ff.net.2 + residual in one launch, the hidden activation never in HBM) vs fp32 torch
@@ -220,6 +257,37 @@ def test_attn_chain_fused_matches_torch(ops, B, HW, T, C):
     assert e_y < REL, e_y
     assert e_p < 8 * 2e-3, e_p                             # sum of 8 heads' probabilities (2e-3 each: bf16 Q / K operands)
     got2, pr2 = ops.attn_chain(cu(x), cu(ga), cu(be), cu(wq), cu(kv), cu(wo), cu(bo), heads=H, return_probs=True)
+    assert torch.equal(got, got2) and torch.equal(pr, pr2)                               # run-to-run identical (no atomics)
+
+
+@pytest.mark.parametrize("B,HW,T", [(2, 256, 77), (1, 64, 77), (2, 256, 50), (1, 128, 80), (3, 64, 1)])
+def test_xattn_premul_matches_torch(ops, B, HW, T):
+    """xattn_pre.hip (attn2 of the C = 1280 blocks against per-image pre-multiplied context matrices: K'' = gamma scale (k Wq), V'' = Wo v built first, then
+    S = folded-LayerNorm(x) K''^T -> softmax (+ per-head recorder rows) -> P V''^T + bo + x as two GEMMs) vs fp32 torch on bf16-exact inputs: the op sequence of
+    data_generation/hook.py:91-120 (explicit softmax) behind a LayerNorm, at SD-1.5's 16 x 16 / 8 x 8 block shape (C = 1280, 8 heads of 160), with fewer
+    tokens than 77 (padded columns masked), the full 80, and a single token (softmax of one column = 1)."""
+    C, H = 1280, 8
+    D = C // H
+    g = torch.Generator().manual_seed(B * 1000 + HW + T)
+    x = bfr(torch.randn(B, HW, C, generator=g) * 1.2 + 0.2)
+    ga, be = torch.randn(C, generator=g) * 0.2 + 1, torch.randn(C, generator=g) * 0.2
+    wq = bfr(torch.randn(C, C, generator=g) / math.sqrt(C)); wo = bfr(torch.randn(C, C, generator=g) / math.sqrt(C))
+    bo = torch.randn(C, generator=g) * 0.1
+    kv = bfr(torch.randn(B, T, 2 * C, generator=g))
+    qh = F.linear(F.layer_norm(x, (C,), ga, be, 1e-5), wq).reshape(B, HW, H, D).permute(0, 2, 1, 3)
+    kh = kv[..., :C].reshape(B, T, H, D).permute(0, 2, 1, 3); vh = kv[..., C:].reshape(B, T, H, D).permute(0, 2, 1, 3)
+    P = torch.softmax(qh @ kh.transpose(-1, -2) / math.sqrt(D), dim=-1)                  # [B, H, HW, T]
+    want = x + F.linear((P @ vh).permute(0, 2, 1, 3).reshape(B, HW, C), wo, bo)
+    want_p = P.transpose(2, 3)                                                           # [B, H, T, HW]
+    cu = lambda t: t.cuda()
+    got, pr = ops.xattn_premul(cu(x), cu(ga), cu(be), cu(wq), cu(kv), cu(wo), cu(bo), heads=H, return_probs=True)
+    e_y, e_p = rel_err(got, want), float((pr.cpu() - want_p).abs().max())
+    print(f"xattn_premul B={B} HW={HW} T={T}: out {e_y:.5f}, probabilities max abs {e_p:.5f}")
+    report(f"op_xattn_premul[B={B},HW={HW},T={T}]", out_max_rel=e_y, probs_max_abs=e_p)
+    assert e_y < REL, e_y
+    assert e_p < 2e-3, e_p                                 # the bound of the attention kernel's recorder (bf16 operands of the score GEMM)
+    assert float((pr.sum(2) - 1).abs().max()) < 1e-5       # every row of every head sums to one: probability mass is conserved in the recorder
+    got2, pr2 = ops.xattn_premul(cu(x), cu(ga), cu(be), cu(wq), cu(kv), cu(wo), cu(bo), heads=H, return_probs=True)
     assert torch.equal(got, got2) and torch.equal(pr, pr2)                               # run-to-run identical (no atomics)
 
 

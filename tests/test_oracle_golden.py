@@ -87,12 +87,12 @@ def _bf16bits(a):
     return torch.from_numpy((a.astype(np.uint32) << 16).view(np.float32).copy())
 
 
-@pytest.mark.parametrize("name,C", [("chain320", 320), ("chain640", 640)])
+@pytest.mark.parametrize("name,C", [("chain320", 320), ("chain640", 640), ("chain1280", 1280)])
 def test_processor_call_at_chain_kernel_shapes_matches_reference(golden_dir, name, C):
-    """hook.py:83-122 at the shapes of SD-1.5's 64 x 64 / 32 x 32 blocks (8 heads of 40 / 80, hw = 1024 / 256), called behind
+    """hook.py:83-122 at the shapes of SD-1.5's 64 x 64 / 32 x 32 / 16 x 16 blocks (8 heads of 40 / 80 / 160, hw = 1024 / 256 / 256), called behind
     diffusers' norm2 (F.layer_norm of the raw residual stream): the fixture tests/test_golden_gpu.py drives the fused attn2 chain
     kernel with.  The oracle's restatement on the same inputs."""
-    z = _load(golden_dir, "hook_chain.npz")
+    z = _load(golden_dir, "hook_chain1280.npz" if C == 1280 else "hook_chain.npz")
     x = _bf16bits(z[name + "_x_bf16bits"])
     w = {k: _bf16bits(z[f"{name}_{k}_bf16bits"]) for k in ("wq", "wk", "wv", "wo")}
     ctx, ga, be, bo = (torch.from_numpy(z[f"{name}_{k}"]) for k in ("ctx", "gamma", "beta", "bo"))
