@@ -90,6 +90,19 @@ AGD_DEV int xcd_remap(int bid, int nwg) {
   return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
 }
 
+// Tile (tm, tn) of a logical block id (xcd_remap: the ids [c q, (c + 1) q), q = tiles / 8, share one XCD's L2).  xb_m > 0: the launcher cut the tile grid into eight
+// xb_m x xb_n blocks, one per XCD, chosen so that the XCD's working set (xb_m A panels + xb_n W panels) is smallest -- tools/ubench/l2_stride.hip: a CU takes in
+// 113 GB/s while its XCD's working set fits the 4 MB L2 and 79 GB/s once it does not; a row of tiles (the A-major / W-major walks) is the WORST shape for that.
+AGD_DEV void tile_of(int bid, int tiles_m, int tiles_n, int wmajor, int xb_m, int xb_n, int& tm, int& tn) {
+  if (xb_m > 0) {
+    const int q = xb_m * xb_n, c = bid / q, j = bid - c * q;
+    const int nbn = tiles_n / xb_n, cm = c / nbn, cn = c - cm * nbn;
+    const int jm = j / xb_n;
+    tm = cm * xb_m + jm; tn = cn * xb_n + (j - jm * xb_n);
+  } else if (wmajor) { tm = bid % tiles_m; tn = bid / tiles_m; }
+  else { tn = bid % tiles_n; tm = bid / tiles_n; }
+}
+
 #define HIP_CHECK_RET(expr)                                                      \
   do {                                                                           \
     hipError_t _e = (expr);                                                      \

@@ -83,8 +83,7 @@ __global__ __launch_bounds__(WM * WN * 64 * KG, 2) void igemm_kernel(const Igemm
   // weights outweigh the activations (16x16 / 8x8 maps): otherwise every XCD streams the whole weight matrix from the
   // fabric (rocprofv3 FETCH_SIZE: 211 MB per launch for a 29 MB weight matrix)
   int tn, tm;
-  if (p.wmajor) { const int tiles_m = (p.M + BM - 1) / BM; tm = bid % tiles_m; tn = bid / tiles_m; }
-  else { tn = bid % tiles_n; tm = bid / tiles_n; }
+  tile_of(bid, (p.M + BM - 1) / BM, tiles_n, p.wmajor, p.xb_m, p.xb_n, tm, tn);
   const int bz = blockIdx.y;
   const int m0 = tm * BM, n0 = tn * BN;
 
@@ -531,8 +530,37 @@ static int launch_splitk_reduce(const IgemmP& p, int splits, hipStream_t st) {
   return 0;
 }
 
+// XCD-aware tile blocks (IgemmP::xb_m / xb_n, tile_of in common.h): the eight XCDs each get an a x b block of the tile grid instead of q = tiles / 8 consecutive tiles of
+// the A-major (or W-major) walk, (a, b) minimising the XCD's working set a x (A panel) + b x (W panel).  tools/ubench/l2_stride.hip: with the XCD's working set inside its
+// 4 MB L2 a CU's LDS-DMA stream runs at 113 GB/s beside the tile's MFMAs, beyond it at 79 GB/s -- and a row of tiles is the largest working set q tiles can have
+// (M = 2048, K = N = 1280 on 64 x 160 tiles: 4 x 8 tiles = 0.66 + 3.3 MB of operands per XCD, 8 x 4 tiles = 1.3 + 1.6 MB).
+static void pick_xcd_block(IgemmP& p, int BM, int BN) {
+  p.xb_m = p.xb_n = 0;
+  if (!p.xcd_block || p.batch > 1 || p.w_per_image) return;
+  const int tm = (p.M + BM - 1) / BM, tn = (p.N + BN - 1) / BN;
+  const long long T = (long long)tm * tn;
+  if (T % 8 || T < 16 || T > (1 << 20)) return;
+  const int q = (int)(T / 8);
+  const double ca = (double)BM * (p.C0 + p.C1), cw = (double)BN * p.K;      // elements of one A panel (unique pixels) / one W panel
+  double best = 1e300; int ba = 0, bb = 0;
+  for (int a = 1; a <= q; ++a) {
+    if (q % a) continue;
+    const int b = q / a;
+    if (tm % a || tn % b) continue;
+    const double cost = a * ca + b * cw;
+    if (cost < best) { best = cost; ba = a; bb = b; }
+  }
+  if (!ba) return;
+  // the walk's own shape: q consecutive ids of an A-major walk cover ceil(q / tn) (+1 when they straddle) rows of tiles x min(q, tn) columns; W-major alike
+  double def;
+  if (!p.wmajor) { const int rows = q >= tn ? (q + tn - 1) / tn + ((q % tn) ? 1 : 0) : ((tn % q) ? 2 : 1); def = rows * ca + (q >= tn ? tn : q) * cw; }
+  else { const int cols = q >= tm ? (q + tm - 1) / tm + ((q % tm) ? 1 : 0) : ((tm % q) ? 2 : 1); def = cols * cw + (q >= tm ? tm : q) * ca; }
+  if (best < 0.9 * def) { p.xb_m = ba; p.xb_n = bb; if (p.warm == 1) p.warm = 2; }      // (the W-major warm-up streams the walk's per-XCD row range: with blocks, the whole matrix once)
+}
+
 template <int BM, int BN, int WM, int WN, int KS, int STAGES, int GEGLU, int SPLITK, int KG = 1>
-static int launch_one(const IgemmP& p, int splits, hipStream_t st) {
+static int launch_one(const IgemmP& p_in, int splits, hipStream_t st) {
+  IgemmP p = p_in; pick_xcd_block(p, BM, BN);
   constexpr int NT = WM * WN * 64 * KG;
   constexpr int stage = (BM + BN) * 128;
   constexpr int lds = KG * (STAGES * stage + 4096) + BM * 8;    // per K group: the ring + one scratch KiB per wave (cold-weight warm-up pieces); + (mean, rstd) of the tile's rows
@@ -557,7 +585,8 @@ static bool halo_ok(const IgemmP& p) {
          (long long)p.Hin * p.Win * (p.C0 > p.C1 ? p.C0 : p.C1) * (p.M / (p.Hin * p.Win) + 1) < (1LL << 30);   // 32-bit byte offsets per source
 }
 template <int BN, int SPLITK, int BST>
-static int launch_halo(const IgemmP& p, int splits, hipStream_t st) {
+static int launch_halo(const IgemmP& p_in, int splits, hipStream_t st) {
+  IgemmP p = p_in; pick_xcd_block(p, 128, BN);
   const int Wt = p.Wout < 128 ? p.Wout : 128;
   const int hr = (128 / Wt) * (Wt + 2), HRP = (hr + 7) & ~7;
   const int lds = 2 * HRP * 128 + BST * BN * 128 + 4096;   // two A images of the tile's halo rows + the weight ring + the dead-piece sink
@@ -661,7 +690,7 @@ static int launch_pc(const IgemmP& p, int splits, hipStream_t st) {
   if (dev < 0 || dev >= AGD_MAX_DEVICES) { agd_set_error("igemm_pc: device ordinal %d out of range", dev); return -1; }
   const int slot = (p.ksize == 3 ? 2 : 0) + (splits > 1 ? 1 : 0);
   if (!attr[dev][slot]) { HIP_CHECK_RET(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS)); attr[dev][slot] = true; }
-  IgemmP pp = p;
+  IgemmP pp = p; pick_xcd_block(pp, BM, BN);
   void* args[] = {&pp};
   HIP_CHECK_RET(hipLaunchKernel(kfn, dim3((unsigned)tiles, 1, (unsigned)splits), dim3(G::THREADS), args, G::LDS, st));
   if (splits > 1) return launch_splitk_reduce(pp, splits, st);
@@ -691,7 +720,7 @@ static int launch_8p(const IgemmP& p, hipStream_t st) {
   if (dev < 0 || dev >= AGD_MAX_DEVICES) { agd_set_error("igemm8p: device ordinal %d out of range", dev); return -1; }
   const int slot = p.geglu ? 2 : p.ksize == 3 ? 1 : p.ksize == 2 ? 3 : 0;
   if (!attr[dev][slot]) { HIP_CHECK_RET(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS)); attr[dev][slot] = true; }
-  IgemmP pp = p;
+  IgemmP pp = p; pick_xcd_block(pp, G::BM, G::BN);
   void* args[] = {&pp};
   HIP_CHECK_RET(hipLaunchKernel(kfn, dim3(tiles), dim3(512), args, G::LDS, st));
   return 0;
@@ -887,7 +916,7 @@ int launch_igemm(const IgemmP& p_in, hipStream_t st) {
                         w160 ? (kg2 ? (const void*)igemm_wreg_kernel<2, 0, 5, 2> : (const void*)igemm_wreg_kernel<2, 0, 5>) :
                                (kg2 ? (const void*)igemm_wreg_kernel<2, 0, 4, 2> : (const void*)igemm_wreg_kernel<2, 0>);
       const int wn = w160 ? 5 : 4, kgn = kg2 ? 2 : 1;
-      IgemmP pp = p;
+      IgemmP pp = p; pick_xcd_block(pp, 64, bn);
       void* args[] = {&pp};
       HIP_CHECK_RET(hipLaunchKernel(kfn, dim3((unsigned)tiles), dim3(wn * 64 * kgn), args, kgn * (3 * 64 * 128 + wn * 1024) + 64 * 8, st));
       return 0;

@@ -66,8 +66,7 @@ __global__ __launch_bounds__(512, 2) void igemm8p_kernel(const IgemmP p) {
   const int tiles_n = (p.N + BN - 1) / BN;
   const int bid = xcd_remap(blockIdx.x, gridDim.x);
   int tn, tm;
-  if (p.wmajor) { const int tiles_m = (p.M + BM - 1) / BM; tm = bid % tiles_m; tn = bid / tiles_m; }
-  else { tn = bid % tiles_n; tm = bid / tiles_n; }
+  tile_of(bid, (p.M + BM - 1) / BM, tiles_n, p.wmajor, p.xb_m, p.xb_n, tm, tn);
   const int m0 = tm * BM, n0 = tn * BN;
   const int nk = p.K >> 6;
   const bf16_t* const base0 = p.src0;

@@ -31,7 +31,8 @@ __global__ __launch_bounds__(256, BST == 2 ? 2 : 1) void igemm_halo_kernel(const
   const int wm = wid / WN, wn = wid % WN;
   const int tiles_n = (p.N + BN - 1) / BN;
   const int bid = xcd_remap(blockIdx.x, gridDim.x);
-  const int tn = bid % tiles_n, tm = bid / tiles_n;    // A-major walk: consecutive tiles share the pixel rows
+  int tn, tm;                                           // A-major walk (consecutive tiles share the pixel rows) or the launcher's XCD blocks
+  tile_of(bid, (p.M + BM - 1) / BM, tiles_n, 0, p.xb_m, p.xb_n, tm, tn);
   const int m0 = tm * BM, n0 = tn * BN;
   const int W = p.Wout, H = p.Hout, HW = H * W;         // output grid (= the nearest-2x upsampled input grid when p.up == 2)
   const int ush = p.up == 2 ? 1 : 0;

@@ -29,7 +29,7 @@ struct PcGeom {
   static constexpr int THREADS = (NW + NLW) * 64;
   static constexpr int LDS = STAGES * STAGE + NLW * 1024 + BM * 8;       // ring + a sink KiB per loader wave + (mean, rstd) of the tile's rows
   static_assert(LDS <= 160 * 1024, "LDS");
-  static_assert((STAGES - 2) * LPW < 64, "vmcnt field");
+  static_assert((STAGES - 2) * LPW < 64 && STAGES >= 4, "vmcnt field; the consumers' fragment prefetch needs one stage more");
 };
 
 template <int BM, int BN, int NLW, int STAGES, int KS, int GEGLU, int SPLITK>
@@ -45,8 +45,10 @@ __global__ __launch_bounds__((4 + NLW) * 64) void igemm_pc_kernel(const IgemmP p
   const int tiles_n = (p.N + BN - 1) / BN;
   const int bid = xcd_remap(blockIdx.x, gridDim.x);
   int tn, tm;
-  if (p.wmajor) { const int tiles_m = (p.M + BM - 1) / BM; tm = bid % tiles_m; tn = bid / tiles_m; }
-  else { tn = bid % tiles_n; tm = bid / tiles_n; }
+  tile_of(bid, (p.M + BM - 1) / BM, tiles_n, p.wmajor, p.xb_m, p.xb_n, tm, tn);
+#ifdef AGD_EXPERIMENTS
+  if (p.dbg & 8) { tm = 0; tn = 0; }                  // timing variant (tools/kb_pc_parts.py): every workgroup computes tile (0, 0) -- one A panel and one W panel for the whole chip
+#endif
   const int m0 = tm * BM, n0 = tn * BN;
   const int HWo = p.Hout * p.Wout;
   // K steps of this block: 1x1: the chunks of source 0 then source 1; 3x3: (tap, chunk) with the tap outer, as the weight rows are laid out
@@ -126,6 +128,11 @@ __global__ __launch_bounds__((4 + NLW) * 64) void igemm_pc_kernel(const IgemmP p
     // 3x3 = (tap, chunk) with k = tap * (C0 + C1) + c); steps past the range go through zero-record descriptors (dropped; the hardware writes zeros)
     int cur_s = 0, cur_cc = ks0, cur_tap = 0;
     if constexpr (KS == 3) { cur_tap = ks0 / nkc; cur_cc = ks0 - cur_tap * nkc; }
+#ifdef AGD_EXPERIMENTS
+    const bool nodma = (p.dbg & 1) != 0;                      // timing variant (tools/kb_pc_parts.py): no LDS-DMA instructions at all (results are garbage)
+#else
+    constexpr bool nodma = false;
+#endif
     auto issue = [&](int slot) {
       const bool live = cur_s < nk;
       char* const sA = ring + slot * STAGE;
@@ -139,6 +146,7 @@ __global__ __launch_bounds__((4 + NLW) * 64) void igemm_pc_kernel(const IgemmP p
 #pragma unroll
         for (int j = 0; j < LPW; ++j) {
           const int g = lw + NLW * j;
+          if (nodma) continue;
           if (g < G::A_Q) bufdma16(bA, sA + g * 1024, s1 ? voff1[j] : voff0[j], aso, nr);
           else bufdma16(baseW, sB + (g - G::A_Q) * 1024, voff0[j], bso, nr);
         }
@@ -148,6 +156,7 @@ __global__ __launch_bounds__((4 + NLW) * 64) void igemm_pc_kernel(const IgemmP p
 #pragma unroll
         for (int j = 0; j < LPW; ++j) {
           const int g = lw + NLW * j;
+          if (nodma) continue;
           if (g < G::A_Q) {
             const int iy = arow_y[j] + kh, ix = arow_x[j] + kw;
             const bool ok = a_ok[j] && (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win;
@@ -158,12 +167,17 @@ __global__ __launch_bounds__((4 + NLW) * 64) void igemm_pc_kernel(const IgemmP p
       }
       if (live) { ++cur_s; if (++cur_cc == nkc) { cur_cc = 0; ++cur_tap; } }
     };
+    // Protocol (the consumers read the fragments of step ks + 1 UNDER the MFMAs of step ks, so a stage must have landed one barrier earlier than it is
+    // multiplied): barrier P -- stage 0 landed; barrier B_ks (one per K step) -- stage ks + 1 landed, and every consumer has the fragments of stage
+    // ks - 1 in registers (it issued that step's MFMAs), so the loaders refill that slot with stage ks + STAGES - 1.
 #pragma unroll
     for (int s = 0; s < STAGES - 1; ++s) issue(s);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"i"((STAGES - 2) * LPW) : "memory");        // this wave's pieces of stage 0 have landed
+    asm volatile("s_barrier" ::: "memory");                                           // P
     for (int ks = 0; ks < nk; ++ks) {
-      asm volatile("s_waitcnt vmcnt(%0)" ::"i"((STAGES - 2) * LPW) : "memory");      // this wave's pieces of stage ks have landed
-      asm volatile("s_barrier" ::: "memory");
-      issue((ks + STAGES - 1) % STAGES);                       // into the slot the consumers left at step ks - 1
+      asm volatile("s_waitcnt vmcnt(%0)" ::"i"((STAGES - 3) * LPW) : "memory");      // ... of stage ks + 1 (stages up to ks + STAGES - 2 are issued)
+      asm volatile("s_barrier" ::: "memory");                                         // B_ks
+      issue((ks + STAGES - 1) % STAGES);                       // stage ks + STAGES - 1 into the slot of stage ks - 1
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // (dead tail pieces still write zeros into LDS: let them land before the epilogue reuses it)
     if constexpr (!SPLITK) igemm_epilogue_ghost(p);
@@ -194,27 +208,87 @@ __global__ __launch_bounds__((4 + NLW) * 64) void igemm_pc_kernel(const IgemmP p
     foff[kk] = frow * 128 + sw;
     foffB[kk] = (frow >> 2) * (4 * NI * 128) + (frow & 3) * 128 + sw;
   }
-  for (int ks = 0; ks < nk; ++ks) {
-    asm volatile("s_barrier" ::: "memory");
-    const char* sA = ring + (ks % STAGES) * STAGE + wm * WTM * 128;
-    const char* sB = ring + (ks % STAGES) * STAGE + A_BYTES + wn * WTN * 128;
-    bf16x8 a0[MI], b0[NI], a1[MI], b1[NI];
+#ifdef AGD_EXPERIMENTS
+  if (p.dbg & 6) {
+    // timing variants (tools/kb_pc_parts.py; results are garbage): bit 1 = the consumers read no fragments (MFMAs on register constants), bit 2 = fragment reads but no MFMAs
+    bf16x8 ca = {}, cb = {};
+    ca[0] = (__bf16)(float)lane; cb[1] = (__bf16)1.0f;
+    asm volatile("s_barrier" ::: "memory");                    // P
+    for (int ks = 0; ks < nk; ++ks) {
+      asm volatile("s_barrier" ::: "memory");
+      const char* sA = ring + (ks % STAGES) * STAGE + wm * WTM * 128;
+      const char* sB = ring + (ks % STAGES) * STAGE + A_BYTES + wn * WTN * 128;
+      if (p.dbg & 2) {
 #pragma unroll
-    for (int i = 0; i < MI; ++i) a0[i] = *(const bf16x8*)(sA + i * 2048 + foff[0]);
+        for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-    for (int j = 0; j < NI; ++j) b0[j] = *(const bf16x8*)(sB + j * 512 + foffB[0]);
+          for (int i = 0; i < MI; ++i)
 #pragma unroll
-    for (int i = 0; i < MI; ++i) a1[i] = *(const bf16x8*)(sA + i * 2048 + foff[1]);
+            for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cb, ca, acc[i][j], 0, 0, 0);
+      } else {
+        float t = 0.f;
 #pragma unroll
-    for (int j = 0; j < NI; ++j) b1[j] = *(const bf16x8*)(sB + j * 512 + foffB[1]);
+        for (int kk = 0; kk < 2; ++kk) {
 #pragma unroll
-    for (int i = 0; i < MI; ++i)
+          for (int i = 0; i < MI; ++i) { const bf16x8 v = *(const bf16x8*)(sA + i * 2048 + foff[kk]); t += (float)v[0]; }
 #pragma unroll
-      for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0[j], a0[i], acc[i][j], 0, 0, 0);      // D = W . X^T
+          for (int j = 0; j < NI; ++j) { const bf16x8 v = *(const bf16x8*)(sB + j * 512 + foffB[kk]); t += (float)v[0]; }
+        }
+        acc[0][0][0] += t;
+      }
+    }
+  } else
+#endif
+  {
+    // two fragment sets: the reads of step ks + 1 are issued right behind barrier B_ks and land under the MFMAs of step ks (one wave per SIMD has no
+    // partner to hide the fragment-read latency behind: without this a K step was barrier -> reads -> wait -> MFMAs, ~0.4 us for 0.17 us of matrix-pipe work)
+    bf16x8 fa[2][2][MI], fb[2][2][NI];
+    auto rd = [&](bf16x8 (&ra)[2][MI], bf16x8 (&rb)[2][NI], int stage) {
+      const char* sA = ring + (stage % STAGES) * STAGE + wm * WTM * 128;
+      const char* sB = ring + (stage % STAGES) * STAGE + A_BYTES + wn * WTN * 128;
 #pragma unroll
-    for (int i = 0; i < MI; ++i)
+      for (int kk = 0; kk < 2; ++kk) {
 #pragma unroll
-      for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1[j], a1[i], acc[i][j], 0, 0, 0);
+        for (int i = 0; i < MI; ++i) ra[kk][i] = *(const bf16x8*)(sA + i * 2048 + foff[kk]);
+#pragma unroll
+        for (int j = 0; j < NI; ++j) rb[kk][j] = *(const bf16x8*)(sB + j * 512 + foffB[kk]);
+      }
+    };
+    auto mm = [&](const bf16x8 (&ra)[2][MI], const bf16x8 (&rb)[2][NI]) {
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rb[kk][j], ra[kk][i], acc[i][j], 0, 0, 0);      // D = W . X^T
+    };
+    // (sched_barrier(0): hipcc otherwise sinks the next step's reads behind this step's MFMAs and hoists MFMAs over the s_barrier -- the reads must be
+    //  ISSUED first to land under the MFMAs)
+    // (every scalar load -- kernel arguments -- is retired before the loop: with one pending on the loop's entry edge hipcc's wait-count pass can only emit
+    //  lgkmcnt(0) inside it, scalar loads returning out of order, and the first MFMA would wait for the reads just issued instead of the previous step's)
+    __builtin_amdgcn_s_waitcnt(0xC07F);                        // lgkmcnt(0)
+    asm volatile("s_barrier" ::: "memory");                    // P: stage 0 has landed
+    if (nk > 0) rd(fa[0], fb[0], 0);
+    int ks = 0;
+    for (; ks + 1 < nk; ks += 2) {
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_barrier" ::: "memory");                  // B_ks: stage ks + 1 has landed
+      __builtin_amdgcn_sched_barrier(0);
+      rd(fa[1], fb[1], ks + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mm(fa[0], fb[0]);
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_barrier" ::: "memory");                  // B_(ks + 1)
+      __builtin_amdgcn_sched_barrier(0);
+      rd(fa[0], fb[0], ks + 2 < nk ? ks + 2 : nk - 1);         // (unconditional: a constant number of reads in flight lets hipcc emit counted lgkmcnt waits; past the end it re-reads the last stage, unused)
+      __builtin_amdgcn_sched_barrier(0);
+      mm(fa[1], fb[1]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (ks < nk) {                                             // odd step count: the last step's fragments are in set 0
+      asm volatile("s_barrier" ::: "memory");
+      mm(fa[0], fb[0]);
+    }
   }
   igemm_epilogue<BM, BN, WM, WN, GEGLU, SPLITK>(p, acc, smem, lane, wm, wn, m0, n0, tn, 0, (!SPLITK && p.ln_stats && nk_total > 0) ? lnst : nullptr);
 }

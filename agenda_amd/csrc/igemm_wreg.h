@@ -32,7 +32,7 @@ __global__ __launch_bounds__(WN * 64 * KG, 2) void igemm_wreg_kernel(const Igemm
   const int tiles_n = p.N / BN, tiles_m = (p.M + BM - 1) / BM;
   const int bid = xcd_remap(blockIdx.x, gridDim.x);
   int tn, tm;
-  if (p.wmajor) { tm = bid % tiles_m; tn = bid / tiles_m; } else { tn = bid % tiles_n; tm = bid / tiles_n; }
+  tile_of(bid, tiles_m, tiles_n, p.wmajor, p.xb_m, p.xb_n, tm, tn);
   const int m0 = tm * BM, n0 = tn * BN;
   const int nk = (p.K >> 6) / KG;                       // this group's stages of 64 k: global stage KG * s + kg
 

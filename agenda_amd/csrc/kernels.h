@@ -60,6 +60,8 @@ struct IgemmP {
   int smap;                         // caller: 1 = 3x3 stride-1 convs on 8 x 8 maps take the whole-images-resident kernel (igemm_smap.h)
   int wreg, wreg_mmin, wreg_mmax;   // caller: bit 0 = plain / bit 1 = GEGLU 1x1 launches with wreg_mmin <= M <= wreg_mmax take the weight-streaming kernel when Wfrag is set; bit 2 = two K groups of waves where the launch is at most one workgroup per CU
   const bf16_t* Wfrag; int wfrag_ni; // the same matrix in MFMA fragment order for the weight-streaming kernel (igemm_wreg.h): column ranges of wfrag_ni x 16, KC = K
+  int xb_m, xb_n;                   // set by the launcher: the tile grid is cut into eight xb_m x xb_n blocks, one per XCD (tile_of, common.h); 0 = the A-major / W-major walk
+  int xcd_block;                    // caller: 1 = allow that
   int pc;                           // caller: producer / consumer kernel (igemm_pc.h) -- bit 0 = the 1x1 launches on 64 x 160 tiles (16 x 16 / 8 x 8 maps), bit 1 = 3x3 convs of the 16 x 16 maps
   int stagger;                      // timing experiments only: start delay of the CU's second workgroup, x1024 cycles
   int dbg;                          // timing experiments only (builds with -DAGD_EXPERIMENTS)

@@ -131,7 +131,8 @@ struct agd_ctx {
   hipStream_t side = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   int opt_smap = 1;                                   // agd_set_option("conv_smap"): 3x3 convs of the 8 x 8 maps through the whole-images-resident kernel (igemm_smap.h)
   int opt_reduce_gn = 1;                              // agd_set_option("reduce_gn"): split-K slab sum + the GroupNorm that reads it as one launch (igemm.hip splitk_reduce_gn_kernel)
-  int opt_pc = 0;                                     // agd_set_option("igemm_pc"): producer / consumer igemm (igemm_pc.h) -- bit 0: 1x1 launches on 64 x 160 tiles, bit 1: 3x3 convs of the 16 x 16 maps
+  int opt_xcd_block = 1;                              // agd_set_option("xcd_block"): the igemm tile grid cut into one block per XCD that minimises the XCD's L2 working set (igemm.hip pick_xcd_block)
+  int opt_pc = 1;                                     // agd_set_option("igemm_pc"): producer / consumer igemm (igemm_pc.h) -- bit 0: 1x1 launches on 64 x 160 tiles, bit 1: 3x3 convs of the 16 x 16 maps
   int opt_xpre = 1;                                   // agd_set_option("attn2_premul"): attn2 of the C = 1280 blocks as two GEMMs against per-image pre-multiplied context matrices (xattn_pre.hip)
   int opt_touch = 3;                                  // agd_set_option("weight_touch"): n > 0 = stream 1x1 weight matrices of >= n MB through the caches right before their launch
   unsigned* touch_sink = nullptr;
@@ -201,6 +202,7 @@ struct GemmOpt {
   const float* gn_gamma = nullptr; const float* gn_beta = nullptr; bf16_t* gn_y = nullptr; int gn_groups = 0; float gn_eps = 0.f; int gn_silu = 0, gn_keep_out = 0; int* gn_fused = nullptr;
   int kg2 = 0;                  // benches / tests: two K groups of waves per workgroup on the 64-row 1x1 tiles (the walk sets it through the ctx option)
   int smap = 0;                 // benches / tests: allow the 8 x 8 whole-images-resident 3x3 kernel (the walk sets it through the ctx option)
+  int xcd_block = 0;            // benches / tests: XCD-aware tile blocks (IgemmP::xcd_block; the walk sets it through the ctx option)
   int pc = 0;                   // benches / tests: producer / consumer kernel mask (IgemmP::pc; the walk sets it through the ctx option)
   int wreg = 0;                 // benches / tests: weight-streaming kernel for this launch when the WMat carries a fragment-order copy (bit 0 plain, bit 1 GEGLU)
   const bf16_t* sc0 = nullptr; const bf16_t* sc1 = nullptr; int sc_C0 = 0, sc_C1 = 0;   // the block's 1x1 conv_shortcut as extra K of this 3x3 launch (WMat::sc_cols)
@@ -243,6 +245,7 @@ static int run_conv(agd_ctx* c, hipStream_t st, const bf16_t* s0, int C0, const 
   p.smap = (c && c->opt_smap) || o.smap;
   p.kg2 = (c && c->opt_kg2) || o.kg2;
   p.pc = (c ? c->opt_pc : 0) | o.pc;
+  p.xcd_block = (c ? c->opt_xcd_block : 0) | o.xcd_block;
   p.p8 = o.p8 < 0 ? 0 : o.p8 ? o.p8 : c ? c->opt_p8 : 0;          // before any igemm_query: the tile shape depends on it (-1: not for this launch)
   if (o.query_cfg) { if (o.want_rowstat && !p.rowstat_out) { p.rowstat_out = (float*)16; p.rowstat_slots = 0; } return igemm_query(p, o.query_cfg); }   // (nothing is launched)
   if (o.out_act) {
@@ -1520,6 +1523,7 @@ AGD_API int agd_set_option(agd_ctx* c, const char* name, int value) {
   if (!strcmp(name, "gn_proj_fold")) { c->opt_gn_proj_fold = value < 0 ? 0 : value; return 0; }   // 0 off, 1: blocks with C <= 320, 2: C <= 640 (A/B)
   if (!strcmp(name, "tblock_fuse")) { c->opt_tb_fuse = value < 0 ? 0 : value; return 0; }   // bit 0: fused feed-forward, bit 1: fused attn2 chain (C = 320 blocks)
   if (!strcmp(name, "reduce_gn")) { c->opt_reduce_gn = value != 0; return 0; }
+  if (!strcmp(name, "xcd_block")) { c->opt_xcd_block = value != 0; return 0; }
   if (!strcmp(name, "igemm_pc")) { c->opt_pc = value < 0 ? 0 : value; return 0; }
   if (!strcmp(name, "attn2_premul")) { c->opt_xpre = value != 0; return 0; }     // takes effect at the next agd_set_context (the products are built there)
   if (!strcmp(name, "conv_smap")) { c->opt_smap = value != 0; return 0; }
@@ -1840,6 +1844,7 @@ AGD_API int agd_op_conv2d_ex(const float* x, const float* w, const float* bias, 
   GemmOpt o; o.bias = bias; o.stride = stride; o.up = up; o.out_f32 = 1; o.halo = flags & 1; o.p8 = (flags & 4) ? 2 : (flags & 8) ? 3 : (flags & 2) ? 1 : 0;
   o.smap = (flags & 16) ? 1 : 0;
   o.pc = (flags >> 7) & 15;                          // the producer / consumer kernel (igemm_pc.h): IgemmP::pc mask in bits 7..10
+  o.xcd_block = (flags >> 11) & 1;                   // XCD-aware tile blocks (igemm.hip pick_xcd_block)
   if ((flags & 64) && upsample && ksize == 3 && stride == 1) {     // the upsampling conv as four 2x2 phase convs (IgemmP::ups4); bf16 output (that form's only one), widened afterwards
     bf16_t* w4 = tmp.get<bf16_t>((size_t)4 * Cout * 4 * Cpad); float* b4 = tmp.get<float>((size_t)4 * Cout); bf16_t* yb = tmp.get<bf16_t>((size_t)B * Ho * Wo * Cout);
     if (!w4 || !b4 || !yb) return -1;
@@ -1875,6 +1880,7 @@ AGD_API int agd_op_linear(const float* x, const float* w, const float* bias, con
   GemmOpt o; o.bias = bias; o.residual = rb; o.geglu = geglu; o.out_f32 = 1; o.p8 = (flags & 4) ? 2 : (flags & 8) ? 3 : (flags & 2) ? 1 : 0;
   o.kg2 = (flags & 32) ? 1 : 0;                      // two K groups of waves per workgroup where the launcher's 64-row unsplit tiles apply
   o.pc = (flags >> 7) & 15;                          // the producer / consumer kernel (igemm_pc.h): IgemmP::pc mask in bits 7..10
+  o.xcd_block = (flags >> 11) & 1;                   // XCD-aware tile blocks (igemm.hip pick_xcd_block)
   if (flags & 16) {                                  // the weight-streaming kernel (igemm_wreg.h); bf16 output (that kernel's only form), widened afterwards
     const int ni = geglu ? 4 : 2;
     if (N % (ni * 64)) { agd_set_error("op_linear: the weight-streaming kernel needs N %% %d == 0", ni * 64); return -1; }
@@ -2138,6 +2144,7 @@ AGD_API int agd_bench_conv(int B, int H, int W, int C0, int C1, int Cout, int ks
   o.smap = (mode & 256) ? 1 : 0;
   o.kg2 = (mode & 512) ? 1 : 0;
   o.pc = (mode >> 11) & 15;                          // producer / consumer kernel (igemm_pc.h): IgemmP::pc mask in bits 11..14
+  o.xcd_block = (mode >> 15) & 1;                    // XCD-aware tile blocks
   if (mode & 128) {                                  // weight-streaming kernel (igemm_wreg.h): the matrix once more in fragment order
     const int ni = geglu ? 4 : 2;
     wm.wfrag = tmp.get<bf16_t>((size_t)Cout * taps * Ctot); if (!wm.wfrag) return -1;

@@ -50,13 +50,15 @@ def _is(name, cls):
     ig, i8, at = _targs(name, "igemm_kernel"), _targs(name, "igemm8p_kernel"), _targs(name, "attn_kernel")
     if cls == "igemm_conv3x3":
         # (KS = 2: the phase convs of the upsampling convs -- booked under the convs by the walk's profile scopes too)
-        return (ig is not None and ig[4] in ("2", "3")) or (i8 is not None and i8[5] in ("2", "3")) or "igemm_halo_kernel<" in name or "igemm_smap_kernel<" in name
+        pc = _targs(name, "igemm_pc_kernel")                        # igemm_pc_kernel<BM, BN, NLW, STAGES, KS, GEGLU, SPLITK>
+        return (ig is not None and ig[4] in ("2", "3")) or (i8 is not None and i8[5] in ("2", "3")) or "igemm_halo_kernel<" in name or "igemm_smap_kernel<" in name or (pc is not None and pc[4] == "3")
     if cls == "igemm_linear_1x1":
-        return (ig is not None and ig[4] == "1") or (i8 is not None and i8[5] == "1") or any(k in name for k in ("ff_fused_kernel<", "qkv_chain_kernel<", "igemm_wreg_kernel<"))
+        pc = _targs(name, "igemm_pc_kernel")
+        return (ig is not None and ig[4] == "1") or (i8 is not None and i8[5] == "1") or (pc is not None and pc[4] == "1") or any(k in name for k in ("ff_fused_kernel<", "qkv_chain_kernel<", "igemm_wreg_kernel<"))
     if cls == "attn_self_flash":
         return at is not None and at[3] == "0"
     if cls == "attn_cross_daam":
-        return (at is not None and at[3] != "0") or "attn_chain_kernel<" in name
+        return (at is not None and at[3] != "0") or "attn_chain_kernel<" in name or "xattn_s_kernel" in name or "premul_" in name
     if cls == "groupnorm":
         return "gn_" in name and "splitk_reduce" not in name
     if cls == "layernorm":

@@ -189,6 +189,31 @@ def test_linear_producer_consumer_kernel(ops, M, K, N, res):
     assert torch.equal(got, ops.linear(*args, pc=1))
 
 
+@pytest.mark.parametrize("kind,args", [("lin", (2048, 1280, 1280)), ("lin", (2048, 6400, 1280)), ("lin", (8192, 640, 1920)), ("lin", (512, 1280, 1280)), ("lin", (2048, 1280, 3840)),
+                                       ("conv", (8, 16, 1280, 1280)), ("conv", (8, 32, 640, 640)), ("conv", (4, 64, 320, 320)), ("conv", (8, 8, 1280, 1280)), ("conv", (3, 16, 192, 320))])
+def test_xcd_tile_blocks_do_not_change_results(ops, kind, args):
+    """`xcd_block` (igemm.hip pick_xcd_block): the tile grid cut into one block of tiles per XCD so that the XCD's L2 working set is smallest -- the same tiles computed by
+    other workgroups, so every output must be BIT-identical to the default walk's (4-wave, row-halo, 8-phase, whole-images and producer / consumer kernels, split-K included),
+    and every tile must still be computed exactly once (vs fp32 torch)."""
+    g = torch.Generator().manual_seed(sum(args))
+    if kind == "lin":
+        M, K, N = args
+        x = bfr(torch.randn(M, K, generator=g)); w = bfr(torch.randn(N, K, generator=g) / math.sqrt(K)); b = torch.randn(N, generator=g) * 0.1
+        want = F.linear(x, w, b)
+        for kw in ({}, {"pc": 1}, {"p8": 1}):
+            a0 = ops.linear(x.cuda(), w.cuda(), b.cuda(), **kw)
+            a1 = ops.linear(x.cuda(), w.cuda(), b.cuda(), xcd_block=True, **kw)
+            assert rel_err(a1, want) < 1e-4 and torch.equal(a0, a1), kw
+    else:
+        B, H, Cin, Cout = args
+        x = bfr(torch.randn(B, Cin, H, H, generator=g)); w = bfr(torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(Cin * 9)); b = torch.randn(Cout, generator=g) * 0.1
+        want = F.conv2d(x, w, b, padding=1)
+        for kw in ({}, {"halo": True}, {"halo": True, "smap": True}, {"p8": 1}):
+            a0 = ops.conv2d(x.cuda(), w.cuda(), b.cuda(), **kw)
+            a1 = ops.conv2d(x.cuda(), w.cuda(), b.cuda(), xcd_block=True, **kw)
+            assert rel_err(a1, want) < 1e-4 and torch.equal(a0, a1), kw
+
+
 @pytest.mark.parametrize("B,H,Cin,Cout,pc", [(8, 16, 1280, 1280, 2), (8, 16, 1280, 1280, 4), (8, 16, 640, 1280, 2), (2, 32, 128, 1280, 2), (8, 8, 1280, 1280, 8), (8, 8, 2560, 1280, 8),
                                               (6, 16, 192, 1280, 2)])
 def test_conv3x3_producer_consumer_kernel(ops, B, H, Cin, Cout, pc):

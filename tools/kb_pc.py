@@ -22,11 +22,16 @@ def conv(B, H, C0, C1, Cout, k=1, mode=0, res=0, iters=50):
 shapes = [("1x1 M2048 K1280 N1280 +res", (8, 16, 1280, 0, 1280, 1), 1), ("1x1 M2048 K1280 N1280", (8, 16, 1280, 0, 1280, 1), 0), ("1x1 M2048 K640 N1280 +res", (8, 16, 640, 0, 1280, 1), 1),
           ("1x1 M2048 K5120+1280 N1280 +res", (8, 16, 5120, 1280, 1280, 1), 1), ("1x1 M2048 K2560 N1280", (8, 16, 2560, 0, 1280, 1), 0),
           ("3x3 M2048 1280->1280", (8, 16, 1280, 0, 1280, 3), 0), ("3x3 M2048 2560->1280", (8, 16, 2560, 0, 1280, 3), 0), ("3x3 M2048 640->1280", (8, 16, 640, 0, 1280, 3), 0),
-          ("3x3 M512 1280->1280", (8, 8, 1280, 0, 1280, 3), 0), ("3x3 M512 2560->1280", (8, 8, 2560, 0, 1280, 3), 0)]
-print(f"{'shape':36s} {'launcher':>9s} {'pc 64x160':>10s} {'pc 128x160 x2':>14s} {'pc 8x8 split':>13s}   TF/s (best pc)")
+          ("3x3 M512 1280->1280", (8, 8, 1280, 0, 1280, 3), 0), ("3x3 M512 2560->1280", (8, 8, 2560, 0, 1280, 3), 0),
+          ("1x1 M2048 K1280 N3840 (qkv)", (8, 16, 1280, 0, 3840, 1), 0), ("1x1 M512 K1280 N1280 +res", (8, 8, 1280, 0, 1280, 1), 1), ("1x1 M8192 K640 N640 +res", (8, 32, 640, 0, 640, 1), 1),
+          ("1x1 M8192 K2560+640 N640 +res", (8, 32, 2560, 640, 640, 1), 1), ("1x1 M8192 K640 N1920", (8, 32, 640, 0, 1920, 1), 0),
+          ("3x3 M8192 640->640", (8, 32, 640, 0, 640, 3), 0), ("3x3 M8192 1280->640", (8, 32, 1280, 0, 640, 3), 0), ("3x3 M32768 320->320", (8, 64, 320, 0, 320, 3), 0),
+          ("3x3 M32768 640->320", (8, 64, 640, 0, 320, 3), 0)]
+XB = 1 << 15      # XCD-aware tile blocks (igemm.hip pick_xcd_block)
+print(f"{'shape':36s} {'launcher':>9s} {'+ blocks':>9s} {'pc':>9s} {'pc+blocks':>10s}   TF/s (best)")
 for name, a, res in shapes:
     base_mode = 8 | 256 if a[5] == 3 else 0
-    t0 = conv(*a[:5], k=a[5], mode=base_mode, res=res)
-    ts = [conv(*a[:5], k=a[5], mode=base_mode | (m << 11), res=res) for m in ((1, 4, 8) if a[5] == 1 else (2, 4, 8))]
+    pcm = (1 if a[5] == 1 else (2 if a[1] == 16 else 8)) << 11
+    ts = [conv(*a[:5], k=a[5], mode=base_mode | m, res=res) for m in (0, XB, pcm, pcm | XB)]
     fl = 2.0 * a[0] * a[1] * a[1] * a[4] * a[5] * a[5] * (a[2] + a[3])
-    print(f"{name:36s} {t0:9.1f} {ts[0]:10.1f} {ts[1]:14.1f} {ts[2]:13.1f}   {fl / min(ts) / 1e6:7.0f}", flush=True)
+    print(f"{name:36s} {ts[0]:9.1f} {ts[1]:9.1f} {ts[2]:9.1f} {ts[3]:10.1f}   {fl / min(ts) / 1e6:7.0f}", flush=True)
