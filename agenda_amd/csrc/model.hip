@@ -612,8 +612,10 @@ static int transformer(agd_ctx* c, hipStream_t st, const std::string& pre, const
   // fused row-panel kernels of this block (tblock.hip), where their shape is built: C = 320, 8 heads, <= 96 keys, whole 128-row tiles per
   // image; the hook.py recorder (per-head maps of every call) keeps the kernel chain
   const bool ff_fused = (c->opt_tb_fuse & 1) && fold && C == 320 && c->W.count(t + "ff.w1.frag");
+  bool xpre_ready = false;                               // the pre-multiplied attn2 form is ready for this block (agd_set_context built its products)
+  { auto itx = c->xl_idx.find(t + "attn2"); if (itx != c->xl_idx.end()) { const XLayer& xq = c->xl[itx->second]; xpre_ready = xq.pm_ready && c->opt_xpre && c->opt_ln_fold && HW % 64 == 0 && c->rec_mode != 2 && !dup; } }
   const bool chain_fuse = (c->opt_tb_fuse & 2) && (C == 320 || (C == 640 && (c->opt_tb_fuse & 32))) && heads == 8 && HW % (C == 320 ? 128 : 64) == 0 && c->ctx_T <= 96 &&
-                          c->rec_mode != 2 && c->W.count(t + "attn2.to_q.frag");
+                          c->rec_mode != 2 && c->W.count(t + "attn2.to_q.frag") && !xpre_ready;
   // CFG-shared prefix with the fused kernels behind it: the duplication of the B' rows happens INSIDE them (the chain reads input row m % M', the feed-forward's
   // proj_out stage adds block-input row m % M'): no copy launches, and attn1.to_out joins the chain here too
   const bool lazy_dup = dup && (c->opt_tb_fuse & 64) && chain_fuse && C == 320 && ff_fused && (c->opt_tb_fuse & 8) && c->W.count(pre + "proj_out.frag");
@@ -755,7 +757,7 @@ static int transformer(agd_ctx* c, hipStream_t st, const std::string& pre, const
   return 0;
 }
 
-// time embeddings of n <= 8 timesteps (inference: one timestep serves every batch row); scratch = n * 9 * dim floats,
+// time embeddings of n <= 25 timesteps (inference: one timestep serves every batch row); scratch = n * 9 * dim floats,
 // out = [n][tproj_total]: every resnet's time_emb_proj(silu(temb)) from one stacked matrix
 static int time_embed(agd_ctx* c, hipStream_t st, const float* ts, int n, float* scratch, float* out) {
   const int dim = c->cfg.block_out_channels[0], td = dim * 4;
@@ -1115,7 +1117,9 @@ AGD_API int agd_finalize(agd_ctx* c) {
     { const WMat* wq2 = getW(c, t + "attn2.to_q.weight"); const WMat* wo2 = getW(c, t + "attn2.to_out.0.weight");
       auto be2 = c->V.find(t + "norm2.bias");
       const int C2 = xl.C, D2 = C2 / xl.heads;
-      if (wq2 && wo2 && be2 != c->V.end() && D2 % 32 == 0 && C2 % 160 == 0 && (xl.heads * XATTN_TP) % 64 == 0 && xl.heads * XATTN_TP * 2 <= C2 &&
+      // (option bit 1, off by default: also where the columns equal C -- head dim 80, the C = 640 blocks: no fewer MACs, but three full-chip launches instead of the
+      //  half-chip chain kernel)
+      if (wq2 && wo2 && be2 != c->V.end() && D2 % 8 == 0 && C2 % 160 == 0 && (xl.heads * XATTN_TP) % 64 == 0 && xl.heads * XATTN_TP <= C2 &&
           wq2->taps == 1 && wq2->N == C2 && wq2->Cpad == C2 && wo2->taps == 1 && wo2->N == C2 && wo2->Cpad == C2) {
         xl.pm_wqT = dmalloc<bf16_t>(c, (size_t)C2 * C2); xl.pm_wqb = dmalloc<float>(c, C2);
         if (!xl.pm_wqT || !xl.pm_wqb) return fail_ctx(c);
@@ -1334,7 +1338,7 @@ AGD_API int agd_set_context(agd_ctx* c, const float* ctx_emb, int batch2, int to
     API_CK(c, run_conv(c, st, c->ctx_bf16, Dc, nullptr, 0, 1, 1, batch2 * tokens, xl.wkv, 1, xl.kv, o, c->zero_page));
     // the context products of the pre-multiplied attn2 form, once per prompt batch (xattn_pre.hip)
     xl.pm_ready = false;
-    if (c->opt_xpre && xl.pm_wqT && tokens <= XATTN_TP) {
+    if (c->opt_xpre && xl.pm_wqT && tokens <= XATTN_TP && ((c->opt_xpre & 2) || xl.heads * XATTN_TP * 2 <= xl.C)) {
       const std::string t = xl.name.substr(0, xl.name.size() - 5);          // "...transformer_blocks.0."
       const WMat* wo2 = getW(c, t + "attn2.to_out.0.weight"); const float* g2 = getV(c, t + "norm2.weight");
       if (!wo2 || !g2) return fail_ctx(c);
@@ -1409,7 +1413,7 @@ AGD_API int agd_cfg_ddim_step(agd_ctx* c, const float* eps, float* latents, int 
 // ~50 MB of weights: streamed ceil(n/8) times instead of once per step); returns [n][tproj_total] in *out
 static int embed_all_timesteps(agd_ctx* c, hipStream_t st, const float* timesteps, int n, const float** out) {
   const int dim0 = c->cfg.block_out_channels[0];
-  const size_t per_step = (size_t)c->tproj_total + (size_t)9 * dim0;
+  const size_t per_step = (size_t)c->tproj_total + (size_t)9 * dim0;         // (scratch: 9 dim floats per row of a chunk; chunk <= n rows at a time)
   if (c->tsteps_cap < n) {
     if (c->tsteps_buf) { hipDeviceSynchronize(); hipFree(c->tsteps_buf); }
     c->tsteps_buf = nullptr; c->tsteps_cap = 0;
@@ -1418,8 +1422,9 @@ static int embed_all_timesteps(agd_ctx* c, hipStream_t st, const float* timestep
   }
   float* tp_all = c->tsteps_buf;                                  // [n][tproj_total]
   float* tscratch = c->tsteps_buf + (size_t)c->tproj_total * n;
-  for (int s0 = 0; s0 < n; s0 += 8) {
-    const int m = n - s0 < 8 ? n - s0 : 8;
+  const int chunk = (size_t)25 * 4 * dim0 * 4 <= 160 * 1024 ? 25 : 8;      // rows per launch: the 4 dim-wide fp32 rows of a chunk sit in LDS (misc.hip small_linear_kernel)
+  for (int s0 = 0; s0 < n; s0 += chunk) {
+    const int m = n - s0 < chunk ? n - s0 : chunk;
     CK(time_embed(c, st, timesteps + s0, m, tscratch, tp_all + (size_t)s0 * c->tproj_total));
   }
   *out = tp_all;
@@ -1525,7 +1530,7 @@ AGD_API int agd_set_option(agd_ctx* c, const char* name, int value) {
   if (!strcmp(name, "reduce_gn")) { c->opt_reduce_gn = value != 0; return 0; }
   if (!strcmp(name, "xcd_block")) { c->opt_xcd_block = value != 0; return 0; }
   if (!strcmp(name, "igemm_pc")) { c->opt_pc = value < 0 ? 0 : value; return 0; }
-  if (!strcmp(name, "attn2_premul")) { c->opt_xpre = value != 0; return 0; }     // takes effect at the next agd_set_context (the products are built there)
+  if (!strcmp(name, "attn2_premul")) { c->opt_xpre = value < 0 ? 0 : value; return 0; }     // takes effect at the next agd_set_context (the products are built there)
   if (!strcmp(name, "conv_smap")) { c->opt_smap = value != 0; return 0; }
   if (!strcmp(name, "side_stream")) { c->opt_side = value < 0 ? 0 : value; return 0; }
   if (!strcmp(name, "igemm_kgroups")) { c->opt_kg2 = value != 0; return 0; }
@@ -2019,7 +2024,7 @@ AGD_API int agd_op_xattn_premul(const float* x, const float* gamma, const float*
                                 const float* bo, float* y, float* probs, int B, int HW, int T, int C, int heads, float eps, void* stream) {
   hipStream_t st = S(stream); Tmp tmp;
   const long long M = (long long)B * HW;
-  if (heads < 1 || C % heads || (C / heads) % 32 || C % 160 || HW % 64 || T < 1 || T > XATTN_TP || (heads * XATTN_TP) % 64) { agd_set_error("op_xattn_premul: C %d heads %d HW %d T %d", C, heads, HW, T); return -1; }
+  if (heads < 1 || C % heads || (C / heads) % 8 || C % 160 || HW % 64 || T < 1 || T > XATTN_TP || (heads * XATTN_TP) % 64) { agd_set_error("op_xattn_premul: C %d heads %d HW %d T %d", C, heads, HW, T); return -1; }
   const size_t HT = (size_t)heads * XATTN_TP;
   bf16_t* xb = tmp.get<bf16_t>((size_t)M * C); bf16_t* yb = tmp.get<bf16_t>((size_t)M * C); bf16_t* kvb = tmp.get<bf16_t>((size_t)B * T * 2 * C);
   bf16_t* wqb = tmp.get<bf16_t>((size_t)C * C); bf16_t* wqT = tmp.get<bf16_t>((size_t)C * C); bf16_t* wob = tmp.get<bf16_t>((size_t)C * C);

@@ -29,7 +29,7 @@ typedef u32x4 __attribute__((aligned(8))) u32x4_a8_;
 
 // ---------------------------------------------------------------------------------------
 // out[z][m][n] = bf16(alpha * colscale[n] * sum_k A[z][m][k] B[z][n][k]),  z = (b, h);  rows m >= Mv and columns n >= Nv are written as zeros
-// (the padded token rows / columns).  K % 32 == 0, 16-byte aligned rows.  One wave = a 16 x 80 strip, a workgroup 64 x 80.
+// (the padded token rows / columns).  K % 8 == 0, 16-byte aligned rows.  One wave = a 16 x 80 strip, a workgroup 64 x 80.
 // ---------------------------------------------------------------------------------------
 struct PremulP {
   const bf16_t* A; long long sAb, sAh; int lda;
@@ -54,13 +54,14 @@ __global__ __launch_bounds__(256) void premul_gemm_kernel(const PremulP p) {
 #pragma unroll
   for (int j = 0; j < 5; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
   for (int k0 = 0; k0 < p.K; k0 += 32) {
+    const bool k_ok = k0 + kc < p.K;                   // K % 8 == 0: the last 32-deep step may be ragged (head dim 80 = 2 x 32 + 16)
     bf16x8 a = {};
-    if (a_ok) a = *(const bf16x8*)(A + (long long)am * p.lda + k0 + kc);
+    if (a_ok && k_ok) a = *(const bf16x8*)(A + (long long)am * p.lda + k0 + kc);
 #pragma unroll
     for (int j = 0; j < 5; ++j) {
       const int bn = n0 + j * 16 + fr;
       bf16x8 w = {};
-      if (bn < p.Nv) w = *(const bf16x8*)(B + (long long)bn * p.ldb + k0 + kc);
+      if (bn < p.Nv && k_ok) w = *(const bf16x8*)(B + (long long)bn * p.ldb + k0 + kc);
       // operands swapped: acc[r] = out[m = lane & 15][n = 16 j + 4 (lane >> 4) + r] -- four consecutive columns of one row per lane
       acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, a, acc[j], 0, 0, 0);
     }
@@ -135,7 +136,7 @@ int launch_rowstat_bf16(const bf16_t* x, float* out, int M, int C, hipStream_t s
 
 int launch_xattn_premul(const XattnPremulP& x, hipStream_t st) {
   const int C = x.C, H = x.H, D = C / H, TP = XATTN_TP;
-  if (C % H || D % 32 || x.T < 1 || x.T > TP || (C % 80)) { agd_set_error("xattn_premul: C %d heads %d tokens %d", C, H, x.T); return -1; }
+  if (C % H || D % 8 || x.T < 1 || x.T > TP || (C % 80)) { agd_set_error("xattn_premul: C %d heads %d tokens %d", C, H, x.T); return -1; }
   // K''[b][(h,t)][c] = gamma[c] scale sum_d k[b][t][h D + d] WqT[c][h D + d]
   PremulP k{};
   k.A = x.kv; k.sAb = x.skv; k.sAh = D; k.lda = x.ldkv;
