@@ -122,6 +122,7 @@ struct AttnChainP {
   float* rowstat_out;               // optional: [M] float2 (sum, sum of squares) of the bf16 outputs (LayerNorm-fold producer, one slot)
   // optional prologue (o1 != NULL): h1 = o1 . Wo1^T + bo1 + h first (attn1.to_out + residual); h1 goes to `out` (!= h) and is the chain's input
   const bf16_t* o1; const bf16_t* wo1f; const float* bo1;
+  int rows32;                       // C = 640: allow 32-row panels (twice the workgroups) where 64-row panels leave CUs idle
   int src_rows;                     // > 0: the INPUT tensors (h, o1) hold src_rows rows and output row m reads input row m % src_rows -- the CFG-shared prefix's
                                     // duplication happens here instead of in copy launches (needs out != h)
 };

@@ -120,8 +120,8 @@ struct agd_ctx {
   int opt_gn_proj_fold = 1;                           // agd_set_option("gn_proj_fold"): the transformers' GroupNorm folded into per-image proj_in matrices (1: C <= 320, 2: C <= 640)
   int opt_p8 = 1;                                     // agd_set_option("igemm8p"): 256-row 8-wave / 8-phase igemm for launches with enough tiles (igemm8p.h)
   int opt_halo = 1;                                   // agd_set_option("conv_halo"): 3x3 stride-1 convs through the row-halo kernel (igemm_halo.h)
-  int opt_tb_fuse = 255 | 512;                               // agd_set_option("tblock_fuse"): fused row-panel kernels of the C = 320 transformer blocks (tblock.hip): bit 0 = feed-forward (bit 3: + proj_out),
-                                                      // bit 1 = attn2 chain (bit 2: + attn1.to_out in front of it), bit 4 = proj_in -> norm1 -> qkv, bit 5 = the attn2 chain for the C = 640 blocks too, bit 6 = the CFG-shared prefix's duplication inside the fused kernels, bit 7 = the GroupNorm applied inside the bit-4 launch (no fold launch), bit 8 (off) = the bit-4 launch with the GroupNorm inside for the C = 640 blocks, bit 9 = ff.net.2 / proj_out pre-multiplied inside the feed-forward kernel
+  int opt_tb_fuse = 255 | 512 | 1024;                               // agd_set_option("tblock_fuse"): fused row-panel kernels of the C = 320 transformer blocks (tblock.hip): bit 0 = feed-forward (bit 3: + proj_out),
+                                                      // bit 1 = attn2 chain (bit 2: + attn1.to_out in front of it), bit 4 = proj_in -> norm1 -> qkv, bit 5 = the attn2 chain for the C = 640 blocks too, bit 6 = the CFG-shared prefix's duplication inside the fused kernels, bit 7 = the GroupNorm applied inside the bit-4 launch (no fold launch), bit 8 (off) = the bit-4 launch with the GroupNorm inside for the C = 640 blocks, bit 9 = ff.net.2 / proj_out pre-multiplied inside the feed-forward kernel, bit 10 = 32-row panels for the C = 640 attn2 chain where 64-row panels would fill half the chip
   int opt_ups4 = 7; /* see agd_set_option */                                   // agd_set_option("upsample_phases"): the UNet's nearest-2x upsampling convs as four 2x2 phase convs on the un-upsampled map (one launch, 4/9 of the MACs)
   int opt_ffproj = 1;                                 // agd_set_option("ff_proj_fuse"): ff.net.2 and proj_out as ONE GEMM with the pre-multiplied matrix [Wp W2 | Wp] over [hidden | h] (blocks whose feed-forward is not the fused row-panel kernel)
   int opt_sc_fuse = 3;                                // agd_set_option("shortcut_fuse"): a UNet resnet's 1x1 conv_shortcut runs as extra K of its conv2 launch where that is an unsplit row-halo launch
@@ -668,6 +668,7 @@ static int transformer(agd_ctx* c, hipStream_t st, const std::string& pre, const
         ap.o1 = att; ap.wo1f = f1o->w; ap.bo1 = bo1; ap.out = h2;
       } else if (lazy_dup) { bf16_t* h2 = (bf16_t*)c->arena.alloc((size_t)M * C * 2); if (!h2) return -1; ap.out = h2; }
       if (lazy_dup) ap.src_rows = Mshared;
+      ap.rows32 = (c->opt_tb_fuse & 1024) ? 1 : 0;       // bit 10: 32-row panels for the C = 640 chain where 64-row panels fill half the chip
       if (fold && !ff_fused) {                           // the GEGLU consumer of the LayerNorm fold reads one slot of row statistics
         slots = 1; stats = (float*)c->arena.alloc((size_t)M * 2 * sizeof(float)); if (!stats) return -1;
         ap.rowstat_out = stats;
@@ -2007,6 +2008,7 @@ AGD_API int agd_op_attn_chain(const float* x, const float* gamma, const float* b
   CK(launch_convert_weight(wq, wqb, C, C, 1, C, 0, st)); CK(launch_frag_order_w(wqb, wqf, C, C, 5, C, st));
   CK(launch_convert_weight(wo, wob, C, C, 1, C, 0, st)); CK(launch_frag_order_w(wob, wof, C, C, 5, C, st));
   AttnChainP ap{}; ap.h = xb; ap.out = yb; ap.gamma = gamma; ap.beta = beta; ap.ln_eps = eps; ap.wqf = wqf; ap.wof = wof; ap.bo = bo;
+  ap.rows32 = (heads >> 8) & 1; heads &= 255;            // (bit 8 of `heads`: the 32-row panel form of the C = 640 kernel, tests)
   ap.kv = kvb; ap.ldkv = 2 * C; ap.skv = (long long)T * 2 * C; ap.M = (int)M; ap.HW = HW; ap.T = T; ap.scale = 1.0f / sqrtf((float)(C / heads));
   if (probs_sum) {
     if (hipMemsetAsync(probs_sum, 0, (size_t)B * T * HW * 4, st) != hipSuccess) { agd_set_error("memset probs"); return -1; }

@@ -168,18 +168,18 @@ AGD_DEV void panel_gemm_head(u32x4 (&ring)[TB_F], const bf16_t* wf, unsigned wba
 #pragma unroll
   for (int f = 0; f < TB_D; ++f) ring[f % TB_F] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, lane16, wbase + (unsigned)f * 1024u, 0));
 }
-template <int C, bool ZERO = true>     // ZERO = false: accumulate on top of what acc holds
-AGD_DEV void panel_gemm_body(u32x4 (&ring)[TB_F], f32x4 (&acc)[4][5], const bf16_t* wf, unsigned wbase, unsigned lane16, const char* xrow, const XOff<C>& xo,
+template <int C, bool ZERO = true, int MI = 4>     // ZERO = false: accumulate on top of what acc holds; MI: 16-row tiles of the wave (4: 64 rows; 2: the 32-row panels of attn_chain_kernel<640, ., 2>)
+AGD_DEV void panel_gemm_body(u32x4 (&ring)[TB_F], f32x4 (&acc)[MI][5], const bf16_t* wf, unsigned wbase, unsigned lane16, const char* xrow, const XOff<C>& xo,
                              unsigned wbytes = C * C * 2) {
-  constexpr int NI = 5, KS = C / 32, NFR = KS * NI, PITCH = C * 2;       // a wave's tile is 64 rows x 80 columns whatever C
+  constexpr int NI = 5, KS = C / 32, NFR = KS * NI, PITCH = C * 2;       // a wave's tile is 16 MI rows x 80 columns whatever C
   const auto wrs = __builtin_amdgcn_make_buffer_rsrc((void*)wf, 0, wbytes, 0x00020000);
   if constexpr (ZERO) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < MI; ++i)
 #pragma unroll
     for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
-  bf16x8 xf[4];
+  bf16x8 xf[MI];
 #pragma unroll
   for (int f = 0; f < NFR; ++f) {
     if (f + TB_D < NFR) ring[(f + TB_D) % TB_F] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, lane16, wbase + (unsigned)(f + TB_D) * 1024u, 0));
@@ -187,10 +187,10 @@ AGD_DEV void panel_gemm_body(u32x4 (&ring)[TB_F], f32x4 (&acc)[4][5], const bf16
     if (f % NI == 0) {
       const int ks = f / NI;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) xf[i] = *(const bf16x8*)(xrow + i * 16 * PITCH + xo.at(ks));
+      for (int i = 0; i < MI; ++i) xf[i] = *(const bf16x8*)(xrow + i * 16 * PITCH + xo.at(ks));
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MI; ++i)
       acc[i][f % NI] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ring[f % TB_F]), xf[i], acc[i][f % NI], 0, 0, 0);
   }
 }
@@ -489,12 +489,15 @@ int launch_ff_fused(const FFusedP& p, int C, hipStream_t st) {
 // ---------------------------------------------------------------------------------------------------------------------------
 // PRE = 1: the kernel starts one GEMM earlier, at attn1's to_out: h1 = o1 . Wo1^T + bo1 + h (written to `out`, the residual of the final
 // epilogue), norm2's statistics from the rounded h1 held in registers -- the launch between the self-attention and this chain disappears too
-template <int C, int PRE>
+template <int C, int PRE, int MI = 4>
 __global__ __launch_bounds__(512, 2) void attn_chain_kernel(const AttnChainP p) {
   // geometry: a wave's GEMM tile is always 64 rows x 80 columns, so C / 80 column ranges x (8 waves / that) row halves: C = 320: 128 rows per
   // workgroup, 2 x 4 waves; C = 640 (the 32 x 32 maps): 64 rows, 1 x 8 waves -- the panel is 80 KB either way.  Attention: BM / 32 query blocks x 2
   // head slots of four heads; at C = 640 (two query blocks) waves 2, 3, 6, 7 only help loading K / V.
-  constexpr int NQ = C / 80, MH = 8 / NQ, BM = 64 * MH, QBN = BM / 32;
+  // MI = 2 (C = 640 only, round 5): 32-row panels -- twice the workgroups (M = 8192: 256 instead of 128, the whole chip instead of half of it); a wave's GEMM tile is
+  // 32 x 80, ONE query block, so waves 0 and 4 run the attention of their four heads and the others only help staging K / V
+  constexpr int NQ = C / 80, MH = 8 / NQ, BM = 16 * MI * MH, QBN = BM / 32;
+  static_assert(MI == 4 || (MI == 2 && C == 640), "32-row panels: C = 640 only");
   constexpr int H = 8, D = C / H, KS = C / 32, NI = 5, PITCH = C * 2, CHR = C / 8;
   static_assert(C == 320 || C == 640, "8 heads of 40 / 80");
   constexpr int KB = 3, KEYS = 96, KSTEPS = (D + 15) / 16, DBLK = (D + 31) / 32, CH = D / 8;   // 96 keys; d = 40: 48 (QK^T) / 64 (PV); d = 80: 80 / 96
@@ -512,7 +515,7 @@ __global__ __launch_bounds__(512, 2) void attn_chain_kernel(const AttnChainP p) 
   const int mh = wid / NQ, nq = wid % NQ;               // GEMM roles
   const int q = lane >> 4, px = lane & 15;
   const int qb = wid & (QBN - 1), hhalf = wid >> 2;     // attention roles: query block, head slot (heads 4 hhalf .. + 3)
-  const bool attn_wave = QBN == 4 || !(wid & 2);        // wave-uniform
+  const bool attn_wave = QBN == 4 || (wid & 3) < QBN;   // wave-uniform
   const int c = lane & 31, hh = lane >> 5;
   const int m0 = blockIdx.x * BM;
   const int b = m0 / p.HW, pix0 = m0 - b * p.HW;        // tiles stay inside one image (HW % 128 == 0)
@@ -555,15 +558,15 @@ __global__ __launch_bounds__(512, 2) void attn_chain_kernel(const AttnChainP p) 
   kv_load(4 * hhalf);
 
   // ---- GEMM stage: acc[4][NI] = W[80 nq .. +80][:] . panel[64 mh .. +64][:]^T ----
-  const int rbase = 64 * mh + px;
+  const int rbase = 16 * MI * mh + px;
   const XOff<C> xo(q, px);
   const char* xrow = panel + rbase * PITCH;
-  f32x4 acc[4][NI];
+  f32x4 acc[MI][NI];
   u32x4 ring[TB_F];
   const unsigned lane16 = (unsigned)lane * 16u;
   const unsigned wbase = __builtin_amdgcn_readfirstlane((unsigned)(nq * KS * NI) * 1024u);
   auto gemm_head = [&](const bf16_t* wf) { panel_gemm_head<C>(ring, wf, wbase, lane16); };
-  auto gemm_body = [&](const bf16_t* wf) { panel_gemm_body<C>(ring, acc, wf, wbase, lane16, xrow, xo); };
+  auto gemm_body = [&](const bf16_t* wf) { panel_gemm_body<C, true, MI>(ring, acc, wf, wbase, lane16, xrow, xo); };
   const int ncol0 = 16 * NI * nq + 4 * NI * q;          // first of this lane's 4 NI consecutive channels (GEMM epilogues)
 
   if constexpr (PRE) gemm_head(p.wo1f);
@@ -578,17 +581,17 @@ __global__ __launch_bounds__(512, 2) void attn_chain_kernel(const AttnChainP p) 
 
   if constexpr (PRE) {
     // ---- attn1.to_out + bias + residual -> h1 (rounded once, stored), its row statistics, norm2 from registers into the panel ----
-    u32x2 hr[4][NI];                                    // residual rows of h, requested ahead of the GEMM
+    u32x2 hr[MI][NI];                                    // residual rows of h, requested ahead of the GEMM
 #pragma unroll
-    for (int i = 0; i < 4; ++i) load_row_chunk<NI>(p.h + (long long)(m0s + rbase + 16 * i) * C + ncol0, hr[i]);
+    for (int i = 0; i < MI; ++i) load_row_chunk<NI>(p.h + (long long)(m0s + rbase + 16 * i) * C + ncol0, hr[i]);
     gemm_body(p.wo1f);
     gemm_head(p.wqf);
     float bv1[NI * 4];
 #pragma unroll
     for (int t = 0; t < NI; ++t) *(f32x4*)&bv1[4 * t] = *(const f32x4*)(p.bo1 + ncol0 + 4 * t);
-    float rs1[4], rq1[4];
+    float rs1[MI], rq1[MI];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < MI; ++i) {
       const int m = m0 + rbase + 16 * i;
       bf16_t* op = p.out + (long long)m * C + ncol0;
       u32x2 pkk[NI];
@@ -614,7 +617,7 @@ __global__ __launch_bounds__(512, 2) void attn_chain_kernel(const AttnChainP p) 
 #pragma unroll
     for (int t = 0; t < NI; ++t) { *(f32x4*)&g2[4 * t] = *(const f32x4*)(p.gamma + ncol0 + 4 * t); *(f32x4*)&b2[4 * t] = *(const f32x4*)(p.beta + ncol0 + 4 * t); }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < MI; ++i) {
       const int row = rbase + 16 * i;
       float S = 0.f, Q = 0.f;
 #pragma unroll
@@ -655,7 +658,7 @@ __global__ __launch_bounds__(512, 2) void attn_chain_kernel(const AttnChainP p) 
   gemm_body(p.wqf);
   __syncthreads();
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < MI; ++i) {
     const int row = rbase + 16 * i;
 #pragma unroll
     for (int t = 0; t < NI; ++t) {
@@ -819,16 +822,16 @@ __global__ __launch_bounds__(512, 2) void attn_chain_kernel(const AttnChainP p) 
   __syncthreads();                                       // O complete in the panel (and the exchange buffer is free)
 
   // ---- to_out + bias + residual, one rounding; optional norm3 row statistics of the rounded outputs ----
-  u32x2 fr[4][NI];                                      // residual rows, requested ahead of the GEMM (PRE: h1, stored by this very lane above)
+  u32x2 fr[MI][NI];                                      // residual rows, requested ahead of the GEMM (PRE: h1, stored by this very lane above)
 #pragma unroll
-  for (int i = 0; i < 4; ++i) load_row_chunk<NI>((PRE ? (const bf16_t*)p.out : p.h) + (long long)((PRE ? m0 : m0s) + rbase + 16 * i) * C + ncol0, fr[i]);
+  for (int i = 0; i < MI; ++i) load_row_chunk<NI>((PRE ? (const bf16_t*)p.out : p.h) + (long long)((PRE ? m0 : m0s) + rbase + 16 * i) * C + ncol0, fr[i]);
   gemm_body(p.wof);
   float bv[NI * 4];
 #pragma unroll
   for (int t = 0; t < NI; ++t) *(f32x4*)&bv[4 * t] = *(const f32x4*)(p.bo + ncol0 + 4 * t);
-  float rs[4], rq[4];
+  float rs[MI], rq[MI];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < MI; ++i) {
     const int m = m0 + rbase + 16 * i;
     rs[i] = 0.f; rq[i] = 0.f;
     bf16_t* op = p.out + (long long)m * C + ncol0;
@@ -847,14 +850,14 @@ __global__ __launch_bounds__(512, 2) void attn_chain_kernel(const AttnChainP p) 
   }
   if (p.rowstat_out) {                                  // wave-uniform (kernel argument); fixed summation order: reproducible
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < MI; ++i) {
       rs[i] += __shfl_xor(rs[i], 16); rs[i] += __shfl_xor(rs[i], 32);
       rq[i] += __shfl_xor(rq[i], 16); rq[i] += __shfl_xor(rq[i], 32);
     }
     float* stg = (float*)kvs;                            // [NQ][BM][2]
     if (q == 0) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) { stg[(nq * BM + rbase + 16 * i) * 2] = rs[i]; stg[(nq * BM + rbase + 16 * i) * 2 + 1] = rq[i]; }
+      for (int i = 0; i < MI; ++i) { stg[(nq * BM + rbase + 16 * i) * 2] = rs[i]; stg[(nq * BM + rbase + 16 * i) * 2 + 1] = rq[i]; }
     }
     __syncthreads();
     if (tid < BM) {
@@ -868,7 +871,9 @@ __global__ __launch_bounds__(512, 2) void attn_chain_kernel(const AttnChainP p) 
 
 int launch_attn_chain(const AttnChainP& p, int C, int heads, hipStream_t st) {
   if ((C != 320 && C != 640) || heads != 8) { agd_set_error("attn_chain: C = %d / heads = %d is not built (320 or 640 / 8 only)", C, heads); return -1; }
-  const int BM = C == 320 ? 128 : 64;
+  // C = 640: 64-row panels, or 32-row panels where the 64-row ones would leave CUs idle (fewer than 200 workgroups) and the caller allows it (rows32)
+  const bool r32 = C == 640 && p.rows32 && p.M / 64 < 200 && p.HW % 32 == 0;
+  const int BM = C == 320 ? 128 : r32 ? 32 : 64;
   if (p.M < BM || p.M % BM || p.HW % BM || p.M % p.HW) { agd_set_error("attn_chain: M %d / HW %d must be multiples of %d (whole images)", p.M, p.HW, BM); return -1; }
   if (p.T < 1 || p.T > 96) { agd_set_error("attn_chain: %d keys (1..96)", p.T); return -1; }
   if ((long long)p.M * C * 2 >= (1LL << 31)) { agd_set_error("attn_chain: activation too large for 32-bit offsets"); return -1; }
@@ -879,11 +884,12 @@ int launch_attn_chain(const AttnChainP& p, int C, int heads, hipStream_t st) {
   if (pre && (!p.wo1f || !p.bo1 || p.out == p.h)) { agd_set_error("attn_chain: the to_out prologue needs its weights and out != h"); return -1; }
   if (p.src_rows > 0 && (p.src_rows % BM || p.M % p.src_rows || p.out == p.h)) { agd_set_error("attn_chain: src_rows %d must divide M, be a multiple of %d and out != h", p.src_rows, BM); return -1; }
   const void* kfn = C == 320 ? (pre ? (const void*)attn_chain_kernel<320, 1> : (const void*)attn_chain_kernel<320, 0>)
+                    : r32    ? (pre ? (const void*)attn_chain_kernel<640, 1, 2> : (const void*)attn_chain_kernel<640, 0, 2>)
                              : (pre ? (const void*)attn_chain_kernel<640, 1> : (const void*)attn_chain_kernel<640, 0>);
-  static bool attr[AGD_MAX_DEVICES][4] = {};
+  static bool attr[AGD_MAX_DEVICES][6] = {};
   int dev = 0; HIP_CHECK_RET(hipGetDevice(&dev));
   if (dev < 0 || dev >= AGD_MAX_DEVICES) { agd_set_error("attn_chain: device ordinal %d out of range", dev); return -1; }
-  const int slot = (C == 640 ? 2 : 0) + (pre ? 1 : 0);
+  const int slot = (C == 640 ? (r32 ? 4 : 2) : 0) + (pre ? 1 : 0);
   if (!attr[dev][slot]) { HIP_CHECK_RET(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); attr[dev][slot] = true; }
   AttnChainP pp = p;
   void* args[] = {&pp};

@@ -81,7 +81,7 @@ def ff_fused(x, gamma, beta, w1, b1, w2, b2, eps=1e-5):
     return y.reshape(x.shape)
 
 
-def attn_chain(x, gamma, beta, wq, kv, wo, bo, heads=8, eps=1e-5, return_probs=False):
+def attn_chain(x, gamma, beta, wq, kv, wo, bo, heads=8, eps=1e-5, return_probs=False, rows32=False):
     """x + to_out(attention(to_q(LayerNorm(x)), k, v)) as ONE launch (tblock.hip); x [B, HW, C], kv [B, T, 2C] (K columns then V columns).
     With return_probs: also the probabilities summed over the heads, [B, T, HW]."""
     lib = _lib.load()
@@ -91,7 +91,7 @@ def attn_chain(x, gamma, beta, wq, kv, wo, bo, heads=8, eps=1e-5, return_probs=F
     y = torch.empty_like(x)
     pr = torch.empty(B, T, HW, device=x.device, dtype=torch.float32) if return_probs else None
     _lib.check(lib.agd_op_attn_chain(_lib.ptr(x), _lib.ptr(_f32c(gamma)), _lib.ptr(_f32c(beta)), _lib.ptr(_f32c(wq)), _lib.ptr(kv), _lib.ptr(_f32c(wo)),
-                                     _lib.ptr(_f32c(bo)), _lib.ptr(y), _lib.ptr(pr), B, HW, T, Cc, heads, float(eps), _lib.current_stream_ptr()),
+                                     _lib.ptr(_f32c(bo)), _lib.ptr(y), _lib.ptr(pr), B, HW, T, Cc, heads | (256 if rows32 else 0), float(eps), _lib.current_stream_ptr()),
                None, "agd_op_attn_chain")
     return (y, pr) if return_probs else y
 

@@ -117,10 +117,10 @@ int agd_vae_encode(agd_ctx* ctx, const float* image, int batch, int side, float*
  * "igemm8p" (default 1): launches with enough 256-row tiles (wide 1x1 projections, 3x3 convs with N a multiple of 256, the
  * upsampling convs) run the 8-wave / 8-phase implicit-GEMM kernel (igemm8p.h); 0 = the 4-wave kernels everywhere; tests: 2 / 3 / 4
  * force its 256-wide / 160-wide / any legal tile.
- * "tblock_fuse" (default 767): fused row-panel kernels of the transformer blocks at C = 320 (tblock.hip) -- bit 0: norm3 -> GEGLU ->
+ * "tblock_fuse" (default 1791): fused row-panel kernels of the transformer blocks at C = 320 (tblock.hip) -- bit 0: norm3 -> GEGLU ->
  * ff.net.2 + residual as one launch, bit 1: norm2 -> to_q -> cross-attention (+ recorder) -> to_out + residual as one launch, bit 2: that
  * launch starts at attn1.to_out + residual, bit 3: the feed-forward launch ends with proj_out + residual (+ the next GroupNorm's sums), bit 4: proj_in (GroupNorm folded) -> norm1 ->
- * q / k / v projections as one launch, bit 5: the attn2 chain (bits 1, 2) for the C = 640 blocks of the 32 x 32 maps as well (64-row panels), bit 6: under `cfg_shared_prefix` the duplication of the shared rows happens inside the fused kernels (no copy launches), bit 7: the bit-4 launch applies the transformer's GroupNorm itself (statistics from the producer's partial sums, rows normalised in its LDS panel) instead of reading per-image folded matrices from a fold launch, bit 8 (not in the default: measured slower): that launch, GroupNorm inside, for the C = 640 blocks too, bit 9: inside the feed-forward launch (bits 0, 3) ff.net.2 and proj_out are pre-multiplied (Wp W2 at load time; the proj_out stage adds Wp . h on the same accumulators -- no intermediate h3).
+ * q / k / v projections as one launch, bit 5: the attn2 chain (bits 1, 2) for the C = 640 blocks of the 32 x 32 maps as well (64-row panels), bit 6: under `cfg_shared_prefix` the duplication of the shared rows happens inside the fused kernels (no copy launches), bit 7: the bit-4 launch applies the transformer's GroupNorm itself (statistics from the producer's partial sums, rows normalised in its LDS panel) instead of reading per-image folded matrices from a fold launch, bit 8 (not in the default: measured slower): that launch, GroupNorm inside, for the C = 640 blocks too, bit 9: inside the feed-forward launch (bits 0, 3) ff.net.2 and proj_out are pre-multiplied (Wp W2 at load time; the proj_out stage adds Wp . h on the same accumulators -- no intermediate h3), bit 10: the attn2 chain of the C = 640 blocks on 32-row panels where 64-row panels give fewer than 200 workgroups (M = 8192: 256 workgroups instead of 128).
  * "reduce_gn" (default 1): the slab-sum pass of a split-K conv also applies the GroupNorm (+ SiLU) that reads its output next (conv1 -> norm2 of a
  * ResnetBlock2D; conv2 -> the following module's norm where that reads this output alone); 0 = separate statistics / apply launches.
  * "conv_smap" (default 1): 3x3 convs of the 8 x 8 maps run the whole-images-resident kernel (igemm_smap.h).
@@ -133,7 +133,11 @@ int agd_vae_encode(agd_ctx* ctx, const float* image, int batch, int side, float*
  * "wreg_mask" (default 3): the weight-streaming kernel (igemm_wreg.h: weight fragments straight to registers) for bit 0 = the GEGLU projection of the C = 1280 blocks at 16 x 16,
  * bit 1 = proj_in / proj_out of the C = 640 transformer blocks.
  * "igemm_kgroups" (default 1): the unsplit 1x1 launches on 64 x 64 tiles (8 x 8 maps: at most one workgroup per CU) run two K groups of four waves per workgroup.
- * "attn2_premul" (default 1; read at the next agd_set_context): attn2 of the blocks with head dim >= 160 (SD-1.x: C = 1280, the 16 x 16 and 8 x 8 maps) runs against per-image
+ * "igemm_pc" (default 1): producer / consumer implicit GEMM (csrc/igemm_pc.h: loader waves issue the ring's LDS-DMA pieces, consumer waves read fragments one K step ahead and run the MFMAs) --
+ * bit 0: the 1x1 launches on 64 x 160 tiles (one workgroup per CU: the 16 x 16 / 8 x 8 maps), bits 1 - 3 (measured slower, off): 3x3 convs of the 16 x 16 / 8 x 8 maps.
+ * "xcd_block" (default 1): the igemm tile grid is cut into one a x b block of tiles per XCD, (a, b) minimising the XCD's L2 working set, instead of tiles / 8 consecutive tiles of the
+ * A-major / W-major walk (same tiles, same results bit for bit).
+ * "attn2_premul" (default 1, bit 1 -- also the head-dim-80 blocks -- off: a tie; read at the next agd_set_context): attn2 of the blocks with head dim >= 160 (SD-1.x: C = 1280, the 16 x 16 and 8 x 8 maps) runs against per-image
  * PRE-MULTIPLIED context matrices built once per agd_set_context (csrc/xattn_pre.hip; hook.py:91-120): S = LN(h) . K'' with K'' = gamma scale (k Wq), softmax + recorder in that GEMM's
  * epilogue, out = P . V'' + bo + h with V'' = Wo v -- two launches instead of to_q, the attention kernel and to_out; 0 = the kernel chain.  The hook.py recorder keeps the chain.
  * "side_stream" (default 0; measured slower, kept for the A/B): a resnet's 1x1 conv_shortcut runs on a second stream beside norm1 / conv1 / norm2. */

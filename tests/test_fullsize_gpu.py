@@ -201,7 +201,7 @@ def test_fused_transformer_block_kernels_match_the_kernel_chain_512px(sd15_host_
     want, whm, _ = _ORACLE_CACHE["unet512"]
     outs = {}
     try:
-        for fuse, rg in ((0, 0), (1, 1), (2, 1), (6, 1), (9, 1), (16, 1), (31, 1), (34, 1), (63, 1), (63, 0), (144, 1), (176, 1), (255, 1), (767, 1)):
+        for fuse, rg in ((0, 0), (1, 1), (2, 1), (6, 1), (9, 1), (16, 1), (31, 1), (34, 1), (63, 1), (63, 0), (144, 1), (176, 1), (255, 1), (767, 1), (1791, 1)):
             pipe.engine.set_option("tblock_fuse", fuse)
             pipe.engine.set_option("reduce_gn", rg)
             pipe.engine.set_context(ctx)
@@ -215,7 +215,7 @@ def test_fused_transformer_block_kernels_match_the_kernel_chain_512px(sd15_host_
                 again = pipe.engine.unet_forward(x, 981.0)
                 assert torch.equal(got, again) and torch.equal(hm, pipe.engine.daam_global(0, 77, L).cpu())
     finally:
-        pipe.engine.set_option("tblock_fuse", 767)
+        pipe.engine.set_option("tblock_fuse", 1791)
         pipe.engine.set_option("reduce_gn", 1)
         pipe.engine.record_config(0)
     base, bhm = outs[(0, 0)]
@@ -241,8 +241,10 @@ def test_merged_launches_at_odd_sizes_match_the_unmerged_walk(sd15_host_weights,
     L = side // 8
     ctx = synthetic.make_context(cfg, B, seed=side)
     lat = synthetic.make_latents(cfg, list(range(B)), L)
-    off = {"tblock_fuse": 0, "reduce_gn": 0, "shortcut_fuse": 0, "ff_proj_fuse": 0, "upsample_phases": 0, "igemm_kgroups": 0, "wreg_mask": 0, "conv_smap": 0}
-    on = {"tblock_fuse": 767, "reduce_gn": 1, "shortcut_fuse": 3, "ff_proj_fuse": 1, "upsample_phases": 7, "igemm_kgroups": 1, "wreg_mask": 3, "conv_smap": 1}
+    off = {"tblock_fuse": 0, "reduce_gn": 0, "shortcut_fuse": 0, "ff_proj_fuse": 0, "upsample_phases": 0, "igemm_kgroups": 0, "wreg_mask": 0, "conv_smap": 0, "attn2_premul": 0,
+           "igemm_pc": 0, "xcd_block": 0}
+    on = {"tblock_fuse": 1791, "reduce_gn": 1, "shortcut_fuse": 3, "ff_proj_fuse": 1, "upsample_phases": 7, "igemm_kgroups": 1, "wreg_mask": 3, "conv_smap": 1, "attn2_premul": 1,
+          "igemm_pc": 1, "xcd_block": 1}
 
     def run():
         return pipe(prompt_embeds=ctx, latents=lat, num_inference_steps=2, height=side, width=side, output_type="latent").latents.clone()
@@ -292,12 +294,12 @@ def test_cfg_shared_prefix_inside_the_fused_kernels_512px(sd15_pipe):
 
     try:
         a = run(); a2 = run()
-        pipe.engine.set_option("tblock_fuse", 767 & ~64)
+        pipe.engine.set_option("tblock_fuse", 1791 & ~64)
         b = run()
         pipe.engine.set_option("cfg_shared_prefix", 0)
         c0 = run()
     finally:
-        pipe.engine.set_option("tblock_fuse", 767)
+        pipe.engine.set_option("tblock_fuse", 1791)
         pipe.engine.set_option("cfg_shared_prefix", 1)
     assert torch.equal(a[0], a2[0]) and torch.equal(a[1], a2[1])
     # calibration: how far two VALID realisations of the same two steps drift apart (classifier-free guidance multiplies the bf16 noise of eps by ~10)
@@ -335,12 +337,12 @@ def test_sd15_unet_forward_512px_batch4_matches_oracle(sd15_host_weights, sd15_p
         hm = torch.stack([pipe.engine.daam_global(i, 77, L).cpu() for i in range(B)])
         # tblock_fuse bit 8 (off by default: measured slower): proj_in -> norm1 -> q / k / v with the GroupNorm inside for the C = 640 blocks too
         # (only at this batch do the 32 x 32 convs leave the partial sums the kernel needs)
-        pipe.engine.set_option("tblock_fuse", 767 | 256)
+        pipe.engine.set_option("tblock_fuse", 1791 | 256)
         pipe.engine.record_reset(B, L)
         got8 = pipe.engine.unet_forward(x, 601.0).clone()
         hm8 = torch.stack([pipe.engine.daam_global(i, 77, L).cpu() for i in range(B)])
         # shortcut_fuse off: the resnets' 1x1 conv_shortcut as its own launch (its bf16-rounded output added as conv2's residual) instead of extra K of conv2
-        pipe.engine.set_option("tblock_fuse", 767)
+        pipe.engine.set_option("tblock_fuse", 1791)
         pipe.engine.set_option("shortcut_fuse", 0)
         pipe.engine.record_reset(B, L)
         got_s = pipe.engine.unet_forward(x, 601.0).clone()
@@ -354,9 +356,26 @@ def test_sd15_unet_forward_512px_batch4_matches_oracle(sd15_host_weights, sd15_p
         pipe.engine.set_option("upsample_phases", 0)
         pipe.engine.record_reset(B, L)
         got_u = pipe.engine.unet_forward(x, 601.0).clone()
-    finally:
         pipe.engine.set_option("upsample_phases", 7)
-        pipe.engine.set_option("tblock_fuse", 767)
+        # round 5: attn2_premul off -- attn2 of the C = 1280 blocks as to_q, the attention kernel and to_out instead of two GEMMs against per-image pre-multiplied context matrices
+        pipe.engine.set_option("attn2_premul", 0)
+        pipe.engine.set_context(ctx)                               # (the products are built in agd_set_context)
+        pipe.engine.record_reset(B, L)
+        got_p = pipe.engine.unet_forward(x, 601.0).clone()
+        hm_p = torch.stack([pipe.engine.daam_global(i, 77, L).cpu() for i in range(B)])
+        pipe.engine.set_option("attn2_premul", 1)
+        pipe.engine.set_context(ctx)
+        # round 5: the producer / consumer igemm and the XCD tile blocks compute the same tiles with the same summation order: bit-identical outputs
+        pipe.engine.set_option("igemm_pc", 0)
+        pipe.engine.set_option("xcd_block", 0)
+        pipe.engine.record_reset(B, L)
+        got_x = pipe.engine.unet_forward(x, 601.0).clone()
+    finally:
+        pipe.engine.set_option("igemm_pc", 1)
+        pipe.engine.set_option("xcd_block", 1)
+        pipe.engine.set_option("attn2_premul", 1)
+        pipe.engine.set_option("upsample_phases", 7)
+        pipe.engine.set_option("tblock_fuse", 1791)
         pipe.engine.set_option("shortcut_fuse", 3)
         pipe.engine.set_option("ff_proj_fuse", 1)
         pipe.engine.record_config(0)
@@ -380,6 +399,12 @@ def test_sd15_unet_forward_512px_batch4_matches_oracle(sd15_host_weights, sd15_p
     print(f"  upsampling convs on the upsampled map: {err_u:.5f} vs the oracle, {d_u:.5f} vs the phase form")
     report("config2_forward_512px_batch4", upsample_3x3_rms_rel=err_u, upsample_3x3_vs_default=d_u)
     assert err_u < 2.0 ** -6 and 0 < d_u < 2.0 ** -5, (err_u, d_u)
+    err_p, d_p = _rms_rel(got_p, want), _rms_rel(got_p, got.cpu())
+    hm_p_err = float((hm_p - whm).abs().max() / whm.abs().max())
+    print(f"  attn2 of the C = 1280 blocks as the kernel chain: {err_p:.5f} vs the oracle (heat map {hm_p_err:.4f}), {d_p:.5f} vs the pre-multiplied form")
+    report("config2_forward_512px_batch4", attn2_chain_rms_rel=err_p, attn2_chain_heat_map_rel=hm_p_err, attn2_chain_vs_default=d_p)
+    assert err_p < 2.0 ** -6 and hm_p_err < 0.02 and 0 < d_p < 2.0 ** -5, (err_p, hm_p_err, d_p)
+    assert torch.equal(got_x, got)                                 # igemm_pc / xcd_block off: the same bits
 
 
 def _oracle_cfg_pairs(u, ucfg, x, t, ctx, L, tokens=77):

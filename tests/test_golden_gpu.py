@@ -132,8 +132,8 @@ def _bf16bits(a):
     return torch.from_numpy((a.astype(np.uint32) << 16).view(np.float32).copy())
 
 
-@pytest.mark.parametrize("name,C", [("chain320", 320), ("chain640", 640)])
-def test_attn_chain_kernel_matches_reference_hook_call_at_production_shapes(golden_dir, name, C):
+@pytest.mark.parametrize("name,C,r32", [("chain320", 320, 0), ("chain640", 640, 0), ("chain640", 640, 1)])      # r32: the 32-row panel form of the C = 640 kernel
+def test_attn_chain_kernel_matches_reference_hook_call_at_production_shapes(golden_dir, name, C, r32):
     """since round 4 the attn2 layers of the 64 x 64 / 32 x 32 maps run `attn_chain_kernel<320>` / `<640>` (tblock.hip), not the
     kernel the older fixtures drive.  This pins THAT kernel to the reference's own outputs: hook.py:83-122 (`UNetCrossAttentionHooker.__call__`,
     inference mode) run on F.layer_norm(x_raw) at C = 320 / 8 heads of 40 / hw = 1024 and C = 640 / 8 heads of 80 / hw = 256
@@ -149,7 +149,7 @@ def test_attn_chain_kernel_matches_reference_hook_call_at_production_shapes(gold
     ctx, ga, be, bo = (torch.from_numpy(z[f"{name}_{k}"]) for k in ("ctx", "gamma", "beta", "bo"))
     kv = torch.cat([F.linear(ctx, w["wk"]), F.linear(ctx, w["wv"])], dim=-1)               # [B, T, 2C]
     cu = lambda t: t.cuda()
-    got, pr = ops.attn_chain(cu(x), cu(ga), cu(be), cu(w["wq"]), cu(kv), cu(w["wo"]), cu(bo), heads=H, return_probs=True)
+    got, pr = ops.attn_chain(cu(x), cu(ga), cu(be), cu(w["wq"]), cu(kv), cu(w["wo"]), cu(bo), heads=H, return_probs=True, rows32=bool(r32))
     y1 = (got.cpu() - x)[1]
     want_y1 = torch.from_numpy(z[name + "_y1_f16"].astype(np.float32))
     e_y = float((y1 - want_y1).abs().max() / want_y1.abs().max())
@@ -158,7 +158,7 @@ def test_attn_chain_kernel_matches_reference_hook_call_at_production_shapes(gold
     m = (pr.cpu()[1:] / H).reshape(1, pr.shape[1], side, side)
     e_m = float((m - want_m).abs().max())
     print(f"attn_chain_kernel<{C}> vs the reference's __call__: output max rel {e_y:.5f}, map max abs {e_m:.6f}")
-    report(f"golden_attn_chain_kernel[C={C}]", out_max_rel=e_y, map_max_abs=e_m)
+    report(f"golden_attn_chain_kernel[C={C},rows32={r32}]", out_max_rel=e_y, map_max_abs=e_m)
     assert e_y < 2.0 ** -6, e_y          # bf16 operands / fp32 accumulate + a bf16 residual stream vs the reference's fp32
     assert e_m < 2e-3, e_m
 
