@@ -25,8 +25,8 @@ TFLOP_PER_IMAGE = {50: 82.84}          # 2*50*803.3 GF + 2514.5 
 UNET_GF, VAE_GF = 803.3, 2514.5
 MFMA_PEAK_TF = 2500.0                  # bf16 dense, MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0                  # HBM3E spec, MI355X_MICROARCH.md (6.3 TB/s is what a copy achieves)
-PMC_CSV = os.path.join("profiles", "r04_pmc_traffic_summary.csv")
-STATS_CSV = os.path.join("profiles", "r04_bench_kernel_stats.csv")
+PMC_CSV = os.path.join("profiles", "r05_pmc_traffic_summary.csv")
+STATS_CSV = os.path.join("profiles", "r05_bench_kernel_stats.csv")
 
 # the kernel instantiations behind each class, as rocprofv3 names them: igemm_kernel<BM, BN, WM, WN, KS, ...>,
 # igemm_halo_kernel<BN, SPLITK, BST> (3x3 only), igemm8p_kernel<WM, WN, MI, NI0, NI1, KS, GEGLU>

@@ -2,7 +2,7 @@
 # Round profile set on the GPU box (one gpurun call): kernel stats of the bench command, FETCH/WRITE PMC passes (separate
 # runs, no trace domains mixed with --pmc), MFMA-busy PMC pass, per-layer report.  Outputs under gpurun_out/prof_$1/.
 set -e
-R=${1:-r03}
+R=${1:-r05}
 OUT=gpurun_out/prof_$R
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT

@@ -54,6 +54,7 @@ template <int MODE, int DEPTH> void run(const char* name, const char* buf, unsig
   for (int waves = 4; waves <= 16; waves *= 2) {
     const int threads = waves * 64, blocks = 256, iters = 2000;
     const size_t lds = (size_t)waves * DEPTH * 1024;
+    if (lds > 160 * 1024) continue;                          // (16 waves x 16 pieces would need 256 KB of LDS)
     auto kf = k<MODE, DEPTH>;
     hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
