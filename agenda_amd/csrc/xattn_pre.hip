@@ -177,8 +177,10 @@ __global__ __launch_bounds__(256) void xattn_s_kernel(const XattnSP p) {
   char* const sink = smem + STAGES * STAGE;                // 4 x 1 KiB: where the dead pieces land
   float* const lnst = (float*)(sink + 4096);               // [64] (mean, rstd)
   const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
-  const int head = blockIdx.y, m0 = blockIdx.x * BM;
-  const int img = m0 / p.HW;
+  // grid (images, row tiles of an image x heads): workgroups are dealt round-robin over the XCDs, so with the image on blockIdx.x every workgroup of an image lands on
+  // ONE XCD (8 images: exactly one each) and that XCD's L2 holds the image's K'' (1.6 MB at C = 1280) once -- with the row tile on x each XCD pulled four images' matrices
+  const int img = blockIdx.x, head = (int)blockIdx.y % p.H;
+  const int m0 = img * p.HW + ((int)blockIdx.y / p.H) * BM;
   const bf16_t* baseA = p.x;
   const bf16_t* baseW = p.kpp + ((long long)img * p.H + head) * BN * p.C;
 
@@ -306,7 +308,7 @@ __global__ __launch_bounds__(256) void xattn_s_kernel(const XattnSP p) {
 }
 
 int launch_xattn_s(const XattnSP& p, hipStream_t st) {
-  if (p.M % 64 || p.HW % 64 || p.C % 64 || p.T < 1 || p.T > XATTN_TP || !p.ln_stats || p.ln_slots < 1) {
+  if (p.M % 64 || p.HW % 64 || p.M % p.HW || p.C % 64 || p.T < 1 || p.T > XATTN_TP || !p.ln_stats || p.ln_slots < 1) {
     agd_set_error("xattn_s: M %d HW %d C %d T %d slots %d", p.M, p.HW, p.C, p.T, p.ln_slots); return -1;
   }
   if ((long long)p.M * p.C * 2 >= (1LL << 31) || (long long)XATTN_TP * p.C * 2 >= (1LL << 31)) { agd_set_error("xattn_s: 32-bit offsets"); return -1; }
@@ -315,7 +317,7 @@ int launch_xattn_s(const XattnSP& p, hipStream_t st) {
   int dev = 0; HIP_CHECK_RET(hipGetDevice(&dev));
   if (dev < 0 || dev >= AGD_MAX_DEVICES) { agd_set_error("xattn_s: device ordinal %d out of range", dev); return -1; }
   if (!attr[dev]) { HIP_CHECK_RET(hipFuncSetAttribute((const void*)xattn_s_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); attr[dev] = true; }
-  hipLaunchKernelGGL(xattn_s_kernel, dim3(p.M / 64, p.H), dim3(256), lds, st, p);
+  hipLaunchKernelGGL(xattn_s_kernel, dim3(p.M / p.HW, (p.HW / 64) * p.H), dim3(256), lds, st, p);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }
