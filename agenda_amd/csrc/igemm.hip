@@ -25,12 +25,22 @@
 #include "kernels.h"
 #include <cstdio>
 #include <cstdlib>
+#ifdef AGD_EXPERIMENTS
+// in-kernel time stamps of one wave (tools/kb_*_trace.py; AGD_IGEMM_CFG bit 10 = dbg & 64): the chosen wave of workgroup (g_smap_ts_wg, z = 0) stores s_memtime at every mark;
+// a kernel declares `const bool ts_on = ...; int ts_n = 0;` and finishes with g_smap_ts[1023] = ts_n
+__device__ unsigned long long g_smap_ts[1024];
+__device__ int g_smap_ts_wg;
+#define AGD_TS(k) do { if (ts_on && ts_n < 1000) { g_smap_ts[ts_n++] = ((unsigned long long)(k) << 56) | (__builtin_amdgcn_s_memtime() & 0x00FFFFFFFFFFFFFFull); } } while (0)
+#else
+#define AGD_TS(k) do { } while (0)
+#endif
 #include "igemm_epilogue.h"
 #include "igemm_halo.h"
 #include "igemm8p.h"
 #include "igemm_wreg.h"
 #include "igemm_smap.h"
 #include "igemm_pc.h"
+#include "igemm_pch.h"
 #include <type_traits>
 #include <cstdlib>
 #define CK0(expr) do { if ((expr) != 0) return -1; } while (0)
@@ -601,6 +611,29 @@ static int launch_halo(const IgemmP& p_in, int splits, hipStream_t st) {
   return 0;
 }
 
+// producer / consumer row-halo kernel (igemm_pch.h): 128 x 160 tiles, one workgroup per CU (IgemmP::pc bit 4)
+static bool pch_ok(const IgemmP& p, int splits) {
+  if (!(p.pc & 16) || !halo_ok(p) || p.up != 1 || p.sc0 || p.w_per_image) return false;
+  const long long tiles = (long long)((p.M + 127) / 128) * ((p.N + 159) / 160);
+  return tiles * splits <= 256;
+}
+template <int SPLITK>
+static int launch_pch(const IgemmP& p_in, int splits, hipStream_t st) {
+  IgemmP p = p_in; pick_xcd_block(p, 128, 160);
+  const int Wt = p.Wout < 128 ? p.Wout : 128;
+  const int hr = (128 / Wt) * (Wt + 2), HRP = (hr + 7) & ~7;
+  const int lds = 3 * HRP * 128 + 5 * 160 * 128 + 4 * 1024;      // three A images (Wout >= 16: at most 144 halo rows) + five weight stages + the dead-piece sink: <= 158 KB
+  const int tiles = ((p.M + 127) / 128) * ((p.N + 159) / 160);
+  auto kfn = igemm_pch_kernel<160, SPLITK>;
+  static bool attr[AGD_MAX_DEVICES] = {};
+  int dev = 0; HIP_CHECK_RET(hipGetDevice(&dev));
+  if (dev < 0 || dev >= AGD_MAX_DEVICES) { agd_set_error("igemm_pch: device ordinal %d out of range", dev); return -1; }
+  if (!attr[dev]) { HIP_CHECK_RET(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 144 * 128 + 5 * 160 * 128 + 4 * 1024)); attr[dev] = true; }
+  hipLaunchKernelGGL(kfn, dim3(tiles, 1, splits), dim3(512), lds, st, p, Wt, HRP);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+
 template <int BM, int BN, int WM, int WN, int STAGES = 2, int KG = 1, int KGS = 2>      // KGS: ring slots per K group when KG = 2
 static int launch_cfg(const IgemmP& p, int splits, hipStream_t st) {
   if (p.cfg_out) { p.cfg_out[0] = BM; p.cfg_out[1] = BN; p.cfg_out[2] = splits; return 0; }   // igemm_query: report the dispatch decision only
@@ -616,7 +649,7 @@ static int launch_cfg(const IgemmP& p, int splits, hipStream_t st) {
   if (p.sc0 && !HALO_TILE) { agd_set_error("igemm: shortcut fusion on a launch that is not a row-halo launch (tile %dx%d, %d K slices)", BM, BN, splits); return -1; }
   if (splits > 1) {
     int rc;
-    if constexpr (HALO_TILE) { rc = halo_ok(p) ? launch_halo<BN, 1, STAGES == 4 ? 4 : 2>(p, splits, st) : (p.ksize == 3) ? launch_one<BM, BN, WM, WN, 3, STAGES, 0, 1>(p, splits, st) : launch_one<BM, BN, WM, WN, 1, STAGES, 0, 1>(p, splits, st); }
+    if constexpr (HALO_TILE) { rc = (BN == 160 && pch_ok(p, splits)) ? launch_pch<1>(p, splits, st) : halo_ok(p) ? launch_halo<BN, 1, STAGES == 4 ? 4 : 2>(p, splits, st) : (p.ksize == 3) ? launch_one<BM, BN, WM, WN, 3, STAGES, 0, 1>(p, splits, st) : launch_one<BM, BN, WM, WN, 1, STAGES, 0, 1>(p, splits, st); }
     else rc = (p.ksize == 3) ? launch_one<BM, BN, WM, WN, 3, STAGES, 0, 1>(p, splits, st) : launch_one<BM, BN, WM, WN, 1, STAGES, 0, 1>(p, splits, st);
     if (rc) return rc;
     return launch_splitk_reduce(p, splits, st);
@@ -625,7 +658,10 @@ static int launch_cfg(const IgemmP& p, int splits, hipStream_t st) {
     if constexpr (BN / WN == 64) { if (p.ksize == 1) return launch_one<BM, BN, WM, WN, 1, STAGES, 1, 0>(p, 1, st); }
     agd_set_error("igemm: geglu only on 1x1 with the 128-wide tile"); return -1;
   }
-  if constexpr (HALO_TILE) { if (halo_ok(p)) return launch_halo<BN, 0, STAGES == 4 ? 4 : 2>(p, 1, st); }
+  if constexpr (HALO_TILE) {
+    if (BN == 160 && pch_ok(p, 1)) return launch_pch<0>(p, 1, st);
+    if (halo_ok(p)) return launch_halo<BN, 0, STAGES == 4 ? 4 : 2>(p, 1, st);
+  }
   if (p.ksize == 3) return launch_one<BM, BN, WM, WN, 3, STAGES, 0, 0>(p, 1, st);
   if (p.ksize == 2) {
     if constexpr (BM == 128 && STAGES == 2 && KG == 1) return launch_one<BM, BN, WM, WN, 2, 2, 0, 0>(p, 1, st);
@@ -759,6 +795,11 @@ static int pick_8p(const IgemmP& p) {
 #ifdef AGD_EXPERIMENTS
 int g_igemm_cfg = 0;   // experiment knob (tools/ only; production builds have no run-time dispatch knobs)
 extern "C" __attribute__((visibility("default"))) void agd_set_igemm_cfg(int v) { g_igemm_cfg = v; }
+// in-kernel time stamps of igemm_smap_kernel (tools/kb_smap_trace.py): pick the workgroup, read the marks back
+extern "C" __attribute__((visibility("default"))) int agd_smap_ts(int wg, unsigned long long* out) {
+  if (out) return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_smap_ts), 1024 * 8) == hipSuccess ? 0 : -1;
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_smap_ts_wg), &wg, 4) == hipSuccess ? 0 : -1;
+}
 #define KNOB(n) ((g_igemm_cfg & 15) == (n))
 #else
 #define KNOB(n) false

@@ -70,8 +70,10 @@ __global__ __launch_bounds__(256, BST == 2 ? 2 : 1) void igemm_halo_kernel(const
     bvoff[i] = (n < p.N) ? (unsigned)(((long long)n * p.K + ((lane & 7) ^ key) * 8) * 2) : 0x80000000u;
   }
 
-  // K range: groups (ky, source, chunk); split-K slices whole groups
-  const int gpk = Ct >> 6;                              // groups per ky
+  // K range: groups (source, chunk, ky) -- the three ky images of a 64-channel chunk back to back: they are the same cache lines of the tile's pixel rows (one row up /
+  // down), so A crosses L2 -> HBM once per launch instead of once per ky (FETCH_SIZE of the 16 x 16 maps' 1280 -> 1280 conv: 150 -> ~75 MB; an XCD's A panels exceed its
+  // 4 MB L2 from C ~ 1000 on); split-K slices whole groups
+  const int gpk = Ct >> 6;                              // chunks (groups per ky)
   const int ngr = 3 * gpk;
   int g0 = 0, g1 = ngr;
   if constexpr (SPLITK) {
@@ -184,7 +186,11 @@ __global__ __launch_bounds__(256, BST == 2 ? 2 : 1) void igemm_halo_kernel(const
       for (long long pc = p0 + wid; pc < p1; pc += NW) bufdma16(p.W, scr + wid * 1024, (unsigned)(pc * 1024 + lane * 16), 0u);
     }
   }
-  int ky = g0 / gpk, r = g0 - ky * gpk;                 // current group
+#ifdef AGD_KY_OUTER                                     // A/B builds only (tools/ab_bench_libs.sh): the former order, ky outer
+  int ky = g0 / gpk, r = g0 - ky * gpk;
+#else
+  int r = g0 / 3, ky = g0 - r * 3;                      // current group: chunk r, ky
+#endif
   unsigned bso = (unsigned)(((ky * 3) * Ct + r * 64) * 2);   // weights of (ky, kx = 0, r)
   const unsigned tapb = (unsigned)(Ct * 2);            // one tap further
   if (g1 > g0) {                                        // prologue: A image of the first group, weights of its first tap(s)
@@ -207,8 +213,13 @@ __global__ __launch_bounds__(256, BST == 2 ? 2 : 1) void igemm_halo_kernel(const
   for (int g = g0; g < g1; ++g) {
     const int aslot = (g - g0) & 1;
     const bool more = g + 1 < g1;
-    int kyn = ky, rn = r + 1;                           // next group
+#ifdef AGD_KY_OUTER
+    int kyn = ky, rn = r + 1;
     if (rn == gpk) { rn = 0; ++kyn; }
+#else
+    int kyn = ky + 1, rn = r;                           // next group
+    if (kyn == 3) { kyn = 0; ++rn; }
+#endif
     const unsigned bson = (unsigned)(((kyn * 3) * Ct + rn * 64) * 2);
     if (more) setA(kyn, rn);                            // descriptors of the next group's image (issued inside step kx = 0)
     const unsigned nrn = more ? LIVE : 0u;

@@ -20,6 +20,13 @@
 #include "igemm_epilogue.h"
 #include <type_traits>
 
+#ifdef AGD_EXPERIMENTS
+// in-kernel time stamps of one wave (tools/kb_smap_trace.py): AGD_IGEMM_CFG bit 10 (dbg & 64); wave 0 of workgroup (g_smap_ts_wg, z = 0) stores s_memtime at every mark
+#define SMAP_TS(k) AGD_TS(k)
+#else
+#define SMAP_TS(k) do { } while (0)
+#endif
+
 template <int SPLITK>
 __global__ __launch_bounds__(512, 2) void igemm_smap_kernel(const IgemmP p) {
   constexpr int BM = 512, BN = 64, WM = 4, WN = 2, NW = 8, WTN = 32, MI = 8, NI = 2;
@@ -34,6 +41,11 @@ __global__ __launch_bounds__(512, 2) void igemm_smap_kernel(const IgemmP p) {
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef AGD_EXPERIMENTS
+  const bool ts_on = (p.dbg & 64) && tid == 0 && (int)blockIdx.x == g_smap_ts_wg && blockIdx.z == 0;
+  int ts_n = 0;
+#endif
+  SMAP_TS(1);
   const int wm = wid >> 1, wn = wid & 1;
   const int tiles_n = p.N / BN;
   const int tn = blockIdx.x % tiles_n, tm = blockIdx.x / tiles_n;
@@ -61,6 +73,11 @@ __global__ __launch_bounds__(512, 2) void igemm_smap_kernel(const IgemmP p) {
     a_key[i] = xx & 7;
     a_live |= (ok ? 1u : 0u) << i;
   }
+#ifdef AGD_EXPERIMENTS   // timing variants (tools/kb_smap_parts.py; results are garbage): bit 0 no weight DMA, bit 1 no image DMA, bit 2 no MFMAs, bit 3 no fragment reads
+  const bool no_w = p.dbg & 1, no_a = p.dbg & 2, no_mm = p.dbg & 4, no_rd = p.dbg & 8;
+#else
+  constexpr bool no_w = false, no_a = false, no_mm = false, no_rd = false;
+#endif
   auto a_issue = [&](int cc) {                                     // chunk cc of the concatenated channels
     const bool s1 = cc >= c0n;
     const int Cs = s1 ? p.C1 : p.C0;
@@ -71,7 +88,7 @@ __global__ __launch_bounds__(512, 2) void igemm_smap_kernel(const IgemmP p) {
       const int piece = i * NW + wid;
       const unsigned voff = ((a_live >> i) & 1) ? (unsigned)(a_pix[i] * Cs + (((lane & 7) ^ a_key[i]) << 3)) * 2u : 0x80000000u;
       char* dst = piece < A_ROWS / 8 ? sA + piece * 1024 : scr + wid * 1024;
-      bufdma16(base, dst, voff, so);
+      if (!no_a) bufdma16(base, dst, voff, so);
     }
   };
 
@@ -80,11 +97,15 @@ __global__ __launch_bounds__(512, 2) void igemm_smap_kernel(const IgemmP p) {
   const int bqp = (brow % WTN) / (4 * NI);
   const int bkey = (brow & 3) | ((bqp & 1) << 2);                  // permuted rows: fragment-row swizzle key (igemm.hip)
   const unsigned bvoff = (unsigned)(((long long)(n0 + brow) * p.K + (((lane & 7) ^ bkey) << 3)) * 2);
+#ifdef AGD_EXPERIMENTS
+  const int nsteps = (p.dbg & 16) ? 0 : (ch1 - ch0) * 9;          // timing variant: no main loop
+#else
   const int nsteps = (ch1 - ch0) * 9;
+#endif
   auto b_issue = [&](int t, bool live) {
     const int cc = ch0 + t / 9, tap = t - (t / 9) * 9;
     const unsigned so = __builtin_amdgcn_readfirstlane((unsigned)((tap * Ct + cc * 64) * 2));
-    bufdma16(p.W, sBr + (t % BST) * B_BYTES + wid * 1024, bvoff, so, live ? 0x7FFFFFF0u : 0u);
+    if (!no_w) bufdma16(p.W, sBr + (t % BST) * B_BYTES + wid * 1024, bvoff, so, live ? 0x7FFFFFF0u : 0u);
   };
 
   f32x4 acc[MI][NI];
@@ -107,16 +128,22 @@ __global__ __launch_bounds__(512, 2) void igemm_smap_kernel(const IgemmP p) {
     for (int s = 0; s < BST - 1; ++s) b_issue(s, s < nsteps);
     for (int t = 0; t < nsteps; ++t) {
       const int tap = t % 9;
+      SMAP_TS(2);
       if (tap == 0) {
         // chunk boundary: every wave has left the previous chunk's last tap -> refill the image, wait for everything in flight
         asm volatile("s_barrier" ::: "memory");
+        SMAP_TS(3);
         a_issue(ch0 + t / 9);
+        SMAP_TS(4);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       } else {
         asm volatile("s_waitcnt vmcnt(%0)" ::"i"(BST - 2) : "memory");   // this step's weight stage has landed (two younger ones may fly)
       }
+      SMAP_TS(5);
       asm volatile("s_barrier" ::: "memory");
+      SMAP_TS(6);
       b_issue(t + BST - 1, t + BST - 1 < nsteps);                  // into the slot step t - 1 released
+      SMAP_TS(7);
       const int ky = tap / 3, kx = tap - ky * 3;
       const char* sB = sBr + (t % BST) * B_BYTES + wn * WTN * 128;
       const int aoff = abase + (ky * HP + kx) * 128;
@@ -125,18 +152,25 @@ __global__ __launch_bounds__(512, 2) void igemm_smap_kernel(const IgemmP p) {
       for (int kk = 0; kk < 2; ++kk) {
         bf16x8 b[NI], a[MI];
 #pragma unroll
-        for (int j = 0; j < NI; ++j) b[j] = *(const bf16x8*)(sB + j * 512 + foffB[kk]);
+        for (int j = 0; j < NI; ++j) b[j] = no_rd ? bf16x8{} : *(const bf16x8*)(sB + j * 512 + foffB[kk]);
         const int ach = (((kk << 2) + q) ^ akey) << 4;
 #pragma unroll
-        for (int i = 0; i < MI; ++i) a[i] = *(const bf16x8*)(sA + aoff + ((i >> 2) * IMG + 2 * (i & 3) * HP) * 128 + ach);
+        for (int i = 0; i < MI; ++i) a[i] = no_rd ? bf16x8{} : *(const bf16x8*)(sA + aoff + ((i >> 2) * IMG + 2 * (i & 3) * HP) * 128 + ach);
+        if (no_mm) {
+#pragma unroll
+          for (int i = 0; i < MI; ++i) acc[i][0][0] += (float)a[i][0] + (float)b[i & 1][0];
+        } else {
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
           for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);   // D = W . X^T
+        }
       }
     }
   }
+  SMAP_TS(8);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // dead tail pieces still write zeros to LDS: let them land
+  SMAP_TS(9);
   if (p.sc0) {
     // ---- the block's 1x1 conv_shortcut as extra K (IgemmP::sc0, as in igemm_halo.h): 64-channel chunks of the raw block input (one or two sources), dealt to the K
     // slices like the 3x3 chunks; per chunk one LDS image (the centre tap reads it) and ONE weight tile (columns 9 Ct + 64 r ... of the rows) into ring slot 0
@@ -177,5 +211,11 @@ __global__ __launch_bounds__(512, 2) void igemm_smap_kernel(const IgemmP p) {
     }
     asm volatile("s_barrier" ::: "memory");                        // (the epilogue's LDS-staged paths start behind their own barriers; the register path touches no LDS)
   }
+#ifdef AGD_EXPERIMENTS
+  if (p.dbg & 32) { if (acc[0][0][0] == 12345.f) ((float*)p.out)[0] = 1.f; return; }      // timing variant: no epilogue
+#endif
   igemm_epilogue<BM, BN, WM, WN, 0, SPLITK>(p, acc, smem, lane, wm, wn, m0, n0, tn, 0, nullptr);
+#ifdef AGD_EXPERIMENTS
+  if (ts_on) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); SMAP_TS(10); g_smap_ts[1023] = ts_n; }
+#endif
 }

@@ -213,7 +213,6 @@ __global__ __launch_bounds__(512, 2) void ff_fused_kernel(const FFusedP p) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int mh = wid >> 2, nq = wid & 3;
-  const int q = lane >> 4, px = lane & 15;
   const int m0 = blockIdx.x * BM;
 
   panel_load_dma<C>(p.h, m0, p.M, panel, wid, lane);
@@ -222,13 +221,7 @@ __global__ __launch_bounds__(512, 2) void ff_fused_kernel(const FFusedP p) {
   panel_row_stats<C>(panel, lnst, tid, p.ln_eps);
   __syncthreads();
 
-  const int rbase = 64 * mh + px;                       // + 16 i: this lane's row in row tile i
-
-  // X fragment (MFMA B operand) addresses in the panel: row rbase + 16 i, logical chunk 4 ks + q
-  const int sx = (px >> 1) & 7;
-  const int xoff0 = ((q ^ sx) << 4), xoff1 = (((4 + q) ^ sx) << 4);
-  const char* xrow = panel + rbase * PITCH;
-
+  // (this lane's rows: rbase + 16 i with rbase = 64 mh + (lane & 15); X fragment (MFMA B operand) addresses in the panel: row rbase + 16 i, logical chunk 4 ks + q)
   f32x4 acc2[4][NI2];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
@@ -239,9 +232,8 @@ __global__ __launch_bounds__(512, 2) void ff_fused_kernel(const FFusedP p) {
   // weight fragments through buffer loads: per-lane offset lane * 16 (one VGPR for the whole kernel), the fragment's byte offset in an SGPR
   const auto w1rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.w1f, 0, (unsigned)(2 * HID * C * 2), 0x00020000);
   const auto w2rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.w2f, 0, (unsigned)(HID * C * 2), 0x00020000);
-  const unsigned lane16 = (unsigned)lane * 16u;
-  auto ldw1 = [&](unsigned sbase, int f) { return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(w1rs, lane16, sbase + (unsigned)f * 1024u, 0)); };
-  auto ldw2 = [&](unsigned sbase, int f) { return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(w2rs, lane16, sbase + (unsigned)f * 1024u, 0)); };
+#define ldw1(sbase, f) __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(w1rs, lane16, (sbase) + (unsigned)(f) * 1024u, 0))
+#define ldw2(sbase, f) __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(w2rs, lane16, (sbase) + (unsigned)(f) * 1024u, 0))
   constexpr bool NOW = (VAR & 2) != 0, NOX = (VAR & 4) != 0;
 
   // The weight stream: a ring of F fragment registers, filled D fragments ahead of use with plain 16-byte-per-lane global loads (one
@@ -255,8 +247,13 @@ __global__ __launch_bounds__(512, 2) void ff_fused_kernel(const FFusedP p) {
   static_assert((N1 + N2) % F == 0 && D < F && D <= N2 && DX <= D, "ring geometry");
   u32x4 ring[F];
 
-  auto gemm2 = [&](int c, bool pre, bool has_next, unsigned nexts) {       // nexts: GEMM1's stream of this interval (if has_next)
-    const char* hb = hbuf + (c & 1) * (BM * HC * 2) + rbase * (HC * 2);
+  // Lane-derived addresses are RE-DERIVED inside each phase from a laundered copy of the lane id: hoisted out of the chunk loop they stayed live across every phase, the
+  // kernel spilled 14 of them (256 VGPRs at two waves per SIMD), and each reload's s_waitcnt vmcnt(0) also drained the weight stream (buffer loads count in vmcnt, in order)
+  auto lane_now = [&]() __attribute__((always_inline)) { int l = lane; asm volatile("" : "+v"(l)); return l; };
+  auto gemm2 = [&](int c, bool pre, bool has_next, unsigned nexts) __attribute__((always_inline)) {       // nexts: GEMM1's stream of this interval (if has_next)
+    const int l_ = lane_now(), q = l_ >> 4, px = l_ & 15;
+    const unsigned lane16 = (unsigned)l_ * 16u;
+    const char* hb = hbuf + (c & 1) * (BM * HC * 2) + (64 * mh + px) * (HC * 2);
     const unsigned wp = __builtin_amdgcn_readfirstlane((unsigned)(((c * 4 + nq) * KS2) * NI2) * 1024u);
     if (!pre && !NOW) {
 #pragma unroll
@@ -285,12 +282,17 @@ __global__ __launch_bounds__(512, 2) void ff_fused_kernel(const FFusedP p) {
     }
   };
 
-  auto gemm1 = [&](int c, bool pre, bool has_next, unsigned nexts) {       // nexts: the NEXT interval's GEMM2 stream (if has_next)
+  auto gemm1 = [&](int c, bool pre, bool has_next, unsigned nexts) __attribute__((always_inline)) {       // nexts: the NEXT interval's GEMM2 stream (if has_next)
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc1[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     const unsigned wp = __builtin_amdgcn_readfirstlane((unsigned)(((c * 4 + nq) * KS1) * 4) * 1024u);
+    const int l_ = lane_now(), q = l_ >> 4, px = l_ & 15;
+    const unsigned lane16 = (unsigned)l_ * 16u;
+    const int sx = (px >> 1) & 7;
+    const int xoff0 = ((q ^ sx) << 4), xoff1 = (((4 + q) ^ sx) << 4);
+    const char* xrow = panel + (64 * mh + px) * PITCH;
     if (!pre && !NOW) {
 #pragma unroll
       for (int f = 0; f < D; ++f) ring[(N2 + f) % F] = ldw1(wp, f);
@@ -316,17 +318,23 @@ __global__ __launch_bounds__(512, 2) void ff_fused_kernel(const FFusedP p) {
   };
 
   // LayerNorm fold + bias + value * gelu(gate) of chunk c -> hbuf[c & 1]; lane (q, px) owns hidden columns 128 c + 32 nq + 8 q .. + 8
-  auto geglu = [&](int c) {
-    const int hcol0 = HC * c + 32 * nq + 8 * q;
+  const auto cs1rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.cs1, 0, (unsigned)(2 * HID * 4), 0x00020000);
+  const auto b1rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.b1, 0, (unsigned)(2 * HID * 4), 0x00020000);
+  auto geglu = [&](int c) __attribute__((always_inline)) {
+    const int l_ = lane_now(), q = l_ >> 4, px = l_ & 15;
+    const int rbase = 64 * mh + px;
+    const unsigned hcol0b = (unsigned)(32 * nq + 8 * q) * 4u;            // byte offset of this lane's first column inside the chunk (one VGPR; the chunk's base in an SGPR)
+    const unsigned cbase = __builtin_amdgcn_readfirstlane((unsigned)(HC * c) * 4u);
     char* hb = hbuf + (c & 1) * (BM * HC * 2);
-    u32x2 pk[4][2];
     float mu[4], rs[4];                                // (re-read per chunk: eight registers less across the MFMA phases)
 #pragma unroll
     for (int i = 0; i < 4; ++i) { const f32x2_t v = *(const f32x2_t*)(lnst + (rbase + 16 * i) * 2); mu[i] = v[0]; rs[i] = v[1]; }
 #pragma unroll
     for (int t = 0; t < 2; ++t) {                      // four columns at a time: 16 epilogue constants live instead of 32
-      const f32x4 csv = *(const f32x4*)(p.cs1 + hcol0 + 4 * t), csg = *(const f32x4*)(p.cs1 + HID + hcol0 + 4 * t);
-      const f32x4 bv = *(const f32x4*)(p.b1 + hcol0 + 4 * t), bg = *(const f32x4*)(p.b1 + HID + hcol0 + 4 * t);
+      const f32x4 csv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(cs1rs, hcol0b, cbase + 16u * t, 0));
+      const f32x4 csg = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(cs1rs, hcol0b, cbase + (unsigned)HID * 4u + 16u * t, 0));
+      const f32x4 bv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(b1rs, hcol0b, cbase + 16u * t, 0));
+      const f32x4 bg = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(b1rs, hcol0b, cbase + (unsigned)HID * 4u + 16u * t, 0));
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         float o[4];
@@ -336,12 +344,10 @@ __global__ __launch_bounds__(512, 2) void ff_fused_kernel(const FFusedP p) {
           const float g = rs[i] * (acc1[i][2 + t][r] - mu[i] * csg[r]) + bg[r];
           o[r] = (VAR & 1) ? v + g : v * gelu_erf_f(g);
         }
-        pk[i][t][0] = pack_bf2(o[0], o[1]); pk[i][t][1] = pack_bf2(o[2], o[3]);
+        // eight bytes at a time (the row's 16-byte slot in two halves): no packed values held across the second half's arithmetic
+        *(u32x2*)(hb + (rbase + 16 * i) * (HC * 2) + (((4 * nq + q) ^ px) << 4) + 8 * t) = u32x2{pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3])};
       }
     }
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-      *(u32x4*)(hb + (rbase + 16 * i) * (HC * 2) + (((4 * nq + q) ^ px) << 4)) = u32x4{pk[i][0][0], pk[i][0][1], pk[i][1][0], pk[i][1][1]};
   };
 
   // staggered chunk pipeline: interval k, half 0: GEMM2(k-1), GEMM1(k), GEGLU(k); half 1: GEGLU(k-1), GEMM2(k-2), GEMM1(k).
@@ -349,10 +355,13 @@ __global__ __launch_bounds__(512, 2) void ff_fused_kernel(const FFusedP p) {
   // intervals after GEMM2(c-2) read it.  All branches are wave-uniform.
   bool pre2 = false;                                    // this interval's GEMM2 stream head is already in flight
   if constexpr (NOW) {
+    const unsigned lane16 = (unsigned)lane * 16u;
 #pragma unroll
     for (int f = 0; f < F; ++f) ring[f] = ldw1(0u, f);
   }
-  for (int k = 0; k <= NCH + 1; ++k) {
+  // The intervals 2 .. NCH - 1 run every phase in both halves: they get a loop of their own per half (mh), straight-line and with the stream flags constant -- the
+  // general form's paths (phase present or not, GEGLU before or after) merged with different register assignments: a spilled ring fragment and ~40 v_mov per interval.
+  auto interval = [&](int k) __attribute__((always_inline)) {                          // general form: the first two and the last two intervals
     if (!(VAR & 8) && mh == 1 && k >= 1 && k <= NCH) geglu(k - 1);
     const int c2 = k - 1 - mh, c2n = k - mh;
     const bool v2 = c2 >= 0 && c2 < NCH, v1 = k < NCH, v2n = c2n >= 0 && c2n < NCH;
@@ -363,12 +372,41 @@ __global__ __launch_bounds__(512, 2) void ff_fused_kernel(const FFusedP p) {
     pre2 = v1 && v2n;
     if (!(VAR & 8) && mh == 0 && k < NCH) geglu(k);
     if (k <= NCH) __syncthreads();
+  };
+  static_assert(NCH >= 4, "steady intervals");
+#pragma unroll 1
+  for (int k = 0; k < 2; ++k) interval(k);
+  if (mh == 0) {
+    for (int k = 2; k < NCH; ++k) {
+      const unsigned w1s = __builtin_amdgcn_readfirstlane((unsigned)(((k * 4 + nq) * KS1) * 4) * 1024u);
+      const unsigned w2ns = __builtin_amdgcn_readfirstlane((unsigned)(((k * 4 + nq) * KS2) * NI2) * 1024u);
+      gemm2(k - 1, true, true, w1s);
+      gemm1(k, true, true, w2ns);
+      if (!(VAR & 8)) geglu(k);
+      __syncthreads();
+    }
+  } else {
+    for (int k = 2; k < NCH; ++k) {
+      if (!(VAR & 8)) geglu(k - 1);
+      const unsigned w1s = __builtin_amdgcn_readfirstlane((unsigned)(((k * 4 + nq) * KS1) * 4) * 1024u);
+      const unsigned w2ns = __builtin_amdgcn_readfirstlane((unsigned)((((k - 1) * 4 + nq) * KS2) * NI2) * 1024u);
+      gemm2(k - 2, true, true, w1s);
+      gemm1(k, true, true, w2ns);
+      __syncthreads();
+    }
   }
+  pre2 = true;
+#pragma unroll 1
+  for (int k = NCH; k <= NCH + 1; ++k) interval(k);
 
   // epilogue: + bias + residual (the raw rows are still in the panel), one rounding to bf16, 8-byte row chunks.
   // With a proj_out stage behind it (p.wpf), the rounded rows go back into the panel instead of to HBM -- nothing else reads them --
   // and one more C -> C GEMM runs over them: out = h3 . Wp^T + bp + xres, plus the per-(128-row tile, channel) sums the next
   // GroupNorm reads (IgemmP::colstat_out's layout).
+  const int l_e = lane_now(), q = l_e >> 4, px = l_e & 15;
+  const int rbase = 64 * mh + px;
+  const unsigned lane16 = (unsigned)l_e * 16u;
+  const char* xrow = panel + rbase * PITCH;
   const int ncol0 = (C / 4) * nq + 4 * NI2 * q;
   constexpr bool post = POST != 0;
   // POST = 2: ff.net.2 and proj_out pre-multiplied (model.hip, ff_proj_fuse): w2f holds Wp W2, bp holds Wp b2 + bp, and the proj_out stage is the REST of the product,

@@ -230,6 +230,22 @@ def test_conv3x3_producer_consumer_kernel(ops, B, H, Cin, Cout, pc):
     assert torch.equal(got, ops.conv2d(x.cuda(), w.cuda(), b.cuda(), pc=pc))
 
 
+@pytest.mark.parametrize("B,H,Cin,Cout", [(8, 32, 640, 640), (8, 32, 1280, 640), (8, 16, 1280, 1280), (2, 32, 320, 640), (1, 64, 128, 200), (3, 16, 192, 320), (1, 128, 64, 160)])
+def test_conv3x3_row_halo_producer_consumer_kernel(ops, B, H, Cin, Cout):
+    """igemm_pch.h (igemm_pc bit 4): the row-halo 3x3 kernel's tiles and operand scheme with loader / consumer waves, one workgroup per CU -- unsplit (256 tiles at 32 x 32,
+    UNet batch 8) and split-K (16 x 16); fewer tiles, a ragged N tile (200 = 160 + 40), a ragged M tile (3 x 256 pixels = 6 tiles), whole 128-pixel rows.
+    vs F.conv2d in fp32 on bf16-exact operands, BIT-IDENTICAL to igemm_halo_kernel (same tiles, fragments and summation order) and run-to-run identical."""
+    g = torch.Generator().manual_seed(B + H + Cin + Cout)
+    x = bfr(torch.randn(B, Cin, H, H, generator=g))
+    w = bfr(torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(Cin * 9))
+    b = torch.randn(Cout, generator=g) * 0.1
+    want = F.conv2d(x, w, b, padding=1)
+    got = ops.conv2d(x.cuda(), w.cuda(), b.cuda(), halo=True, pc=16)
+    assert rel_err(got, want) < 1e-4, rel_err(got, want)
+    assert torch.equal(got, ops.conv2d(x.cuda(), w.cuda(), b.cuda(), halo=True))
+    assert torch.equal(got, ops.conv2d(x.cuda(), w.cuda(), b.cuda(), halo=True, pc=16))
+
+
 @pytest.mark.parametrize("M", [128, 1000, 4096 * 2])      # one tile; ragged tail (1000 = 7 x 128 + 104); many tiles
 def test_ff_fused_matches_torch_and_the_unfused_kernels(ops, M):
     """tblock.hip ff_fused_kernel (norm3 -> GEGLU -> ff.net.2 + residual in one launch, the hidden activation never in HBM) vs fp32 torch
