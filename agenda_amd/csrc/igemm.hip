@@ -921,7 +921,7 @@ int launch_igemm(const IgemmP& p_in, hipStream_t st) {
     { static const bool logit = getenv("AGD_IGEMM_LOG") != nullptr;
       if (logit) fprintf(stderr, "IGEMM M=%d N=%d K=%d ks=3 stride=1 up=1 geglu=0 res=%d tile=512x64 splits=%d batch=1\n", p.M, p.N, p.K, p.residual ? 1 : 0, S); }
 #endif
-    constexpr int lds = 800 * 128 + 4 * 64 * 128 + 8192;
+    constexpr int lds = 800 * 128 + 6 * 64 * 128 + 8192;
     if (S >= 2) CK0(ensure_splitk(p, S));
     const void* kfn = S >= 2 ? (const void*)igemm_smap_kernel<1> : (const void*)igemm_smap_kernel<0>;
     static bool attr[AGD_MAX_DEVICES][2] = {};

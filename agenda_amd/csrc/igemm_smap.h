@@ -28,12 +28,12 @@
 #endif
 
 template <int SPLITK>
-__global__ __launch_bounds__(512, 2) void igemm_smap_kernel(const IgemmP p) {
+__global__ __launch_bounds__(512) void igemm_smap_kernel(const IgemmP p) {
   constexpr int BM = 512, BN = 64, WM = 4, WN = 2, NW = 8, WTN = 32, MI = 8, NI = 2;
   constexpr int HS = 8, HP = HS + 2, IMG = HP * HP;               // 8 x 8 maps, halo pitch 10, 100 halo rows per image
   constexpr int A_ROWS = 8 * IMG, A_BYTES = A_ROWS * 128;         // 800 rows = 100 pieces of 8 rows
   constexpr int A_IT = (A_ROWS / 8 + NW - 1) / NW;                // 13 pieces per wave (the last four waves' 13th piece is dead)
-  constexpr int BST = 4, B_BYTES = BN * 128;                      // weight ring: 4 slots of [64 rows][64 k]
+  constexpr int BST = 6, B_BYTES = BN * 128;                      // weight ring: 6 slots of [64 rows][64 k]
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const sA = smem;
   char* const sBr = smem + A_BYTES;
@@ -73,11 +73,6 @@ __global__ __launch_bounds__(512, 2) void igemm_smap_kernel(const IgemmP p) {
     a_key[i] = xx & 7;
     a_live |= (ok ? 1u : 0u) << i;
   }
-#ifdef AGD_EXPERIMENTS   // timing variants (tools/kb_smap_parts.py; results are garbage): bit 0 no weight DMA, bit 1 no image DMA, bit 2 no MFMAs, bit 3 no fragment reads
-  const bool no_w = p.dbg & 1, no_a = p.dbg & 2, no_mm = p.dbg & 4, no_rd = p.dbg & 8;
-#else
-  constexpr bool no_w = false, no_a = false, no_mm = false, no_rd = false;
-#endif
   auto a_issue = [&](int cc) {                                     // chunk cc of the concatenated channels
     const bool s1 = cc >= c0n;
     const int Cs = s1 ? p.C1 : p.C0;
@@ -88,7 +83,7 @@ __global__ __launch_bounds__(512, 2) void igemm_smap_kernel(const IgemmP p) {
       const int piece = i * NW + wid;
       const unsigned voff = ((a_live >> i) & 1) ? (unsigned)(a_pix[i] * Cs + (((lane & 7) ^ a_key[i]) << 3)) * 2u : 0x80000000u;
       char* dst = piece < A_ROWS / 8 ? sA + piece * 1024 : scr + wid * 1024;
-      if (!no_a) bufdma16(base, dst, voff, so);
+      bufdma16(base, dst, voff, so);
     }
   };
 
@@ -97,15 +92,11 @@ __global__ __launch_bounds__(512, 2) void igemm_smap_kernel(const IgemmP p) {
   const int bqp = (brow % WTN) / (4 * NI);
   const int bkey = (brow & 3) | ((bqp & 1) << 2);                  // permuted rows: fragment-row swizzle key (igemm.hip)
   const unsigned bvoff = (unsigned)(((long long)(n0 + brow) * p.K + (((lane & 7) ^ bkey) << 3)) * 2);
-#ifdef AGD_EXPERIMENTS
-  const int nsteps = (p.dbg & 16) ? 0 : (ch1 - ch0) * 9;          // timing variant: no main loop
-#else
   const int nsteps = (ch1 - ch0) * 9;
-#endif
   auto b_issue = [&](int t, bool live) {
     const int cc = ch0 + t / 9, tap = t - (t / 9) * 9;
     const unsigned so = __builtin_amdgcn_readfirstlane((unsigned)((tap * Ct + cc * 64) * 2));
-    if (!no_w) bufdma16(p.W, sBr + (t % BST) * B_BYTES + wid * 1024, bvoff, so, live ? 0x7FFFFFF0u : 0u);
+    bufdma16(p.W, sBr + (t % BST) * B_BYTES + wid * 1024, bvoff, so, live ? 0x7FFFFFF0u : 0u);
   };
 
   f32x4 acc[MI][NI];
@@ -122,50 +113,84 @@ __global__ __launch_bounds__(512, 2) void igemm_smap_kernel(const IgemmP p) {
 #pragma unroll
   for (int kk = 0; kk < 2; ++kk) foffB[kk] = (frow >> 2) * (4 * NI * 128) + (frow & 3) * 128 + ((((kk << 2) + q) ^ (lane & 7)) << 4);
 
-  if (nsteps > 0) {
-    // prologue: the first three weight stages, then the first activation chunk
+  // Main loop, software-pipelined over the two 32-deep halves of a tap (K step) and across taps: behind barrier B_t a wave reads the fragments of half kk1 of tap t UNDER
+  // the MFMAs of half kk0 (read one half step earlier), then those of half kk0 of tap t + 1 under the MFMAs of kk1 -- one fragment read behind each of the first ten
+  // MFMAs of a half, the other six cover the last reads' latency.  (Round 5, in-kernel time stamps: with barrier -> wait -> 10 reads -> 16 MFMAs -> 10 reads -> 16 MFMAs
+  // a tap took ~2200 cycles for 1024 cycles of matrix-pipe work per SIMD -- the two waves of a SIMD run in lockstep and hide nothing for each other.)
+  // Ring: stage t + 1 has landed before B_t (vmcnt(3): stages t + 2 .. t + 4 may fly), stage t + 5 goes out behind B_t into the slot of tap t - 1.  A chunk's first
+  // tap has no predecessor in the same image: its kk0 fragments are read in the open behind the image's barrier.
+  using K0 = std::integral_constant<int, 0>; using K1 = std::integral_constant<int, 1>;
+  bf16x8 fa[2][MI], fb[2][NI];
+  auto rd = [&](auto kk_tag, int aoff, int akey, const char* sB) __attribute__((always_inline)) {
+    constexpr int kk = decltype(kk_tag)::value;
 #pragma unroll
-    for (int s = 0; s < BST - 1; ++s) b_issue(s, s < nsteps);
-    for (int t = 0; t < nsteps; ++t) {
-      const int tap = t % 9;
+    for (int j = 0; j < NI; ++j) fb[kk][j] = *(const bf16x8*)(sB + j * 512 + foffB[kk]);
+    const int ach = (((kk << 2) + q) ^ akey) << 4;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) fa[kk][i] = *(const bf16x8*)(sA + aoff + ((i >> 2) * IMG + 2 * (i & 3) * HP) * 128 + ach);
+  };
+  auto mm = [&](auto kk_tag) __attribute__((always_inline)) {
+    constexpr int kk = decltype(kk_tag)::value;
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[kk][j], fa[kk][i], acc[i][j], 0, 0, 0);   // D = W . X^T
+  };
+  auto interleave = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int n = 0; n < MI + NI; ++n) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);           // 1 MFMA
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);           // 1 DS read
+    }
+    __builtin_amdgcn_sched_group_barrier(0x008, MI * NI - (MI + NI), 0);
+  };
+  int t = 0, bs = 0;                                               // tap counter of this K slice; ring slot of tap t
+  auto tapstep = [&](auto tap_tag) __attribute__((always_inline)) {
+    constexpr int TAP = decltype(tap_tag)::value, ky = TAP / 3, kx = TAP - ky * 3, kyn = (TAP + 1) / 3, kxn = (TAP + 1) - kyn * 3;
+    const int bsn = bs + 1 == BST ? 0 : bs + 1;
+    const char* sB = sBr + bs * B_BYTES + wn * WTN * 128;
+    SMAP_TS(2);
+    if constexpr (TAP > 0) {
+      asm volatile("s_waitcnt vmcnt(%0)" ::"i"(BST - 3) : "memory");
+      SMAP_TS(5);
+      asm volatile("s_barrier" ::: "memory");                      // B_t
+      SMAP_TS(6);
+    }
+    b_issue(t + BST - 1, t + BST - 1 < nsteps);                    // into the slot tap t - 1 released
+    __builtin_amdgcn_sched_barrier(0);
+    rd(K1{}, abase + (ky * HP + kx) * 128, (fx + kx) & 7, sB);
+    mm(K0{});
+    interleave();
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (TAP < 8) {
+      rd(K0{}, abase + (kyn * HP + kxn) * 128, (fx + kxn) & 7, sBr + bsn * B_BYTES + wn * WTN * 128);
+      mm(K1{});
+      interleave();
+    } else {
+      mm(K1{});
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    ++t; bs = bsn;
+  };
+  if (nsteps > 0) {
+#pragma unroll
+    for (int s = 0; s < BST - 1; ++s) b_issue(s, s < nsteps);      // prologue: the first five weight stages
+    for (int c = ch0; c < ch1; ++c) {
+      // chunk boundary: every wave has left the previous chunk's last tap -> refill the image, wait for everything in flight
       SMAP_TS(2);
-      if (tap == 0) {
-        // chunk boundary: every wave has left the previous chunk's last tap -> refill the image, wait for everything in flight
-        asm volatile("s_barrier" ::: "memory");
-        SMAP_TS(3);
-        a_issue(ch0 + t / 9);
-        SMAP_TS(4);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      } else {
-        asm volatile("s_waitcnt vmcnt(%0)" ::"i"(BST - 2) : "memory");   // this step's weight stage has landed (two younger ones may fly)
-      }
+      asm volatile("s_barrier" ::: "memory");
+      SMAP_TS(3);
+      a_issue(c);
+      SMAP_TS(4);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       SMAP_TS(5);
       asm volatile("s_barrier" ::: "memory");
       SMAP_TS(6);
-      b_issue(t + BST - 1, t + BST - 1 < nsteps);                  // into the slot step t - 1 released
-      SMAP_TS(7);
-      const int ky = tap / 3, kx = tap - ky * 3;
-      const char* sB = sBr + (t % BST) * B_BYTES + wn * WTN * 128;
-      const int aoff = abase + (ky * HP + kx) * 128;
-      const int akey = (fx + kx) & 7;
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
-        bf16x8 b[NI], a[MI];
-#pragma unroll
-        for (int j = 0; j < NI; ++j) b[j] = no_rd ? bf16x8{} : *(const bf16x8*)(sB + j * 512 + foffB[kk]);
-        const int ach = (((kk << 2) + q) ^ akey) << 4;
-#pragma unroll
-        for (int i = 0; i < MI; ++i) a[i] = no_rd ? bf16x8{} : *(const bf16x8*)(sA + aoff + ((i >> 2) * IMG + 2 * (i & 3) * HP) * 128 + ach);
-        if (no_mm) {
-#pragma unroll
-          for (int i = 0; i < MI; ++i) acc[i][0][0] += (float)a[i][0] + (float)b[i & 1][0];
-        } else {
-#pragma unroll
-        for (int i = 0; i < MI; ++i)
-#pragma unroll
-          for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);   // D = W . X^T
-        }
-      }
+      rd(K0{}, abase, fx & 7, sBr + bs * B_BYTES + wn * WTN * 128);
+      __builtin_amdgcn_sched_barrier(0);
+      tapstep(std::integral_constant<int, 0>{}); tapstep(std::integral_constant<int, 1>{}); tapstep(std::integral_constant<int, 2>{});
+      tapstep(std::integral_constant<int, 3>{}); tapstep(std::integral_constant<int, 4>{}); tapstep(std::integral_constant<int, 5>{});
+      tapstep(std::integral_constant<int, 6>{}); tapstep(std::integral_constant<int, 7>{}); tapstep(std::integral_constant<int, 8>{});
     }
   }
   SMAP_TS(8);
@@ -211,9 +236,6 @@ __global__ __launch_bounds__(512, 2) void igemm_smap_kernel(const IgemmP p) {
     }
     asm volatile("s_barrier" ::: "memory");                        // (the epilogue's LDS-staged paths start behind their own barriers; the register path touches no LDS)
   }
-#ifdef AGD_EXPERIMENTS
-  if (p.dbg & 32) { if (acc[0][0][0] == 12345.f) ((float*)p.out)[0] = 1.f; return; }      // timing variant: no epilogue
-#endif
   igemm_epilogue<BM, BN, WM, WN, 0, SPLITK>(p, acc, smem, lane, wm, wn, m0, n0, tn, 0, nullptr);
 #ifdef AGD_EXPERIMENTS
   if (ts_on) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); SMAP_TS(10); g_smap_ts[1023] = ts_n; }
