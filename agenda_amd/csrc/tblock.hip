@@ -27,6 +27,21 @@ typedef __attribute__((ext_vector_type(2))) float f32x2_t;
 #ifdef AGD_EXPERIMENTS
 int g_tb_variant = 0;   // timing variants of the fused kernels (tools/ only)
 extern "C" __attribute__((visibility("default"))) void agd_set_tb_variant(int v) { g_tb_variant = v; }
+// in-kernel time stamps (tools/kb_tblock_trace.py): wave g_tb_ts_sel[1] of workgroup g_tb_ts_sel[0] stores s_memtime at the marks of the row-panel kernels
+__device__ unsigned long long g_tb_ts[256];
+__device__ int g_tb_ts_sel[2] = {-1, 0};
+extern "C" __attribute__((visibility("default"))) int agd_tb_ts(int wg, int wave, unsigned long long* out) {
+  if (out) return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tb_ts), 256 * 8) == hipSuccess ? 0 : -1;
+  const int sel[2] = {wg, wave};
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_tb_ts_sel), sel, 8) == hipSuccess ? 0 : -1;
+}
+#define TB_TS_DECL const bool ts_on = (int)blockIdx.x == g_tb_ts_sel[0] && (int)threadIdx.x == g_tb_ts_sel[1] * 64; int ts_n = 0; if (ts_on) g_tb_ts[250] = __builtin_amdgcn_s_memrealtime();
+#define TB_TS(k) do { if (ts_on && ts_n < 240) g_tb_ts[ts_n++] = ((unsigned long long)(k) << 56) | (__builtin_amdgcn_s_memtime() & 0x00FFFFFFFFFFFFFFull); } while (0)
+#define TB_TS_END do { if (ts_on) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); TB_TS(99); g_tb_ts[255] = ts_n; g_tb_ts[251] = __builtin_amdgcn_s_memrealtime(); } } while (0)
+#else
+#define TB_TS_DECL
+#define TB_TS(k) do { } while (0)
+#define TB_TS_END do { } while (0)
 #endif
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -558,7 +573,8 @@ __global__ __launch_bounds__(512, 2) void attn_chain_kernel(const AttnChainP p) 
   const int m0 = blockIdx.x * BM;
   const int b = m0 / p.HW, pix0 = m0 - b * p.HW;        // tiles stay inside one image (HW % 128 == 0)
   const int m0s = p.src_rows > 0 ? m0 % p.src_rows : m0;     // first INPUT row of this tile (CFG-shared prefix: both halves read the same rows)
-
+  TB_TS_DECL
+  TB_TS(1);
   panel_load_dma<C, BM>(PRE ? p.o1 : p.h, m0s, p.src_rows > 0 ? p.src_rows : p.M, panel, wid, lane);
 
   // K / V staging of this wave's head half: pad chunks once, then head `h` through registers
@@ -608,8 +624,10 @@ __global__ __launch_bounds__(512, 2) void attn_chain_kernel(const AttnChainP p) 
   const int ncol0 = 16 * NI * nq + 4 * NI * q;          // first of this lane's 4 NI consecutive channels (GEMM epilogues)
 
   if constexpr (PRE) gemm_head(p.wo1f);
+  TB_TS(2);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (also drains the ring's head: it is ten L2-resident KiB)
   __syncthreads();
+  TB_TS(3);
   kv_store();
   if constexpr (!PRE) {
     panel_row_stats<C, BM>(panel, lnst, tid, p.ln_eps);
@@ -623,6 +641,7 @@ __global__ __launch_bounds__(512, 2) void attn_chain_kernel(const AttnChainP p) 
 #pragma unroll
     for (int i = 0; i < MI; ++i) load_row_chunk<NI>(p.h + (long long)(m0s + rbase + 16 * i) * C + ncol0, hr[i]);
     gemm_body(p.wo1f);
+    TB_TS(4);
     gemm_head(p.wqf);
     float bv1[NI * 4];
 #pragma unroll
@@ -650,6 +669,7 @@ __global__ __launch_bounds__(512, 2) void attn_chain_kernel(const AttnChainP p) 
       rq1[i] += __shfl_xor(rq1[i], 16); rq1[i] += __shfl_xor(rq1[i], 32);
       if (q == 0) *(f32x2_t*)(pst + (nq * BM + rbase + 16 * i) * 2) = f32x2_t{rs1[i], rq1[i]};
     }
+    TB_TS(5);
     __syncthreads();                                    // partial sums staged AND every wave is done reading o1 from the panel
     float g2[NI * 4], b2[NI * 4];
 #pragma unroll
@@ -690,10 +710,13 @@ __global__ __launch_bounds__(512, 2) void attn_chain_kernel(const AttnChainP p) 
     *(u32x4*)(panel + row * PITCH + pc * 16) = v;
   }
   }
+  TB_TS(6);
   __syncthreads();
 
   // ---- to_q: Q over the normalised rows (every wave has finished reading them before anyone overwrites) ----
+  TB_TS(7);
   gemm_body(p.wqf);
+  TB_TS(8);
   __syncthreads();
 #pragma unroll
   for (int i = 0; i < MI; ++i) {
@@ -706,6 +729,7 @@ __global__ __launch_bounds__(512, 2) void attn_chain_kernel(const AttnChainP p) 
     }
   }
   __syncthreads();
+  TB_TS(9);
 
   // ---- attention: wave = query block qb (32 rows) x heads 4 hhalf .. 4 hhalf + 3 ----
   {
@@ -834,8 +858,10 @@ __global__ __launch_bounds__(512, 2) void attn_chain_kernel(const AttnChainP p) 
           for (int j = 0; j < 16; ++j) pacc[kb][j] = 0.f;
       }
       }
+      TB_TS(10 + hi);
       __syncthreads();                                 // every wave is done with this head's K / V
       if (hi + 1 < 4) { kv_store(); __syncthreads(); }
+      TB_TS(20 + hi);
     }
     gemm_head(p.wof);                                   // to_out's first weight fragments fly under the recorder hand-off
     // all heads in one recorder slice: the upper head half hands its sum to the lower one through LDS (the K / V stage is free now)
@@ -857,13 +883,16 @@ __global__ __launch_bounds__(512, 2) void attn_chain_kernel(const AttnChainP p) 
       }
     }
   }
+  TB_TS(30);
   __syncthreads();                                       // O complete in the panel (and the exchange buffer is free)
+  TB_TS(31);
 
   // ---- to_out + bias + residual, one rounding; optional norm3 row statistics of the rounded outputs ----
   u32x2 fr[MI][NI];                                      // residual rows, requested ahead of the GEMM (PRE: h1, stored by this very lane above)
 #pragma unroll
   for (int i = 0; i < MI; ++i) load_row_chunk<NI>((PRE ? (const bf16_t*)p.out : p.h) + (long long)((PRE ? m0 : m0s) + rbase + 16 * i) * C + ncol0, fr[i]);
   gemm_body(p.wof);
+  TB_TS(32);
   float bv[NI * 4];
 #pragma unroll
   for (int t = 0; t < NI; ++t) *(f32x4*)&bv[4 * t] = *(const f32x4*)(p.bo + ncol0 + 4 * t);
@@ -905,6 +934,7 @@ __global__ __launch_bounds__(512, 2) void attn_chain_kernel(const AttnChainP p) 
       *(f32x2_t*)(p.rowstat_out + (long long)(m0 + tid) * 2) = f32x2_t{S, Q};
     }
   }
+  TB_TS_END;
 }
 
 int launch_attn_chain(const AttnChainP& p, int C, int heads, hipStream_t st) {

@@ -9,6 +9,7 @@ lib = C.CDLL(os.environ.get("AGD_LIB", os.path.join(ROOT, "agenda_amd", "libagen
 lib.agd_bench_conv.argtypes = [C.c_int] * 12 + [C.POINTER(C.c_double)]
 lib.agd_smap_ts.argtypes = [C.c_int, C.POINTER(C.c_ulonglong)]
 C0 = int(sys.argv[1]) if len(sys.argv) > 1 else 640
+H = int(os.environ.get("KB_H", "32")); N = int(os.environ.get("KB_N", "640"))      # KB_H=16 KB_N=1280: the 16 x 16 maps (2 K slices)
 extra = int(sys.argv[2]) if len(sys.argv) > 2 else 0       # timing-variant bits of AGD_IGEMM_CFG (tools/kb_pch_parts.py)
 brief = len(sys.argv) > 3
 for who, bit in (("consumer wave 0", 0), ("loader wave 0", 2048)):
@@ -16,7 +17,7 @@ for who, bit in (("consumer wave 0", 0), ("loader wave 0", 2048)):
         lib.agd_smap_ts(wg, None)
         lib.agd_set_igemm_cfg(1024 | bit | extra)
         ms = C.c_double()
-        lib.agd_bench_conv(8, 32, 32, C0, 0, 640, 3, 1, 1, 8 | 256 | (1 << 16) | (1 << 15), 0, 20, C.byref(ms))
+        lib.agd_bench_conv(8, H, H, C0, 0, N, 3, 1, 1, 8 | 256 | (1 << 16) | (1 << 15), 0, 20, C.byref(ms))
         buf = (C.c_ulonglong * 1024)()
         lib.agd_smap_ts(0, buf)
         n = int(buf[1023])
