@@ -61,6 +61,13 @@ __global__ __launch_bounds__(512, 2) void igemm8p_kernel(const IgemmP p) {
 #endif
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef AGD_EXPERIMENTS
+  // time stamps (tools/kb_8p_trace.py): dbg bit 6; bit 7 picks wave 4 (the group that runs one barrier behind) instead of wave 0
+  const bool ts_on = (p.dbg & 64) && tid == ((p.dbg & 128) ? 256 : 0) && (int)blockIdx.x == g_smap_ts_wg;
+  int ts_n = 0;
+  if (ts_on) g_smap_ts[1020] = __builtin_amdgcn_s_memrealtime();
+#endif
+  AGD_TS(1);
   const int grp = wid >> 2;                           // waves 4..7 share the SIMDs of waves 0..3: they run one barrier behind
   const int wm = wid / WN, wn = wid % WN;
   const int tiles_n = (p.N + BN - 1) / BN;
@@ -245,6 +252,7 @@ __global__ __launch_bounds__(512, 2) void igemm8p_kernel(const IgemmP p) {
   const bool live1 = nk > 1;
   if (live1) advance();
   stageB0(1, live1); stageA(1, 0, live1); stageB1(1, live1);
+  AGD_TS(2);
   // LayerNorm-fold consumer: one thread per tile row sums the producer's partial sums (its `slots` dependent loads run beside the
   // prologue's LDS-DMA) and leaves (mean, rstd) in LDS for the epilogue -- the eight rows of a lane would otherwise cost the epilogue
   // eight x slots exposed L2 round trips with nothing to overlap them (one workgroup per CU)
@@ -259,22 +267,17 @@ __global__ __launch_bounds__(512, 2) void igemm8p_kernel(const IgemmP p) {
   if (grp == 0) p8_wait_vm<INFL_G0>(); else p8_wait_vm<INFL_G1>();
   P8_BAR();
   if (grp == 1) P8_BAR();
+  AGD_TS(3);
   int t = 0;
-  for (; t + 1 < nk; t += 2) { ktile(I0{}, t); ktile(I1{}, t + 1); }
+  for (; t + 1 < nk; t += 2) { ktile(I0{}, t); AGD_TS(4); ktile(I1{}, t + 1); AGD_TS(4); }
   if (t < nk) ktile(I0{}, t);
+  AGD_TS(5);
   if (grp == 0) P8_BAR();
   p8_wait_vm<0>();                                   // dead tail pieces still write zeros into LDS: let them land before the epilogue reuses it
 
-#ifdef AGD_EXPERIMENTS
-  if (p.dbg & 64) {                                // timing experiment (agd_set_igemm_cfg(1024)): no epilogue (keeps acc live)
-    float sacc = 0.f;
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-      for (int j = 0; j < NI; ++j) sacc += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
-    if (sacc == 1.2345e-30f) ((float*)p.out)[0] = sacc;
-    return;
-  }
-#endif
+  AGD_TS(6);
   igemm_epilogue<BM, BN, WM, WN, GEGLU, 0, 1>(p, acc, smem, lane, wm, wn, m0, n0, tn, 0, p.ln_stats ? (const float*)(smem + G::STATS_OFF) : nullptr);
+#ifdef AGD_EXPERIMENTS
+  if (ts_on) { AGD_TS(7); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); AGD_TS(8); g_smap_ts[1023] = ts_n; g_smap_ts[1021] = __builtin_amdgcn_s_memrealtime(); }
+#endif
 }

@@ -544,6 +544,8 @@ int launch_ff_fused(const FFusedP& p, int C, hipStream_t st) {
 // epilogue), norm2's statistics from the rounded h1 held in registers -- the launch between the self-attention and this chain disappears too
 template <int C, int PRE, int MI = 4>
 __global__ __launch_bounds__(512, 2) void attn_chain_kernel(const AttnChainP p) {
+  TB_TS_DECL
+  TB_TS(0);
   // geometry: a wave's GEMM tile is always 64 rows x 80 columns, so C / 80 column ranges x (8 waves / that) row halves: C = 320: 128 rows per
   // workgroup, 2 x 4 waves; C = 640 (the 32 x 32 maps): 64 rows, 1 x 8 waves -- the panel is 80 KB either way.  Attention: BM / 32 query blocks x 2
   // head slots of four heads; at C = 640 (two query blocks) waves 2, 3, 6, 7 only help loading K / V.
@@ -573,17 +575,20 @@ __global__ __launch_bounds__(512, 2) void attn_chain_kernel(const AttnChainP p) 
   const int m0 = blockIdx.x * BM;
   const int b = m0 / p.HW, pix0 = m0 - b * p.HW;        // tiles stay inside one image (HW % 128 == 0)
   const int m0s = p.src_rows > 0 ? m0 % p.src_rows : m0;     // first INPUT row of this tile (CFG-shared prefix: both halves read the same rows)
-  TB_TS_DECL
   TB_TS(1);
   panel_load_dma<C, BM>(PRE ? p.o1 : p.h, m0s, p.src_rows > 0 ? p.src_rows : p.M, panel, wid, lane);
+  TB_TS(40);
 
   // K / V staging of this wave's head half: pad chunks once, then head `h` through registers
   char* sK = kvs + hhalf * KVSTAGE;
   char* sV = sK + KEYS * KPITCH;
   const int t4 = tid & 255;
-  constexpr int KPADC = KPITCH / 16 - CH, VPADC = VPITCH / 16 - CH;          // pad chunks behind the real d columns (never overwritten)
+  constexpr int KPADC = KPITCH / 16 - CH;                                     // pad chunks behind the real d columns (never overwritten)
+  // K's pad chunks meet Q's zero pad in the d sum (0 x a stale NaN would poison S): zeroed once.  V's pad COLUMNS only ever reach the output rows d >= D, which are
+  // dropped (an output row depends on its own V column alone), and its pad ROWS (keys >= T) are staged as the buffer loads' out-of-range zeros: no pass over V
+  // (round 5, in-kernel stamps: the two passes cost ~4100 cycles, 4 % of the launch, most of it the three V iterations under the panel's LDS-DMA writes).
   for (int i = t4; i < KEYS * KPADC; i += 256) { const int r = i / KPADC, cc = CH + i % KPADC; *(u32x4*)(sK + r * KPITCH + cc * 16) = u32x4{0, 0, 0, 0}; }
-  for (int i = t4; i < KEYS * VPADC; i += 256) { const int r = i / VPADC, cc = CH + i % VPADC; *(u32x4*)(sV + r * VPITCH + cc * 16) = u32x4{0, 0, 0, 0}; }
+  TB_TS(41);
   u32x4 kreg[LD_IT], vreg[LD_IT];
   unsigned kvoff[LD_IT];
 #pragma unroll
@@ -610,6 +615,7 @@ __global__ __launch_bounds__(512, 2) void attn_chain_kernel(const AttnChainP p) 
     }
   };
   kv_load(4 * hhalf);
+  TB_TS(42);
 
   // ---- GEMM stage: acc[4][NI] = W[80 nq .. +80][:] . panel[64 mh .. +64][:]^T ----
   const int rbase = 16 * MI * mh + px;
@@ -670,10 +676,10 @@ __global__ __launch_bounds__(512, 2) void attn_chain_kernel(const AttnChainP p) 
       if (q == 0) *(f32x2_t*)(pst + (nq * BM + rbase + 16 * i) * 2) = f32x2_t{rs1[i], rq1[i]};
     }
     TB_TS(5);
-    __syncthreads();                                    // partial sums staged AND every wave is done reading o1 from the panel
-    float g2[NI * 4], b2[NI * 4];
+    float g2[NI * 4], b2[NI * 4];                        // (requested in front of the barrier: their L2 round trip runs under the wait for the slowest wave)
 #pragma unroll
     for (int t = 0; t < NI; ++t) { *(f32x4*)&g2[4 * t] = *(const f32x4*)(p.gamma + ncol0 + 4 * t); *(f32x4*)&b2[4 * t] = *(const f32x4*)(p.beta + ncol0 + 4 * t); }
+    __syncthreads();                                    // partial sums staged AND every wave is done reading o1 from the panel
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
       const int row = rbase + 16 * i;
