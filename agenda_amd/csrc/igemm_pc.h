@@ -262,8 +262,19 @@ __global__ __launch_bounds__((4 + NLW) * 64) void igemm_pc_kernel(const IgemmP p
 #pragma unroll
           for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rb[kk][j], ra[kk][i], acc[i][j], 0, 0, 0);      // D = W . X^T
     };
-    // (sched_barrier(0): hipcc otherwise sinks the next step's reads behind this step's MFMAs and hoists MFMAs over the s_barrier -- the reads must be
-    //  ISSUED first to land under the MFMAs)
+    // the step's schedule: one fragment read of the NEXT step behind each of this step's first MFMAs (igemm_pch.h: a read between two MFMAs costs the matrix pipe
+    // nothing, a burst of them idles it), the remaining MFMAs cover the last reads' latency
+    auto interleave = [&]() {
+      constexpr int NR = 2 * (MI + NI), NM = 2 * MI * NI;
+      static_assert(NM >= NR, "more MFMAs than fragment reads per step");
+#pragma unroll
+      for (int n = 0; n < NR; ++n) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // 1 MFMA
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // 1 DS read
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, NM - NR, 0);
+    };
+    // (sched_barrier(0): hipcc otherwise hoists MFMAs over the s_barrier)
     // (every scalar load -- kernel arguments -- is retired before the loop: with one pending on the loop's entry edge hipcc's wait-count pass can only emit
     //  lgkmcnt(0) inside it, scalar loads returning out of order, and the first MFMA would wait for the reads just issued instead of the previous step's)
     __builtin_amdgcn_s_waitcnt(0xC07F);                        // lgkmcnt(0)
@@ -275,14 +286,14 @@ __global__ __launch_bounds__((4 + NLW) * 64) void igemm_pc_kernel(const IgemmP p
       asm volatile("s_barrier" ::: "memory");                  // B_ks: stage ks + 1 has landed
       __builtin_amdgcn_sched_barrier(0);
       rd(fa[1], fb[1], ks + 1);
-      __builtin_amdgcn_sched_barrier(0);
       mm(fa[0], fb[0]);
+      interleave();
       __builtin_amdgcn_sched_barrier(0);
       asm volatile("s_barrier" ::: "memory");                  // B_(ks + 1)
       __builtin_amdgcn_sched_barrier(0);
       rd(fa[0], fb[0], ks + 2 < nk ? ks + 2 : nk - 1);         // (unconditional: a constant number of reads in flight lets hipcc emit counted lgkmcnt waits; past the end it re-reads the last stage, unused)
-      __builtin_amdgcn_sched_barrier(0);
       mm(fa[1], fb[1]);
+      interleave();
     }
     __builtin_amdgcn_sched_barrier(0);
     if (ks < nk) {                                             // odd step count: the last step's fragments are in set 0
