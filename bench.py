@@ -29,7 +29,7 @@ PMC_CSV = os.path.join("profiles", "r05_pmc_traffic_summary.csv")
 STATS_CSV = os.path.join("profiles", "r05_bench_kernel_stats.csv")
 
 # the kernel instantiations behind each class, as rocprofv3 names them: igemm_kernel<BM, BN, WM, WN, KS, ...>,
-# igemm_halo_kernel<BN, SPLITK, BST> (3x3 only), igemm8p_kernel<WM, WN, MI, NI0, NI1, KS, GEGLU>
+# igemm_halo_kernel<BN, SPLITK, BST> / igemm_pch_kernel<BN, SPLITK> (3x3 only), igemm8p_kernel<WM, WN, MI, NI0, NI1, KS, GEGLU>
 # round 4: the fused row-panel kernels of the C = 320 blocks (tblock.hip) are booked where the launches they replace were: ff_fused / qkv_chain
 # under the linears, attn_chain under cross-attention; igemm_smap_kernel (8 x 8 maps) and the split-K slab passes under the convs
 CLASS_REP = {"igemm_conv3x3": "igemm_kernel", "igemm_linear_1x1": "igemm_kernel", "attn_self_flash": "attn_kernel", "attn_cross_daam": "attn_kernel", "groupnorm": "gn_apply_part_kernel"}
@@ -51,7 +51,7 @@ def _is(name, cls):
     if cls == "igemm_conv3x3":
         # (KS = 2: the phase convs of the upsampling convs -- booked under the convs by the walk's profile scopes too)
         pc = _targs(name, "igemm_pc_kernel")                        # igemm_pc_kernel<BM, BN, NLW, STAGES, KS, GEGLU, SPLITK>
-        return (ig is not None and ig[4] in ("2", "3")) or (i8 is not None and i8[5] in ("2", "3")) or "igemm_halo_kernel<" in name or "igemm_smap_kernel<" in name or (pc is not None and pc[4] == "3")
+        return (ig is not None and ig[4] in ("2", "3")) or (i8 is not None and i8[5] in ("2", "3")) or "igemm_halo_kernel<" in name or "igemm_pch_kernel<" in name or "igemm_smap_kernel<" in name or (pc is not None and pc[4] == "3")
     if cls == "igemm_linear_1x1":
         pc = _targs(name, "igemm_pc_kernel")
         return (ig is not None and ig[4] == "1") or (i8 is not None and i8[5] == "1") or (pc is not None and pc[4] == "1") or any(k in name for k in ("ff_fused_kernel<", "qkv_chain_kernel<", "igemm_wreg_kernel<"))

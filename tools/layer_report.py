@@ -19,9 +19,9 @@ with open(trace) as f:
 rows.sort()
 # every igemm launch logs one line, whichever kernel family it dispatches to (4-wave general / row-halo / 8-phase); the log and the
 # trace are both in launch order on the one stream
-ig = [(i, r) for i, r in enumerate(rows) if r[2].startswith(("void igemm_kernel", "void igemm_halo_kernel", "void igemm8p_kernel", "void igemm_smap_kernel", "void igemm_wreg_kernel", "void igemm_pc_kernel"))]
+ig = [(i, r) for i, r in enumerate(rows) if r[2].startswith(("void igemm_kernel", "void igemm_halo_kernel", "void igemm8p_kernel", "void igemm_smap_kernel", "void igemm_wreg_kernel", "void igemm_pc_kernel", "void igemm_pch_kernel"))]
 assert len(ig) == len(shapes), (len(ig), len(shapes))
-fam = {"void igemm_kernel": "4w", "void igemm_halo_kernel": "halo", "void igemm8p_kernel": "8p", "void igemm_smap_kernel": "smap", "void igemm_wreg_kernel": "wreg", "void igemm_pc_kernel": "pc"}
+fam = {"void igemm_kernel": "4w", "void igemm_halo_kernel": "halo", "void igemm8p_kernel": "8p", "void igemm_smap_kernel": "smap", "void igemm_wreg_kernel": "wreg", "void igemm_pc_kernel": "pc", "void igemm_pch_kernel": "pch"}
 marks = [i for i, r in enumerate(rows) if "timestep_embed" in r[2] or "prep_latents" in r[2]]
 prep = [i for i, r in enumerate(rows) if "prep_latents" in r[2]]
 a, b = prep[fwd], prep[fwd + 1]
