@@ -613,7 +613,7 @@ static int launch_halo(const IgemmP& p_in, int splits, hipStream_t st) {
 
 // producer / consumer row-halo kernel (igemm_pch.h): 128 x 160 tiles, one workgroup per CU (IgemmP::pc bit 4)
 static bool pch_ok(const IgemmP& p, int splits) {
-  if (!(p.pc & 16) || !halo_ok(p) || p.up != 1 || p.sc0 || p.w_per_image) return false;
+  if (!(p.pc & 16) || !halo_ok(p) || p.up != 1 || p.w_per_image) return false;
   const long long tiles = (long long)((p.M + 127) / 128) * ((p.N + 159) / 160);
   return tiles * splits <= 256;
 }

@@ -163,6 +163,43 @@ __global__ __launch_bounds__(512) void igemm_pch_kernel(const IgemmP p, const in
     for (int t = 0; t < nsteps; t += 3) { lstep(t, K0{}); lstep(t + 1, K1{}); lstep(t + 2, K2{}); }
     AGD_TS(5);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (dead tail pieces still write zeros into LDS)
+    if (p.sc0) {
+      // ---- the block's 1x1 conv_shortcut as extra K (IgemmP::sc0, as in igemm_halo.h): 64-channel chunks of the raw block input (one or two sources), the tile's own pixel
+      // rows (ky = 1; the consumers read the centre tap), weight columns 9 Ct + 64 r ...; A images 0 / 1 and weight slots 0 / 1, chunk r + 1 requested behind barrier S_r
+      // (the consumers have left chunk r - 1, whose slots it takes) and landed in full before S_(r + 1): it flies under the MFMAs of chunk r
+      asm volatile("s_barrier" ::: "memory");             // Z: every consumer has left the 3x3 loop: the rings are free
+      const int nsc = (p.sc_C0 + p.sc_C1) >> 6, sc0n = p.sc_C0 >> 6;
+      int r0 = 0, r1 = nsc;                               // split-K: the chunks are dealt to the K slices like the 3x3 groups
+      if constexpr (SPLITK) { const int per = (nsc + (int)gridDim.z - 1) / (int)gridDim.z; r0 = (int)blockIdx.z * per; r1 = r0 + per < nsc ? r0 + per : nsc; if (r1 < r0) r1 = r0; }
+      auto issue_sc = [&](int r, bool live) {
+        const bool s1 = r >= sc0n;
+        const int Cs = s1 ? p.sc_C1 : p.sc_C0;
+        const bf16_t* abase = s1 ? p.sc1 : p.sc0;
+        const unsigned aso = __builtin_amdgcn_readfirstlane((unsigned)((s1 ? r - sc0n : r) * 128));
+        const int slot = (r - r0) & 1;
+        char* const dA = sAr + slot * A_BYTES;
+        char* const dB = sBr + slot * B_BYTES;
+        const unsigned nr = live ? 0x7FFFFFF0u : 0u;
+#pragma unroll
+        for (int i = 0; i < A_ITH; ++i) {
+          const bool ok = ((a_ok >> i) & 1) && (unsigned)(a_y[i] + 1) < (unsigned)H;
+          const int pix = (a_brow[i] + a_y[i] + 1) * p.Win + a_ix[i];
+          const unsigned off = ok ? (unsigned)(pix * Cs + lchunk * 8) * 2u : 0x80000000u;
+          const int pc = i * NLW + lw;
+          bufdma16(abase, pc * 8 < HRP ? dA + pc * 1024 : sink, off, aso, nr);
+        }
+        const unsigned bso = __builtin_amdgcn_readfirstlane((unsigned)((9 * Ct + r * 64) * 2));
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i) bufdma16(p.W, dB + (i * NLW + lw) * 1024, bvoff[i], bso, nr);
+      };
+      if (r1 > r0) issue_sc(r0, true);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      for (int r = r0; r < r1; ++r) {
+        asm volatile("s_barrier" ::: "memory");           // S_r
+        issue_sc(r + 1, r + 1 < r1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+    }
 #ifdef AGD_EXPERIMENTS
     if (ts_on) { AGD_TS(6); g_smap_ts[1023] = ts_n; g_smap_ts[1021] = __builtin_amdgcn_s_memrealtime(); }
 #endif
@@ -277,6 +314,25 @@ __global__ __launch_bounds__(512) void igemm_pch_kernel(const IgemmP p, const in
     step(K1{}, K2{}, as, b1, as, b2);
     step(K2{}, K0{}, as, b2, asn, b3);                    // (behind the last group: prefetches from slots nobody filled -- in bounds, never used)
     as = asn; bs = b3;
+  }
+  if (p.sc0) {                                           // the conv_shortcut chunks (loader side above): centre tap of image / weight slot (r - r0) & 1
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_barrier" ::: "memory");              // Z
+    const int nsc = (p.sc_C0 + p.sc_C1) >> 6;
+    int r0 = 0, r1 = nsc;
+    if constexpr (SPLITK) { const int per = (nsc + (int)gridDim.z - 1) / (int)gridDim.z; r0 = (int)blockIdx.z * per; r1 = r0 + per < nsc ? r0 + per : nsc; if (r1 < r0) r1 = r0; }
+    for (int r = r0; r < r1; ++r) {
+      const int slot = (r - r0) & 1;
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_barrier" ::: "memory");            // S_r
+      __builtin_amdgcn_sched_barrier(0);
+      rd(K1{}, K0{}, slot, slot);
+      rd(K1{}, K1{}, slot, slot);
+      __builtin_amdgcn_sched_barrier(0);
+      mm(K0{});
+      mm(K1{});
+    }
+    __builtin_amdgcn_sched_barrier(0);
   }
   AGD_TS(5);
   igemm_epilogue<BM, BN, WM, WN, 0, SPLITK>(p, acc, smem, lane, wm, wn, m0, n0, tn, 0, nullptr);
