@@ -132,8 +132,9 @@ struct agd_ctx {
   int opt_smap = 1;                                   // agd_set_option("conv_smap"): 3x3 convs of the 8 x 8 maps through the whole-images-resident kernel (igemm_smap.h)
   int opt_reduce_gn = 1;                              // agd_set_option("reduce_gn"): split-K slab sum + the GroupNorm that reads it as one launch (igemm.hip splitk_reduce_gn_kernel)
   int opt_xcd_block = 1;                              // agd_set_option("xcd_block"): the igemm tile grid cut into one block per XCD that minimises the XCD's L2 working set (igemm.hip pick_xcd_block)
-  int opt_pc = 17;                                    // agd_set_option("igemm_pc"): producer / consumer igemm (igemm_pc.h) -- bit 0: 1x1 launches on 64 x 160 tiles, bit 1: 3x3 convs of the 16 x 16 maps;
-                                                      // bit 4: the row-halo producer / consumer kernel (igemm_pch.h) for 3x3 convs whose 128 x 160 tiles (x K slices) fit one wave of workgroups
+  int opt_pc = 49;                                    // agd_set_option("igemm_pc"): producer / consumer igemm (igemm_pc.h) -- bit 0: 1x1 launches on 64 x 160 tiles, bit 1: 3x3 convs of the 16 x 16 maps;
+                                                      // bit 4: the row-halo producer / consumer kernel (igemm_pch.h) for 3x3 convs whose 128 x 160 tiles (x K slices) fit one wave of workgroups;
+                                                      // bit 5: the 1x1 launches of one 128 x 160 tile per CU (M = 8192, N = 640) on igemm_pc.h's 128-row form
   int opt_xpre = 1;                                   // agd_set_option("attn2_premul"): attn2 of the C = 1280 blocks as two GEMMs against per-image pre-multiplied context matrices (xattn_pre.hip)
   int opt_touch = 3;                                  // agd_set_option("weight_touch"): n > 0 = stream 1x1 weight matrices of >= n MB through the caches right before their launch
   unsigned* touch_sink = nullptr;
@@ -1850,7 +1851,7 @@ AGD_API int agd_op_conv2d_ex(const float* x, const float* w, const float* bias, 
   WMat wm; wm.w = wb; wm.N = Cout; wm.Cin = Cin; wm.Cpad = Cpad; wm.taps = taps;
   GemmOpt o; o.bias = bias; o.stride = stride; o.up = up; o.out_f32 = 1; o.halo = flags & 1; o.p8 = (flags & 4) ? 2 : (flags & 8) ? 3 : (flags & 2) ? 1 : 0;
   o.smap = (flags & 16) ? 1 : 0;
-  o.pc = ((flags >> 7) & 15) | ((flags >> 8) & 16); // the producer / consumer kernels (igemm_pc.h, igemm_pch.h): IgemmP::pc mask bits 0..3 in bits 7..10, bit 4 in bit 12
+  o.pc = ((flags >> 7) & 15) | ((flags >> 8) & 48); // the producer / consumer kernels (igemm_pc.h, igemm_pch.h): IgemmP::pc mask bits 0..3 in bits 7..10, bits 4 / 5 in bits 12 / 13
   o.xcd_block = (flags >> 11) & 1;                   // XCD-aware tile blocks (igemm.hip pick_xcd_block)
   if ((flags & 64) && upsample && ksize == 3 && stride == 1) {     // the upsampling conv as four 2x2 phase convs (IgemmP::ups4); bf16 output (that form's only one), widened afterwards
     bf16_t* w4 = tmp.get<bf16_t>((size_t)4 * Cout * 4 * Cpad); float* b4 = tmp.get<float>((size_t)4 * Cout); bf16_t* yb = tmp.get<bf16_t>((size_t)B * Ho * Wo * Cout);
@@ -1886,7 +1887,7 @@ AGD_API int agd_op_linear(const float* x, const float* w, const float* bias, con
   WMat wm; wm.w = wb; wm.N = N; wm.Cin = K; wm.Cpad = K; wm.taps = 1;
   GemmOpt o; o.bias = bias; o.residual = rb; o.geglu = geglu; o.out_f32 = 1; o.p8 = (flags & 4) ? 2 : (flags & 8) ? 3 : (flags & 2) ? 1 : 0;
   o.kg2 = (flags & 32) ? 1 : 0;                      // two K groups of waves per workgroup where the launcher's 64-row unsplit tiles apply
-  o.pc = (flags >> 7) & 15;                          // the producer / consumer kernel (igemm_pc.h): IgemmP::pc mask in bits 7..10
+  o.pc = ((flags >> 7) & 15) | ((flags >> 8) & 48); // the producer / consumer kernel (igemm_pc.h): IgemmP::pc mask bits 0..3 in bits 7..10, bits 4 / 5 in bits 12 / 13
   o.xcd_block = (flags >> 11) & 1;                   // XCD-aware tile blocks (igemm.hip pick_xcd_block)
   if (flags & 16) {                                  // the weight-streaming kernel (igemm_wreg.h); bf16 output (that kernel's only form), widened afterwards
     const int ni = geglu ? 4 : 2;
@@ -2151,7 +2152,7 @@ AGD_API int agd_bench_conv(int B, int H, int W, int C0, int C1, int Cout, int ks
   o.p8 = (mode & 32) ? 2 : (mode & 64) ? 3 : (mode & 16) ? 1 : 0;
   o.smap = (mode & 256) ? 1 : 0;
   o.kg2 = (mode & 512) ? 1 : 0;
-  o.pc = ((mode >> 11) & 15) | ((mode >> 12) & 16);  // producer / consumer kernels (igemm_pc.h, igemm_pch.h): IgemmP::pc mask bits 0..3 in bits 11..14, bit 4 in bit 16
+  o.pc = ((mode >> 11) & 15) | ((mode >> 12) & 48);  // producer / consumer kernels (igemm_pc.h, igemm_pch.h): IgemmP::pc mask bits 0..3 in bits 11..14, bit 4 in bit 16
   o.xcd_block = (mode >> 15) & 1;                    // XCD-aware tile blocks
   if (mode & 128) {                                  // weight-streaming kernel (igemm_wreg.h): the matrix once more in fragment order
     const int ni = geglu ? 4 : 2;

@@ -28,7 +28,7 @@ def conv2d(x, w, bias=None, stride=1, padding=None, upsample=False, halo=False, 
     Wo = (W * up + 2 * pad - k) // stride + 1
     y = torch.empty(B, Cout, Ho, Wo, device=x.device, dtype=torch.float32)
     _lib.check(lib.agd_op_conv2d_ex(_lib.ptr(x), _lib.ptr(w), _lib.ptr(b), _lib.ptr(y), B, Cin, H, W, Cout, k, stride,
-                                    pad, int(upsample), (1 if halo else 0) | _P8[p8] | (16 if smap else 0) | (64 if phases else 0) | ((int(pc) & 15) << 7) | (4096 if int(pc) & 16 else 0) | (2048 if xcd_block else 0), _lib.current_stream_ptr()), None, "agd_op_conv2d")
+                                    pad, int(upsample), (1 if halo else 0) | _P8[p8] | (16 if smap else 0) | (64 if phases else 0) | ((int(pc) & 15) << 7) | ((int(pc) & 48) << 8) | (2048 if xcd_block else 0), _lib.current_stream_ptr()), None, "agd_op_conv2d")
     return y
 
 
@@ -42,7 +42,7 @@ def linear(x, w, bias=None, residual=None, geglu=False, p8=0, wreg=False, kgroup
     b = _f32c(bias) if bias is not None else None
     r = _f32c(residual).reshape(M, Nout) if residual is not None else None
     y = torch.empty(M, Nout, device=x.device, dtype=torch.float32)
-    _lib.check(lib.agd_op_linear(_lib.ptr(x2), _lib.ptr(w), _lib.ptr(b), _lib.ptr(r), _lib.ptr(y), M, K, N, int(geglu) | _P8[p8] | (16 if wreg else 0) | (32 if kgroups else 0) | (64 if (wreg and kgroups) else 0) | ((int(pc) & 15) << 7) | (2048 if xcd_block else 0),
+    _lib.check(lib.agd_op_linear(_lib.ptr(x2), _lib.ptr(w), _lib.ptr(b), _lib.ptr(r), _lib.ptr(y), M, K, N, int(geglu) | _P8[p8] | (16 if wreg else 0) | (32 if kgroups else 0) | (64 if (wreg and kgroups) else 0) | ((int(pc) & 15) << 7) | ((int(pc) & 48) << 8) | (2048 if xcd_block else 0),
                                  _lib.current_stream_ptr()), None, "agd_op_linear")
     return y.reshape(*x.shape[:-1], Nout)
 

@@ -133,10 +133,11 @@ int agd_vae_encode(agd_ctx* ctx, const float* image, int batch, int side, float*
  * "wreg_mask" (default 3): the weight-streaming kernel (igemm_wreg.h: weight fragments straight to registers) for bit 0 = the GEGLU projection of the C = 1280 blocks at 16 x 16,
  * bit 1 = proj_in / proj_out of the C = 640 transformer blocks.
  * "igemm_kgroups" (default 1): the unsplit 1x1 launches on 64 x 64 tiles (8 x 8 maps: at most one workgroup per CU) run two K groups of four waves per workgroup.
- * "igemm_pc" (default 17): producer / consumer implicit GEMM (csrc/igemm_pc.h: loader waves issue the ring's LDS-DMA pieces, consumer waves read fragments one K step ahead and run the MFMAs) --
+ * "igemm_pc" (default 49): producer / consumer implicit GEMM (csrc/igemm_pc.h: loader waves issue the ring's LDS-DMA pieces, consumer waves read fragments one K step ahead and run the MFMAs) --
  * bit 0: the 1x1 launches on 64 x 160 tiles (one workgroup per CU: the 16 x 16 / 8 x 8 maps), bits 1 - 3 (measured slower, off): 3x3 convs of the 16 x 16 / 8 x 8 maps,
  * bit 4: the row-halo producer / consumer kernel (csrc/igemm_pch.h) for the 3x3 stride-1 convs whose 128 x 160 tiles (x K slices) make at most one workgroup per CU (the
- * 32 x 32 and 16 x 16 maps at UNet batch 8), fused conv_shortcut included; same tiles and summation order as the row-halo kernel: bit-identical.
+ * 32 x 32 and 16 x 16 maps at UNet batch 8), fused conv_shortcut included; same tiles and summation order as the row-halo kernel: bit-identical;
+ * bit 5: the plain 1x1 launches of one 128 x 160 tile per CU (M = 8192, N = 640: ff.net.2 + proj_out of the 32 x 32 blocks) on igemm_pc.h's 128-row form; bit-identical.
  * "xcd_block" (default 1): the igemm tile grid is cut into one a x b block of tiles per XCD, (a, b) minimising the XCD's L2 working set, instead of tiles / 8 consecutive tiles of the
  * A-major / W-major walk (same tiles, same results bit for bit).
  * "attn2_premul" (default 1, bit 1 -- also the head-dim-80 blocks -- off: a tie; read at the next agd_set_context): attn2 of the blocks with head dim >= 160 (SD-1.x: C = 1280, the 16 x 16 and 8 x 8 maps) runs against per-image

@@ -244,7 +244,7 @@ def test_merged_launches_at_odd_sizes_match_the_unmerged_walk(sd15_host_weights,
     off = {"tblock_fuse": 0, "reduce_gn": 0, "shortcut_fuse": 0, "ff_proj_fuse": 0, "upsample_phases": 0, "igemm_kgroups": 0, "wreg_mask": 0, "conv_smap": 0, "attn2_premul": 0,
            "igemm_pc": 0, "xcd_block": 0}
     on = {"tblock_fuse": 1791, "reduce_gn": 1, "shortcut_fuse": 3, "ff_proj_fuse": 1, "upsample_phases": 7, "igemm_kgroups": 1, "wreg_mask": 3, "conv_smap": 1, "attn2_premul": 1,
-          "igemm_pc": 17, "xcd_block": 1}
+          "igemm_pc": 49, "xcd_block": 1}
 
     def run():
         return pipe(prompt_embeds=ctx, latents=lat, num_inference_steps=2, height=side, width=side, output_type="latent").latents.clone()
@@ -371,7 +371,7 @@ def test_sd15_unet_forward_512px_batch4_matches_oracle(sd15_host_weights, sd15_p
         pipe.engine.record_reset(B, L)
         got_x = pipe.engine.unet_forward(x, 601.0).clone()
     finally:
-        pipe.engine.set_option("igemm_pc", 17)
+        pipe.engine.set_option("igemm_pc", 49)
         pipe.engine.set_option("xcd_block", 1)
         pipe.engine.set_option("attn2_premul", 1)
         pipe.engine.set_option("upsample_phases", 7)

@@ -169,12 +169,12 @@ def test_linear_two_k_groups_per_workgroup(ops, M, K, N, res):
 
 
 @pytest.mark.parametrize("M,K,N,res", [(2048, 1280, 1280, True), (2048, 1280, 1280, False), (2048, 6400, 1280, True), (2048, 640, 1280, False), (1536, 1024, 1280, True),
-                                        (2000, 1280, 1280, True)])
+                                        (2000, 1280, 1280, True), (8192, 3200, 640, True), (8192, 1280, 640, False), (8100, 2560, 640, True)])
 def test_linear_producer_consumer_kernel(ops, M, K, N, res):
     """igemm_pc.h (round 5): the 1x1 launches of the 16 x 16 maps (M = 2048, N = 1280: 256 tiles of 64 x 160, one workgroup per CU) with the roles split over the waves of a
     workgroup -- four loader waves issue the ring's LDS-DMA pieces, four consumer waves read fragments and run the MFMAs.  Same tiles, fragment layout and epilogue as the
     4-wave kernel: vs fp32 torch, and bit-identical to the 4-wave kernel's result (the same products summed in the same order); short K (fewer steps than ring stages + 1),
-    a K that is not a multiple of the ring depth, and a ragged M tail."""
+    a K that is not a multiple of the ring depth, and a ragged M tail.  M = 8192 / 8100, N = 640: the 128 x 160-tile form (igemm_pc bit 5: 256 tiles, one per CU)."""
     g = torch.Generator().manual_seed(M + K + N)
     x = bfr(torch.randn(M, K, generator=g))
     w = bfr(torch.randn(N, K, generator=g) / math.sqrt(K))
@@ -182,11 +182,11 @@ def test_linear_producer_consumer_kernel(ops, M, K, N, res):
     r = bfr(torch.randn(M, N, generator=g)) if res else None
     y = F.linear(x, w, b) + (r if res else 0)
     args = (x.cuda(), w.cuda(), b.cuda(), r.cuda() if res else None)
-    got = ops.linear(*args, pc=1)
+    got = ops.linear(*args, pc=33)
     ref = ops.linear(*args)
     assert rel_err(got, y) < 1e-4, rel_err(got, y)            # fp32 output of bf16-exact operands
     assert torch.equal(got, ref)
-    assert torch.equal(got, ops.linear(*args, pc=1))
+    assert torch.equal(got, ops.linear(*args, pc=33))
 
 
 @pytest.mark.parametrize("kind,args", [("lin", (2048, 1280, 1280)), ("lin", (2048, 6400, 1280)), ("lin", (8192, 640, 1920)), ("lin", (512, 1280, 1280)), ("lin", (2048, 1280, 3840)),
