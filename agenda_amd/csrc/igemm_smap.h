@@ -87,6 +87,10 @@ __global__ __launch_bounds__(512) void igemm_smap_kernel(const IgemmP p) {
     }
   };
 
+  // the first chunk's image goes out as soon as its offsets exist: the 100 KB fly under the rest of the prologue (weight offsets, accumulator and fragment set-up)
+  // instead of behind it (stamps: 5.3 k cycles of prologue, then 3.1 k of fill, of a 42 k-cycle launch)
+  if (ch1 > ch0) a_issue(ch0);
+
   // ---- weight ring: stage t = (chunk, tap): rows n0 .. n0 + 63, k = tap * Ct + chunk * 64 .. + 63; one piece per wave ----
   const int brow = wid * 8 + lrow;                                 // tile-local weight row this lane fetches
   const int bqp = (brow % WTN) / (4 * NI);
@@ -98,6 +102,11 @@ __global__ __launch_bounds__(512) void igemm_smap_kernel(const IgemmP p) {
     const unsigned so = __builtin_amdgcn_readfirstlane((unsigned)((tap * Ct + cc * 64) * 2));
     bufdma16(p.W, sBr + (t % BST) * B_BYTES + wid * 1024, bvoff, so, live ? 0x7FFFFFF0u : 0u);
   };
+
+  if (nsteps > 0) {
+#pragma unroll
+    for (int s = 0; s < BST - 1; ++s) b_issue(s, s < nsteps);      // prologue: the first five weight stages
+  }
 
   f32x4 acc[MI][NI];
 #pragma unroll
@@ -173,14 +182,14 @@ __global__ __launch_bounds__(512) void igemm_smap_kernel(const IgemmP p) {
     ++t; bs = bsn;
   };
   if (nsteps > 0) {
-#pragma unroll
-    for (int s = 0; s < BST - 1; ++s) b_issue(s, s < nsteps);      // prologue: the first five weight stages
     for (int c = ch0; c < ch1; ++c) {
-      // chunk boundary: every wave has left the previous chunk's last tap -> refill the image, wait for everything in flight
+      // chunk boundary: every wave has left the previous chunk's last tap -> refill the image (the first one is already on its way), wait for everything in flight
       SMAP_TS(2);
-      asm volatile("s_barrier" ::: "memory");
-      SMAP_TS(3);
-      a_issue(c);
+      if (c > ch0) {
+        asm volatile("s_barrier" ::: "memory");
+        SMAP_TS(3);
+        a_issue(c);
+      }
       SMAP_TS(4);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       SMAP_TS(5);
