@@ -25,7 +25,7 @@
 #include "kernels.h"
 #include <cstdio>
 #include <cstdlib>
-#ifdef AGD_EXPERIMENTS
+#ifdef AGD_STAMPS   // `make stamps` (libagenda_hip_stamps.so = the experiments build + these marks; the experiments build proper carries none, so its kernels are the product's)
 // in-kernel time stamps of one wave (tools/kb_*_trace.py; AGD_IGEMM_CFG bit 10 = dbg & 64): the chosen wave of workgroup (g_smap_ts_wg, z = 0) stores s_memtime at every mark;
 // a kernel declares `const bool ts_on = ...; int ts_n = 0;` and finishes with g_smap_ts[1023] = ts_n
 __device__ unsigned long long g_smap_ts[1024];
@@ -795,11 +795,13 @@ static int pick_8p(const IgemmP& p) {
 #ifdef AGD_EXPERIMENTS
 int g_igemm_cfg = 0;   // experiment knob (tools/ only; production builds have no run-time dispatch knobs)
 extern "C" __attribute__((visibility("default"))) void agd_set_igemm_cfg(int v) { g_igemm_cfg = v; }
-// in-kernel time stamps of igemm_smap_kernel (tools/kb_smap_trace.py): pick the workgroup, read the marks back
+#ifdef AGD_STAMPS
+// in-kernel time stamps (tools/kb_*_trace.py): pick the workgroup, read the marks back
 extern "C" __attribute__((visibility("default"))) int agd_smap_ts(int wg, unsigned long long* out) {
   if (out) return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_smap_ts), 1024 * 8) == hipSuccess ? 0 : -1;
   return hipMemcpyToSymbol(HIP_SYMBOL(g_smap_ts_wg), &wg, 4) == hipSuccess ? 0 : -1;
 }
+#endif
 #define KNOB(n) ((g_igemm_cfg & 15) == (n))
 #else
 #define KNOB(n) false

@@ -61,7 +61,7 @@ __global__ __launch_bounds__(512, 2) void igemm8p_kernel(const IgemmP p) {
 #endif
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-#ifdef AGD_EXPERIMENTS
+#ifdef AGD_STAMPS
   // time stamps (tools/kb_8p_trace.py): dbg bit 6; bit 7 picks wave 4 (the group that runs one barrier behind) instead of wave 0
   const bool ts_on = (p.dbg & 64) && tid == ((p.dbg & 128) ? 256 : 0) && (int)blockIdx.x == g_smap_ts_wg;
   int ts_n = 0;
@@ -277,7 +277,7 @@ __global__ __launch_bounds__(512, 2) void igemm8p_kernel(const IgemmP p) {
 
   AGD_TS(6);
   igemm_epilogue<BM, BN, WM, WN, GEGLU, 0, 1>(p, acc, smem, lane, wm, wn, m0, n0, tn, 0, p.ln_stats ? (const float*)(smem + G::STATS_OFF) : nullptr);
-#ifdef AGD_EXPERIMENTS
+#ifdef AGD_STAMPS
   if (ts_on) { AGD_TS(7); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); AGD_TS(8); g_smap_ts[1023] = ts_n; g_smap_ts[1021] = __builtin_amdgcn_s_memrealtime(); }
 #endif
 }

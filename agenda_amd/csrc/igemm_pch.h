@@ -37,9 +37,6 @@ __global__ __launch_bounds__(512) void igemm_pch_kernel(const IgemmP p, const in
   const int bid = xcd_remap(blockIdx.x, gridDim.x);
   int tn, tm;
   tile_of(bid, (p.M + BM - 1) / BM, tiles_n, 0, p.xb_m, p.xb_n, tm, tn);
-#ifdef AGD_EXPERIMENTS
-  if (p.dbg & 8) { tm = 0; tn = 0; }                     // timing variant (tools/kb_pch_parts.py): every workgroup computes tile (0, 0)
-#endif
   const int m0 = tm * BM, n0 = tn * BN;
   const int W = p.Wout, H = p.Hout, HW = H * W;
   const int hw2 = Wt + 2, trows = BM / Wt;
@@ -54,7 +51,7 @@ __global__ __launch_bounds__(512) void igemm_pch_kernel(const IgemmP p, const in
   const int nsteps = 3 * (g1 - g0);
   using K0 = std::integral_constant<int, 0>; using K1 = std::integral_constant<int, 1>; using K2 = std::integral_constant<int, 2>;
 
-#ifdef AGD_EXPERIMENTS
+#ifdef AGD_STAMPS
   // time stamps (tools/kb_pch_trace.py): dbg bit 6; bit 7 picks loader wave 0 instead of consumer wave 0
   const bool ts_on = (p.dbg & 64) && (int)threadIdx.x == ((p.dbg & 128) ? NW * 64 : 0) && (int)blockIdx.x == g_smap_ts_wg && blockIdx.z == 0;
   int ts_n = 0;
@@ -100,11 +97,6 @@ __global__ __launch_bounds__(512) void igemm_pch_kernel(const IgemmP p, const in
         for (long long pc = p0 + lw; pc < p1; pc += NLW) bufdma16(p.W, sink, (unsigned)(pc * 1024 + lane * 16), 0u);
       }
     }
-#ifdef AGD_EXPERIMENTS
-    const bool nodma = (p.dbg & 1) != 0;                 // timing variant: no LDS-DMA instructions at all (results are garbage)
-#else
-    constexpr bool nodma = false;
-#endif
     // image cursor: next group whose image goes out; weight cursor: next step (group, kx) whose stage goes out
     int ig = g0, ir = g0 / 3, iky = g0 - (g0 / 3) * 3;    // groups in igemm_halo.h's order: chunk outer, ky inner (A crosses L2 -> HBM once)
     int ws = 0, wky = iky, wr = ir, wkx = 0;
@@ -125,7 +117,7 @@ __global__ __launch_bounds__(512) void igemm_pch_kernel(const IgemmP p, const in
         const int pix = (a_brow[i] + a_y[i] + iky) * p.Win + a_ix[i];
         const unsigned off = ok ? (unsigned)(pix * Cs + lchunk * 8) * 2u : 0x80000000u;            // < 2^31 bytes per source (launcher)
         const int pc = i * NLW + lw;
-        if (!nodma) bufdma16(abase, pc * 8 < HRP ? dA + pc * 1024 : sink, off, aso, nr);
+        bufdma16(abase, pc * 8 < HRP ? dA + pc * 1024 : sink, off, aso, nr);
       }
       if (KXI == 2 && live) { ++ig; if (++iky == 3) { iky = 0; ++ir; } }
     };
@@ -135,7 +127,7 @@ __global__ __launch_bounds__(512) void igemm_pch_kernel(const IgemmP p, const in
       char* const dB = sBr + (ws % NB) * B_BYTES;
       const unsigned nr = live ? 0x7FFFFFF0u : 0u;
 #pragma unroll
-      for (int i = 0; i < B_IT; ++i) if (!nodma) bufdma16(p.W, dB + (i * NLW + lw) * 1024, bvoff[i], bso, nr);
+      for (int i = 0; i < B_IT; ++i) bufdma16(p.W, dB + (i * NLW + lw) * 1024, bvoff[i], bso, nr);
       ++ws;
       if (live && ++wkx == 3) { wkx = 0; if (++wky == 3) { wky = 0; ++wr; } }
     };
@@ -200,7 +192,7 @@ __global__ __launch_bounds__(512) void igemm_pch_kernel(const IgemmP p, const in
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
     }
-#ifdef AGD_EXPERIMENTS
+#ifdef AGD_STAMPS
     if (ts_on) { AGD_TS(6); g_smap_ts[1023] = ts_n; g_smap_ts[1021] = __builtin_amdgcn_s_memrealtime(); }
 #endif
     if constexpr (!SPLITK) igemm_epilogue_ghost(p);
@@ -273,38 +265,6 @@ __global__ __launch_bounds__(512) void igemm_pch_kernel(const IgemmP p, const in
   };
   __builtin_amdgcn_s_waitcnt(0xC07F);                    // lgkmcnt(0): no scalar load pending on the loop's entry edge (igemm_pc.h)
   asm volatile("s_barrier" ::: "memory");                // P: image g0 and stage 0 have landed
-#ifdef AGD_EXPERIMENTS
-  if (p.dbg & 6) {
-    // timing variants (results are garbage): bit 1 = the consumers read no fragments (MFMAs on register constants), bit 2 = fragment reads but no MFMAs
-    bf16x8 ca = {}, cb = {};
-    ca[0] = (__bf16)(float)lane; cb[1] = (__bf16)1.0f;
-    for (int t = 0; t < nsteps; ++t) {
-      asm volatile("s_barrier" ::: "memory");
-      const char* sA = sAr + ((t / 3) % NA) * A_BYTES;
-      const char* sB = sBr + (t % NB) * B_BYTES;
-      if (p.dbg & 2) {
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-          for (int i = 0; i < MI; ++i)
-#pragma unroll
-            for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cb, ca, acc[i][j], 0, 0, 0);
-      } else {
-        float tt = 0.f;
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-#pragma unroll
-          for (int i = 0; i < MI; ++i) { const bf16x8 v = *(const bf16x8*)(sA + (kk ? aaddr[1][i] ^ 64 : aaddr[1][i])); tt += (float)v[0]; }
-#pragma unroll
-          for (int j = 0; j < NI; ++j) { const bf16x8 v = *(const bf16x8*)(sB + j * 512 + foffB[kk]); tt += (float)v[0]; }
-        }
-        acc[0][0][0] += tt;
-      }
-    }
-    igemm_epilogue<BM, BN, WM, WN, 0, SPLITK>(p, acc, smem, lane, wm, wn, m0, n0, tn, 0, nullptr);
-    return;
-  }
-#endif
   if (nsteps > 0) rd(K0{}, K0{}, 0, 0);
   int as = 0, bs = 0;                                    // slots of the current group's image / the current step's weights
   for (int g = g0; g < g1; ++g) {
@@ -336,7 +296,7 @@ __global__ __launch_bounds__(512) void igemm_pch_kernel(const IgemmP p, const in
   }
   AGD_TS(5);
   igemm_epilogue<BM, BN, WM, WN, 0, SPLITK>(p, acc, smem, lane, wm, wn, m0, n0, tn, 0, nullptr);
-#ifdef AGD_EXPERIMENTS
+#ifdef AGD_STAMPS
   if (ts_on) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); AGD_TS(6); g_smap_ts[1023] = ts_n; g_smap_ts[1021] = __builtin_amdgcn_s_memrealtime(); }
 #endif
 }

@@ -20,7 +20,7 @@
 #include "igemm_epilogue.h"
 #include <type_traits>
 
-#ifdef AGD_EXPERIMENTS
+#ifdef AGD_STAMPS
 // in-kernel time stamps of one wave (tools/kb_smap_trace.py): AGD_IGEMM_CFG bit 10 (dbg & 64); wave 0 of workgroup (g_smap_ts_wg, z = 0) stores s_memtime at every mark
 #define SMAP_TS(k) AGD_TS(k)
 #else
@@ -41,7 +41,7 @@ __global__ __launch_bounds__(512) void igemm_smap_kernel(const IgemmP p) {
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-#ifdef AGD_EXPERIMENTS
+#ifdef AGD_STAMPS
   const bool ts_on = (p.dbg & 64) && tid == 0 && (int)blockIdx.x == g_smap_ts_wg && blockIdx.z == 0;
   int ts_n = 0;
 #endif
@@ -246,7 +246,7 @@ __global__ __launch_bounds__(512) void igemm_smap_kernel(const IgemmP p) {
     asm volatile("s_barrier" ::: "memory");                        // (the epilogue's LDS-staged paths start behind their own barriers; the register path touches no LDS)
   }
   igemm_epilogue<BM, BN, WM, WN, 0, SPLITK>(p, acc, smem, lane, wm, wn, m0, n0, tn, 0, nullptr);
-#ifdef AGD_EXPERIMENTS
+#ifdef AGD_STAMPS
   if (ts_on) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); SMAP_TS(10); g_smap_ts[1023] = ts_n; }
 #endif
 }

@@ -27,6 +27,8 @@ typedef __attribute__((ext_vector_type(2))) float f32x2_t;
 #ifdef AGD_EXPERIMENTS
 int g_tb_variant = 0;   // timing variants of the fused kernels (tools/ only)
 extern "C" __attribute__((visibility("default"))) void agd_set_tb_variant(int v) { g_tb_variant = v; }
+#endif
+#ifdef AGD_STAMPS   // `make stamps`
 // in-kernel time stamps (tools/kb_tblock_trace.py): wave g_tb_ts_sel[1] of workgroup g_tb_ts_sel[0] stores s_memtime at the marks of the row-panel kernels
 __device__ unsigned long long g_tb_ts[256];
 __device__ int g_tb_ts_sel[2] = {-1, 0};

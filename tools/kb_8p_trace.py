@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
-"""In-kernel time line of igemm8p_kernel (experiments library, AGD_IGEMM_CFG bit 10; bit 11: wave 4) on 1x1 launches at M = 8192:
+"""In-kernel time line of igemm8p_kernel (stamps library: `make -C agenda_amd/csrc stamps`, AGD_IGEMM_CFG bit 10; bit 11: wave 4) on 1x1 launches at M = 8192:
 1 start | 2 prologue issued | 3 first K tile landed | 4 per K tile | 5 loop left | 6 epilogue starts | 7 epilogue issued | 8 stores drained.
 python tools/kb_8p_trace.py K N [geglu]"""
 import ctypes as C
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-lib = C.CDLL(os.environ.get("AGD_LIB", os.path.join(ROOT, "agenda_amd", "libagenda_hip_exp.so")))
+lib = C.CDLL(os.environ.get("AGD_LIB", os.path.join(ROOT, "agenda_amd", "libagenda_hip_stamps.so")))
 lib.agd_bench_conv.argtypes = [C.c_int] * 12 + [C.POINTER(C.c_double)]
 lib.agd_smap_ts.argtypes = [C.c_int, C.POINTER(C.c_ulonglong)]
 K = int(sys.argv[1]) if len(sys.argv) > 1 else 640

@@ -1,16 +1,16 @@
 #!/usr/bin/env python3
-"""In-kernel time line of igemm_pch_kernel (experiments library, AGD_IGEMM_CFG bit 10; bit 11: loader wave 0 instead of consumer wave 0) on the 3x3 conv 640 -> 640 of the
+"""In-kernel time line of igemm_pch_kernel (stamps library: `make -C agenda_amd/csrc stamps`, AGD_IGEMM_CFG bit 10; bit 11: loader wave 0 instead of consumer wave 0) on the 3x3 conv 640 -> 640 of the
 32 x 32 maps at UNet batch 8.  Consumer marks: 1 start | per step 2 at the barrier, 3 behind it | 5 loop left, 6 epilogue done.
 Loader marks: 1 start | per step 2 top, 3 operands landed, 4 behind the barrier | 5 loop left, 6 drained.  Ticks of s_memtime from the start."""
 import ctypes as C
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-lib = C.CDLL(os.environ.get("AGD_LIB", os.path.join(ROOT, "agenda_amd", "libagenda_hip_exp.so")))
+lib = C.CDLL(os.environ.get("AGD_LIB", os.path.join(ROOT, "agenda_amd", "libagenda_hip_stamps.so")))
 lib.agd_bench_conv.argtypes = [C.c_int] * 12 + [C.POINTER(C.c_double)]
 lib.agd_smap_ts.argtypes = [C.c_int, C.POINTER(C.c_ulonglong)]
 C0 = int(sys.argv[1]) if len(sys.argv) > 1 else 640
 H = int(os.environ.get("KB_H", "32")); N = int(os.environ.get("KB_N", "640"))      # KB_H=16 KB_N=1280: the 16 x 16 maps (2 K slices)
-extra = int(sys.argv[2]) if len(sys.argv) > 2 else 0       # timing-variant bits of AGD_IGEMM_CFG (tools/kb_pch_parts.py)
+extra = int(sys.argv[2]) if len(sys.argv) > 2 else 0       # further AGD_IGEMM_CFG bits
 brief = len(sys.argv) > 3
 for who, bit in (("consumer wave 0", 0), ("loader wave 0", 2048)):
     for wg in (0, 100):

@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
-"""In-kernel time line of igemm_smap_kernel (experiments library, AGD_IGEMM_CFG bit 10): wave 0 of one workgroup stores s_memtime at marks
+"""In-kernel time line of igemm_smap_kernel (stamps library: `make -C agenda_amd/csrc stamps`, AGD_IGEMM_CFG bit 10): wave 0 of one workgroup stores s_memtime at marks
 1 start | per step: 2 top, (3 behind the chunk barrier, 4 image issued), 5 operands landed, 6 behind the step barrier, 7 weight piece issued | 8 loop left, 9 drained, 10 epilogue done.
 Prints the gaps in the counter's ticks, scaled so that start -> end matches the launch's duration."""
 import ctypes as C
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-lib = C.CDLL(os.environ.get("AGD_LIB", os.path.join(ROOT, "agenda_amd", "libagenda_hip_exp.so")))
+lib = C.CDLL(os.environ.get("AGD_LIB", os.path.join(ROOT, "agenda_amd", "libagenda_hip_stamps.so")))
 lib.agd_bench_conv.argtypes = [C.c_int] * 12 + [C.POINTER(C.c_double)]
 lib.agd_smap_ts.argtypes = [C.c_int, C.POINTER(C.c_ulonglong)]
 C0 = int(sys.argv[1]) if len(sys.argv) > 1 else 1280

@@ -1,12 +1,12 @@
 #!/usr/bin/env python3
-"""In-kernel time line of attn_chain_kernel (experiments library): one wave of one workgroup stores s_memtime at the phase marks
+"""In-kernel time line of attn_chain_kernel (stamps library: `make -C agenda_amd/csrc stamps`): one wave of one workgroup stores s_memtime at the phase marks
 1 start | 2 panel + K/V requested, 3 landed | (PRE: 4 to_out(attn1) GEMM done, 5 h1 stored + statistics) | 6 norm2 in the panel | 7 .. 8 to_q GEMM | 9 Q in the panel |
 10 + h head h's attention done, 20 + h next head's K / V staged | 30 recorder flushed | 31 | 32 to_out GEMM done | 99 stores drained.
 python tools/kb_tblock_trace.py [kind]   (kind 3: C = 320 from attn1.to_out, the production form; 1: plain; 5 / 4: C = 640)"""
 import ctypes as C
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-lib = C.CDLL(os.environ.get("AGD_LIB", os.path.join(ROOT, "agenda_amd", "libagenda_hip_exp.so")))
+lib = C.CDLL(os.environ.get("AGD_LIB", os.path.join(ROOT, "agenda_amd", "libagenda_hip_stamps.so")))
 lib.agd_bench_tblock.argtypes = [C.c_int] * 4 + [C.POINTER(C.c_double)]
 lib.agd_tb_ts.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_ulonglong)]
 kind = int(sys.argv[1]) if len(sys.argv) > 1 else 3
