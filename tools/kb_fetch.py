@@ -1,3 +1,4 @@
+"""Launch list of tools/kb_fetch.sh: four 3x3 shapes x (row-halo, + XCD blocks, producer / consumer + XCD blocks), 10 launches each (experiments library)."""
 import ctypes as C, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 lib = C.CDLL(os.path.join(ROOT, "agenda_amd", "libagenda_hip_exp.so"))
