@@ -1032,6 +1032,8 @@ int launch_igemm(const IgemmP& p_in, hipStream_t st) {
     // <= 256 tiles: one workgroup per CU whatever the ring -> take the 4-stage ring (147 / 128 KB LDS)
     const long long Tsel = (long long)((p.M + 127) / 128) * ((p.N + (n160 ? 159 : 127)) / (n160 ? 160 : 128)) * batch;
     const bool deep = Tsel <= 256 && nk >= 8 && !KNOB(9);
+    // at most HALF a round of 128 x 160 tiles (the stride-2 downsampling conv of the 64 x 64 maps: M = 8192, N = 320 -> 128 tiles): 64-row tiles fill the chip instead
+    if (n160 && deep && !KNOB(12) && Tsel <= 128 && batch == 1 && !halo_ok(p) && (p.M % 64) == 0 && (long long)(p.M / 64) * (p.N / 160) <= 256) return launch_cfg<64, 160, 2, 2, 4>(p, 1, st);
     // (IgemmP::pc bit 5: the 1x1 launches of one 128 x 160 tile per CU on the producer / consumer kernel)
     if (n160 && deep && (p.pc & 32) && p.ksize == 1 && batch == 1 && !p.geglu && pc_ok(p)) return launch_pc<128, 160, 4, 4>(p, 1, st);
     if (n160) return deep ? launch_cfg<128, 160, 2, 2, 4>(p, 1, st) : launch_cfg<128, 160, 2, 2>(p, 1, st);
