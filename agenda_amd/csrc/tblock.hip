@@ -231,6 +231,8 @@ __global__ __launch_bounds__(512, 2) void ff_fused_kernel(const FFusedP p) {
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int mh = wid >> 2, nq = wid & 3;
   const int m0 = blockIdx.x * BM;
+  TB_TS_DECL
+  TB_TS(1);
 
   panel_load_dma<C>(p.h, m0, p.M, panel, wid, lane);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -391,30 +393,42 @@ __global__ __launch_bounds__(512, 2) void ff_fused_kernel(const FFusedP p) {
     if (k <= NCH) __syncthreads();
   };
   static_assert(NCH >= 4, "steady intervals");
+  TB_TS(2);
 #pragma unroll 1
   for (int k = 0; k < 2; ++k) interval(k);
+  TB_TS(3);
   if (mh == 0) {
     for (int k = 2; k < NCH; ++k) {
       const unsigned w1s = __builtin_amdgcn_readfirstlane((unsigned)(((k * 4 + nq) * KS1) * 4) * 1024u);
       const unsigned w2ns = __builtin_amdgcn_readfirstlane((unsigned)(((k * 4 + nq) * KS2) * NI2) * 1024u);
       gemm2(k - 1, true, true, w1s);
+      TB_TS(10);
       gemm1(k, true, true, w2ns);
+      TB_TS(11);
       if (!(VAR & 8)) geglu(k);
+      TB_TS(12);
       __syncthreads();
+      TB_TS(13);
     }
   } else {
     for (int k = 2; k < NCH; ++k) {
       if (!(VAR & 8)) geglu(k - 1);
+      TB_TS(12);
       const unsigned w1s = __builtin_amdgcn_readfirstlane((unsigned)(((k * 4 + nq) * KS1) * 4) * 1024u);
       const unsigned w2ns = __builtin_amdgcn_readfirstlane((unsigned)((((k - 1) * 4 + nq) * KS2) * NI2) * 1024u);
       gemm2(k - 2, true, true, w1s);
+      TB_TS(10);
       gemm1(k, true, true, w2ns);
+      TB_TS(11);
       __syncthreads();
+      TB_TS(13);
     }
   }
+  TB_TS(4);
   pre2 = true;
 #pragma unroll 1
   for (int k = NCH; k <= NCH + 1; ++k) interval(k);
+  TB_TS(5);
 
   // epilogue: + bias + residual (the raw rows are still in the panel), one rounding to bf16, 8-byte row chunks.
   // With a proj_out stage behind it (p.wpf), the rounded rows go back into the panel instead of to HBM -- nothing else reads them --
@@ -503,6 +517,7 @@ __global__ __launch_bounds__(512, 2) void ff_fused_kernel(const FFusedP p) {
     }
   }
   }
+  TB_TS_END;
 }
 
 int launch_ff_fused(const FFusedP& p, int C, hipStream_t st) {
