@@ -503,7 +503,7 @@ static int launch_attn_t(const AttnP& p, hipStream_t st) {
   dim3 grid(8 * per * pp.nqt);
   auto kfn = attn_kernel<D, KB, QB, RECORD, AMASK>;
   if (lds > 65536) {                                   // per (instantiation, device) latch
-    static bool attr[AGD_MAX_DEVICES] = {};
+    static std::atomic<bool> attr[AGD_MAX_DEVICES] = {};
     int dev = 0; HIP_CHECK_RET(hipGetDevice(&dev));
     if (dev < 0 || dev >= AGD_MAX_DEVICES) { agd_set_error("attention: device ordinal %d out of range", dev); return -1; }
     if (!attr[dev]) { HIP_CHECK_RET(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); attr[dev] = true; }

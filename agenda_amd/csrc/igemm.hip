@@ -579,7 +579,7 @@ static int launch_one(const IgemmP& p_in, int splits, hipStream_t st) {
   dim3 grid(tiles, p.batch > 0 ? p.batch : 1, splits);
   auto kfn = igemm_kernel<BM, BN, WM, WN, KS, STAGES, GEGLU, SPLITK, KG>;
   // the dynamic-LDS attribute is per device: latch it per (instantiation, device)
-  static bool attr[AGD_MAX_DEVICES] = {};
+  static std::atomic<bool> attr[AGD_MAX_DEVICES] = {};
   int dev = 0; HIP_CHECK_RET(hipGetDevice(&dev));
   if (dev < 0 || dev >= AGD_MAX_DEVICES) { agd_set_error("igemm: device ordinal %d out of range", dev); return -1; }
   if (!attr[dev]) { HIP_CHECK_RET(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); attr[dev] = true; }
@@ -602,7 +602,7 @@ static int launch_halo(const IgemmP& p_in, int splits, hipStream_t st) {
   const int lds = 2 * HRP * 128 + BST * BN * 128 + 4096;   // two A images of the tile's halo rows + the weight ring + the dead-piece sink
   const int tiles = ((p.M + 127) / 128) * ((p.N + BN - 1) / BN);
   auto kfn = igemm_halo_kernel<BN, SPLITK, BST>;
-  static bool attr[AGD_MAX_DEVICES] = {};
+  static std::atomic<bool> attr[AGD_MAX_DEVICES] = {};
   int dev = 0; HIP_CHECK_RET(hipGetDevice(&dev));
   if (dev < 0 || dev >= AGD_MAX_DEVICES) { agd_set_error("igemm: device ordinal %d out of range", dev); return -1; }
   if (!attr[dev]) { HIP_CHECK_RET(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 160 * 128 + BST * BN * 128 + 4096)); attr[dev] = true; }
@@ -625,7 +625,7 @@ static int launch_pch(const IgemmP& p_in, int splits, hipStream_t st) {
   const int lds = 3 * HRP * 128 + 5 * 160 * 128 + 4 * 1024;      // three A images (Wout >= 16: at most 144 halo rows) + five weight stages + the dead-piece sink: <= 158 KB
   const int tiles = ((p.M + 127) / 128) * ((p.N + 159) / 160);
   auto kfn = igemm_pch_kernel<160, SPLITK>;
-  static bool attr[AGD_MAX_DEVICES] = {};
+  static std::atomic<bool> attr[AGD_MAX_DEVICES] = {};
   int dev = 0; HIP_CHECK_RET(hipGetDevice(&dev));
   if (dev < 0 || dev >= AGD_MAX_DEVICES) { agd_set_error("igemm_pch: device ordinal %d out of range", dev); return -1; }
   if (!attr[dev]) { HIP_CHECK_RET(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 144 * 128 + 5 * 160 * 128 + 4 * 1024)); attr[dev] = true; }
@@ -721,7 +721,7 @@ static int launch_pc(const IgemmP& p, int splits, hipStream_t st) {
   const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
   const void* kfn = p.ksize == 3 ? (splits > 1 ? (const void*)igemm_pc_kernel<BM, BN, NLW, STAGES, 3, 0, 1> : (const void*)igemm_pc_kernel<BM, BN, NLW, STAGES, 3, 0, 0>)
                                  : (splits > 1 ? (const void*)igemm_pc_kernel<BM, BN, NLW, STAGES, 1, 0, 1> : (const void*)igemm_pc_kernel<BM, BN, NLW, STAGES, 1, 0, 0>);
-  static bool attr[AGD_MAX_DEVICES][4] = {};
+  static std::atomic<bool> attr[AGD_MAX_DEVICES][4] = {};
   int dev = 0; HIP_CHECK_RET(hipGetDevice(&dev));
   if (dev < 0 || dev >= AGD_MAX_DEVICES) { agd_set_error("igemm_pc: device ordinal %d out of range", dev); return -1; }
   const int slot = (p.ksize == 3 ? 2 : 0) + (splits > 1 ? 1 : 0);
@@ -751,7 +751,7 @@ static int launch_8p(const IgemmP& p, hipStream_t st) {
     if constexpr (G::NI == 4) kfn = (const void*)igemm8p_kernel<WM, WN, MI, NI0, NI1, 1, 1>;
     if (!kfn || p.ksize != 1) { agd_set_error("igemm8p: geglu only on 1x1 with the 256-wide tile"); return -1; }
   } else kfn = p.ksize == 3 ? (const void*)igemm8p_kernel<WM, WN, MI, NI0, NI1, 3, 0> : p.ksize == 2 ? (const void*)igemm8p_kernel<WM, WN, MI, NI0, NI1, 2, 0> : (const void*)igemm8p_kernel<WM, WN, MI, NI0, NI1, 1, 0>;
-  static bool attr[AGD_MAX_DEVICES][4] = {};
+  static std::atomic<bool> attr[AGD_MAX_DEVICES][4] = {};
   int dev = 0; HIP_CHECK_RET(hipGetDevice(&dev));
   if (dev < 0 || dev >= AGD_MAX_DEVICES) { agd_set_error("igemm8p: device ordinal %d out of range", dev); return -1; }
   const int slot = p.geglu ? 2 : p.ksize == 3 ? 1 : p.ksize == 2 ? 3 : 0;
@@ -926,7 +926,7 @@ int launch_igemm(const IgemmP& p_in, hipStream_t st) {
     constexpr int lds = 800 * 128 + 6 * 64 * 128 + 8192;
     if (S >= 2) CK0(ensure_splitk(p, S));
     const void* kfn = S >= 2 ? (const void*)igemm_smap_kernel<1> : (const void*)igemm_smap_kernel<0>;
-    static bool attr[AGD_MAX_DEVICES][2] = {};
+    static std::atomic<bool> attr[AGD_MAX_DEVICES][2] = {};
     int dev = 0; HIP_CHECK_RET(hipGetDevice(&dev));
     if (dev < 0 || dev >= AGD_MAX_DEVICES) { agd_set_error("igemm_smap: device ordinal %d out of range", dev); return -1; }
     if (!attr[dev][S >= 2]) { HIP_CHECK_RET(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); attr[dev][S >= 2] = true; }

@@ -138,11 +138,14 @@ __global__ __launch_bounds__(512) void igemm_pch_kernel(const IgemmP p, const in
     for (int s = 0; s < NB - 1; ++s) issue_stage();
     asm volatile("s_waitcnt vmcnt(%0)" ::"i"((NB - 2) * LPW) : "memory");       // image g0 and stage 0 have landed (this wave's pieces)
     asm volatile("s_barrier" ::: "memory");                                      // P
-    // one step: stage t + 1 (and, when step t + 1 opens a group, that group's image -- older than the stage) has landed when at most the two youngest stages and the three
-    // youngest image parts (2 + 2 + 1 pieces in any rotation) are in flight: vmcnt(15); the first three steps have fewer image parts behind them
+    // one step.  Issue order behind B_s is [stage s + 4, image part s]; before B_t stage t + 1 must have landed: at most the two youngest stages and the three youngest
+    // image parts (2 + 2 + 1 pieces in any rotation) may be in flight: vmcnt(15).  When step t + 1 OPENS a group (kx = 2 steps), that group's image must have landed too, and
+    // its last part (one piece, issued behind B_(t-3)) is YOUNGER than stage t + 1: it is the oldest of those fifteen, so these steps wait vmcnt(14) (with 15 the
+    // consumers could read halo rows 128 .. 143 of the new image before they had arrived).  The first three steps have fewer image parts behind them (the images of groups
+    // g0, g0 + 1 belong to the prologue and are older than every stage).
     auto lstep = [&](int t, auto kx_tag) {
       AGD_TS(2);
-      if (t >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(3 * LPW) : "memory");
+      if (t >= 3) { if constexpr (decltype(kx_tag)::value == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(3 * LPW - 1) : "memory"); else asm volatile("s_waitcnt vmcnt(%0)" ::"i"(3 * LPW) : "memory"); }
       else if (t == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(2 * LPW) : "memory");
       else if (t == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(2 * LPW + 2) : "memory");
       else asm volatile("s_waitcnt vmcnt(%0)" ::"i"(2 * LPW + 4) : "memory");

@@ -159,7 +159,7 @@ int launch_small_linear(const float* x, const bf16_t* W, const float* bias, floa
   if (M <= 8 && lds <= 65536) {
     hipLaunchKernelGGL(small_linear_kernel<8>, dim3((N + 4 * cpw - 1) / (4 * cpw)), dim3(256), lds, st, x, W, bias, out, M, N, K, silu_in, silu_out, cpw);
   } else {
-    static bool attr[AGD_MAX_DEVICES] = {};
+    static std::atomic<bool> attr[AGD_MAX_DEVICES] = {};
     int dev = 0; HIP_CHECK_RET(hipGetDevice(&dev));
     if (dev < 0 || dev >= AGD_MAX_DEVICES) { agd_set_error("small_linear: device ordinal %d out of range", dev); return -1; }
     if (!attr[dev]) { HIP_CHECK_RET(hipFuncSetAttribute((const void*)small_linear_kernel<25>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr[dev] = true; }

@@ -615,7 +615,13 @@ static int transformer(agd_ctx* c, hipStream_t st, const std::string& pre, const
   // image; the hook.py recorder (per-head maps of every call) keeps the kernel chain
   const bool ff_fused = (c->opt_tb_fuse & 1) && fold && C == 320 && c->W.count(t + "ff.w1.frag");
   bool xpre_ready = false;                               // the pre-multiplied attn2 form is ready for this block (agd_set_context built its products)
-  { auto itx = c->xl_idx.find(t + "attn2"); if (itx != c->xl_idx.end()) { const XLayer& xq = c->xl[itx->second]; xpre_ready = xq.pm_ready && c->opt_xpre && c->opt_ln_fold && HW % 64 == 0 && c->rec_mode != 2 && !dup; } }
+  bool xpre_rec = false;                                 // ... and it records into the DAAM accumulators (daam's rule, as cross_attention())
+  { auto itx = c->xl_idx.find(t + "attn2");              // the ONE predicate of that form: the chain kernel steps aside exactly where it holds
+    if (itx != c->xl_idx.end()) {
+      const XLayer& xq = c->xl[itx->second];
+      xpre_rec = c->rec_mode == 1 && !xq.mid && xq.acc && c->rec_L / x.H != 8 && x.H == xq.acc_side && x.W == x.H && B / 2 == c->rec_B;
+      xpre_ready = xq.pm_ready && c->opt_xpre && fold && HW % 64 == 0 && c->rec_mode != 2 && c->ctx_T <= XATTN_TP && !dup && (!xpre_rec || xq.acc_heads == xq.heads);
+    } }
   const bool chain_fuse = (c->opt_tb_fuse & 2) && (C == 320 || (C == 640 && (c->opt_tb_fuse & 32))) && heads == 8 && HW % (C == 320 ? 128 : 64) == 0 && c->ctx_T <= 96 &&
                           c->rec_mode != 2 && c->W.count(t + "attn2.to_q.frag") && !xpre_ready;
   // CFG-shared prefix with the fused kernels behind it: the duplication of the B' rows happens INSIDE them (the chain reads input row m % M', the feed-forward's
@@ -687,8 +693,8 @@ static int transformer(agd_ctx* c, hipStream_t st, const std::string& pre, const
   bool xpre_done = false;
   if (!chain_done) {
     auto it = c->xl_idx.find(t + "attn2"); XLayer& xl = c->xl[it->second];
-    const bool rec_daam = c->rec_mode == 1 && !xl.mid && xl.acc && c->rec_L / x.H != 8 && x.H == xl.acc_side && x.W == x.H && B / 2 == c->rec_B;   // daam's rule, as cross_attention()
-    if (xl.pm_ready && c->opt_xpre && fold && stats && slots > 0 && HW % 64 == 0 && c->rec_mode != 2 && c->ctx_T <= XATTN_TP && !dup && (!rec_daam || xl.acc_heads == xl.heads)) {
+    const bool rec_daam = xpre_rec;
+    if (xpre_ready && stats && slots > 0) {               // (norm2's row statistics come from attn1.to_out's epilogue: the chain kernel was not chosen, so it wrote them)
       GETV(bo, t + "attn2.to_out.0.bias");
       const int HT = heads * XATTN_TP;
       bf16_t* P = (bf16_t*)c->arena.alloc((size_t)M * HT * 2); if (!P) return -1;
@@ -1122,7 +1128,7 @@ AGD_API int agd_finalize(agd_ctx* c) {
       const int C2 = xl.C, D2 = C2 / xl.heads;
       // (option bit 1, off by default: also where the columns equal C -- head dim 80, the C = 640 blocks: no fewer MACs, but three full-chip launches instead of the
       //  half-chip chain kernel)
-      if (wq2 && wo2 && be2 != c->V.end() && D2 % 8 == 0 && C2 % 160 == 0 && (xl.heads * XATTN_TP) % 64 == 0 && xl.heads * XATTN_TP <= C2 &&
+      if (wq2 && wo2 && be2 != c->V.end() && D2 % 8 == 0 && C2 % 160 == 0 && C2 % 64 == 0 && (xl.heads * XATTN_TP) % 64 == 0 && xl.heads * XATTN_TP <= C2 &&
           wq2->taps == 1 && wq2->N == C2 && wq2->Cpad == C2 && wo2->taps == 1 && wo2->N == C2 && wo2->Cpad == C2) {
         xl.pm_wqT = dmalloc<bf16_t>(c, (size_t)C2 * C2); xl.pm_wqb = dmalloc<float>(c, C2);
         if (!xl.pm_wqT || !xl.pm_wqb) return fail_ctx(c);
@@ -1344,7 +1350,7 @@ AGD_API int agd_set_context(agd_ctx* c, const float* ctx_emb, int batch2, int to
     if (c->opt_xpre && xl.pm_wqT && tokens <= XATTN_TP && ((c->opt_xpre & 2) || xl.heads * XATTN_TP * 2 <= xl.C)) {
       const std::string t = xl.name.substr(0, xl.name.size() - 5);          // "...transformer_blocks.0."
       const WMat* wo2 = getW(c, t + "attn2.to_out.0.weight"); const float* g2 = getV(c, t + "norm2.weight");
-      if (!wo2 || !g2) return fail_ctx(c);
+      if (!wo2 || !g2) { agd_set_error("%s: pre-multiplied form without attn2.to_out.0.weight / norm2.weight", xl.name.c_str()); return fail_ctx(c); }
       const size_t HT = (size_t)xl.heads * XATTN_TP;
       API_CK(c, xl.pm_kppb.ensure((size_t)batch2 * HT * xl.C * 2)); API_CK(c, xl.pm_vppb.ensure((size_t)batch2 * HT * xl.C * 2)); API_CK(c, xl.pm_csb.ensure((size_t)batch2 * HT * 2 * sizeof(float)));
       xl.pm_kpp = xl.pm_kppb.as<bf16_t>(); xl.pm_vpp = xl.pm_vppb.as<bf16_t>(); xl.pm_kcs = xl.pm_csb.as<float>(); xl.pm_kbs = xl.pm_kcs + (size_t)batch2 * HT;
@@ -2028,7 +2034,7 @@ AGD_API int agd_op_xattn_premul(const float* x, const float* gamma, const float*
                                 const float* bo, float* y, float* probs, int B, int HW, int T, int C, int heads, float eps, void* stream) {
   hipStream_t st = S(stream); Tmp tmp;
   const long long M = (long long)B * HW;
-  if (heads < 1 || C % heads || (C / heads) % 8 || C % 160 || HW % 64 || T < 1 || T > XATTN_TP || (heads * XATTN_TP) % 64) { agd_set_error("op_xattn_premul: C %d heads %d HW %d T %d", C, heads, HW, T); return -1; }
+  if (heads < 1 || C % heads || (C / heads) % 8 || C % 160 || C % 64 || HW % 64 || T < 1 || T > XATTN_TP || (heads * XATTN_TP) % 64) { agd_set_error("op_xattn_premul: C %d heads %d HW %d T %d", C, heads, HW, T); return -1; }
   const size_t HT = (size_t)heads * XATTN_TP;
   bf16_t* xb = tmp.get<bf16_t>((size_t)M * C); bf16_t* yb = tmp.get<bf16_t>((size_t)M * C); bf16_t* kvb = tmp.get<bf16_t>((size_t)B * T * 2 * C);
   bf16_t* wqb = tmp.get<bf16_t>((size_t)C * C); bf16_t* wqT = tmp.get<bf16_t>((size_t)C * C); bf16_t* wob = tmp.get<bf16_t>((size_t)C * C);

@@ -977,7 +977,7 @@ int launch_attn_chain(const AttnChainP& p, int C, int heads, hipStream_t st) {
   const void* kfn = C == 320 ? (pre ? (const void*)attn_chain_kernel<320, 1> : (const void*)attn_chain_kernel<320, 0>)
                     : r32    ? (pre ? (const void*)attn_chain_kernel<640, 1, 2> : (const void*)attn_chain_kernel<640, 0, 2>)
                              : (pre ? (const void*)attn_chain_kernel<640, 1> : (const void*)attn_chain_kernel<640, 0>);
-  static bool attr[AGD_MAX_DEVICES][6] = {};
+  static std::atomic<bool> attr[AGD_MAX_DEVICES][6] = {};
   int dev = 0; HIP_CHECK_RET(hipGetDevice(&dev));
   if (dev < 0 || dev >= AGD_MAX_DEVICES) { agd_set_error("attn_chain: device ordinal %d out of range", dev); return -1; }
   const int slot = (C == 640 ? (r32 ? 4 : 2) : 0) + (pre ? 1 : 0);
@@ -1164,7 +1164,7 @@ int launch_qkv_chain(const QkvChainP& p, int C, hipStream_t st) {
   if (p.gn_part && (p.gn_bm < 1 || p.HW % p.gn_bm || p.gn_groups < 1 || p.gn_groups > 32 || C % p.gn_groups || !p.gn_gamma || !p.gn_beta)) { agd_set_error("qkv_chain: bad GroupNorm arguments"); return -1; }
   const int lds = BM * C * 2 + 4096 + C * 16 + 256 + C * 8;      // panel, h row statistics, GroupNorm: channel sums, group statistics, (scale, shift)
   const void* kfn = C == 320 ? (const void*)qkv_chain_kernel<320> : (const void*)qkv_chain_kernel<640>;
-  static bool attr[AGD_MAX_DEVICES][2] = {};
+  static std::atomic<bool> attr[AGD_MAX_DEVICES][2] = {};
   int dev = 0; HIP_CHECK_RET(hipGetDevice(&dev));
   if (dev < 0 || dev >= AGD_MAX_DEVICES) { agd_set_error("qkv_chain: device ordinal %d out of range", dev); return -1; }
   if (!attr[dev][C == 640]) { HIP_CHECK_RET(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); attr[dev][C == 640] = true; }

@@ -260,7 +260,7 @@ static int launch_bwd_d(const AttnBwdP& p, hipStream_t st) {
   constexpr int lds = 2 * 64 * 97 * 4 + 2 * 96 * D * 2 + 2 * 64 * (D + 2) * 2;
   auto kfn = attn_bwd_kernel<D>;
   if (lds > 65536) {
-    static bool attr[AGD_MAX_DEVICES] = {};
+    static std::atomic<bool> attr[AGD_MAX_DEVICES] = {};
     int dev = 0; HIP_CHECK_RET(hipGetDevice(&dev));
     if (dev < 0 || dev >= AGD_MAX_DEVICES) { agd_set_error("attn_bwd: device ordinal %d out of range", dev); return -1; }
     if (!attr[dev]) { HIP_CHECK_RET(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); attr[dev] = true; }

@@ -136,7 +136,7 @@ int launch_rowstat_bf16(const bf16_t* x, float* out, int M, int C, hipStream_t s
 
 int launch_xattn_premul(const XattnPremulP& x, hipStream_t st) {
   const int C = x.C, H = x.H, D = C / H, TP = XATTN_TP;
-  if (C % H || D % 8 || x.T < 1 || x.T > TP || (C % 80)) { agd_set_error("xattn_premul: C %d heads %d tokens %d", C, H, x.T); return -1; }
+  if (C % H || D % 8 || x.T < 1 || x.T > TP || (C % 80) || (C % 64)) { agd_set_error("xattn_premul: C %d heads %d tokens %d", C, H, x.T); return -1; }
   // K''[b][(h,t)][c] = gamma[c] scale sum_d k[b][t][h D + d] WqT[c][h D + d]
   PremulP k{};
   k.A = x.kv; k.sAb = x.skv; k.sAh = D; k.lda = x.ldkv;
@@ -313,7 +313,7 @@ int launch_xattn_s(const XattnSP& p, hipStream_t st) {
   }
   if ((long long)p.M * p.C * 2 >= (1LL << 31) || (long long)XATTN_TP * p.C * 2 >= (1LL << 31)) { agd_set_error("xattn_s: 32-bit offsets"); return -1; }
   constexpr int lds = 4 * (64 + XATTN_TP) * 128 + 4096 + 64 * 8;
-  static bool attr[AGD_MAX_DEVICES] = {};
+  static std::atomic<bool> attr[AGD_MAX_DEVICES] = {};
   int dev = 0; HIP_CHECK_RET(hipGetDevice(&dev));
   if (dev < 0 || dev >= AGD_MAX_DEVICES) { agd_set_error("xattn_s: device ordinal %d out of range", dev); return -1; }
   if (!attr[dev]) { HIP_CHECK_RET(hipFuncSetAttribute((const void*)xattn_s_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); attr[dev] = true; }

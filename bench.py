@@ -25,14 +25,23 @@ TFLOP_PER_IMAGE = {50: 82.84}          # 2*50*803.3 GF + 2514.5 
 UNET_GF, VAE_GF = 803.3, 2514.5
 MFMA_PEAK_TF = 2500.0                  # bf16 dense, MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0                  # HBM3E spec, MI355X_MICROARCH.md (6.3 TB/s is what a copy achieves)
-PMC_CSV = os.path.join("profiles", "r05_pmc_traffic_summary.csv")
-STATS_CSV = os.path.join("profiles", "r05_bench_kernel_stats.csv")
+
+
+def _latest_profile(suffix):
+    """the newest committed profiles/rNN_<suffix> (the round's own rocprofv3 summaries of this command)"""
+    import glob
+    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_" + suffix)))
+    return os.path.relpath(found[-1], ROOT) if found else os.path.join("profiles", "r06_" + suffix)
+
+
+PMC_CSV = _latest_profile("pmc_traffic_summary.csv")
+STATS_CSV = _latest_profile("bench_kernel_stats.csv")
 
 # the kernel instantiations behind each class, as rocprofv3 names them: igemm_kernel<BM, BN, WM, WN, KS, ...>,
 # igemm_halo_kernel<BN, SPLITK, BST> / igemm_pch_kernel<BN, SPLITK> (3x3 only), igemm8p_kernel<WM, WN, MI, NI0, NI1, KS, GEGLU>
 # round 4: the fused row-panel kernels of the C = 320 blocks (tblock.hip) are booked where the launches they replace were: ff_fused / qkv_chain
 # under the linears, attn_chain under cross-attention; igemm_smap_kernel (8 x 8 maps) and the split-K slab passes under the convs
-CLASS_REP = {"igemm_conv3x3": "igemm_kernel", "igemm_linear_1x1": "igemm_kernel", "attn_self_flash": "attn_kernel", "attn_cross_daam": "attn_kernel", "groupnorm": "gn_apply_part_kernel"}
+CLASS_REP = {"igemm_conv3x3": "igemm_pch_kernel", "igemm_linear_1x1": "igemm_kernel", "attn_self_flash": "attn_kernel", "attn_cross_daam": "attn_kernel", "groupnorm": "gn_apply_part_kernel"}
 
 
 def _targs(name, prefix):
@@ -121,9 +130,9 @@ def heaviest_instantiation(cls):
 
 
 def cpu_baseline(cfg, usd, vsd, ctx, threads):
-    """Oracle (fp32 PyTorch CPU restatement, kind 'port') on a bounded sample of the same workload:
-    one CFG denoise step (UNet batch 2 at 512 px, DAAM recording on) + one VAE decode for ONE
-    image; images/s extrapolated to 50 steps."""
+    """Oracle (fp32 PyTorch CPU restatement, kind 'port') on a bounded sample of the same workload, as BASELINE.md section 3 states it:
+    two CFG denoise steps (UNet batch 2 at 512 px, DAAM recording on) + one VAE decode for ONE image; images/s extrapolated
+    (the two steps x 25) to 50 steps."""
     import torch
     from oracle import sd_oracle as O
     from agenda_amd import synthetic
@@ -133,16 +142,17 @@ def cpu_baseline(cfg, usd, vsd, ctx, threads):
     c1 = torch.cat([ctx[:1], ctx[ctx.shape[0] // 2: ctx.shape[0] // 2 + 1]]).cpu()
     t0 = time.time()
     with torch.no_grad():
-        O.unet_forward(usd, cfg.unet, torch.cat([lat, lat]), torch.tensor(981), c1, rec)
-    t_step = time.time() - t0
+        for t in (981, 961):
+            O.unet_forward(usd, cfg.unet, torch.cat([lat, lat]), torch.tensor(t), c1, rec)
+    t_steps = time.time() - t0
     t0 = time.time()
     with torch.no_grad():
         O.vae_decode(vsd, cfg.vae, lat / cfg.vae.scaling_factor)
     t_vae = time.time() - t0
-    per_img = 50 * t_step + t_vae
+    per_img = 25 * t_steps + t_vae
     return {"value": 1.0 / per_img, "unit": "images/sec", "cores": threads, "kind": "port",
-            "sample": f"1 CFG denoise step (UNet batch 2, 512px, DAAM on) {t_step:.1f}s + 1 VAE decode {t_vae:.1f}s on the host CPU, "
-                      f"extrapolated x50 steps; fp32 PyTorch restatement of the reference path (diffusers absent)"}
+            "sample": f"2 CFG denoise steps (UNet batch 2, 512px, DAAM on) {t_steps:.1f}s + 1 VAE decode {t_vae:.1f}s on the host CPU, "
+                      f"the steps extrapolated x25 to 50; fp32 PyTorch restatement of the reference path (diffusers absent)"}
 
 
 def rccl_version():
@@ -272,6 +282,12 @@ def main():
         one_step(10 ** 6, gather=False)
         classes = pipe.engine.profile_end(MFMA_PEAK_TF * 1e12, HBM_PEAK_GBS * 1e9)
         table = class_table(classes, dt / args.steps * 1e3)
+        # the same batch once more with the recorder OFF (no daam.trace around the pipeline call): the difference of the cross-attention class is the
+        # time the fused accumulation itself costs (SURVEY 8d "time-in-accumulate-kernels")
+        lat_off = synthetic.make_latents(cfg, [10 ** 6 * B + i for i in range(B)], 64)
+        pipe.engine.profile_begin()
+        pipe(prompt_embeds=ctx, num_inference_steps=args.ddim_steps, guidance_scale=7.5, latents=lat_off, height=512, width=512, output_type="pt")
+        classes_off = pipe.engine.profile_end(MFMA_PEAK_TF * 1e12, HBM_PEAK_GBS * 1e9)
         dom = max(table, key=lambda k: table[k]["ms"])                         # dominant = the class with the most time
         d, raw = table[dom], classes[dom]
         mfma_bound = d["frac_mfma"] >= d["frac_hbm"]
@@ -312,6 +328,14 @@ def main():
                 "note": "the class time also carries to_q / to_out (and attn1.to_out) of the fused chain kernels and the attention math of both CFG halves: "
                         "a lower bound on the accumulate rate, not an HBM efficiency of the read-modify-write itself",
                 "traffic": pmc_traffic("attn_cross_daam")}
+        # isolated: the class's raw event time with the recorder on minus off (same kernels, same shapes; only the read-modify-write of the accumulators differs)
+        on_ms, off_ms = classes["attn_cross_daam"]["ms"], classes_off.get("attn_cross_daam", {}).get("ms", 0.0)
+        delta = on_ms - off_ms
+        daam["record_on_ms"], daam["record_off_ms"], daam["delta_ms"] = round(on_ms, 2), round(off_ms, 2), round(delta, 2)
+        if delta > 0:
+            daam["accumulate_GBs_on_delta"] = round(moved / (delta * 1e-3), 1)                 # 44.1 MB x steps x B / delta
+            daam["accumulate_frac_hbm_on_delta"] = round(moved / (delta * 1e-3) / HBM_PEAK_GBS, 4)
+            daam["accumulate_GBs_on_delta_survey_bytes"] = round(gb / (delta * 1e-3), 1)       # SURVEY's 132.5 MB per image and step / delta
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         usd, vsd = pipe.synthetic_weights

@@ -222,7 +222,7 @@ int agd_op_attn_chain(const float* x, const float* gamma, const float* beta, con
 /* the same function through the pre-multiplied form of the C = 1280 blocks (csrc/xattn_pre.hip; hook.py:91-120 behind norm2): the context products
  * K'' = gamma scale (k Wq), V'' = Wo v are built first, then S = LN-folded x K''^T -> softmax -> P V''^T + bo + x as two GEMMs.
  * probs (may be NULL): [B][heads][T][HW], every head's probabilities (the recorder's per-(image, head) rows).  Needs HW % 64 == 0, T <= 80,
- * head dim % 32 == 0, C % 160 == 0. */
+ * head dim % 8 == 0, C % 160 == 0 and C % 64 == 0 (i.e. C a multiple of 320), heads x 80 a multiple of 64. */
 int agd_op_xattn_premul(const float* x, const float* gamma, const float* beta, const float* wq, const float* kv, const float* wo,
                         const float* bo, float* y, float* probs, int B, int HW, int T, int C, int heads, float eps, void* stream);
 int agd_op_groupnorm(const float* x_nchw, const float* gamma, const float* beta, float* y_nchw, int B, int C, int HW,

@@ -16,11 +16,23 @@ def _rms_rel(got, want):
     return float(((got - want) ** 2).mean().sqrt() / ((want ** 2).mean().sqrt() + 1e-12))
 
 
-def _norm_map_err_255(got, want):
+def _norm_map_diff_255(got, want):
     lo, hi = got.amin((-1, -2), keepdim=True), got.amax((-1, -2), keepdim=True)
     wlo, whi = want.amin((-1, -2), keepdim=True), want.amax((-1, -2), keepdim=True)
-    d = ((got - lo) / (hi - lo + 1e-8) - (want - wlo) / (whi - wlo + 1e-8)).abs() * 255
+    return ((got - lo) / (hi - lo + 1e-8) - (want - wlo) / (whi - wlo + 1e-8)).abs() * 255
+
+
+def _norm_map_err_255(got, want):
+    d = _norm_map_diff_255(got, want)
     return float(d.max()), float(d.mean())
+
+
+def _norm_map_stats_255(got, want):
+    """max, 99.9th percentile and mean of the error of the min-max-normalised maps (what data_generation.py:82-84 exports), in 1/255.  The max is ONE pixel of a
+    normalised low-contrast row and moves between 6 and 12 with any change of summation order (profiles/r06_bisect_config1.txt); the percentile and the mean
+    do not -- they are the robust figures."""
+    d = _norm_map_diff_255(got, want)
+    return float(d.max()), float(d.flatten().float().quantile(0.999)), float(d.mean())
 
 
 @pytest.fixture(scope="module")
@@ -262,9 +274,10 @@ def test_merged_launches_at_odd_sizes_match_the_unmerged_walk(sd15_host_weights,
     print(f"{side} px, batch {B}: merged vs unmerged walk, two steps: latents rms rel {e:.5f}")
     report(f"odd_size_merged_vs_unmerged[{side}px,B={B}]", latents_rms_rel=e)
     assert e < 0.08, e
-    if side == 256:
-        # ... and "is right", not only "agrees with itself" (VERDICT r4 weak #5): the same two CFG steps through the fp32 oracle (batch 5 at 256 px is
-        # seconds of host work); both walks within the two-step bound of the CFG-pair tests (classifier-free guidance multiplies the bf16 noise of eps)
+    if True:
+        # ... and "is right", not only "agrees with itself" (every size now): the same two CFG steps through the fp32 oracle (batch 5 at
+        # 256 px is seconds of host work, batch 3 at 384 px and batch 1 at 640 px under a minute each); both walks within the two-step bound of the CFG-pair tests
+        # (classifier-free guidance multiplies the bf16 noise of eps)
         from oracle import sd_oracle as O
         cfg, u, v = sd15_host_weights
         _, want = O.generate(u, v, cfg, ctx, lat, 2, 7.5, decode=False)
@@ -510,6 +523,18 @@ def test_config3_sd15_vae_encode_512_and_img2img_match_oracle(sd15_host_weights,
     assert e_m < 2.0 ** -6 and e_l < 2.0 ** -6, (e_m, e_l)
     assert lat_err < 0.05, lat_err
     assert psnr > 30.0, psnr
+    # config 3's per-GPU share of the encoder: eight DIFFERENT images in one `vae_encode` call against the oracle's moments of each
+    # (the decoder and the UNet were already checked at that batch; the encoder had only seen batch 1)
+    imgs8 = (torch.rand(8, 3, S, S, generator=g) * 2 - 1).to(torch.bfloat16).float()
+    m8, l8 = pipe.engine.vae_encode(imgs8)
+    with torch.no_grad():
+        mo = [O.vae_encode_moments(v, cfg.vae, imgs8[i:i + 1]) for i in range(8)]        # image by image: bounded host memory
+    wm8, wl8 = torch.cat([a for a, _ in mo]), torch.cat([b for _, b in mo])
+    per_m = [_rms_rel(m8[i], wm8[i]) for i in range(8)]
+    per_l = [_rms_rel(l8[i], wl8[i]) for i in range(8)]
+    print(f"config3 share, vae_encode at batch 8: moments rms rel worst image {max(per_m):.5f}/{max(per_l):.5f}")
+    report("config3_share_vae_encode_512px_batch8", moments_mean_rms_rel_worst=max(per_m), moments_logvar_rms_rel_worst=max(per_l))
+    assert max(per_m) < 2.0 ** -6 and max(per_l) < 2.0 ** -6, (per_m, per_l)
     assert hm_err < 0.03, hm_err
     assert float(hm.sum(0).mean()) == pytest.approx(3, rel=0.02)       # 3 of the 5 steps ran
 
@@ -537,18 +562,22 @@ def test_config1_sd15_256px_10_steps_end_to_end_vs_oracle():
     lat_err = _rms_rel(out.latents, want_lat)
     psnr = _psnr_u8(out.images, want_img)
     hm_err = float((got - want).abs().max() / want.abs().max())
-    lo, hi = got.amin((-1, -2), keepdim=True), got.amax((-1, -2), keepdim=True)
-    wlo, whi = want.amin((-1, -2), keepdim=True), want.amax((-1, -2), keepdim=True)
-    norm_err = float(((got - lo) / (hi - lo + 1e-8) - (want - wlo) / (whi - wlo + 1e-8)).abs().max()) * 255
+    norm_err, norm_p999, norm_mean = _norm_map_stats_255(got, want)
     print(f"config1: latents rms rel {lat_err:.4f}, image PSNR {psnr:.1f} dB, heat map rel {hm_err:.4f}, "
-          f"normalised-map max err {norm_err:.1f}/255")
-    report("config1_256px_10_steps_end_to_end", latents_rms_rel=lat_err, psnr_db=psnr, heat_map_rel=hm_err, norm_map_max_255=norm_err)
-    # measured on MI355X (bf16 storage / fp32 accumulate vs the fp32 oracle, 10 steps): latents 2.2 %, PSNR 43.3 dB,
-    # heat map 0.8 %, min-max-normalised map 6.3/255 -- bounds carry ~2x headroom (SURVEY 8c asks PSNR >= 30 dB)
+          f"normalised-map err max {norm_err:.1f}/255, 99.9th percentile {norm_p999:.2f}/255, mean {norm_mean:.2f}/255")
+    report("config1_256px_10_steps_end_to_end", latents_rms_rel=lat_err, psnr_db=psnr, heat_map_rel=hm_err, norm_map_max_255=norm_err,
+           norm_map_p999_255=norm_p999, norm_map_mean_255=norm_mean)
+    # measured on MI355X (bf16 storage / fp32 accumulate vs the fp32 oracle, 10 steps): latents 2.1 %, PSNR 43.7 dB, heat map 0.8 %; min-max-normalised
+    # maps: max 12.3/255, 99.9th percentile 6.0, mean 1.0.  The max sits on one pixel of a row whose range is 0.066 around a mean of 0.128; across twenty
+    # builds / option sets of round 6's bisect (profiles/r06_bisect_config1.txt) it lands anywhere in 6.0 .. 12.3 while the percentile
+    # stays in 4.2 .. 6.0 and the mean in 0.91 .. 1.05: the robust figures carry the tight bounds, the max keeps 1.5x over the worst value seen
+    # (SURVEY 8c's 2/255 aspiration is not met by any of them on random synthetic weights; PSNR >= 30 dB is, with 13 dB to spare)
     assert lat_err < 0.05, lat_err
     assert psnr > 36.0, psnr
     assert hm_err < 0.02, hm_err
-    assert norm_err < 13.0, norm_err
+    assert norm_p999 < 9.0, norm_p999
+    assert norm_mean < 1.6, norm_mean
+    assert norm_err < 19.0, norm_err
     pipe.engine.close()
 
 
@@ -604,18 +633,20 @@ def test_config2_sd15_512px_50_steps_end_to_end_vs_oracle(sd15_host_weights, sd1
     lat_err = _rms_rel(out.latents, want_lat)
     psnr = _psnr_u8(out.images, want_img)
     hm_err = float((got - want).abs().max() / want.abs().max())
-    norm_max, norm_mean = _norm_map_err_255(got, want)
+    norm_max, norm_p999, norm_mean = _norm_map_stats_255(got, want)
     print(f"config2 50 steps (512 px, oracle {_C2['t']:.0f} s): latents rms rel {lat_err:.4f}, image PSNR {psnr:.1f} dB, "
-          f"heat map rel {hm_err:.4f}, normalised-map err max {norm_max:.1f}/255 mean {norm_mean:.2f}/255")
-    report("config2_512px_50_steps_end_to_end", latents_rms_rel=lat_err, psnr_db=psnr, heat_map_rel=hm_err, norm_map_max_255=norm_max, norm_map_mean_255=norm_mean,
-           oracle_seconds=_C2["t"])
+          f"heat map rel {hm_err:.4f}, normalised-map err max {norm_max:.1f}/255, 99.9th percentile {norm_p999:.2f}/255, mean {norm_mean:.2f}/255")
+    report("config2_512px_50_steps_end_to_end", latents_rms_rel=lat_err, psnr_db=psnr, heat_map_rel=hm_err, norm_map_max_255=norm_max, norm_map_p999_255=norm_p999,
+           norm_map_mean_255=norm_mean, oracle_seconds=_C2["t"])
     assert len(rec.acc) == 15 * 8
     assert float(got.sum(0).mean()) == pytest.approx(steps, rel=0.02)      # every step recorded, probability mass conserved
     # bounds: see DESIGN section 2 (measured on MI355X, random synthetic weights)
     assert lat_err < 0.10, lat_err
     assert psnr > 30.0, psnr
     assert hm_err < 0.03, hm_err
-    assert norm_max < 13.0, norm_max
+    assert norm_max < 13.0, norm_max                                       # measured 4.0 (one pixel; config 1's test explains the statistic)
+    assert norm_mean < 1.0, norm_mean                                      # measured 0.47
+    assert norm_p999 < 6.0, norm_p999
     for k in ("x", "rec", "ctx", "lat"):
         _C2.pop(k, None)
 
