@@ -107,6 +107,7 @@ struct FFusedP {
   // colstat (optional): [M / 128][C] float2 per-(tile, channel) sums of the bf16 outputs for the GroupNorm that reads pout
   const bf16_t* wpf; const float* bp; const bf16_t* xres; bf16_t* pout; float* colstat;
   int xres_rows;                    // > 0: xres holds xres_rows rows, output row m adds row m % xres_rows (CFG-shared prefix)
+  int late_res;                     // residual rows requested behind the proj_out stage's last weight load instead of ahead of it (tblock_fuse bit 14)
   int premul;                       // 1 (with wpf): w2f holds Wp W2 and bp holds Wp b2 + bp (pre-multiplied at load time); the proj_out stage adds Wp . h on top of GEMM2's sums
 };
 int launch_ff_fused(const FFusedP& p, int C, hipStream_t st);
@@ -122,6 +123,7 @@ struct AttnChainP {
   float* rowstat_out;               // optional: [M] float2 (sum, sum of squares) of the bf16 outputs (LayerNorm-fold producer, one slot)
   // optional prologue (o1 != NULL): h1 = o1 . Wo1^T + bo1 + h first (attn1.to_out + residual); h1 goes to `out` (!= h) and is the chain's input
   const bf16_t* o1; const bf16_t* wo1f; const float* bo1;
+  int late_res;                     // residual rows requested behind each GEMM stage's last weight load instead of ahead of it (tblock_fuse bit 14)
   int rows32;                       // C = 640: allow 32-row panels (twice the workgroups) where 64-row panels leave CUs idle
   int src_rows;                     // > 0: the INPUT tensors (h, o1) hold src_rows rows and output row m reads input row m % src_rows -- the CFG-shared prefix's
                                     // duplication happens here instead of in copy launches (needs out != h)
@@ -142,6 +144,8 @@ struct QkvChainP {
   // per-(M tile, channel) partial sums [B][HW / gn_bm][C][2], rows normalised (and rounded to bf16, as gn_apply would) inside the LDS panel;
   // wbf is then the plain proj_in matrix in fragment order (wb_stride 0) and rowadd its bias
   const float* gn_part; int gn_bm, gn_groups; float gn_eps; const float* gn_gamma; const float* gn_beta;
+  int rows64;                       // C = 320: 64-row panels on four waves, two workgroups co-resident per CU (tblock_fuse bit 11)
+  int sched2;                       // round 6's schedule (qkv_chain2_kernel, tblock_fuse bit 12): same results bit for bit
 };
 int launch_qkv_chain(const QkvChainP& p, int C, hipStream_t st);
 int launch_frag_order_w1(const bf16_t* src, bf16_t* dst, int C, int HID, hipStream_t st);

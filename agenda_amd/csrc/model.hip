@@ -120,8 +120,9 @@ struct agd_ctx {
   int opt_gn_proj_fold = 1;                           // agd_set_option("gn_proj_fold"): the transformers' GroupNorm folded into per-image proj_in matrices (1: C <= 320, 2: C <= 640)
   int opt_p8 = 1;                                     // agd_set_option("igemm8p"): 256-row 8-wave / 8-phase igemm for launches with enough tiles (igemm8p.h)
   int opt_halo = 1;                                   // agd_set_option("conv_halo"): 3x3 stride-1 convs through the row-halo kernel (igemm_halo.h)
-  int opt_tb_fuse = 255 | 512 | 1024;                               // agd_set_option("tblock_fuse"): fused row-panel kernels of the C = 320 transformer blocks (tblock.hip): bit 0 = feed-forward (bit 3: + proj_out),
-                                                      // bit 1 = attn2 chain (bit 2: + attn1.to_out in front of it), bit 4 = proj_in -> norm1 -> qkv, bit 5 = the attn2 chain for the C = 640 blocks too, bit 6 = the CFG-shared prefix's duplication inside the fused kernels, bit 7 = the GroupNorm applied inside the bit-4 launch (no fold launch), bit 8 (off) = the bit-4 launch with the GroupNorm inside for the C = 640 blocks, bit 9 = ff.net.2 / proj_out pre-multiplied inside the feed-forward kernel, bit 10 = 32-row panels for the C = 640 attn2 chain where 64-row panels would fill half the chip
+  int opt_tb_fuse = 255 | 512 | 1024 | 2048 | 4096;                 // agd_set_option("tblock_fuse"): fused row-panel kernels of the C = 320 transformer blocks (tblock.hip): bit 0 = feed-forward (bit 3: + proj_out),
+                                                      // bit 1 = attn2 chain (bit 2: + attn1.to_out in front of it), bit 4 = proj_in -> norm1 -> qkv, bit 5 = the attn2 chain for the C = 640 blocks too, bit 6 = the CFG-shared prefix's duplication inside the fused kernels, bit 7 = the GroupNorm applied inside the bit-4 launch (no fold launch), bit 8 (off) = the bit-4 launch with the GroupNorm inside for the C = 640 blocks too, bit 9 = ff.net.2 / proj_out pre-multiplied inside the feed-forward launch, bit 10 = 32-row panels for the C = 640 attn2 chain,
+                                                      // round 6: bit 11 = the bit-4 launch on 64-row panels (two co-resident four-wave workgroups per CU), bit 12 = on qkv_chain2_kernel's schedule, bit 14 (off) = residual rows requested behind a stage's last weight load for the C = 640 blocks, bit 9 = ff.net.2 / proj_out pre-multiplied inside the feed-forward kernel, bit 10 = 32-row panels for the C = 640 attn2 chain where 64-row panels would fill half the chip
   int opt_ups4 = 7; /* see agd_set_option */                                   // agd_set_option("upsample_phases"): the UNet's nearest-2x upsampling convs as four 2x2 phase convs on the un-upsampled map (one launch, 4/9 of the MACs)
   int opt_ffproj = 1;                                 // agd_set_option("ff_proj_fuse"): ff.net.2 and proj_out as ONE GEMM with the pre-multiplied matrix [Wp W2 | Wp] over [hidden | h] (blocks whose feed-forward is not the fused row-panel kernel)
   int opt_sc_fuse = 3;                                // agd_set_option("shortcut_fuse"): a UNet resnet's 1x1 conv_shortcut runs as extra K of its conv2 launch where that is an unsplit row-halo launch
@@ -580,6 +581,8 @@ static int transformer(agd_ctx* c, hipStream_t st, const std::string& pre, const
         GETW(fqkv, t + "attn1.qkv.frag"); GETV(g1, t + "norm1.weight"); GETV(b1_, t + "norm1.bias");
         QkvChainP qp{}; qp.x = x.p; qp.wbf = wb; qp.wb_stride = (long long)w->N * C; qp.rowadd = radd; qp.rowadd_stride = C; qp.h = h.p; qp.gamma = g1; qp.beta = b1_; qp.ln_eps = lneps;
         qp.wqkvf = fqkv->w; qp.qkv = qkv; qp.M = M; qp.HW = HW;
+        qp.rows64 = (c->opt_tb_fuse & 2048) && HW % 64 == 0 ? 1 : 0;
+        qp.sched2 = (c->opt_tb_fuse & 4096) ? 1 : 0;
         if (gn_inside) {
           GETW(fpi, pre + "proj_in.frag");
           if (!b) FAIL("proj_in without bias");
@@ -601,6 +604,7 @@ static int transformer(agd_ctx* c, hipStream_t st, const std::string& pre, const
       QkvChainP qp{}; qp.x = x.p; qp.wbf = fpi->w; qp.wb_stride = 0; qp.rowadd = b; qp.rowadd_stride = 0; qp.h = h.p; qp.gamma = g1; qp.beta = b1_; qp.ln_eps = lneps;
       qp.wqkvf = fqkv->w; qp.qkv = qkv; qp.M = M; qp.HW = HW;
       qp.gn_part = x.cpart; qp.gn_bm = x.cpart_bm; qp.gn_groups = groups; qp.gn_eps = 1e-6f; qp.gn_gamma = gg; qp.gn_beta = gb;
+      qp.sched2 = (c->opt_tb_fuse & 4096) ? 1 : 0;
       stats = nullptr; slots = 0;
       ProfScope ps(c, st, PC_GEMM, 8.0 * M * (double)C * C, 2.0 * M * (double)C * 5.0 + 2.0 * 4.0 * C * (double)C);
       CK(launch_qkv_chain(qp, C, st));
@@ -676,6 +680,7 @@ static int transformer(agd_ctx* c, hipStream_t st, const std::string& pre, const
         ap.o1 = att; ap.wo1f = f1o->w; ap.bo1 = bo1; ap.out = h2;
       } else if (lazy_dup) { bf16_t* h2 = (bf16_t*)c->arena.alloc((size_t)M * C * 2); if (!h2) return -1; ap.out = h2; }
       if (lazy_dup) ap.src_rows = Mshared;
+      ap.late_res = (c->opt_tb_fuse & 16384) ? 1 : 0;
       ap.rows32 = (c->opt_tb_fuse & 1024) ? 1 : 0;       // bit 10: 32-row panels for the C = 640 chain where 64-row panels fill half the chip
       if (fold && !ff_fused) {                           // the GEGLU consumer of the LayerNorm fold reads one slot of row statistics
         slots = 1; stats = (float*)c->arena.alloc((size_t)M * 2 * sizeof(float)); if (!stats) return -1;
@@ -737,6 +742,7 @@ static int transformer(agd_ctx* c, hipStream_t st, const std::string& pre, const
         fp.w2f = f2p->w; fp.bp = bcp; fp.premul = 1;
       }
       if (lazy_dup) fp.xres_rows = Mshared;             // xres is still the B'-row block input
+      fp.late_res = (c->opt_tb_fuse & 16384) ? 1 : 0;
       out.cpart_bm = 0;
       if (out.cpart && c->opt_gn_fused && HW % 128 == 0) { fp.colstat = out.cpart; out.cpart_bm = 128; }
       proj_done = true;
@@ -2240,8 +2246,8 @@ AGD_API int agd_bench_conv_cold(int B, int H, int W, int C0, int Cout, int ksize
 // images recording head-summed probabilities, as in a CFG forward)
 AGD_API int agd_bench_tblock(int kind, int B, int HW, int iters, double* ms_out) {
   Tmp tmp;
-  const int C = kind >= 4 ? 640 : 320, T = 77; const long long M = (long long)B * HW;      // kind 4 / 5: the attn2 chain at C = 640 (plain / from attn1.to_out)
-  if (kind >= 4) kind = kind == 4 ? 1 : 3;
+  const int C = (kind == 4 || kind == 5) ? 640 : 320, T = 77; const long long M = (long long)B * HW;      // kind 4 / 5: the attn2 chain at C = 640 (plain / from attn1.to_out)
+  if (kind == 4 || kind == 5) kind = kind == 4 ? 1 : 3;
   bf16_t* h = tmp.get<bf16_t>((size_t)M * C); bf16_t* o = tmp.get<bf16_t>((size_t)M * C);
   bf16_t* w1 = tmp.get<bf16_t>((size_t)8 * C * C); bf16_t* w1f = tmp.get<bf16_t>((size_t)8 * C * C);
   bf16_t* w2 = tmp.get<bf16_t>((size_t)4 * C * C); bf16_t* w2f = tmp.get<bf16_t>((size_t)4 * C * C);
@@ -2276,7 +2282,18 @@ AGD_API int agd_bench_tblock(int kind, int B, int HW, int iters, double* ms_out)
     CK(launch_frag_order_w(w2, wo1f, C, C, 5, C, 0));
     ap.o1 = o2; ap.wo1f = wo1f; ap.bo1 = vec;
   }
-  auto run = [&]() { return (kind == 0 || kind == 2) ? launch_ff_fused(fp, C, 0) : launch_attn_chain(ap, C, 8, 0); };
+  QkvChainP qp{};
+  const bool qkvk = kind >= 6 && kind <= 9;            // (8 / 9: the same on round 6's schedule) the block head (GroupNorm inside -> proj_in -> norm1 -> q / k / v); 7: two co-resident 64-row workgroups per CU
+  if (qkvk) {
+    bf16_t* qkv = tmp.get<bf16_t>((size_t)M * 3 * C); float* part = tmp.get<float>((size_t)B * (HW / 128) * C * 2); float* gv = tmp.get<float>((size_t)4 * C);
+    if (!qkv || !part || !gv) return -1;
+    hipMemset(part, 0x3C, (size_t)B * (HW / 128) * C * 2 * 4); hipMemset(gv, 0x3C, (size_t)4 * C * 4);    // 0x3C3C3C3C = 0.0115f: finite, non-zero everywhere
+    CK(launch_frag_order_w(w2, w2f, C, C, 5, C, 0)); CK(launch_frag_order_w(w1, w1f, 3 * C, C, 5, C, 0));
+    qp.x = h; qp.wbf = w2f; qp.wb_stride = 0; qp.rowadd = gv; qp.rowadd_stride = 0; qp.h = o; qp.gamma = gv + C; qp.beta = gv + 2 * C; qp.ln_eps = 1e-5f;
+    qp.wqkvf = w1f; qp.qkv = qkv; qp.M = (int)M; qp.HW = HW; qp.rows64 = kind == 7 || kind == 9; qp.sched2 = kind >= 8;
+    qp.gn_part = part; qp.gn_bm = 128; qp.gn_groups = 32; qp.gn_eps = 1e-6f; qp.gn_gamma = gv + 3 * C; qp.gn_beta = gv;
+  }
+  auto run = [&]() { return qkvk ? launch_qkv_chain(qp, C, 0) : (kind == 0 || kind == 2) ? launch_ff_fused(fp, C, 0) : launch_attn_chain(ap, C, 8, 0); };
   hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
   for (int i = 0; i < 2; ++i) CK(run());
   hipEventRecord(a, 0);

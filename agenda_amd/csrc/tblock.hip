@@ -22,6 +22,7 @@
 //  * LDS images are XOR-swizzled for conflict-free ds_read_b128 fragment reads (640-B rows: key (row >> 1) & 7 on the low three
 //    chunk bits; 256-B rows: key row & 15).
 #include "kernels.h"
+#include <type_traits>
 
 typedef __attribute__((ext_vector_type(2))) float f32x2_t;
 #ifdef AGD_EXPERIMENTS
@@ -118,13 +119,13 @@ template <int C> struct XOff {
 };
 
 // [128][C] bf16 rows m0 .. m0+127 of `src` -> LDS panel (swizzled), by LDS-DMA; 8 waves, 1 KiB pieces.  Caller waits (vmcnt(0) + barrier).
-template <int C, int BM = 128>
+template <int C, int BM = 128, int NW = 8>
 AGD_DEV void panel_load_dma(const bf16_t* src, int m0, int M, char* panel, int wid, int lane) {
   constexpr int CHR = C / 8, PIECES = BM * CHR / 64;
-  static_assert(PIECES % 8 == 0, "pieces split evenly over 8 waves");
+  static_assert(PIECES % NW == 0, "pieces split evenly over the workgroup's waves");
 #pragma unroll
-  for (int i = 0; i < PIECES / 8; ++i) {
-    const int piece = i * 8 + wid, pos = piece * 64 + lane;
+  for (int i = 0; i < PIECES / NW; ++i) {
+    const int piece = i * NW + wid, pos = piece * 64 + lane;
     const int row = pos / CHR, pc = pos - row * CHR;
     const int lc = panel_swz<C>(pc, row);                 // the swizzle is an involution on the low three chunk bits
     const int m = m0 + row;
@@ -185,9 +186,12 @@ AGD_DEV void panel_gemm_head(u32x4 (&ring)[TB_F], const bf16_t* wf, unsigned wba
 #pragma unroll
   for (int f = 0; f < TB_D; ++f) ring[f % TB_F] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, lane16, wbase + (unsigned)f * 1024u, 0));
 }
-template <int C, bool ZERO = true, int MI = 4>     // ZERO = false: accumulate on top of what acc holds; MI: 16-row tiles of the wave (4: 64 rows; 2: the 32-row panels of attn_chain_kernel<640, ., 2>)
+struct TbNoHook { AGD_DEV void operator()() const {} };
+// `late`: called once, right behind the LAST weight load of the stage (step NFR - TB_D): loads issued there -- residual rows -- are younger than the whole weight stream, so no
+// K step waits for them in the in-order vmcnt queue (issued ahead of the GEMM, an HBM-cold residual row held the stream's first waits for its whole latency: round 6 stamps)
+template <int C, bool ZERO = true, int MI = 4, class Late = TbNoHook>     // ZERO = false: accumulate on top of what acc holds; MI: 16-row tiles of the wave (4: 64 rows; 2: the 32-row panels of attn_chain_kernel<640, ., 2>)
 AGD_DEV void panel_gemm_body(u32x4 (&ring)[TB_F], f32x4 (&acc)[MI][5], const bf16_t* wf, unsigned wbase, unsigned lane16, const char* xrow, const XOff<C>& xo,
-                             unsigned wbytes = C * C * 2) {
+                             unsigned wbytes = C * C * 2, Late&& late = Late()) {
   constexpr int NI = 5, KS = C / 32, NFR = KS * NI, PITCH = C * 2;       // a wave's tile is 16 MI rows x 80 columns whatever C
   const auto wrs = __builtin_amdgcn_make_buffer_rsrc((void*)wf, 0, wbytes, 0x00020000);
   if constexpr (ZERO) {
@@ -200,6 +204,7 @@ AGD_DEV void panel_gemm_body(u32x4 (&ring)[TB_F], f32x4 (&acc)[MI][5], const bf1
 #pragma unroll
   for (int f = 0; f < NFR; ++f) {
     if (f + TB_D < NFR) ring[(f + TB_D) % TB_F] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, lane16, wbase + (unsigned)(f + TB_D) * 1024u, 0));
+    if (f == NFR - TB_D) late();
     __builtin_amdgcn_sched_barrier(0);
     if (f % NI == 0) {
       const int ks = f / NI;
@@ -469,10 +474,13 @@ __global__ __launch_bounds__(512, 2) void ff_fused_kernel(const FFusedP p) {
   }
   if constexpr (post) {
   if constexpr (!premul) __syncthreads();                // h3 complete in the panel (every GEMM1 read of the raw rows is long done)
-  u32x2 xr[4][NI2];                                      // the residual rows (HBM-cold) are requested ahead of the GEMM, not in its epilogue
+  u32x2 xr[4][NI2];                                      // the residual rows (HBM-cold) are requested ahead of the GEMM, not in its epilogue -- or (p.late_res) behind its last weight load
+  auto ld_xr = [&]() __attribute__((always_inline)) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i) { const int m = m0 + rbase + 16 * i, ms = m < p.M ? (p.xres_rows > 0 ? m % p.xres_rows : m) : 0; load_row_chunk<NI2>(p.xres + (long long)ms * C + ncol0, xr[i]); }
-  panel_gemm_body<C, !premul>(ring, acc2, p.wpf, pwbase, lane16, xrow, XOff<C>(q, px));
+    for (int i = 0; i < 4; ++i) { const int m = m0 + rbase + 16 * i, ms = m < p.M ? (p.xres_rows > 0 ? m % p.xres_rows : m) : 0; load_row_chunk<NI2>(p.xres + (long long)ms * C + ncol0, xr[i]); }
+  };
+  if (p.late_res) panel_gemm_body<C, !premul, 4>(ring, acc2, p.wpf, pwbase, lane16, xrow, XOff<C>(q, px), (unsigned)(C * C * 2), ld_xr);
+  else { ld_xr(); panel_gemm_body<C, !premul>(ring, acc2, p.wpf, pwbase, lane16, xrow, XOff<C>(q, px)); }
   float bpv[NI2 * 4];
 #pragma unroll
   for (int t = 0; t < NI2; ++t) *(f32x4*)&bpv[4 * t] = *(const f32x4*)(p.bp + ncol0 + 4 * t);
@@ -644,6 +652,7 @@ __global__ __launch_bounds__(512, 2) void attn_chain_kernel(const AttnChainP p) 
   const unsigned wbase = __builtin_amdgcn_readfirstlane((unsigned)(nq * KS * NI) * 1024u);
   auto gemm_head = [&](const bf16_t* wf) { panel_gemm_head<C>(ring, wf, wbase, lane16); };
   auto gemm_body = [&](const bf16_t* wf) { panel_gemm_body<C, true, MI>(ring, acc, wf, wbase, lane16, xrow, xo); };
+  auto gemm_body_late = [&](const bf16_t* wf, auto&& late) __attribute__((always_inline)) { panel_gemm_body<C, true, MI>(ring, acc, wf, wbase, lane16, xrow, xo, (unsigned)(C * C * 2), late); };
   const int ncol0 = 16 * NI * nq + 4 * NI * q;          // first of this lane's 4 NI consecutive channels (GEMM epilogues)
 
   if constexpr (PRE) gemm_head(p.wo1f);
@@ -660,10 +669,13 @@ __global__ __launch_bounds__(512, 2) void attn_chain_kernel(const AttnChainP p) 
 
   if constexpr (PRE) {
     // ---- attn1.to_out + bias + residual -> h1 (rounded once, stored), its row statistics, norm2 from registers into the panel ----
-    u32x2 hr[MI][NI];                                    // residual rows of h, requested ahead of the GEMM
+    u32x2 hr[MI][NI];                                    // residual rows of h: requested ahead of the GEMM, or (p.late_res) behind its last weight load
+    auto ld_hr = [&]() __attribute__((always_inline)) {
 #pragma unroll
-    for (int i = 0; i < MI; ++i) load_row_chunk<NI>(p.h + (long long)(m0s + rbase + 16 * i) * C + ncol0, hr[i]);
-    gemm_body(p.wo1f);
+      for (int i = 0; i < MI; ++i) load_row_chunk<NI>(p.h + (long long)(m0s + rbase + 16 * i) * C + ncol0, hr[i]);
+    };
+    if (p.late_res) gemm_body_late(p.wo1f, ld_hr);
+    else { ld_hr(); gemm_body(p.wo1f); }
     TB_TS(4);
     gemm_head(p.wqf);
     float bv1[NI * 4];
@@ -911,10 +923,13 @@ __global__ __launch_bounds__(512, 2) void attn_chain_kernel(const AttnChainP p) 
   TB_TS(31);
 
   // ---- to_out + bias + residual, one rounding; optional norm3 row statistics of the rounded outputs ----
-  u32x2 fr[MI][NI];                                      // residual rows, requested ahead of the GEMM (PRE: h1, stored by this very lane above)
+  u32x2 fr[MI][NI];                                      // residual rows (PRE: h1, stored by this very lane above): requested ahead of the GEMM, or (p.late_res) behind its last weight load
+  auto ld_fr = [&]() __attribute__((always_inline)) {
 #pragma unroll
-  for (int i = 0; i < MI; ++i) load_row_chunk<NI>((PRE ? (const bf16_t*)p.out : p.h) + (long long)((PRE ? m0 : m0s) + rbase + 16 * i) * C + ncol0, fr[i]);
-  gemm_body(p.wof);
+    for (int i = 0; i < MI; ++i) load_row_chunk<NI>((PRE ? (const bf16_t*)p.out : p.h) + (long long)((PRE ? m0 : m0s) + rbase + 16 * i) * C + ncol0, fr[i]);
+  };
+  if (p.late_res) gemm_body_late(p.wof, ld_fr);
+  else { ld_fr(); gemm_body(p.wof); }
   TB_TS(32);
   float bv[NI * 4];
 #pragma unroll
@@ -997,10 +1012,13 @@ int launch_attn_chain(const AttnChainP& p, int C, int heads, hipStream_t st) {
 // stages whose outputs go straight to the packed [M][3C] buffer the flash-attention kernel reads.  Replaces two launches and the 21 MB
 // write + re-read of h between them.
 // ---------------------------------------------------------------------------------------------------------------------------
-template <int C>
-__global__ __launch_bounds__(512, 2) void qkv_chain_kernel(const QkvChainP p) {
+// MH: row halves per workgroup.  C = 320, MH = 1 (round 6): 64-row panels on FOUR waves, two such workgroups co-resident per CU -- the same eight waves per CU doing the same
+// per-wave work, but the two panels are not coupled by barriers, so one's latency phases (panel DMA + GroupNorm statistics, the h / q / k / v stores) can run under the
+// other's GEMMs.
+template <int C, int MH = 8 / (C / 80)>
+__global__ __launch_bounds__(64 * MH * (C / 80), 2) void qkv_chain_kernel(const QkvChainP p) {
   // C = 320: 128-row panels, waves 2 row halves x 4 column quarters; C = 640: 64-row panels, 1 x 8 -- a wave's GEMM tile is 64 rows x 80 columns either way
-  constexpr int NQ = C / 80, MH = 8 / NQ, BM = 64 * MH, KS = C / 32, NI = 5, PITCH = C * 2;
+  constexpr int NQ = C / 80, BM = 64 * MH, KS = C / 32, NI = 5, PITCH = C * 2, NT = 64 * MH * NQ;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* panel = smem;
   float* pst = (float*)(smem + BM * PITCH);            // [NQ column ranges][BM] (sum, sum of squares) of h
@@ -1010,8 +1028,10 @@ __global__ __launch_bounds__(512, 2) void qkv_chain_kernel(const QkvChainP p) {
   const int q = lane >> 4, px = lane & 15;
   const int m0 = blockIdx.x * BM;
   const int img = m0 / p.HW;                           // tiles stay inside one image (HW % BM == 0)
+  TB_TS_DECL
+  TB_TS(1);
 
-  panel_load_dma<C, BM>(p.x, m0, p.M, panel, wid, lane);
+  panel_load_dma<C, BM, MH * NQ>(p.x, m0, p.M, panel, wid, lane);
   const int rbase = 64 * mh + px;
   const char* xrow = panel + rbase * PITCH;
   f32x4 acc[4][NI];
@@ -1021,6 +1041,7 @@ __global__ __launch_bounds__(512, 2) void qkv_chain_kernel(const QkvChainP p) {
   const unsigned wbase = __builtin_amdgcn_readfirstlane((unsigned)(nq * KS * NI) * 1024u);
   const bf16_t* wimg = p.wbf + (long long)img * p.wb_stride;
   panel_gemm_head<C>(ring, wimg, wbase, lane16);
+  TB_TS(2);
   if (p.gn_part) {
     // the transformer's GroupNorm, applied here: the image's group statistics from the producer's partial sums (channel sums over the image's
     // tiles, then the groups' channels, fp64, fixed order -- gn_apply_part's arithmetic), under the panel DMA and the first weight fragments
@@ -1028,11 +1049,11 @@ __global__ __launch_bounds__(512, 2) void qkv_chain_kernel(const QkvChainP p) {
     float* gst = (float*)(csum + 2 * C);                              // [groups][2] (mean, rstd)
     float* ab = gst + 64;                                             // [C][2] (scale, shift)
     const int nt = p.HW / p.gn_bm, cpg = C / p.gn_groups;
-    constexpr int CPT = (C + 511) / 512;                              // channels per thread
+    constexpr int CPT = (C + NT - 1) / NT;                              // channels per thread
     float gam[CPT], bet[CPT];
 #pragma unroll
     for (int r = 0; r < CPT; ++r) {
-      const int cch = tid + 512 * r < C ? tid + 512 * r : C - 1;
+      const int cch = tid + NT * r < C ? tid + NT * r : C - 1;
       gam[r] = p.gn_gamma[cch]; bet[r] = p.gn_beta[cch];
       const float* pp = p.gn_part + ((long long)img * nt * C + cch) * 2;
       double a = 0.0, qq = 0.0;
@@ -1043,7 +1064,7 @@ __global__ __launch_bounds__(512, 2) void qkv_chain_kernel(const QkvChainP p) {
 #pragma unroll
         for (int u = 0; u < 16; ++u) if (t0 + u < nt) { a += (double)v[u][0]; qq += (double)v[u][1]; }
       }
-      if (tid + 512 * r < C) { csum[2 * (tid + 512 * r)] = a; csum[2 * (tid + 512 * r) + 1] = qq; }
+      if (tid + NT * r < C) { csum[2 * (tid + NT * r)] = a; csum[2 * (tid + NT * r) + 1] = qq; }
     }
     __syncthreads();
     if (tid < p.gn_groups) {
@@ -1056,19 +1077,21 @@ __global__ __launch_bounds__(512, 2) void qkv_chain_kernel(const QkvChainP p) {
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < CPT; ++r) {
-      const int cch = tid + 512 * r;
+      const int cch = tid + NT * r;
       if (cch < C) { const int g = cch / cpg; const float sc = gst[2 * g + 1] * gam[r]; ab[2 * cch] = sc; ab[2 * cch + 1] = bet[r] - gst[2 * g] * sc; }
     }
   }
+  TB_TS(3);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  TB_TS(4);
   if (p.gn_part) {
-    // rows := bf16(x * scale + shift) in place (the same affine form and rounding as gn_apply): thread owns 16-byte chunks tid, tid + 512, ...
+    // rows := bf16(x * scale + shift) in place (the same affine form and rounding as gn_apply): thread owns 16-byte chunks tid, tid + NT, ...
     const float* ab = (const float*)(smem + BM * PITCH + NQ * BM * 8 + 2 * C * 8) + 64;
     constexpr int CHR = C / 8;
 #pragma unroll
-    for (int k = 0; k < BM * CHR / 512; ++k) {
-      const int id = tid + 512 * k, row = id / CHR, pc = id - row * CHR;
+    for (int k = 0; k < BM * CHR / NT; ++k) {
+      const int id = tid + NT * k, row = id / CHR, pc = id - row * CHR;
       const int c0 = panel_swz<C>(pc, row) * 8;                      // logical channels of this physical chunk
       u32x4* cp = (u32x4*)(panel + row * PITCH + pc * 16);
       const u32x4 v = *cp;
@@ -1085,7 +1108,9 @@ __global__ __launch_bounds__(512, 2) void qkv_chain_kernel(const QkvChainP p) {
 
   // ---- proj_in: h = x . Wb[img]^T + row[img], rounded once, stored; its row statistics ----
   const XOff<C> xo(q, px);
+  TB_TS(5);
   panel_gemm_body<C>(ring, acc, wimg, wbase, lane16, xrow, xo);
+  TB_TS(6);
   panel_gemm_head<C>(ring, p.wqkvf, wbase, lane16, 3u * C * C * 2);
   {
     float rv[NI * 4];
@@ -1112,7 +1137,9 @@ __global__ __launch_bounds__(512, 2) void qkv_chain_kernel(const QkvChainP p) {
       if (q == 0) *(f32x2_t*)(pst + (nq * BM + rbase + 16 * i) * 2) = f32x2_t{rs1, rq1};
     }
   }
+  TB_TS(7);
   __syncthreads();                                      // partial sums staged AND every wave is done reading x from the panel
+  TB_TS(8);
   {
     float g1[NI * 4], b1[NI * 4];
 #pragma unroll
@@ -1137,6 +1164,7 @@ __global__ __launch_bounds__(512, 2) void qkv_chain_kernel(const QkvChainP p) {
     }
   }
   __syncthreads();
+  TB_TS(9);
 
   // ---- q, k, v: three C -> C stages over the normalised rows, each straight to its third of the packed row ----
 #pragma unroll
@@ -1144,6 +1172,7 @@ __global__ __launch_bounds__(512, 2) void qkv_chain_kernel(const QkvChainP p) {
     const unsigned wb_s = __builtin_amdgcn_readfirstlane((unsigned)((NQ * s + nq) * KS * NI) * 1024u);
     if (s > 0) panel_gemm_head<C>(ring, p.wqkvf, wb_s, lane16, 3u * C * C * 2);
     panel_gemm_body<C>(ring, acc, p.wqkvf, wb_s, lane16, xrow, xo, 3u * C * C * 2);
+    TB_TS(10 + s);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int m = m0 + rbase + 16 * i;
@@ -1152,24 +1181,250 @@ __global__ __launch_bounds__(512, 2) void qkv_chain_kernel(const QkvChainP p) {
       for (int t = 0; t < NI; ++t) { pkk[t][0] = pack_bf2(acc[i][t][0], acc[i][t][1]); pkk[t][1] = pack_bf2(acc[i][t][2], acc[i][t][3]); }
       if (m < p.M) store_row_chunk<NI>(p.qkv + (long long)m * 3 * C + s * C + ncol0, pkk);
     }
+    TB_TS(20 + s);
   }
+  TB_TS_END;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Round 6: the same chain on a schedule written from its in-kernel time line (profiles/r06_trace_qkv_chain.txt; 84.6 k cycles per workgroup for 12.8 k of matrix pipe):
+//   * the GroupNorm partial sums were waited for with vmcnt(0) behind the panel's LDS-DMA (hipcc drains the DMA at the first use of an ordinary load: 10.9 k cycles before
+//     anything else moved): they are now fetched FIRST, one round of 32 independent 16-byte loads per channel pair, and summed before the DMA is issued;
+//   * the GroupNorm apply pass re-read (scale, shift) from LDS for every chunk (6.7 k): a thread now owns one LOGICAL 8-channel chunk, keeps its 16 constants in registers
+//     and walks the rows;
+//   * every store burst (h, q, k: 4 - 5 k cycles each, all CUs at once) sat in front of the next GEMM's weight stream in the in-order vmcnt queue and stalled it (+3 k, +6.7 k):
+//     the packed rows now wait in 40 registers and leave one row group at a time BETWEEN the next GEMM's K steps, and the weight stream runs on across the GEMM seams.
+// Same arithmetic, same summation orders, same roundings: bit-identical to qkv_chain_kernel (tools/eq_option.py tblock_fuse 1791,5887).
+// ---------------------------------------------------------------------------------------------------------------------------
+template <int I, int N, class F> AGD_DEV void tb_static_for(F&& f) {
+  if constexpr (I < N) { f(std::integral_constant<int, I>{}); tb_static_for<I + 1, N>(f); }
+}
+// (Measured and rejected in round 6: the same rows through agent-scope write-through (`sc1`) stores, so that nothing stays dirty in the L2s for the end-of-kernel
+// write-back -- 74 us per launch against 52: the 40-byte row chunks become partial-line fabric writes.)
+template <int C, int MH = 8 / (C / 80)>
+__global__ __launch_bounds__(64 * MH * (C / 80), 2) void qkv_chain2_kernel(const QkvChainP p) {
+  constexpr int NQ = C / 80, BM = 64 * MH, KS = C / 32, NI = 5, PITCH = C * 2, NT = 64 * MH * NQ, NFR = KS * NI;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* panel = smem;
+  float* pst = (float*)(smem + BM * PITCH);            // [NQ column ranges][BM] (sum, sum of squares) of h
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int mh = wid / NQ, nq = wid % NQ;
+  const int q = lane >> 4, px = lane & 15;
+  const int m0 = blockIdx.x * BM;
+  const int img = m0 / p.HW;                           // tiles stay inside one image (HW % BM == 0)
+  TB_TS_DECL
+  TB_TS(1);
+
+  double* csum = (double*)(smem + BM * PITCH + NQ * BM * 8);          // [C][2]
+  float* gst = (float*)(csum + 2 * C);                                // [groups][2] (mean, rstd)
+  float* ab = gst + 64;                                               // [C][2] (scale, shift)
+  constexpr int CPT = (C + NT - 1) / NT;                              // channels per thread (affine parameters)
+  float gam[CPT], bet[CPT];
+  if (p.gn_part) {
+    // channel sums over the image's tiles (fp64, tile order -- gn_apply_part's arithmetic): thread = channel PAIR, all of a round's loads in flight, before any LDS-DMA exists
+    const int nt = p.HW / p.gn_bm;
+    const int cp = tid < C / 2 ? tid : C / 2 - 1;
+    const float* pp = p.gn_part + ((long long)img * nt * C + 2 * cp) * 2;
+#pragma unroll
+    for (int r = 0; r < CPT; ++r) { const int cch = tid + NT * r < C ? tid + NT * r : C - 1; gam[r] = p.gn_gamma[cch]; bet[r] = p.gn_beta[cch]; }
+    double a0 = 0.0, q0 = 0.0, a1 = 0.0, q1 = 0.0;
+    for (int t0 = 0; t0 < nt; t0 += 32) {
+      f32x4 v[32];
+#pragma unroll
+      for (int u = 0; u < 32; ++u) { const int tc = t0 + u < nt ? t0 + u : nt - 1; v[u] = *(const f32x4*)(pp + (long long)tc * C * 2); }
+#pragma unroll
+      for (int u = 0; u < 32; ++u) if (t0 + u < nt) { a0 += (double)v[u][0]; q0 += (double)v[u][1]; a1 += (double)v[u][2]; q1 += (double)v[u][3]; }
+    }
+    if (tid < C / 2) { csum[4 * tid] = a0; csum[4 * tid + 1] = q0; csum[4 * tid + 2] = a1; csum[4 * tid + 3] = q1; }
+  }
+  TB_TS(2);
+  panel_load_dma<C, BM, MH * NQ>(p.x, m0, p.M, panel, wid, lane);
+  const int rbase = 64 * mh + px;
+  const char* xrow = panel + rbase * PITCH;
+  f32x4 acc[4][NI];
+  u32x4 ring[TB_F];
+  const unsigned lane16 = (unsigned)lane * 16u;
+  const int ncol0 = 80 * nq + 4 * NI * q;
+  const unsigned wbase = __builtin_amdgcn_readfirstlane((unsigned)(nq * KS * NI) * 1024u);
+  const bf16_t* wimg = p.wbf + (long long)img * p.wb_stride;
+  panel_gemm_head<C>(ring, wimg, wbase, lane16);
+  if (p.gn_part) {
+    const int cpg = C / p.gn_groups;
+    __syncthreads();
+    if (tid < p.gn_groups) {
+      double a = 0.0, qq = 0.0;
+      for (int e = 0; e < cpg; ++e) { a += csum[2 * (tid * cpg + e)]; qq += csum[2 * (tid * cpg + e) + 1]; }
+      const double cnt = (double)p.HW * cpg, mean = a / cnt;
+      double var = qq / cnt - mean * mean; if (var < 0) var = 0;
+      gst[2 * tid] = (float)mean; gst[2 * tid + 1] = (float)(1.0 / sqrt(var + (double)p.gn_eps));
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < CPT; ++r) {
+      const int cch = tid + NT * r;
+      if (cch < C) { const int g = cch / cpg; const float sc = gst[2 * g + 1] * gam[r]; ab[2 * cch] = sc; ab[2 * cch + 1] = bet[r] - gst[2 * g] * sc; }
+    }
+  }
+  TB_TS(3);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  TB_TS(4);
+  if (p.gn_part) {
+    // rows := bf16(x * scale + shift) in place (the same affine form and rounding as gn_apply): thread = logical 8-channel chunk lc of rows r0, r0 + RP, ...
+    constexpr int CHR = C / 8, RP = NT / CHR;
+    const int lc = tid % CHR, r0 = tid / CHR;
+    f32x4 sab[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) sab[e] = *(const f32x4*)(ab + 2 * (lc * 8 + 2 * e));   // (scale, shift) of two channels
+    if (r0 < RP) {
+      for (int row = r0; row < BM; row += RP) {
+        u32x4* cp = (u32x4*)(panel + row * PITCH + panel_swz<C>(lc, row) * 16);          // (the swizzle is an involution: logical chunk lc sits at physical chunk swz(lc))
+        const u32x4 v = *cp;
+        u32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = pack_bf2(fmaf(__uint_as_float(v[e] << 16), sab[e][0], sab[e][1]), fmaf(__uint_as_float(v[e] & 0xFFFF0000u), sab[e][2], sab[e][3]));
+        *cp = o;
+      }
+    }
+    __syncthreads();
+  }
+
+  // one C -> C GEMM over the panel with the weight stream running on into the NEXT GEMM's first TB_D fragments (nextw / nbase / nbytes; nullptr: last stage) and a hook
+  // behind every step's load (the previous stage's stores, one row group at a time)
+  const XOff<C> xo(q, px);
+  auto gemm = [&](const bf16_t* wf, unsigned wb, unsigned wbytes, auto has_next, const bf16_t* nextw, unsigned nb, unsigned nbytes, auto&& hook) __attribute__((always_inline)) {
+    constexpr bool NEXT = decltype(has_next)::value;     // (compile time: a branch on the pointer would end the basic block and drain the stream at every seam)
+    const auto wrs = __builtin_amdgcn_make_buffer_rsrc((void*)wf, 0, wbytes, 0x00020000);
+    const auto nrs = __builtin_amdgcn_make_buffer_rsrc((void*)nextw, 0, nbytes, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bf16x8 xf[4];
+    tb_static_for<0, NFR>([&](auto fc) __attribute__((always_inline)) {
+      constexpr int f = decltype(fc)::value;
+      if constexpr (f + TB_D < NFR) ring[(f + TB_D) % TB_F] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, lane16, wb + (unsigned)(f + TB_D) * 1024u, 0));
+      else if constexpr (NEXT) ring[(f + TB_D) % TB_F] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(nrs, lane16, nb + (unsigned)(f + TB_D - NFR) * 1024u, 0));
+      hook(fc);
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (f % NI == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) xf[i] = *(const bf16x8*)(xrow + i * 16 * PITCH + xo.at(f / NI));
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        acc[i][f % NI] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ring[f % TB_F]), xf[i], acc[i][f % NI], 0, 0, 0);
+    });
+  };
+  static_assert(NFR % TB_F == 0, "ring slots continue across the GEMM seams");
+  auto no_hook = [](auto) {};
+  u32x2 pk[4][NI];                                      // the previous stage's rounded rows, waiting for their turn between the next GEMM's steps
+  bf16_t* st_base = nullptr; int st_pitch = 0;          // where they go: row m at st_base + m * st_pitch
+  auto store_hook = [&](auto fc) __attribute__((always_inline)) {
+    constexpr int f = decltype(fc)::value;
+    if constexpr (f % 10 == 6 && f / 10 < 4) {           // steps 6, 16, 26, 36: row group i = f / 10
+      constexpr int i = f / 10;
+      // (M % BM == 0: the launcher; a bounds branch here would cut the K loop into blocks)
+      store_row_chunk<NI>(st_base + (long long)(m0 + rbase + 16 * i) * st_pitch + ncol0, pk[i]);
+    }
+  };
+  const unsigned qkv_bytes = 3u * C * C * 2;
+  const unsigned wb0 = __builtin_amdgcn_readfirstlane((unsigned)((NQ * 0 + nq) * KS * NI) * 1024u);
+
+  // ---- proj_in: h = x . Wb[img]^T + row[img], rounded once; its row statistics ----
+  TB_TS(5);
+  gemm(wimg, wbase, (unsigned)(C * C * 2), std::true_type{}, p.wqkvf, wb0, qkv_bytes, no_hook);
+  TB_TS(6);
+  {
+    float rv[NI * 4];
+#pragma unroll
+    for (int t = 0; t < NI; ++t) *(f32x4*)&rv[4 * t] = *(const f32x4*)(p.rowadd + (long long)img * p.rowadd_stride + ncol0 + 4 * t);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float rs1 = 0.f, rq1 = 0.f;
+#pragma unroll
+      for (int t = 0; t < NI; ++t) {
+        u32x2 k2;
+        k2[0] = pack_bf2(acc[i][t][0] + rv[4 * t], acc[i][t][1] + rv[4 * t + 1]);
+        k2[1] = pack_bf2(acc[i][t][2] + rv[4 * t + 2], acc[i][t][3] + rv[4 * t + 3]);
+        pk[i][t] = k2;
+        acc[i][t] = f32x4{__uint_as_float(k2[0] << 16), __uint_as_float(k2[0] & 0xFFFF0000u), __uint_as_float(k2[1] << 16), __uint_as_float(k2[1] & 0xFFFF0000u)};
+        rs1 += (acc[i][t][0] + acc[i][t][1]) + (acc[i][t][2] + acc[i][t][3]);
+        rq1 += (acc[i][t][0] * acc[i][t][0] + acc[i][t][1] * acc[i][t][1]) + (acc[i][t][2] * acc[i][t][2] + acc[i][t][3] * acc[i][t][3]);
+      }
+      rs1 += __shfl_xor(rs1, 16); rs1 += __shfl_xor(rs1, 32);
+      rq1 += __shfl_xor(rq1, 16); rq1 += __shfl_xor(rq1, 32);
+      if (q == 0) *(f32x2_t*)(pst + (nq * BM + rbase + 16 * i) * 2) = f32x2_t{rs1, rq1};
+    }
+  }
+  TB_TS(7);
+  __syncthreads();                                      // partial sums staged AND every wave is done reading x from the panel
+  TB_TS(8);
+  {
+    float g1[NI * 4], b1[NI * 4];
+#pragma unroll
+    for (int t = 0; t < NI; ++t) { *(f32x4*)&g1[4 * t] = *(const f32x4*)(p.gamma + ncol0 + 4 * t); *(f32x4*)&b1[4 * t] = *(const f32x4*)(p.beta + ncol0 + 4 * t); }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = rbase + 16 * i;
+      float S = 0.f, Q = 0.f;
+#pragma unroll
+      for (int w = 0; w < NQ; ++w) { const f32x2_t v = *(const f32x2_t*)(pst + (w * BM + row) * 2); S += v[0]; Q += v[1]; }
+      const float mu = S * (1.0f / C);
+      float var = Q * (1.0f / C) - mu * mu; var = var < 0.f ? 0.f : var;
+      const float rstd = rsqrtf(var + p.ln_eps);
+#pragma unroll
+      for (int t = 0; t < NI; ++t) {
+        const int n = ncol0 + 4 * t;
+        u32x2 k2;
+        k2[0] = pack_bf2((acc[i][t][0] - mu) * rstd * g1[4 * t] + b1[4 * t], (acc[i][t][1] - mu) * rstd * g1[4 * t + 1] + b1[4 * t + 1]);
+        k2[1] = pack_bf2((acc[i][t][2] - mu) * rstd * g1[4 * t + 2] + b1[4 * t + 2], (acc[i][t][3] - mu) * rstd * g1[4 * t + 3] + b1[4 * t + 3]);
+        *(u32x2*)(panel + row * PITCH + panel_swz<C>(n >> 3, row) * 16 + (n & 7) * 2) = k2;
+      }
+    }
+  }
+  __syncthreads();
+  TB_TS(9);
+
+  // ---- q, k, v: three C -> C stages over the normalised rows; stage s stores the rows stage s - 1 produced (h first), its own leave behind the next one ----
+  st_base = p.h; st_pitch = C;
+  tb_static_for<0, 3>([&](auto sc_) __attribute__((always_inline)) {
+    constexpr int s = decltype(sc_)::value;
+    const unsigned wb_s = __builtin_amdgcn_readfirstlane((unsigned)((NQ * s + nq) * KS * NI) * 1024u);
+    const unsigned wb_n = __builtin_amdgcn_readfirstlane((unsigned)((NQ * (s + 1) + nq) * KS * NI) * 1024u);
+    gemm(p.wqkvf, wb_s, qkv_bytes, std::integral_constant<bool, (s < 2)>{}, p.wqkvf, wb_n, qkv_bytes, store_hook);
+    TB_TS(10 + s);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int t = 0; t < NI; ++t) { pk[i][t][0] = pack_bf2(acc[i][t][0], acc[i][t][1]); pk[i][t][1] = pack_bf2(acc[i][t][2], acc[i][t][3]); }
+    st_base = p.qkv + s * C; st_pitch = 3 * C;
+    TB_TS(20 + s);
+  });
+#pragma unroll
+  for (int i = 0; i < 4; ++i) store_row_chunk<NI>(st_base + (long long)(m0 + rbase + 16 * i) * st_pitch + ncol0, pk[i]);
+  TB_TS_END;
 }
 
 int launch_qkv_chain(const QkvChainP& p, int C, hipStream_t st) {
   if (C != 320 && C != 640) { agd_set_error("qkv_chain: C = %d is not built (320, 640)", C); return -1; }
-  const int BM = C == 320 ? 128 : 64;
+  const bool half = C == 320 && p.rows64;                // two co-resident 64-row workgroups per CU instead of one 128-row workgroup
+  const int BM = (C == 320 && !half) ? 128 : 64;
   if (p.M < BM || p.M % BM || p.HW % BM || p.M % p.HW) { agd_set_error("qkv_chain: M %d / HW %d must be multiples of %d (whole images)", p.M, p.HW, BM); return -1; }
   if (!p.x || !p.wbf || !p.rowadd || !p.h || !p.gamma || !p.beta || !p.wqkvf || !p.qkv) { agd_set_error("qkv_chain: bad arguments"); return -1; }
   if ((long long)p.M * C * 6 >= (1LL << 31)) { agd_set_error("qkv_chain: activation too large for 32-bit offsets"); return -1; }
   if (p.gn_part && (p.gn_bm < 1 || p.HW % p.gn_bm || p.gn_groups < 1 || p.gn_groups > 32 || C % p.gn_groups || !p.gn_gamma || !p.gn_beta)) { agd_set_error("qkv_chain: bad GroupNorm arguments"); return -1; }
   const int lds = BM * C * 2 + 4096 + C * 16 + 256 + C * 8;      // panel, h row statistics, GroupNorm: channel sums, group statistics, (scale, shift)
-  const void* kfn = C == 320 ? (const void*)qkv_chain_kernel<320> : (const void*)qkv_chain_kernel<640>;
-  static std::atomic<bool> attr[AGD_MAX_DEVICES][2] = {};
+  const void* kfn = C == 320 ? (half ? (const void*)qkv_chain_kernel<320, 1> : (const void*)qkv_chain_kernel<320>) : (const void*)qkv_chain_kernel<640>;
+  if (p.sched2) kfn = C == 320 ? (half ? (const void*)qkv_chain2_kernel<320, 1> : (const void*)qkv_chain2_kernel<320>) : (const void*)qkv_chain2_kernel<640>;
+  const int slot = (C == 640 ? 1 : half ? 2 : 0) + (p.sched2 ? 3 : 0);
+  static std::atomic<bool> attr[AGD_MAX_DEVICES][6] = {};
   int dev = 0; HIP_CHECK_RET(hipGetDevice(&dev));
   if (dev < 0 || dev >= AGD_MAX_DEVICES) { agd_set_error("qkv_chain: device ordinal %d out of range", dev); return -1; }
-  if (!attr[dev][C == 640]) { HIP_CHECK_RET(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); attr[dev][C == 640] = true; }
+  if (!attr[dev][slot]) { HIP_CHECK_RET(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); attr[dev][slot] = true; }
   QkvChainP pp = p;
   void* args[] = {&pp};
-  HIP_CHECK_RET(hipLaunchKernel(kfn, dim3(p.M / BM), dim3(512), args, lds, st));
+  HIP_CHECK_RET(hipLaunchKernel(kfn, dim3(p.M / BM), dim3(half ? 256 : 512), args, lds, st));
   return 0;
 }

@@ -335,7 +335,8 @@ def main():
         if delta > 0:
             daam["accumulate_GBs_on_delta"] = round(moved / (delta * 1e-3), 1)                 # 44.1 MB x steps x B / delta
             daam["accumulate_frac_hbm_on_delta"] = round(moved / (delta * 1e-3) / HBM_PEAK_GBS, 4)
-            daam["accumulate_GBs_on_delta_survey_bytes"] = round(gb / (delta * 1e-3), 1)       # SURVEY's 132.5 MB per image and step / delta
+            daam["delta_note"] = ("difference of two ~37 ms event sums (one batch each): +- 0.3 ms; the 88 MB of accumulators of a 4-image batch fit the "
+                                  "Infinity Cache, so this is the memory system's read-modify-write rate, not necessarily DRAM traffic")
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         usd, vsd = pipe.synthetic_weights

@@ -9,6 +9,7 @@ import torch
 from _report import report
 
 pytestmark = pytest.mark.gpu
+_TB = 7935          # the engine's default "tblock_fuse" mask (model.hip: bits 0 - 7, 9, 10 and round 6's bits 11 = 64-row block-head panels, 12 = its new schedule)
 
 
 def _rms_rel(got, want):
@@ -213,7 +214,8 @@ def test_fused_transformer_block_kernels_match_the_kernel_chain_512px(sd15_host_
     want, whm, _ = _ORACLE_CACHE["unet512"]
     outs = {}
     try:
-        for fuse, rg in ((0, 0), (1, 1), (2, 1), (6, 1), (9, 1), (16, 1), (31, 1), (34, 1), (63, 1), (63, 0), (144, 1), (176, 1), (255, 1), (767, 1), (1791, 1)):
+        for fuse, rg in ((0, 0), (1, 1), (2, 1), (6, 1), (9, 1), (16, 1), (31, 1), (34, 1), (63, 1), (63, 0), (144, 1), (176, 1), (255, 1), (767, 1), (1791, 1), (1791 | 2048, 1),
+                         (1791 | 4096, 1), (_TB, 1), (_TB | 16384, 1)):
             pipe.engine.set_option("tblock_fuse", fuse)
             pipe.engine.set_option("reduce_gn", rg)
             pipe.engine.set_context(ctx)
@@ -227,9 +229,12 @@ def test_fused_transformer_block_kernels_match_the_kernel_chain_512px(sd15_host_
                 again = pipe.engine.unet_forward(x, 981.0)
                 assert torch.equal(got, again) and torch.equal(hm, pipe.engine.daam_global(0, 77, L).cpu())
     finally:
-        pipe.engine.set_option("tblock_fuse", 1791)
+        pipe.engine.set_option("tblock_fuse", _TB)
         pipe.engine.set_option("reduce_gn", 1)
         pipe.engine.record_config(0)
+    # round 6: the block head on 64-row panels (bit 11), on its new schedule (bit 12) and the late residual requests (bit 14) move no arithmetic: bit-identical
+    for k in ((1791 | 2048, 1), (1791 | 4096, 1), (_TB, 1), (_TB | 16384, 1)):
+        assert torch.equal(outs[k][0], outs[(1791, 1)][0]) and torch.equal(outs[k][1], outs[(1791, 1)][1]), k
     base, bhm = outs[(0, 0)]
     for key, (got, hm) in outs.items():
         e_o, e_b = _rms_rel(got, want), _rms_rel(got, base.cpu())
@@ -255,7 +260,7 @@ def test_merged_launches_at_odd_sizes_match_the_unmerged_walk(sd15_host_weights,
     lat = synthetic.make_latents(cfg, list(range(B)), L)
     off = {"tblock_fuse": 0, "reduce_gn": 0, "shortcut_fuse": 0, "ff_proj_fuse": 0, "upsample_phases": 0, "igemm_kgroups": 0, "wreg_mask": 0, "conv_smap": 0, "attn2_premul": 0,
            "igemm_pc": 0, "xcd_block": 0}
-    on = {"tblock_fuse": 1791, "reduce_gn": 1, "shortcut_fuse": 3, "ff_proj_fuse": 1, "upsample_phases": 7, "igemm_kgroups": 1, "wreg_mask": 3, "conv_smap": 1, "attn2_premul": 1,
+    on = {"tblock_fuse": _TB, "reduce_gn": 1, "shortcut_fuse": 3, "ff_proj_fuse": 1, "upsample_phases": 7, "igemm_kgroups": 1, "wreg_mask": 3, "conv_smap": 1, "attn2_premul": 1,
           "igemm_pc": 49, "xcd_block": 1}
 
     def run():
@@ -307,12 +312,12 @@ def test_cfg_shared_prefix_inside_the_fused_kernels_512px(sd15_pipe):
 
     try:
         a = run(); a2 = run()
-        pipe.engine.set_option("tblock_fuse", 1791 & ~64)
+        pipe.engine.set_option("tblock_fuse", _TB & ~64)
         b = run()
         pipe.engine.set_option("cfg_shared_prefix", 0)
         c0 = run()
     finally:
-        pipe.engine.set_option("tblock_fuse", 1791)
+        pipe.engine.set_option("tblock_fuse", _TB)
         pipe.engine.set_option("cfg_shared_prefix", 1)
     assert torch.equal(a[0], a2[0]) and torch.equal(a[1], a2[1])
     # calibration: how far two VALID realisations of the same two steps drift apart (classifier-free guidance multiplies the bf16 noise of eps by ~10)
@@ -350,12 +355,12 @@ def test_sd15_unet_forward_512px_batch4_matches_oracle(sd15_host_weights, sd15_p
         hm = torch.stack([pipe.engine.daam_global(i, 77, L).cpu() for i in range(B)])
         # tblock_fuse bit 8 (off by default: measured slower): proj_in -> norm1 -> q / k / v with the GroupNorm inside for the C = 640 blocks too
         # (only at this batch do the 32 x 32 convs leave the partial sums the kernel needs)
-        pipe.engine.set_option("tblock_fuse", 1791 | 256)
+        pipe.engine.set_option("tblock_fuse", _TB | 256)
         pipe.engine.record_reset(B, L)
         got8 = pipe.engine.unet_forward(x, 601.0).clone()
         hm8 = torch.stack([pipe.engine.daam_global(i, 77, L).cpu() for i in range(B)])
         # shortcut_fuse off: the resnets' 1x1 conv_shortcut as its own launch (its bf16-rounded output added as conv2's residual) instead of extra K of conv2
-        pipe.engine.set_option("tblock_fuse", 1791)
+        pipe.engine.set_option("tblock_fuse", _TB)
         pipe.engine.set_option("shortcut_fuse", 0)
         pipe.engine.record_reset(B, L)
         got_s = pipe.engine.unet_forward(x, 601.0).clone()
@@ -388,7 +393,7 @@ def test_sd15_unet_forward_512px_batch4_matches_oracle(sd15_host_weights, sd15_p
         pipe.engine.set_option("xcd_block", 1)
         pipe.engine.set_option("attn2_premul", 1)
         pipe.engine.set_option("upsample_phases", 7)
-        pipe.engine.set_option("tblock_fuse", 1791)
+        pipe.engine.set_option("tblock_fuse", _TB)
         pipe.engine.set_option("shortcut_fuse", 3)
         pipe.engine.set_option("ff_proj_fuse", 1)
         pipe.engine.record_config(0)
