@@ -107,7 +107,6 @@ struct FFusedP {
   // colstat (optional): [M / 128][C] float2 per-(tile, channel) sums of the bf16 outputs for the GroupNorm that reads pout
   const bf16_t* wpf; const float* bp; const bf16_t* xres; bf16_t* pout; float* colstat;
   int xres_rows;                    // > 0: xres holds xres_rows rows, output row m adds row m % xres_rows (CFG-shared prefix)
-  int late_res;                     // residual rows requested behind the proj_out stage's last weight load instead of ahead of it (tblock_fuse bit 14)
   int premul;                       // 1 (with wpf): w2f holds Wp W2 and bp holds Wp b2 + bp (pre-multiplied at load time); the proj_out stage adds Wp . h on top of GEMM2's sums
 };
 int launch_ff_fused(const FFusedP& p, int C, hipStream_t st);
@@ -123,7 +122,6 @@ struct AttnChainP {
   float* rowstat_out;               // optional: [M] float2 (sum, sum of squares) of the bf16 outputs (LayerNorm-fold producer, one slot)
   // optional prologue (o1 != NULL): h1 = o1 . Wo1^T + bo1 + h first (attn1.to_out + residual); h1 goes to `out` (!= h) and is the chain's input
   const bf16_t* o1; const bf16_t* wo1f; const float* bo1;
-  int late_res;                     // residual rows requested behind each GEMM stage's last weight load instead of ahead of it (tblock_fuse bit 14)
   int rows32;                       // C = 640: allow 32-row panels (twice the workgroups) where 64-row panels leave CUs idle
   int src_rows;                     // > 0: the INPUT tensors (h, o1) hold src_rows rows and output row m reads input row m % src_rows -- the CFG-shared prefix's
                                     // duplication happens here instead of in copy launches (needs out != h)

@@ -122,7 +122,7 @@ struct agd_ctx {
   int opt_halo = 1;                                   // agd_set_option("conv_halo"): 3x3 stride-1 convs through the row-halo kernel (igemm_halo.h)
   int opt_tb_fuse = 255 | 512 | 1024 | 2048 | 4096;                 // agd_set_option("tblock_fuse"): fused row-panel kernels of the C = 320 transformer blocks (tblock.hip): bit 0 = feed-forward (bit 3: + proj_out),
                                                       // bit 1 = attn2 chain (bit 2: + attn1.to_out in front of it), bit 4 = proj_in -> norm1 -> qkv, bit 5 = the attn2 chain for the C = 640 blocks too, bit 6 = the CFG-shared prefix's duplication inside the fused kernels, bit 7 = the GroupNorm applied inside the bit-4 launch (no fold launch), bit 8 (off) = the bit-4 launch with the GroupNorm inside for the C = 640 blocks too, bit 9 = ff.net.2 / proj_out pre-multiplied inside the feed-forward launch, bit 10 = 32-row panels for the C = 640 attn2 chain,
-                                                      // round 6: bit 11 = the bit-4 launch on 64-row panels (two co-resident four-wave workgroups per CU), bit 12 = on qkv_chain2_kernel's schedule, bit 14 (off) = residual rows requested behind a stage's last weight load for the C = 640 blocks, bit 9 = ff.net.2 / proj_out pre-multiplied inside the feed-forward kernel, bit 10 = 32-row panels for the C = 640 attn2 chain where 64-row panels would fill half the chip
+                                                      // round 6: bit 11 = the bit-4 launch on 64-row panels (two co-resident four-wave workgroups per CU), bit 12 = on qkv_chain2_kernel's schedule for the C = 640 blocks, bit 9 = ff.net.2 / proj_out pre-multiplied inside the feed-forward kernel, bit 10 = 32-row panels for the C = 640 attn2 chain where 64-row panels would fill half the chip
   int opt_ups4 = 7; /* see agd_set_option */                                   // agd_set_option("upsample_phases"): the UNet's nearest-2x upsampling convs as four 2x2 phase convs on the un-upsampled map (one launch, 4/9 of the MACs)
   int opt_ffproj = 1;                                 // agd_set_option("ff_proj_fuse"): ff.net.2 and proj_out as ONE GEMM with the pre-multiplied matrix [Wp W2 | Wp] over [hidden | h] (blocks whose feed-forward is not the fused row-panel kernel)
   int opt_sc_fuse = 3;                                // agd_set_option("shortcut_fuse"): a UNet resnet's 1x1 conv_shortcut runs as extra K of its conv2 launch where that is an unsplit row-halo launch
@@ -680,7 +680,6 @@ static int transformer(agd_ctx* c, hipStream_t st, const std::string& pre, const
         ap.o1 = att; ap.wo1f = f1o->w; ap.bo1 = bo1; ap.out = h2;
       } else if (lazy_dup) { bf16_t* h2 = (bf16_t*)c->arena.alloc((size_t)M * C * 2); if (!h2) return -1; ap.out = h2; }
       if (lazy_dup) ap.src_rows = Mshared;
-      ap.late_res = (c->opt_tb_fuse & 16384) ? 1 : 0;
       ap.rows32 = (c->opt_tb_fuse & 1024) ? 1 : 0;       // bit 10: 32-row panels for the C = 640 chain where 64-row panels fill half the chip
       if (fold && !ff_fused) {                           // the GEGLU consumer of the LayerNorm fold reads one slot of row statistics
         slots = 1; stats = (float*)c->arena.alloc((size_t)M * 2 * sizeof(float)); if (!stats) return -1;
@@ -742,7 +741,6 @@ static int transformer(agd_ctx* c, hipStream_t st, const std::string& pre, const
         fp.w2f = f2p->w; fp.bp = bcp; fp.premul = 1;
       }
       if (lazy_dup) fp.xres_rows = Mshared;             // xres is still the B'-row block input
-      fp.late_res = (c->opt_tb_fuse & 16384) ? 1 : 0;
       out.cpart_bm = 0;
       if (out.cpart && c->opt_gn_fused && HW % 128 == 0) { fp.colstat = out.cpart; out.cpart_bm = 128; }
       proj_done = true;

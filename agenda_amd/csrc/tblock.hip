@@ -474,13 +474,13 @@ __global__ __launch_bounds__(512, 2) void ff_fused_kernel(const FFusedP p) {
   }
   if constexpr (post) {
   if constexpr (!premul) __syncthreads();                // h3 complete in the panel (every GEMM1 read of the raw rows is long done)
-  u32x2 xr[4][NI2];                                      // the residual rows (HBM-cold) are requested ahead of the GEMM, not in its epilogue -- or (p.late_res) behind its last weight load
+  u32x2 xr[4][NI2];                                      // the residual rows (HBM-cold) are requested ahead of the GEMM, not in its epilogue (behind the GEMM's last weight load, as attn_chain_kernel does: 1 KB of scratch per lane here)
   auto ld_xr = [&]() __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) { const int m = m0 + rbase + 16 * i, ms = m < p.M ? (p.xres_rows > 0 ? m % p.xres_rows : m) : 0; load_row_chunk<NI2>(p.xres + (long long)ms * C + ncol0, xr[i]); }
   };
-  if (p.late_res) panel_gemm_body<C, !premul, 4>(ring, acc2, p.wpf, pwbase, lane16, xrow, XOff<C>(q, px), (unsigned)(C * C * 2), ld_xr);
-  else { ld_xr(); panel_gemm_body<C, !premul>(ring, acc2, p.wpf, pwbase, lane16, xrow, XOff<C>(q, px)); }
+  ld_xr();
+  panel_gemm_body<C, !premul>(ring, acc2, p.wpf, pwbase, lane16, xrow, XOff<C>(q, px));
   float bpv[NI2 * 4];
 #pragma unroll
   for (int t = 0; t < NI2; ++t) *(f32x4*)&bpv[4 * t] = *(const f32x4*)(p.bp + ncol0 + 4 * t);
@@ -589,6 +589,8 @@ __global__ __launch_bounds__(512, 2) void attn_chain_kernel(const AttnChainP p) 
   char* kvs = smem + BM * PITCH;                        // 2 x KVSTAGE (one head per head half); later: probability hand-off / statistics staging
   float* lnst = (float*)(kvs + 2 * KVSTAGE);
   float* pst = lnst + BM * 2;                           // PRE: [NQ column ranges][BM] (sum, sum of squares) of h1
+  float* gbs = pst + NQ * BM * 2;                       // norm2's (gamma | beta), [2][C]: fetched at the very start, read from LDS where they are needed -- a global load there
+                                                        // would sit behind h1's stores in the in-order vmcnt queue and wait for all of them (round 6 stamps)
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -601,6 +603,8 @@ __global__ __launch_bounds__(512, 2) void attn_chain_kernel(const AttnChainP p) 
   const int b = m0 / p.HW, pix0 = m0 - b * p.HW;        // tiles stay inside one image (HW % 128 == 0)
   const int m0s = p.src_rows > 0 ? m0 % p.src_rows : m0;     // first INPUT row of this tile (CFG-shared prefix: both halves read the same rows)
   TB_TS(1);
+  const int gbi = tid < C / 2 ? tid : 0;                 // thread t < C / 4: four gammas; C / 4 <= t < C / 2: four betas
+  const f32x4 gbv = *(const f32x4*)((gbi < C / 4 ? p.gamma : p.beta - C) + 4 * gbi);
   panel_load_dma<C, BM>(PRE ? p.o1 : p.h, m0s, p.src_rows > 0 ? p.src_rows : p.M, panel, wid, lane);
   TB_TS(40);
 
@@ -658,6 +662,7 @@ __global__ __launch_bounds__(512, 2) void attn_chain_kernel(const AttnChainP p) 
   if constexpr (PRE) gemm_head(p.wo1f);
   TB_TS(2);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (also drains the ring's head: it is ten L2-resident KiB)
+  if (tid < C / 2) *(f32x4*)(gbs + 4 * tid) = gbv;
   __syncthreads();
   TB_TS(3);
   kv_store();
@@ -669,13 +674,12 @@ __global__ __launch_bounds__(512, 2) void attn_chain_kernel(const AttnChainP p) 
 
   if constexpr (PRE) {
     // ---- attn1.to_out + bias + residual -> h1 (rounded once, stored), its row statistics, norm2 from registers into the panel ----
-    u32x2 hr[MI][NI];                                    // residual rows of h: requested ahead of the GEMM, or (p.late_res) behind its last weight load
+    u32x2 hr[MI][NI];                                    // residual rows of h: requested behind the GEMM's last weight load (round 6: ahead of it, they held the weight stream's first waits in the in-order vmcnt queue)
     auto ld_hr = [&]() __attribute__((always_inline)) {
 #pragma unroll
       for (int i = 0; i < MI; ++i) load_row_chunk<NI>(p.h + (long long)(m0s + rbase + 16 * i) * C + ncol0, hr[i]);
     };
-    if (p.late_res) gemm_body_late(p.wo1f, ld_hr);
-    else { ld_hr(); gemm_body(p.wo1f); }
+    gemm_body_late(p.wo1f, ld_hr);
     TB_TS(4);
     gemm_head(p.wqf);
     float bv1[NI * 4];
@@ -705,10 +709,10 @@ __global__ __launch_bounds__(512, 2) void attn_chain_kernel(const AttnChainP p) 
       if (q == 0) *(f32x2_t*)(pst + (nq * BM + rbase + 16 * i) * 2) = f32x2_t{rs1[i], rq1[i]};
     }
     TB_TS(5);
-    float g2[NI * 4], b2[NI * 4];                        // (requested in front of the barrier: their L2 round trip runs under the wait for the slowest wave)
-#pragma unroll
-    for (int t = 0; t < NI; ++t) { *(f32x4*)&g2[4 * t] = *(const f32x4*)(p.gamma + ncol0 + 4 * t); *(f32x4*)&b2[4 * t] = *(const f32x4*)(p.beta + ncol0 + 4 * t); }
     __syncthreads();                                    // partial sums staged AND every wave is done reading o1 from the panel
+    float g2[NI * 4], b2[NI * 4];
+#pragma unroll
+    for (int t = 0; t < NI; ++t) { *(f32x4*)&g2[4 * t] = *(const f32x4*)(gbs + ncol0 + 4 * t); *(f32x4*)&b2[4 * t] = *(const f32x4*)(gbs + C + ncol0 + 4 * t); }
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
       const int row = rbase + 16 * i;
@@ -734,8 +738,8 @@ __global__ __launch_bounds__(512, 2) void attn_chain_kernel(const AttnChainP p) 
     const int pos = i * 512 + tid, row = pos / CHR, pc = pos - row * CHR, lc = panel_swz<C>(pc, row);
     u32x4 v = *(u32x4*)(panel + row * PITCH + pc * 16);
     const f32x2_t st = *(const f32x2_t*)(lnst + row * 2);
-    const f32x4 g0 = *(const f32x4*)(p.gamma + lc * 8), g1 = *(const f32x4*)(p.gamma + lc * 8 + 4);
-    const f32x4 b0 = *(const f32x4*)(p.beta + lc * 8), b1 = *(const f32x4*)(p.beta + lc * 8 + 4);
+    const f32x4 g0 = *(const f32x4*)(gbs + lc * 8), g1 = *(const f32x4*)(gbs + lc * 8 + 4);
+    const f32x4 b0 = *(const f32x4*)(gbs + C + lc * 8), b1 = *(const f32x4*)(gbs + C + lc * 8 + 4);
     float x[8];
 #pragma unroll
     for (int e = 0; e < 4; ++e) { x[2 * e] = __uint_as_float(v[e] << 16); x[2 * e + 1] = __uint_as_float(v[e] & 0xFFFF0000u); }
@@ -923,23 +927,23 @@ __global__ __launch_bounds__(512, 2) void attn_chain_kernel(const AttnChainP p) 
   TB_TS(31);
 
   // ---- to_out + bias + residual, one rounding; optional norm3 row statistics of the rounded outputs ----
-  u32x2 fr[MI][NI];                                      // residual rows (PRE: h1, stored by this very lane above): requested ahead of the GEMM, or (p.late_res) behind its last weight load
+  u32x2 fr[MI][NI];                                      // residual rows (PRE: h1, stored by this very lane above): requested behind the GEMM's last weight load (round 6: ahead of it, they held the weight stream's first waits in the in-order vmcnt queue)
   auto ld_fr = [&]() __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < MI; ++i) load_row_chunk<NI>((PRE ? (const bf16_t*)p.out : p.h) + (long long)((PRE ? m0 : m0s) + rbase + 16 * i) * C + ncol0, fr[i]);
   };
-  if (p.late_res) gemm_body_late(p.wof, ld_fr);
-  else { ld_fr(); gemm_body(p.wof); }
+  gemm_body_late(p.wof, ld_fr);
   TB_TS(32);
   float bv[NI * 4];
 #pragma unroll
   for (int t = 0; t < NI; ++t) *(f32x4*)&bv[4 * t] = *(const f32x4*)(p.bo + ncol0 + 4 * t);
   float rs[MI], rq[MI];
+  // the rows leave as whole 160-byte segments, consecutive lanes on consecutive 16-byte pieces (as qkv_chain2_kernel: 3.4 -> 5.8 TB/s for the burst): two row groups at a
+  // time through 5 KiB of the free K / V stage that only this wave touches (behind the first 4 KiB, which the row statistics below reuse)
+  char* const ostg = kvs + 4096 + wid * 5120;
 #pragma unroll
   for (int i = 0; i < MI; ++i) {
-    const int m = m0 + rbase + 16 * i;
     rs[i] = 0.f; rq[i] = 0.f;
-    bf16_t* op = p.out + (long long)m * C + ncol0;
     u32x2 pkk[NI];
     const u32x2 (&r)[NI] = fr[i];
 #pragma unroll
@@ -951,7 +955,16 @@ __global__ __launch_bounds__(512, 2) void attn_chain_kernel(const AttnChainP p) 
       const float a0 = __uint_as_float(pk[0] << 16), a1 = __uint_as_float(pk[0] & 0xFFFF0000u), a2 = __uint_as_float(pk[1] << 16), a3 = __uint_as_float(pk[1] & 0xFFFF0000u);
       rs[i] += (a0 + a1) + (a2 + a3); rq[i] += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
     }
-    store_row_chunk<NI>(op, pkk);
+#pragma unroll
+    for (int t = 0; t < NI; ++t) *(u32x2*)(ostg + (16 * (i & 1) + px) * 160 + 40 * q + 8 * t) = pkk[t];
+    if (i & 1) {
+#pragma unroll
+      for (int it = 0; it < 5; ++it) {
+        const int id = 64 * it + lane, row = id / 10, pc = id - row * 10;
+        const u32x4 v = *(const u32x4*)(ostg + 16 * id);
+        *(u32x4*)(p.out + (long long)(m0 + 16 * MI * mh + 16 * (i - 1) + row) * C + 80 * nq + 8 * pc) = v;
+      }
+    }
   }
   if (p.rowstat_out) {                                  // wave-uniform (kernel argument); fixed summation order: reproducible
 #pragma unroll
@@ -985,7 +998,7 @@ int launch_attn_chain(const AttnChainP& p, int C, int heads, hipStream_t st) {
   if ((long long)p.M * C * 2 >= (1LL << 31)) { agd_set_error("attn_chain: activation too large for 32-bit offsets"); return -1; }
   if (p.record && (p.rec_hpb < 1 || 8 % p.rec_hpb || !p.rec)) { agd_set_error("attn_chain: recorder head group %d", p.rec_hpb); return -1; }
   const int D = C / 8, ks = (D + 15) / 16, db = (D + 31) / 32;
-  const int lds = BM * C * 2 + 2 * 96 * ((((2 * ks) | 1) * 16) + ((db | 1) * 64)) + BM * 8 + (C / 80) * BM * 8;
+  const int lds = BM * C * 2 + 2 * 96 * ((((2 * ks) | 1) * 16) + ((db | 1) * 64)) + BM * 8 + (C / 80) * BM * 8 + 2 * C * 4;      // ... + norm2's (gamma | beta)
   const bool pre = p.o1 != nullptr;
   if (pre && (!p.wo1f || !p.bo1 || p.out == p.h)) { agd_set_error("attn_chain: the to_out prologue needs its weights and out != h"); return -1; }
   if (p.src_rows > 0 && (p.src_rows % BM || p.M % p.src_rows || p.out == p.h)) { agd_set_error("attn_chain: src_rows %d must divide M, be a multiple of %d and out != h", p.src_rows, BM); return -1; }
@@ -1321,13 +1334,33 @@ __global__ __launch_bounds__(64 * MH * (C / 80), 2) void qkv_chain2_kernel(const
   auto no_hook = [](auto) {};
   u32x2 pk[4][NI];                                      // the previous stage's rounded rows, waiting for their turn between the next GEMM's steps
   bf16_t* st_base = nullptr; int st_pitch = 0;          // where they go: row m at st_base + m * st_pitch
+  // The rows leave as WHOLE 160-byte segments, consecutive lanes on consecutive 16-byte pieces: a lane's own 40-byte chunk (16 + 16 + 8-byte stores, 16 rows per instruction,
+  // every instruction touching 32 lines partially) writes 21 MB at 3.4 TB/s, the transposed shape at 5.8 (tools/ubench/store_pattern.hip, profiles/r06_ubench_store_pattern.txt).
+  // The transpose is the wave's own: 32 rows x 160 bytes (two row groups) through 5 KiB of LDS that only this wave touches -- no barrier; 320 pieces = five full instructions.
+  // (M % BM == 0: the launcher; a bounds branch here would cut the K loop into blocks.)
+  char* const stg = smem + BM * PITCH + 4096 + C * 16 + 256 + C * 8 + wid * 5120;
+  auto stage_rows = [&](auto ic) __attribute__((always_inline)) {            // row groups i, i + 1 -> staging rows (lane's row px of each group at byte 40 q)
+    constexpr int i = decltype(ic)::value;
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+      for (int t = 0; t < NI; ++t) *(u32x2*)(stg + (16 * g + px) * 160 + 40 * q + 8 * t) = pk[i + g][t];
+  };
+  auto store_rows = [&](auto ic) __attribute__((always_inline)) {            // staging -> global: piece id = 64 it + lane of the 32 x 10 pieces
+    constexpr int i = decltype(ic)::value;
+#pragma unroll
+    for (int it = 0; it < 5; ++it) {
+      const int id = 64 * it + lane, row = id / 10, pc = id - row * 10;
+      const u32x4 v = *(const u32x4*)(stg + 16 * id);
+      *(u32x4*)(st_base + (long long)(m0 + 64 * mh + 16 * i + row) * st_pitch + 80 * nq + 8 * pc) = v;
+    }
+  };
   auto store_hook = [&](auto fc) __attribute__((always_inline)) {
     constexpr int f = decltype(fc)::value;
-    if constexpr (f % 10 == 6 && f / 10 < 4) {           // steps 6, 16, 26, 36: row group i = f / 10
-      constexpr int i = f / 10;
-      // (M % BM == 0: the launcher; a bounds branch here would cut the K loop into blocks)
-      store_row_chunk<NI>(st_base + (long long)(m0 + rbase + 16 * i) * st_pitch + ncol0, pk[i]);
-    }
+    if constexpr (f == 4) stage_rows(std::integral_constant<int, 0>{});
+    if constexpr (f == 14) store_rows(std::integral_constant<int, 0>{});
+    if constexpr (f == 24) stage_rows(std::integral_constant<int, 2>{});
+    if constexpr (f == 34) store_rows(std::integral_constant<int, 2>{});
   };
   const unsigned qkv_bytes = 3u * C * C * 2;
   const unsigned wb0 = __builtin_amdgcn_readfirstlane((unsigned)((NQ * 0 + nq) * KS * NI) * 1024u);
@@ -1402,8 +1435,8 @@ __global__ __launch_bounds__(64 * MH * (C / 80), 2) void qkv_chain2_kernel(const
     st_base = p.qkv + s * C; st_pitch = 3 * C;
     TB_TS(20 + s);
   });
-#pragma unroll
-  for (int i = 0; i < 4; ++i) store_row_chunk<NI>(st_base + (long long)(m0 + rbase + 16 * i) * st_pitch + ncol0, pk[i]);
+  stage_rows(std::integral_constant<int, 0>{}); store_rows(std::integral_constant<int, 0>{});
+  stage_rows(std::integral_constant<int, 2>{}); store_rows(std::integral_constant<int, 2>{});
   TB_TS_END;
 }
 
@@ -1415,7 +1448,8 @@ int launch_qkv_chain(const QkvChainP& p, int C, hipStream_t st) {
   if (!p.x || !p.wbf || !p.rowadd || !p.h || !p.gamma || !p.beta || !p.wqkvf || !p.qkv) { agd_set_error("qkv_chain: bad arguments"); return -1; }
   if ((long long)p.M * C * 6 >= (1LL << 31)) { agd_set_error("qkv_chain: activation too large for 32-bit offsets"); return -1; }
   if (p.gn_part && (p.gn_bm < 1 || p.HW % p.gn_bm || p.gn_groups < 1 || p.gn_groups > 32 || C % p.gn_groups || !p.gn_gamma || !p.gn_beta)) { agd_set_error("qkv_chain: bad GroupNorm arguments"); return -1; }
-  const int lds = BM * C * 2 + 4096 + C * 16 + 256 + C * 8;      // panel, h row statistics, GroupNorm: channel sums, group statistics, (scale, shift)
+  int lds = BM * C * 2 + 4096 + C * 16 + 256 + C * 8;            // panel, h row statistics, GroupNorm: channel sums, group statistics, (scale, shift)
+  if (p.sched2) lds += (half ? 4 : 8) * 5120;                    // + the waves' store-transpose staging (qkv_chain2_kernel)
   const void* kfn = C == 320 ? (half ? (const void*)qkv_chain_kernel<320, 1> : (const void*)qkv_chain_kernel<320>) : (const void*)qkv_chain_kernel<640>;
   if (p.sched2) kfn = C == 320 ? (half ? (const void*)qkv_chain2_kernel<320, 1> : (const void*)qkv_chain2_kernel<320>) : (const void*)qkv_chain2_kernel<640>;
   const int slot = (C == 640 ? 1 : half ? 2 : 0) + (p.sched2 ? 3 : 0);
