@@ -231,6 +231,10 @@ __global__ __launch_bounds__(512, 2) void ff_fused_kernel(const FFusedP p) {
   char* panel = smem;                                   // [BM][C] bf16, swizzled: the raw residual rows (GEMM1 operand AND residual)
   char* hbuf = smem + BM * PITCH;                       // 2 x [BM][HC] bf16, swizzled: GEGLU output chunks
   float* lnst = (float*)(hbuf + 2 * BM * HC * 2);       // [BM] (mean, rstd)
+  // GEGLU epilogue constants of a chunk -- [colsum values | colsum gates | bias values | bias gates] x HC floats -- wait in LDS, three chunks deep: fetched one float per thread
+  // at the top of the interval before, written at its end.  Loaded inside the epilogue (round 5) each of its two column groups paid an L2 round trip in the in-order vmcnt queue,
+  // behind whatever weight fragments were in flight, with nothing of its own to overlap it (round 6 stamps: the same stall as qkv_chain's)
+  float* cbufs = lnst + BM * 2;                         // [3][4 * HC]
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -243,6 +247,10 @@ __global__ __launch_bounds__(512, 2) void ff_fused_kernel(const FFusedP p) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   panel_row_stats<C>(panel, lnst, tid, p.ln_eps);
+  { const auto cs1r0 = __builtin_amdgcn_make_buffer_rsrc((void*)p.cs1, 0, (unsigned)(2 * HID * 4), 0x00020000);
+    const auto b1r0 = __builtin_amdgcn_make_buffer_rsrc((void*)p.b1, 0, (unsigned)(2 * HID * 4), 0x00020000);
+    const unsigned off = (unsigned)((((tid >> 7) & 1) ? HID : 0) + (tid & (HC - 1))) * 4u;
+    ((float*)(hbuf + 2 * BM * HC * 2) + BM * 2)[tid] = __builtin_bit_cast(float, wid < 4 ? __builtin_amdgcn_raw_buffer_load_b32(cs1r0, off, 0, 0) : __builtin_amdgcn_raw_buffer_load_b32(b1r0, off, 0, 0)); }   // chunk 0 -> cbufs[0]
   __syncthreads();
 
   // (this lane's rows: rbase + 16 i with rbase = 64 mh + (lane & 15); X fragment (MFMA B operand) addresses in the panel: row rbase + 16 i, logical chunk 4 ks + q)
@@ -344,21 +352,24 @@ __global__ __launch_bounds__(512, 2) void ff_fused_kernel(const FFusedP p) {
   // LayerNorm fold + bias + value * gelu(gate) of chunk c -> hbuf[c & 1]; lane (q, px) owns hidden columns 128 c + 32 nq + 8 q .. + 8
   const auto cs1rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.cs1, 0, (unsigned)(2 * HID * 4), 0x00020000);
   const auto b1rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.b1, 0, (unsigned)(2 * HID * 4), 0x00020000);
+  // thread tid's float of chunk c's constants: row tid >> 7 of [cs values | cs gates | b values | b gates], column tid & 127 (waves 0 .. 3 read cs1, 4 .. 7 b1: wave-uniform)
+  auto cload = [&](int c) __attribute__((always_inline)) {
+    const unsigned off = (unsigned)((((tid >> 7) & 1) ? HID : 0) + HC * c + (tid & (HC - 1))) * 4u;
+    return __builtin_bit_cast(float, wid < 4 ? __builtin_amdgcn_raw_buffer_load_b32(cs1rs, off, 0, 0) : __builtin_amdgcn_raw_buffer_load_b32(b1rs, off, 0, 0));
+  };
+  auto cstore = [&](int c, float v) __attribute__((always_inline)) { cbufs[(c % 3) * (4 * HC) + tid] = v; };
+  static_assert(HC == 128, "one float per thread and chunk");
   auto geglu = [&](int c) __attribute__((always_inline)) {
     const int l_ = lane_now(), q = l_ >> 4, px = l_ & 15;
     const int rbase = 64 * mh + px;
-    const unsigned hcol0b = (unsigned)(32 * nq + 8 * q) * 4u;            // byte offset of this lane's first column inside the chunk (one VGPR; the chunk's base in an SGPR)
-    const unsigned cbase = __builtin_amdgcn_readfirstlane((unsigned)(HC * c) * 4u);
+    const float* cb = cbufs + (c % 3) * (4 * HC) + 32 * nq + 8 * q;      // this lane's first column of the chunk's four constant rows
     char* hb = hbuf + (c & 1) * (BM * HC * 2);
     float mu[4], rs[4];                                // (re-read per chunk: eight registers less across the MFMA phases)
 #pragma unroll
     for (int i = 0; i < 4; ++i) { const f32x2_t v = *(const f32x2_t*)(lnst + (rbase + 16 * i) * 2); mu[i] = v[0]; rs[i] = v[1]; }
 #pragma unroll
     for (int t = 0; t < 2; ++t) {                      // four columns at a time: 16 epilogue constants live instead of 32
-      const f32x4 csv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(cs1rs, hcol0b, cbase + 16u * t, 0));
-      const f32x4 csg = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(cs1rs, hcol0b, cbase + (unsigned)HID * 4u + 16u * t, 0));
-      const f32x4 bv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(b1rs, hcol0b, cbase + 16u * t, 0));
-      const f32x4 bg = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(b1rs, hcol0b, cbase + (unsigned)HID * 4u + 16u * t, 0));
+      const f32x4 csv = *(const f32x4*)(cb + 4 * t), csg = *(const f32x4*)(cb + HC + 4 * t), bv = *(const f32x4*)(cb + 2 * HC + 4 * t), bg = *(const f32x4*)(cb + 3 * HC + 4 * t);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         float o[4];
@@ -386,6 +397,9 @@ __global__ __launch_bounds__(512, 2) void ff_fused_kernel(const FFusedP p) {
   // The intervals 2 .. NCH - 1 run every phase in both halves: they get a loop of their own per half (mh), straight-line and with the stream flags constant -- the
   // general form's paths (phase present or not, GEGLU before or after) merged with different register assignments: a spilled ring fragment and ~40 v_mov per interval.
   auto interval = [&](int k) __attribute__((always_inline)) {                          // general form: the first two and the last two intervals
+    const bool cn = k + 1 < NCH;
+    float cv = 0.f;
+    if (cn) cv = cload(k + 1);
     if (!(VAR & 8) && mh == 1 && k >= 1 && k <= NCH) geglu(k - 1);
     const int c2 = k - 1 - mh, c2n = k - mh;
     const bool v2 = c2 >= 0 && c2 < NCH, v1 = k < NCH, v2n = c2n >= 0 && c2n < NCH;
@@ -395,6 +409,7 @@ __global__ __launch_bounds__(512, 2) void ff_fused_kernel(const FFusedP p) {
     if (v1) gemm1(k, v2, v2n, w2ns);
     pre2 = v1 && v2n;
     if (!(VAR & 8) && mh == 0 && k < NCH) geglu(k);
+    if (cn) cstore(k + 1, cv);
     if (k <= NCH) __syncthreads();
   };
   static_assert(NCH >= 4, "steady intervals");
@@ -406,17 +421,24 @@ __global__ __launch_bounds__(512, 2) void ff_fused_kernel(const FFusedP p) {
     for (int k = 2; k < NCH; ++k) {
       const unsigned w1s = __builtin_amdgcn_readfirstlane((unsigned)(((k * 4 + nq) * KS1) * 4) * 1024u);
       const unsigned w2ns = __builtin_amdgcn_readfirstlane((unsigned)(((k * 4 + nq) * KS2) * NI2) * 1024u);
+      const bool cn = k + 1 < NCH;
+      float cv = 0.f;
+      if (cn) cv = cload(k + 1);
       gemm2(k - 1, true, true, w1s);
       TB_TS(10);
       gemm1(k, true, true, w2ns);
       TB_TS(11);
       if (!(VAR & 8)) geglu(k);
       TB_TS(12);
+      if (cn) cstore(k + 1, cv);
       __syncthreads();
       TB_TS(13);
     }
   } else {
     for (int k = 2; k < NCH; ++k) {
+      const bool cn = k + 1 < NCH;
+      float cv = 0.f;
+      if (cn) cv = cload(k + 1);
       if (!(VAR & 8)) geglu(k - 1);
       TB_TS(12);
       const unsigned w1s = __builtin_amdgcn_readfirstlane((unsigned)(((k * 4 + nq) * KS1) * 4) * 1024u);
@@ -425,6 +447,7 @@ __global__ __launch_bounds__(512, 2) void ff_fused_kernel(const FFusedP p) {
       TB_TS(10);
       gemm1(k, true, true, w2ns);
       TB_TS(11);
+      if (cn) cstore(k + 1, cv);
       __syncthreads();
       TB_TS(13);
     }
@@ -532,7 +555,7 @@ int launch_ff_fused(const FFusedP& p, int C, hipStream_t st) {
   if (C != 320) { agd_set_error("ff_fused: C = %d is not built (320 only)", C); return -1; }
   if (p.M < 1 || !p.h || !p.out || !p.w1f || !p.w2f || !p.cs1 || !p.b1 || !p.b2) { agd_set_error("ff_fused: bad arguments"); return -1; }
   if ((long long)p.M * C * 2 >= (1LL << 31)) { agd_set_error("ff_fused: activation too large for 32-bit offsets"); return -1; }
-  constexpr int lds = 128 * 320 * 2 + 2 * 128 * 128 * 2 + 128 * 8;
+  constexpr int lds = 128 * 320 * 2 + 2 * 128 * 128 * 2 + 128 * 8 + 3 * 4 * 128 * 4;      // panel, two GEGLU chunk buffers, row statistics, three chunks of epilogue constants
   const void* kfn = p.wpf ? (p.premul ? (const void*)ff_fused_kernel<320, 0, 2> : (const void*)ff_fused_kernel<320, 0, 1>) : (const void*)ff_fused_kernel<320>;
   if (p.wpf && (!p.bp || !p.xres || !p.pout)) { agd_set_error("ff_fused: the proj_out stage needs bias, residual and output"); return -1; }
   if (p.premul && !p.wpf) { agd_set_error("ff_fused: the pre-multiplied form is the proj_out stage's"); return -1; }
