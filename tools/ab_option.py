@@ -31,4 +31,4 @@ for r in range(rounds):
         batch(r + 1)
         torch.cuda.synchronize(); res[v].append((time.perf_counter() - t0) * 1e3)
 for v in values:
-    print(f"{opt}={v}: " + " ".join(f"{t:.1f}" for t in res[v]) + f"  median {sorted(res[v])[len(res[v]) // 2]:.1f} ms per batch")
+    print(f"{opt}={v}: " + " ".join(f"{t:.1f}" for t in res[v]) + f"  median {sorted(res[v])[len(res[v]) // 2]:.1f}  min {min(res[v]):.1f} ms per batch")
