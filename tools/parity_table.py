@@ -13,22 +13,23 @@ import sys
 # report id (regex) -> (what is compared, bound as stated in the test)
 ROWS = [
     (r"config2_512px_50_steps_end_to_end", "**config 2 at the metric's own length**: SD-1.5 shapes, one 512 x 512 image, 50 DDIM steps, CFG 7.5, DAAM on, VAE decode vs the oracle's loop",
-     "latents 0.10 / PSNR 30 dB / heat map 3 % / normalised map 13/255"),
+     "latents 0.10 / PSNR 30 dB / heat map 3 % / normalised map: max 13, p99.9 6, mean 1 (/255)"),
     (r"config2_forward_512px_batch4", "config 2 forward at the bench's batch (UNet batch 8, 512 px) + DAAM record vs the oracle; every load-time merge and the round-5 options as separate legs",
      "rms rel 2^-6 (0.0156) / heat map 2 %; legs within 2^-5 of the default"),
     (r"config2_forward_512px_cfg_pair\[igemm8p=(\d)\]", "config 2 forward, CFG pair (igemm8p = \\1)", "rms rel 2^-6 / heat map 2 %"),
     (r"config2_forward_512px_fused_kernels\[tblock_fuse=(\d+),reduce_gn=(\d)\]", "config 2 forward with tblock_fuse = \\1, reduce_gn = \\2", "vs oracle 2^-6, vs kernel chain 2^-5, heat map 2 %"),
     (r"config3_share_forward_512px_unet_batch16", "**config 3's per-GPU share**: UNet batch 16 at 512 px, one forward + DAAM record vs the oracle (round 5)", "rms rel 2^-6 (every image) / heat map 2 %"),
     (r"config5_share_forward_768px_unet_batch8", "**config 5's per-GPU share**: SD-2.1 shapes, UNet batch 8 at 768 px vs the oracle (round 5)", "rms rel 0.02 (every image) / heat map 1 %"),
+    (r"config3_share_vae_encode_512px_batch8", "**config 3's per-GPU share of the encoder** (round 6): eight different images in one `vae_encode` call vs the oracle's moments", "moments 2^-6 (every image)"),
     (r"config3_vae_encode_img2img_512px", "config 3: vae.encode at 512 px + 3 img2img steps vs the oracle", "moments 2^-6 / latents 0.05 / 30 dB / heat map 3 %"),
-    (r"config1_256px_10_steps_end_to_end", "config 1 end to end (1 x 256 x 256, 10 DDIM steps, DAAM on)", "latents 0.05 / 36 dB / heat map 2 % / normalised map 13/255"),
+    (r"config1_256px_10_steps_end_to_end", "config 1 end to end (1 x 256 x 256, 10 DDIM steps, DAAM on)", "latents 0.05 / 36 dB / heat map 2 % / normalised map: max 19, p99.9 9, mean 1.6 (/255; round 6: DESIGN section 2)"),
     (r"config1_forward_256px", "config 1 forward (256 px) + DAAM record", "rms rel 2^-6 / heat map 2 %"),
     (r"config5_forward_768px_cfg_pair", "config 5 forward (SD-2.1, 768 px, CFG pair)", "rms rel 0.02 / heat map 1 %"),
     (r"config5_vpred_3_steps_768px", "config 5: 3 DDIM steps with v-prediction at 768 px", "latents 0.05 / heat map 3 %"),
     (r"config5_vae_decode_768px", "config 5 VAE decode at 768 px", "rms rel 2^-6 / 40 dB"),
     (r"vae_decode_512px\[igemm8p=(\d)\]", "VAE decode at 512 px (igemm8p = \\1)", "rms rel 2^-6 / 40 dB"),
     (r"config4_learned_token_heat_maps_png", "config 4: PNG payloads of the learned-token heat maps vs CLIP + oracle PNDM loop", "max abs 12 / 255"),
-    (r"odd_size_merged_vs_unmerged\[(\d+)px,B=(\d)\]", "every merge on vs off at \\1 px, batch \\2 (two CFG steps); at 256 px both walks also vs the oracle (round 5)", "merged vs unmerged 0.08; vs oracle 0.05"),
+    (r"odd_size_merged_vs_unmerged\[(\d+)px,B=(\d)\]", "every merge on vs off at \\1 px, batch \\2 (two CFG steps); both walks also vs the oracle (every size since round 6)", "merged vs unmerged 0.08; vs oracle 0.05"),
     (r"cfg_shared_prefix_lazy_vs_(\w+)", "CFG-shared prefix inside the fused kernels vs \\1 (two steps)", "latents 0.08 / heat maps 2 % (bit-identical to the unshared run)"),
     (r"golden_attn_chain_kernel\[C=(\d+),rows32=(\d)\]", "**reference fixture** (hook.py `__call__` at C = \\1, 8 heads) driven through `attn_chain_kernel` (rows32 = \\2)", "output 2^-6 / map 2e-3"),
     (r"golden_xattn_premul\[C=1280\]", "**reference fixture** (hook.py `__call__` at C = 1280, hw = 256) driven through the pre-multiplied attn2 form", "output 2^-6 / map 2e-3"),
