@@ -1232,6 +1232,8 @@ __global__ __launch_bounds__(64 * MH * (C / 80), 2) void qkv_chain_kernel(const 
 //     the packed rows now wait in 40 registers and leave one row group at a time BETWEEN the next GEMM's K steps, and the weight stream runs on across the GEMM seams.
 // Same arithmetic, same summation orders, same roundings: bit-identical to qkv_chain_kernel (tools/eq_option.py tblock_fuse 1791,5887).
 // ---------------------------------------------------------------------------------------------------------------------------
+// bytes of the block-head kernels' LDS layout in front of the store-transpose staging: panel, h row statistics (4 KiB), GroupNorm channel sums, group statistics, (scale, shift)
+constexpr int qkv_chain_lds_fixed(int C, int BM) { return BM * C * 2 + 4096 + C * 16 + 256 + C * 8; }
 template <int I, int N, class F> AGD_DEV void tb_static_for(F&& f) {
   if constexpr (I < N) { f(std::integral_constant<int, I>{}); tb_static_for<I + 1, N>(f); }
 }
@@ -1260,19 +1262,20 @@ __global__ __launch_bounds__(64 * MH * (C / 80), 2) void qkv_chain2_kernel(const
   if (p.gn_part) {
     // channel sums over the image's tiles (fp64, tile order -- gn_apply_part's arithmetic): thread = channel PAIR, all of a round's loads in flight, before any LDS-DMA exists
     const int nt = p.HW / p.gn_bm;
-    const int cp = tid < C / 2 ? tid : C / 2 - 1;
-    const float* pp = p.gn_part + ((long long)img * nt * C + 2 * cp) * 2;
 #pragma unroll
     for (int r = 0; r < CPT; ++r) { const int cch = tid + NT * r < C ? tid + NT * r : C - 1; gam[r] = p.gn_gamma[cch]; bet[r] = p.gn_beta[cch]; }
-    double a0 = 0.0, q0 = 0.0, a1 = 0.0, q1 = 0.0;
-    for (int t0 = 0; t0 < nt; t0 += 32) {
-      f32x4 v[32];
+    if (tid < C / 2) {                                   // (the first C / 128 waves; the others have nothing to fetch)
+      const float* pp = p.gn_part + ((long long)img * nt * C + 2 * tid) * 2;
+      double a0 = 0.0, q0 = 0.0, a1 = 0.0, q1 = 0.0;
+      for (int t0 = 0; t0 < nt; t0 += 32) {
+        f32x4 v[32];
 #pragma unroll
-      for (int u = 0; u < 32; ++u) { const int tc = t0 + u < nt ? t0 + u : nt - 1; v[u] = *(const f32x4*)(pp + (long long)tc * C * 2); }
+        for (int u = 0; u < 32; ++u) { const int tc = t0 + u < nt ? t0 + u : nt - 1; v[u] = *(const f32x4*)(pp + (long long)tc * C * 2); }
 #pragma unroll
-      for (int u = 0; u < 32; ++u) if (t0 + u < nt) { a0 += (double)v[u][0]; q0 += (double)v[u][1]; a1 += (double)v[u][2]; q1 += (double)v[u][3]; }
+        for (int u = 0; u < 32; ++u) if (t0 + u < nt) { a0 += (double)v[u][0]; q0 += (double)v[u][1]; a1 += (double)v[u][2]; q1 += (double)v[u][3]; }
+      }
+      csum[4 * tid] = a0; csum[4 * tid + 1] = q0; csum[4 * tid + 2] = a1; csum[4 * tid + 3] = q1;
     }
-    if (tid < C / 2) { csum[4 * tid] = a0; csum[4 * tid + 1] = q0; csum[4 * tid + 2] = a1; csum[4 * tid + 3] = q1; }
   }
   TB_TS(2);
   panel_load_dma<C, BM, MH * NQ>(p.x, m0, p.M, panel, wid, lane);
@@ -1361,7 +1364,7 @@ __global__ __launch_bounds__(64 * MH * (C / 80), 2) void qkv_chain2_kernel(const
   // every instruction touching 32 lines partially) writes 21 MB at 3.4 TB/s, the transposed shape at 5.8 (tools/ubench/store_pattern.hip, profiles/r06_ubench_store_pattern.txt).
   // The transpose is the wave's own: 32 rows x 160 bytes (two row groups) through 5 KiB of LDS that only this wave touches -- no barrier; 320 pieces = five full instructions.
   // (M % BM == 0: the launcher; a bounds branch here would cut the K loop into blocks.)
-  char* const stg = smem + BM * PITCH + 4096 + C * 16 + 256 + C * 8 + wid * 5120;
+  char* const stg = smem + qkv_chain_lds_fixed(C, BM) + wid * 5120;
   auto stage_rows = [&](auto ic) __attribute__((always_inline)) {            // row groups i, i + 1 -> staging rows (lane's row px of each group at byte 40 q)
     constexpr int i = decltype(ic)::value;
 #pragma unroll
@@ -1471,8 +1474,8 @@ int launch_qkv_chain(const QkvChainP& p, int C, hipStream_t st) {
   if (!p.x || !p.wbf || !p.rowadd || !p.h || !p.gamma || !p.beta || !p.wqkvf || !p.qkv) { agd_set_error("qkv_chain: bad arguments"); return -1; }
   if ((long long)p.M * C * 6 >= (1LL << 31)) { agd_set_error("qkv_chain: activation too large for 32-bit offsets"); return -1; }
   if (p.gn_part && (p.gn_bm < 1 || p.HW % p.gn_bm || p.gn_groups < 1 || p.gn_groups > 32 || C % p.gn_groups || !p.gn_gamma || !p.gn_beta)) { agd_set_error("qkv_chain: bad GroupNorm arguments"); return -1; }
-  int lds = BM * C * 2 + 4096 + C * 16 + 256 + C * 8;            // panel, h row statistics, GroupNorm: channel sums, group statistics, (scale, shift)
-  if (p.sched2) lds += (half ? 4 : 8) * 5120;                    // + the waves' store-transpose staging (qkv_chain2_kernel)
+  int lds = qkv_chain_lds_fixed(C, BM);
+  if (p.sched2) lds += (half ? 4 : 8) * 5120;                    // + the waves' store-transpose staging (qkv_chain2_kernel): 5 KiB per wave
   const void* kfn = C == 320 ? (half ? (const void*)qkv_chain_kernel<320, 1> : (const void*)qkv_chain_kernel<320>) : (const void*)qkv_chain_kernel<640>;
   if (p.sched2) kfn = C == 320 ? (half ? (const void*)qkv_chain2_kernel<320, 1> : (const void*)qkv_chain2_kernel<320>) : (const void*)qkv_chain2_kernel<640>;
   const int slot = (C == 640 ? 1 : half ? 2 : 0) + (p.sched2 ? 3 : 0);
